@@ -1,0 +1,204 @@
+/*
+ * lisreg.h — C ABI of liblisreg.so: MI355X-native (gfx950, HIP) LOAM-style scan-to-submap registration.
+ *
+ * This header is the drop-in boundary for ONE hot path of QingzhiWang/LIS-SLAM: the private member
+ * functions scan2SubMapOptimization() / subMap2SubMapOptimization() and everything they call
+ *   copy #1  src/node/odomEstimationNode.cpp:596-1006      (plain PointXYZI, tau=1.0, 15 iters)
+ *   copy #2  src/node/subMapOptmizationNode.cpp:1509-2001  (PointXYZIL, label weights, tau=2.0, 20 iters)
+ *   copy #3  src/node/subMapOptmizationNode.cpp:4485-4977  (as #2, 30 iters, no IMU blend)
+ * The reference has no FFI / plugin layer for this path; this header creates the seam.
+ * Each entry point below cites the reference lines it replaces.  Plain pointers and sizes only; no C++ or
+ * torch types; never throws; every function returns an int status (0 = OK) unless stated otherwise.
+ *
+ * Conventions
+ *   pose      T[6] = {roll, pitch, yaw, x, y, z}, float32 — the reference's transformTobeMapped[6]
+ *             (odomEstimationNode.cpp:66).  M(T) = pcl::getTransformation(x,y,z,roll,pitch,yaw) =
+ *             Rz(yaw)*Ry(pitch)*Rx(roll) + t (src/core/common.cpp:54-57).
+ *   clouds    host clouds are arrays of PCL point structs as the reference holds them
+ *             (`cloud->points.data()`), i.e. stride 32 B, 16-B aligned: PointXYZI = {x,y,z,pad,intensity,pad*3},
+ *             PointXYZIL = {x,y,z,pad,intensity,uint16 label,pad} (src/include/common.h:9,25-35).  Any
+ *             stride >= 12 is accepted; `fmt` says where (whether) a label lives.
+ *   device    device-resident clouds are arrays of lisreg_dpoint (16 B): x,y,z + 32-bit payload whose low
+ *             16 bits are the label (0 when unlabelled).
+ */
+#ifndef LISREG_H_
+#define LISREG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LISREG_VERSION 1
+
+/* ---- status codes (error conventions: SURVEY.md §8b "Error conventions") -------------------------------- */
+#define LISREG_OK                        0
+#define LISREG_NOT_ENOUGH_FEATURES       1   /* guard at odomEstimationNode.cpp:598,623-625 failed: T untouched */
+#define LISREG_TOO_FEW_CORRESPONDENCES   2   /* every iteration hit the `< 50` early return (:870-872): T untouched */
+#define LISREG_ERR_ARG                  -1
+#define LISREG_ERR_HIP                  -2
+#define LISREG_ERR_NO_TARGET            -3
+#define LISREG_ERR_NOMEM                -4
+#define LISREG_ERR_COMM                 -5
+
+/* ---- cloud formats --------------------------------------------------------------------------------------- */
+#define LISREG_FMT_XYZI    0   /* pcl::PointXYZI   : floats x@0 y@4 z@8, intensity@16                        */
+#define LISREG_FMT_XYZIL   1   /* PointXYZIL       : as XYZI + uint16 label@20   (common.h:25-35)            */
+#define LISREG_FMT_DEVICE  2   /* pointer is a DEVICE pointer to lisreg_dpoint[n] (stride ignored)           */
+
+typedef struct lisreg_dpoint {   /* 16-B device record (SURVEY.md §8d "Device record")                        */
+    float    x, y, z;
+    uint32_t payload;            /* low 16 bits: semantic label (RangeNet learning class 0..19)                */
+} lisreg_dpoint;
+
+/* ---- the three reference call sites ---------------------------------------------------------------------- */
+#define LISREG_VARIANT_ODOM      1   /* OdomEstimationNode::scan2SubMapOptimization      odomEstimationNode.cpp:596  */
+#define LISREG_VARIANT_KEYFRAME  2   /* SubMapOdometryNode::scan2SubMapOptimization      subMapOptmizationNode.cpp:1509 */
+#define LISREG_VARIANT_SUBMAP    3   /* SubMapOptmizationNode::subMap2SubMapOptimization subMapOptmizationNode.cpp:4485 */
+
+/* Every literal / rosparam the path reads (SURVEY.md §5 "Config / flags"), gathered in one struct. */
+typedef struct lisreg_params {
+    int   max_iters;            /* loop bound 15 | 20 | 30            (:606 | :1520 | :4501)                   */
+    int   fixed_iters;          /* >0: benchmark mode — run exactly this many iterations, no early exit        */
+    float knn_sq_thresh;        /* pointSearchSqDis[4] < tau: 1.0 | 2.0 | 2.0   (:657,776 | :1610 | :4609)     */
+    float conv_deg;             /* deltaR bound 0.005 | 0.003 | 0.002 (:969 | :1963 | :4962)                   */
+    float conv_cm;              /* deltaT bound 0.05  | 0.03  | 0.02                                            */
+    int   min_corr;             /* laserCloudSelNum < 50 -> no-op iteration (:870)                             */
+    float eig_thresh;           /* degeneracy eigenvalue threshold 100 (:932)                                  */
+    int   edge_min;             /* edgeFeatureMinValidNum (config/params.yaml:119 = -1)                        */
+    int   surf_min;             /* surfFeatureMinValidNum (config/params.yaml:120 = 100)                       */
+    float line_ratio;           /* lambda0 > 3*lambda1 (:692)                                                  */
+    float plane_tol;            /* |n.p + d| > 0.2 invalidates the plane (:798)                                */
+    float accept_s;             /* keep correspondence iff s > 0.1 (:734,814)                                  */
+    int   use_label_weight;     /* w = 2 - LabelSorce[label] (subMapOptmizationNode.cpp:1671,1795)             */
+    float label_score[32];      /* LabelSorce table, config/label.yaml:214-234; index = label & 31             */
+    int   emulate_matp_shadow;  /* 1: reproduce the local-matP quirk; 0: keep P from iter 0 */
+    int   skip_empty_target;    /* variant #3 skips a stage whose target cloud is empty (:4505-4509)           */
+    int   use_imu_blend;        /* transformUpdate slerps roll/pitch toward IMU (#1,#2) or not (#3)            */
+    float imu_rpy_weight;       /* imuRPYWeight (config/params.yaml:88 = 0.1)                                  */
+    float rotation_tol;         /* rotation_tollerance (config/params.yaml:124 = 1000)                         */
+    float z_tol;                /* z_tollerance (config/params.yaml:123 = 1000)                                */
+} lisreg_params;
+
+/* IMU scalars the path reads from cloud_info / semantic_info (msg/cloud_info.msg:4-10). */
+typedef struct lisreg_imu {
+    int   imu_available;        /* cloudInfo.imuAvailable   */
+    float imu_roll_init;        /* cloudInfo.imuRollInit    */
+    float imu_pitch_init;       /* cloudInfo.imuPitchInit   */
+} lisreg_imu;
+
+typedef struct lisreg_stats {
+    int   iters;                /* iterCount as the reference prints it (:620 | :1535 | :4517)                 */
+    float deltaR, deltaT;       /* last computed (deg, cm); 100 if no iteration solved (member init :70-71)    */
+    int   degenerate;           /* isDegenerate after the call (persists in the context, :67)                  */
+    int   n_corr_last;          /* laserCloudSelNum of the last iteration run                                  */
+    int   status;               /* LISREG_OK | LISREG_NOT_ENOUGH_FEATURES | LISREG_TOO_FEW_CORRESPONDENCES     */
+} lisreg_stats;
+
+/* Optional per-iteration trace (parity tests): LISREG_TRACE_STRIDE floats per iteration:
+ *   [0] n_corr  [1..36] AtA row-major  [37..42] AtB  [43..48] X (after projection)  [49..54] T after update
+ *   [55] 1 if this iteration solved (n_corr >= min_corr) else 0 */
+#define LISREG_TRACE_STRIDE 56
+
+/* One independent registration of a batch (independent frames / loop-closure candidate pairs). */
+typedef struct lisreg_item {
+    const void* src_corner; int n_corner;     /* source edge features   (laserCloudSharpCornerLast, :641)      */
+    const void* src_surf;   int n_surf;       /* source planar features (laserCloudSharpSurfLast,  :757)      */
+    int         stride_bytes;                 /* 32 for PCL structs; ignored for LISREG_FMT_DEVICE             */
+    int         fmt;                          /* LISREG_FMT_*                                                  */
+    int         target;                       /* target slot id from lisreg_set_target_slot (0 = default)      */
+    int         degenerate_in;                /* isDegenerate carried in from the previous frame (usually 0)   */
+    lisreg_imu  imu;
+} lisreg_item;
+
+typedef struct lisreg_ctx lisreg_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------- */
+int  lisreg_device_count(void);                                   /* number of visible HIP devices (0 if none)  */
+int  lisreg_create(int device, lisreg_ctx** out);                 /* one context per caller thread (§8b Callers) */
+void lisreg_destroy(lisreg_ctx* ctx);
+const char* lisreg_last_error(const lisreg_ctx* ctx);             /* never NULL                                 */
+/* Use an existing HIP stream (e.g. the caller's); NULL restores the context's own stream. */
+int  lisreg_set_stream(lisreg_ctx* ctx, void* hip_stream);
+void* lisreg_get_stream(const lisreg_ctx* ctx);
+
+/* Fill `p` with the literals of one of the three reference copies. */
+int  lisreg_default_params(int variant, lisreg_params* p);
+
+/* ---- target (local map / submap) ------------------------------------------------------------------------- */
+/* Replaces kdtreeCornerFromMap->setInputCloud / kdtreeSurfFromMap->setInputCloud
+ * (odomEstimationNode.cpp:602-603 | subMapOptmizationNode.cpp:1516-1517 | :4496-4497): uploads the two target
+ * clouds and builds the device search index.  The index persists until the next call for that slot, so a
+ * target shared by many registrations is built once.  Slot 0 is what lisreg_align uses. */
+int  lisreg_set_target(lisreg_ctx* ctx, const void* corner, int n_corner,
+                       const void* surf, int n_surf, int stride_bytes, int fmt);
+int  lisreg_set_target_slot(lisreg_ctx* ctx, int slot, const void* corner, int n_corner,
+                            const void* surf, int n_surf, int stride_bytes, int fmt);
+/* Adapter for the submap API (subMap.h:435-777): concatenates class clouds in the reference's order —
+ * corner = pole; surf = ground, building, dynamic (extractSlidingCloud subMapOptmizationNode.cpp:1408-1419;
+ * extractSubMapCloud :3996-4007) — then behaves as lisreg_set_target_slot.  NULL/0 classes are skipped. */
+int  lisreg_target_from_classes(lisreg_ctx* ctx, int slot,
+                                const void* pole, int n_pole, const void* ground, int n_ground,
+                                const void* building, int n_building, const void* dynamic, int n_dynamic,
+                                int stride_bytes, int fmt);
+
+/* ---- registration ---------------------------------------------------------------------------------------- */
+/* Replaces the whole body of scan2SubMapOptimization() (odomEstimationNode.cpp:596-626 and the two copies):
+ * guard, GN loop {cornerOptimization :633, surfOptimization :749, combineOptimizationCoeffs :829,
+ * LMOptimization :852}, transformUpdate :976.  T: in = initial guess, out = result.  The context keeps
+ * isDegenerate across calls like the reference's member (:67). */
+int  lisreg_align(lisreg_ctx* ctx,
+                  const void* src_corner, int n_corner, const void* src_surf, int n_surf,
+                  int stride_bytes, int fmt,
+                  const lisreg_params* params, const lisreg_imu* imu /* may be NULL */,
+                  float T[6], lisreg_stats* stats /* may be NULL */);
+
+/* Batch of independent registrations (same semantics per item as lisreg_align with its own isDegenerate).
+ * T: n_items x 6 floats in/out; stats: n_items entries (may be NULL).  Returns 0 if the batch ran; per-item
+ * outcomes are in stats[i].status. */
+int  lisreg_align_batch(lisreg_ctx* ctx, int n_items, const lisreg_item* items,
+                        const lisreg_params* params, float* T, lisreg_stats* stats);
+
+/* Asynchronous form for device-resident batches (all items LISREG_FMT_DEVICE): enqueue on the context's
+ * stream with poses/stats left on the device; lisreg_batch_fetch synchronises and copies them out.
+ * `prepare` does all per-batch allocation and item-table upload; `run` only launches kernels (no host sync,
+ * graph-replayed), so it can be timed with events on lisreg_get_stream(). T_init is copied at prepare time
+ * and re-applied on the device at the start of every run. */
+int  lisreg_batch_prepare(lisreg_ctx* ctx, int n_items, const lisreg_item* items,
+                          const lisreg_params* params, const float* T_init);
+int  lisreg_batch_run(lisreg_ctx* ctx);
+int  lisreg_batch_fetch(lisreg_ctx* ctx, float* T, lisreg_stats* stats);
+/* Device pointer to the prepared batch's result block: n_items x 12 floats
+ * {T[6], iters, deltaR, deltaT, degenerate, n_corr_last, status} — what a multi-GPU host all-gathers. */
+void* lisreg_batch_result_device(const lisreg_ctx* ctx);
+
+/* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
+int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);
+
+/* Per-kernel timing of the last align/batch_run when enabled (HIP events on the context's stream):
+ * out[0] = total ms in the correspondence+normal-equation kernel, out[1] = its launch count,
+ * out[2] = total ms in the solve/update kernel, out[3] = its launch count, out[4] = index build ms. */
+int  lisreg_set_profiling(lisreg_ctx* ctx, int enable);
+int  lisreg_get_timing(lisreg_ctx* ctx, double out[5]);
+
+/* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
+/* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */
+void lisreg_pose_to_matrix(const float T[6], float M[12]);
+/* transformUpdate (odomEstimationNode.cpp:976-1006): IMU roll/pitch blend + constraintTransformation clamps. */
+void lisreg_transform_update(const lisreg_params* p, const lisreg_imu* imu, float T[6]);
+
+/* ---- multi-GPU pose gather (one process per GPU) ------------------------------------------ */
+/* RCCL bootstrap without MPI: rank 0 calls lisreg_comm_unique_id, ships the 128 bytes to the other ranks by
+ * any means (file, env, torch.distributed store), then every rank calls lisreg_comm_init.  lisreg_gather_results
+ * all-gathers each rank's n_local x 12-float result block (device memory) into `out_device`
+ * (nranks x n_local x 12 floats) on the context's stream. */
+int  lisreg_comm_unique_id(unsigned char id[128]);
+int  lisreg_comm_init(lisreg_ctx* ctx, int rank, int nranks, const unsigned char id[128]);
+int  lisreg_gather_results(lisreg_ctx* ctx, const void* local_device, int n_local, void* out_device);
+void lisreg_comm_destroy(lisreg_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISREG_H_ */

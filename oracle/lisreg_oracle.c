@@ -1,0 +1,780 @@
+/*
+ * lisreg_oracle.c — CPU restatement of LIS-SLAM's LOAM-style scan-to-submap registration.
+ * TEST INFRASTRUCTURE ONLY (see lisreg_oracle.h for the rules and the "parity unpinned" statement).
+ *
+ * Follows, operation for operation, /root/reference/src/node/odomEstimationNode.cpp:596-1006 (copy #1) and the
+ * label-weighted copies src/node/subMapOptmizationNode.cpp:1509-2001 / :4485-4977; pose algebra from
+ * src/core/common.cpp:54-57,285-291.  All arithmetic is float unless the reference's C++ promotes to double
+ * (the 0.1 / 0.9 / 2.0 literals, pow(), tf's double quaternions) — those promotions are reproduced.
+ * Compile WITHOUT -ffast-math and with -ffp-contract=off (x86-64 reference build has no FMA contraction).
+ */
+#include "lisreg_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* pose algebra — pcl::getTransformation via trans2Affine3f (common.cpp:54-57)                               */
+/* ------------------------------------------------------------------------------------------------------- */
+void orc_pose_to_matrix(const float T[6], float M[12])
+{
+    /* PCL common/impl/eigen.hpp getTransformation(x,y,z,roll,pitch,yaw): Scalar = float */
+    float A = cosf(T[2]), B = sinf(T[2]);   /* yaw   */
+    float C = cosf(T[1]), D = sinf(T[1]);   /* pitch */
+    float E = cosf(T[0]), F = sinf(T[0]);   /* roll  */
+    float DE = D * E, DF = D * F;
+    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
+    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
+    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
+}
+
+/* pointAssociateToMap (odomEstimationNode.cpp:243-258) */
+static void transform_point(const float M[12], const float p[3], float o[3])
+{
+    o[0] = M[0] * p[0] + M[1] * p[1] + M[2]  * p[2] + M[3];
+    o[1] = M[4] * p[0] + M[5] * p[1] + M[6]  * p[2] + M[7];
+    o[2] = M[8] * p[0] + M[9] * p[1] + M[10] * p[2] + M[11];
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* exact k-NN: kd-tree in the shape of FLANN's KDTreeSingleIndex (leaf 15, reordered points, box pruning)   */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct orc_node {
+    int   left, right;      /* child node ids, -1 for leaf                 */
+    int   lo, hi;           /* leaf: point range [lo,hi) in reordered array */
+    int   dim;
+    float divlow, divhigh;
+} orc_node;
+
+struct orc_kdtree {
+    int       n, leaf;
+    float*    pts;          /* reordered xyz */
+    int*      perm;         /* reordered -> original index */
+    orc_node* nodes;
+    int       n_nodes, cap_nodes;
+    float     bbmin[3], bbmax[3];
+};
+
+static void swap_int(int* a, int* b) { int t = *a; *a = *b; *b = t; }
+
+/* quickselect on indices by coordinate `dim` so that ind[lo..mid) <= ind[mid] <= ind(mid..hi) */
+static void select_nth(const float* xyz, int* ind, int lo, int hi, int mid, int dim)
+{
+    while (hi - lo > 1) {
+        int a = lo, c = hi - 1, b = lo + (hi - lo) / 2;
+        /* median of three -> pivot value */
+        float va = xyz[3 * ind[a] + dim], vb = xyz[3 * ind[b] + dim], vc = xyz[3 * ind[c] + dim];
+        float pv = (va < vb) ? ((vb < vc) ? vb : (va < vc ? vc : va)) : ((va < vc) ? va : (vb < vc ? vc : vb));
+        int i = lo, j = hi - 1;
+        while (i <= j) {
+            while (xyz[3 * ind[i] + dim] < pv) i++;
+            while (xyz[3 * ind[j] + dim] > pv) j--;
+            if (i <= j) { swap_int(&ind[i], &ind[j]); i++; j--; }
+        }
+        if (mid <= j) hi = j + 1;
+        else if (mid >= i) lo = i;
+        else return;
+    }
+}
+
+static int build_rec(orc_kdtree* t, const float* xyz, int* ind, int lo, int hi)
+{
+    if (t->n_nodes == t->cap_nodes) {
+        t->cap_nodes = t->cap_nodes * 2 + 16;
+        t->nodes = (orc_node*)realloc(t->nodes, sizeof(orc_node) * (size_t)t->cap_nodes);
+    }
+    int id = t->n_nodes++;
+    orc_node nd; memset(&nd, 0, sizeof nd);
+    nd.left = nd.right = -1; nd.lo = lo; nd.hi = hi;
+    if (hi - lo <= t->leaf) { t->nodes[id] = nd; return id; }
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = lo; i < hi; ++i)
+        for (int d = 0; d < 3; ++d) {
+            float v = xyz[3 * ind[i] + d];
+            if (v < mn[d]) mn[d] = v;
+            if (v > mx[d]) mx[d] = v;
+        }
+    int dim = 0; float ext = mx[0] - mn[0];
+    for (int d = 1; d < 3; ++d) if (mx[d] - mn[d] > ext) { ext = mx[d] - mn[d]; dim = d; }
+    int mid = lo + (hi - lo) / 2;
+    select_nth(xyz, ind, lo, hi, mid, dim);
+    float dl = -FLT_MAX, dh = FLT_MAX;
+    for (int i = lo; i < mid; ++i) { float v = xyz[3 * ind[i] + dim]; if (v > dl) dl = v; }
+    for (int i = mid; i < hi; ++i) { float v = xyz[3 * ind[i] + dim]; if (v < dh) dh = v; }
+    nd.dim = dim; nd.divlow = dl; nd.divhigh = dh;
+    t->nodes[id] = nd;
+    int l = build_rec(t, xyz, ind, lo, mid);
+    int r = build_rec(t, xyz, ind, mid, hi);
+    t->nodes[id].left = l; t->nodes[id].right = r;
+    return id;
+}
+
+orc_kdtree* orc_kdtree_build(const float* xyz, int n, int leaf_size)
+{
+    orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof *t);
+    t->n = n; t->leaf = leaf_size > 0 ? leaf_size : 15;
+    t->perm = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    t->pts = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) t->perm[i] = i;
+    for (int d = 0; d < 3; ++d) { t->bbmin[d] = FLT_MAX; t->bbmax[d] = -FLT_MAX; }
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            float v = xyz[3 * i + d];
+            if (v < t->bbmin[d]) t->bbmin[d] = v;
+            if (v > t->bbmax[d]) t->bbmax[d] = v;
+        }
+    if (n > 0) build_rec(t, xyz, t->perm, 0, n);
+    for (int i = 0; i < n; ++i) memcpy(&t->pts[3 * i], &xyz[3 * t->perm[i]], 3 * sizeof(float));
+    return t;
+}
+
+void orc_kdtree_free(orc_kdtree* t)
+{
+    if (!t) return;
+    free(t->pts); free(t->perm); free(t->nodes); free(t);
+}
+
+typedef struct { int k, cnt; int* idx; float* sqd; } knn_set;
+
+static inline float knn_worst(const knn_set* s) { return s->cnt < s->k ? FLT_MAX : s->sqd[s->k - 1]; }
+
+static inline void knn_add(knn_set* s, float d, int id)
+{
+    /* sorted insertion, ascending; equal distances keep first-come order */
+    int i;
+    if (s->cnt < s->k) i = s->cnt++;
+    else { if (!(d < s->sqd[s->k - 1])) return; i = s->k - 1; }
+    while (i > 0 && s->sqd[i - 1] > d) { s->sqd[i] = s->sqd[i - 1]; s->idx[i] = s->idx[i - 1]; --i; }
+    s->sqd[i] = d; s->idx[i] = id;
+}
+
+/* squared L2 as flann::L2_Simple<float>: sequential float accumulation over x,y,z */
+static inline float sqdist3(const float* a, const float* b)
+{
+    float r = 0.f, d;
+    d = a[0] - b[0]; r += d * d;
+    d = a[1] - b[1]; r += d * d;
+    d = a[2] - b[2]; r += d * d;
+    return r;
+}
+
+static void search_rec(const orc_kdtree* t, int id, const float q[3], float mindist, float dists[3], knn_set* s)
+{
+    const orc_node* nd = &t->nodes[id];
+    if (nd->left < 0) {
+        for (int i = nd->lo; i < nd->hi; ++i) {
+            float d = sqdist3(q, &t->pts[3 * i]);
+            if (d < knn_worst(s) || s->cnt < s->k) knn_add(s, d, t->perm[i]);
+        }
+        return;
+    }
+    int dim = nd->dim;
+    float val = q[dim];
+    float diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+    int best, other; float cut;
+    if (diff1 + diff2 < 0) { best = nd->left;  other = nd->right; cut = diff2 * diff2; }
+    else                   { best = nd->right; other = nd->left;  cut = diff1 * diff1; }
+    search_rec(t, best, q, mindist, dists, s);
+    float dst = dists[dim];
+    mindist = mindist + cut - dst;
+    dists[dim] = cut;
+    if (mindist <= knn_worst(s)) search_rec(t, other, q, mindist, dists, s);
+    dists[dim] = dst;
+}
+
+int orc_kdtree_knn(const orc_kdtree* t, const float q[3], int k, int* idx, float* sqd)
+{
+    knn_set s = { k, 0, idx, sqd };
+    if (t->n == 0) return 0;
+    float dists[3] = { 0, 0, 0 }, mind = 0;
+    for (int d = 0; d < 3; ++d) {
+        if (q[d] < t->bbmin[d]) { dists[d] = (q[d] - t->bbmin[d]) * (q[d] - t->bbmin[d]); mind += dists[d]; }
+        if (q[d] > t->bbmax[d]) { dists[d] = (q[d] - t->bbmax[d]) * (q[d] - t->bbmax[d]); mind += dists[d]; }
+    }
+    search_rec(t, 0, q, mind, dists, &s);
+    return s.cnt;
+}
+
+int orc_bruteforce_knn(const float* xyz, int n, const float q[3], int k, int* idx, float* sqd)
+{
+    knn_set s = { k, 0, idx, sqd };
+    for (int i = 0; i < n; ++i) {
+        float d = sqdist3(q, &xyz[3 * i]);
+        if (s.cnt < k || d < knn_worst(&s)) knn_add(&s, d, i);
+    }
+    return s.cnt;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* small dense algebra                                                                                       */
+/* ------------------------------------------------------------------------------------------------------- */
+static inline float hypot_f(float a, float b)
+{
+    a = fabsf(a); b = fabsf(b);
+    if (a > b) { b /= a; return a * sqrtf(1 + b * b); }
+    if (b > 0) { a /= b; return b * sqrtf(1 + a * a); }
+    return 0.f;
+}
+
+/* cv::eigen for symmetric CV_32F: classical Jacobi with largest-off-diagonal pivoting, then a descending
+ * selection sort that swaps eigenvector ROWS (call sites odomEstimationNode.cpp:690, :928). */
+void orc_eigen_sym(const float* Ain, int n, float* W, float* V)
+{
+    float A[36];
+    int indR[6], indC[6];
+    memcpy(A, Ain, sizeof(float) * (size_t)(n * n));
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.f : 0.f;
+    for (int k = 0; k < n; ++k) {
+        W[k] = A[k * n + k];
+        if (k < n - 1) {
+            int m = k + 1; float mv = fabsf(A[k * n + m]);
+            for (int i = k + 2; i < n; ++i) { float v = fabsf(A[k * n + i]); if (mv < v) { mv = v; m = i; } }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            int m = 0; float mv = fabsf(A[k]);
+            for (int i = 1; i < k; ++i) { float v = fabsf(A[i * n + k]); if (mv < v) { mv = v; m = i; } }
+            indC[k] = m;
+        }
+    }
+    if (n > 1) {
+        int maxIters = n * n * 30;
+        for (int it = 0; it < maxIters; ++it) {
+            int k = 0, l; float mv = fabsf(A[indR[0]]);
+            for (int i = 1; i < n - 1; ++i) { float v = fabsf(A[i * n + indR[i]]); if (mv < v) { mv = v; k = i; } }
+            l = indR[k];
+            for (int i = 1; i < n; ++i) { float v = fabsf(A[indC[i] * n + i]); if (mv < v) { mv = v; k = indC[i]; l = i; } }
+            float p = A[k * n + l];
+            if (fabsf(p) <= FLT_EPSILON) break;
+            float y = (W[l] - W[k]) * 0.5f;
+            float t = fabsf(y) + hypot_f(p, y);
+            float s = hypot_f(p, t);
+            float c = t / s;
+            s = p / s; t = (p / t) * p;
+            if (y < 0) { s = -s; t = -t; }
+            A[k * n + l] = 0;
+            W[k] -= t; W[l] += t;
+#define ORC_ROT(v0, v1) do { float a0_ = (v0), b0_ = (v1); (v0) = a0_ * c - b0_ * s; (v1) = a0_ * s + b0_ * c; } while (0)
+            for (int i = 0; i < k; ++i)      ORC_ROT(A[i * n + k], A[i * n + l]);
+            for (int i = k + 1; i < l; ++i)  ORC_ROT(A[k * n + i], A[i * n + l]);
+            for (int i = l + 1; i < n; ++i)  ORC_ROT(A[k * n + i], A[l * n + i]);
+            for (int i = 0; i < n; ++i)      ORC_ROT(V[k * n + i], V[l * n + i]);
+#undef ORC_ROT
+            for (int j = 0; j < 2; ++j) {
+                int idx = j == 0 ? k : l;
+                if (idx < n - 1) {
+                    int m = idx + 1; float mv2 = fabsf(A[idx * n + m]);
+                    for (int i = idx + 2; i < n; ++i) { float v = fabsf(A[idx * n + i]); if (mv2 < v) { mv2 = v; m = i; } }
+                    indR[idx] = m;
+                }
+                if (idx > 0) {
+                    int m = 0; float mv2 = fabsf(A[idx]);
+                    for (int i = 1; i < idx; ++i) { float v = fabsf(A[i * n + idx]); if (mv2 < v) { mv2 = v; m = i; } }
+                    indC[idx] = m;
+                }
+            }
+        }
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        int m = k;
+        for (int i = k + 1; i < n; ++i) if (W[m] < W[i]) m = i;
+        if (m != k) {
+            float tw = W[m]; W[m] = W[k]; W[k] = tw;
+            for (int i = 0; i < n; ++i) { float tv = V[m * n + i]; V[m * n + i] = V[k * n + i]; V[k * n + i] = tv; }
+        }
+    }
+}
+
+/* Eigen::Matrix<float,5,3>::colPivHouseholderQr().solve(b) (odomEstimationNode.cpp:783) */
+void orc_lstsq5x3(const float Ain[15], const float bin[5], float x[3])
+{
+    enum { R = 5, C = 3 };
+    float A[R][C], c[R];
+    int perm[C] = { 0, 1, 2 };
+    for (int i = 0; i < R; ++i) { c[i] = bin[i]; for (int j = 0; j < C; ++j) A[i][j] = Ain[i * C + j]; }
+    float maxn = 0.f;
+    for (int j = 0; j < C; ++j) {
+        float s = 0.f; for (int i = 0; i < R; ++i) s += A[i][j] * A[i][j];
+        s = sqrtf(s); if (s > maxn) maxn = s;
+    }
+    float thr = (maxn * FLT_EPSILON) * (maxn * FLT_EPSILON) / (float)R;
+    int rank = C;
+    for (int k = 0; k < C; ++k) {
+        int bj = k; float bn = -1.f;
+        for (int j = k; j < C; ++j) {
+            float s = 0.f; for (int i = k; i < R; ++i) s += A[i][j] * A[i][j];
+            if (s > bn) { bn = s; bj = j; }
+        }
+        if (bn < thr * (float)(R - k)) { rank = k; break; }
+        if (bj != k) {
+            for (int i = 0; i < R; ++i) { float t = A[i][k]; A[i][k] = A[i][bj]; A[i][bj] = t; }
+            int tp = perm[k]; perm[k] = perm[bj]; perm[bj] = tp;
+        }
+        /* Householder reflector for column k, rows k..R-1 (Eigen makeHouseholder) */
+        float c0 = A[k][k], tail = 0.f;
+        for (int i = k + 1; i < R; ++i) tail += A[i][k] * A[i][k];
+        float beta, tau, v[R];
+        if (tail <= FLT_MIN) { tau = 0.f; beta = c0; for (int i = k + 1; i < R; ++i) v[i] = 0.f; }
+        else {
+            beta = sqrtf(c0 * c0 + tail);
+            if (c0 >= 0.f) beta = -beta;
+            for (int i = k + 1; i < R; ++i) v[i] = A[i][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        for (int i = k + 1; i < R; ++i) A[i][k] = 0.f;
+        if (tau != 0.f) {
+            for (int j = k + 1; j < C; ++j) {
+                float dot = A[k][j];
+                for (int i = k + 1; i < R; ++i) dot += v[i] * A[i][j];
+                dot *= tau;
+                A[k][j] -= dot;
+                for (int i = k + 1; i < R; ++i) A[i][j] -= dot * v[i];
+            }
+            float dot = c[k];
+            for (int i = k + 1; i < R; ++i) dot += v[i] * c[i];
+            dot *= tau;
+            c[k] -= dot;
+            for (int i = k + 1; i < R; ++i) c[i] -= dot * v[i];
+        }
+    }
+    float y[C] = { 0, 0, 0 };
+    for (int i = rank - 1; i >= 0; --i) {
+        float s = c[i];
+        for (int j = i + 1; j < rank; ++j) s -= A[i][j] * y[j];
+        y[i] = s / A[i][i];
+    }
+    x[0] = x[1] = x[2] = 0.f;
+    for (int i = 0; i < rank; ++i) x[perm[i]] = y[i];
+}
+
+/* cv::solve(AtA, AtB, X, DECOMP_QR) for 6x6 float (odomEstimationNode.cpp:921): Householder QR, no pivoting */
+int orc_solve6(const float Ain[36], const float bin[6], float x[6])
+{
+    enum { N = 6 };
+    float A[N][N], c[N];
+    for (int i = 0; i < N; ++i) { c[i] = bin[i]; for (int j = 0; j < N; ++j) A[i][j] = Ain[i * N + j]; }
+    for (int k = 0; k < N; ++k) {
+        float c0 = A[k][k], tail = 0.f, v[N];
+        for (int i = k + 1; i < N; ++i) tail += A[i][k] * A[i][k];
+        float beta, tau;
+        if (tail <= FLT_MIN) { tau = 0.f; beta = c0; for (int i = k + 1; i < N; ++i) v[i] = 0.f; }
+        else {
+            beta = sqrtf(c0 * c0 + tail);
+            if (c0 >= 0.f) beta = -beta;
+            for (int i = k + 1; i < N; ++i) v[i] = A[i][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        if (tau != 0.f) {
+            for (int j = k + 1; j < N; ++j) {
+                float dot = A[k][j];
+                for (int i = k + 1; i < N; ++i) dot += v[i] * A[i][j];
+                dot *= tau;
+                A[k][j] -= dot;
+                for (int i = k + 1; i < N; ++i) A[i][j] -= dot * v[i];
+            }
+            float dot = c[k];
+            for (int i = k + 1; i < N; ++i) dot += v[i] * c[i];
+            dot *= tau;
+            c[k] -= dot;
+            for (int i = k + 1; i < N; ++i) c[i] -= dot * v[i];
+        }
+    }
+    for (int i = 0; i < N; ++i) if (fabsf(A[i][i]) <= FLT_MIN) { memset(x, 0, sizeof(float) * N); return 0; }
+    for (int i = N - 1; i >= 0; --i) {
+        float s = c[i];
+        for (int j = i + 1; j < N; ++j) s -= A[i][j] * x[j];
+        x[i] = s / A[i][i];
+    }
+    return 1;
+}
+
+/* cv::Mat::inv() default DECOMP_LU for 6x6 float (odomEstimationNode.cpp:945) */
+int orc_inv6(const float Ain[36], float out[36])
+{
+    enum { N = 6 };
+    float A[N][N], B[N][N];
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) { A[i][j] = Ain[i * N + j]; B[i][j] = (i == j) ? 1.f : 0.f; }
+    for (int i = 0; i < N; ++i) {
+        int k = i;
+        for (int j = i + 1; j < N; ++j) if (fabsf(A[j][i]) > fabsf(A[k][i])) k = j;
+        if (fabsf(A[k][i]) < FLT_EPSILON * 100) { memset(out, 0, sizeof(float) * 36); return 0; }
+        if (k != i) for (int j = 0; j < N; ++j) {
+            float t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t;
+            t = B[i][j]; B[i][j] = B[k][j]; B[k][j] = t;
+        }
+        float d = -1.f / A[i][i];
+        for (int j = i + 1; j < N; ++j) {
+            float alpha = A[j][i] * d;
+            for (int m = i + 1; m < N; ++m) A[j][m] += alpha * A[i][m];
+            for (int m = 0; m < N; ++m) B[j][m] += alpha * B[i][m];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i)
+        for (int j = 0; j < N; ++j) {
+            float s = B[i][j];
+            for (int k = i + 1; k < N; ++k) s -= A[i][k] * B[k][j];
+            B[i][j] = s / A[i][i];
+        }
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) out[i * N + j] = B[i][j];
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* per-point residual models                                                                                 */
+/* ------------------------------------------------------------------------------------------------------- */
+int orc_corner_coeff(const float nb[15], const float ps[3], float w, const lisreg_params* p, float coeff[4])
+{
+    /* odomEstimationNode.cpp:658-678 centroid and covariance of the 5 neighbours (float, sequential) */
+    float cx = 0, cy = 0, cz = 0;
+    for (int j = 0; j < 5; ++j) { cx += nb[3 * j]; cy += nb[3 * j + 1]; cz += nb[3 * j + 2]; }
+    cx /= 5; cy /= 5; cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+    for (int j = 0; j < 5; ++j) {
+        float ax = nb[3 * j] - cx, ay = nb[3 * j + 1] - cy, az = nb[3 * j + 2] - cz;
+        a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
+    }
+    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    float A[9] = { a11, a12, a13, a12, a22, a23, a13, a23, a33 }, D[3], V[9];
+    orc_eigen_sym(A, 3, D, V);                                            /* :690 */
+    if (!(D[0] > p->line_ratio * D[1])) return 0;                         /* :692 */
+    float x0 = ps[0], y0 = ps[1], z0 = ps[2];
+    /* :697-702 — `0.1 * float` is double arithmetic, truncated on assignment */
+    float x1 = (float)((double)cx + 0.1 * (double)V[0]);
+    float y1 = (float)((double)cy + 0.1 * (double)V[1]);
+    float z1 = (float)((double)cz + 0.1 * (double)V[2]);
+    float x2 = (float)((double)cx - 0.1 * (double)V[0]);
+    float y2 = (float)((double)cy - 0.1 * (double)V[1]);
+    float z2 = (float)((double)cz - 0.1 * (double)V[2]);
+    float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+    float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+    float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+    float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);               /* :704-709 */
+    float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;         /* :713-715 */
+    float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;        /* :717-719 */
+    float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;        /* :721-723 */
+    float ld2 = a012 / l12;
+    float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));                   /* :727 */
+    coeff[0] = w * s * la; coeff[1] = w * s * lb; coeff[2] = w * s * lc; coeff[3] = w * s * ld2;
+    return s > p->accept_s;                                              /* :734 (uses s, not w*s) */
+}
+
+int orc_surf_coeff(const float nb[15], const float ps[3], float w, const lisreg_params* p, float coeff[4])
+{
+    float b[5] = { -1, -1, -1, -1, -1 }, X[3];
+    orc_lstsq5x3(nb, b, X);                                               /* :783 */
+    float pa = X[0], pb = X[1], pc = X[2], pd = 1;
+    float psn = sqrtf(pa * pa + pb * pb + pc * pc);
+    pa /= psn; pb /= psn; pc /= psn; pd /= psn;                           /* :790-791 */
+    for (int j = 0; j < 5; ++j)                                           /* :794-802 */
+        if (fabsf(pa * nb[3 * j] + pb * nb[3 * j + 1] + pc * nb[3 * j + 2] + pd) > p->plane_tol) return 0;
+    float pd2 = pa * ps[0] + pb * ps[1] + pc * ps[2] + pd;
+    float rng = sqrtf(sqrtf(ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2]));
+    float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)rng);      /* :807 */
+    coeff[0] = w * s * pa; coeff[1] = w * s * pb; coeff[2] = w * s * pc; coeff[3] = w * s * pd2;
+    return s > p->accept_s;                                              /* :814 */
+}
+
+void orc_jacobian_row(const float T[6], const float ori[3], const float cf[4], float row[6], float* b)
+{
+    /* LMOptimization :862-867: lidar -> camera angle naming */
+    float srx = sinf(T[1]), crx = cosf(T[1]);
+    float sry = sinf(T[2]), cry = cosf(T[2]);
+    float srz = sinf(T[0]), crz = cosf(T[0]);
+    float px = ori[1], py = ori[2], pz = ori[0];            /* :889-891 */
+    float cx = cf[1], cy = cf[2], cz = cf[0];               /* :893-895 */
+    float arx = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cx +
+                (-srx * srz * px - crz * srx * py - crx * pz) * cy +
+                (crx * cry * srz * px + crx * cry * crz * py - cry * srx * pz) * cz;
+    float ary = ((cry * srx * srz - crz * sry) * px + (sry * srz + cry * crz * srx) * py + crx * cry * pz) * cx +
+                ((-cry * crz - srx * sry * srz) * px + (cry * srz - crz * srx * sry) * py - crx * sry * pz) * cz;
+    float arz = ((crz * srx * sry - cry * srz) * px + (-cry * crz - srx * sry * srz) * py) * cx +
+                (crx * crz * px - crx * srz * py) * cy +
+                ((sry * srz + cry * crz * srx) * px + (crz * sry - cry * srx * srz) * py) * cz;
+    row[0] = arz; row[1] = arx; row[2] = ary; row[3] = cz; row[4] = cx; row[5] = cy;   /* :909-914 */
+    *b = -cf[3];                                                                         /* :915 */
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* transformUpdate — tf quaternion slerp restated in double (odomEstimationNode.cpp:976-1006)                */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct { double x, y, z, w; } quat;
+
+static quat q_from_rpy(double roll, double pitch, double yaw)
+{
+    double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+    quat q = { sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+               cr * cp * cy + sr * sp * sy };
+    return q;
+}
+static double q_dot(quat a, quat b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+static quat q_slerp(quat a, quat b, double t)
+{
+    double s = sqrt(q_dot(a, a) * q_dot(b, b));
+    double d = q_dot(a, b);
+    double theta = (d < 0 ? acos(-d / s) * 2.0 : acos(d / s) * 2.0) / 2.0;   /* angleShortestPath / 2 */
+    if (theta != 0.0) {
+        double dd = 1.0 / sin(theta), s0 = sin((1.0 - t) * theta), s1 = sin(t * theta);
+        quat r;
+        if (d < 0) { r.x = (a.x * s0 + -b.x * s1) * dd; r.y = (a.y * s0 + -b.y * s1) * dd;
+                     r.z = (a.z * s0 + -b.z * s1) * dd; r.w = (a.w * s0 + -b.w * s1) * dd; }
+        else       { r.x = (a.x * s0 + b.x * s1) * dd;  r.y = (a.y * s0 + b.y * s1) * dd;
+                     r.z = (a.z * s0 + b.z * s1) * dd;  r.w = (a.w * s0 + b.w * s1) * dd; }
+        return r;
+    }
+    return a;
+}
+
+static void q_get_rpy(quat q, double* roll, double* pitch, double* yaw)
+{
+    /* tf::Matrix3x3::setRotation + getEulerYPR (solution 1) */
+    double d = q_dot(q, q), s = 2.0 / d;
+    double xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    double xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    double yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    double m00 = 1.0 - (yy + zz), m01 = xy - wz;
+    double m10 = xy + wz;
+    double m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+    if (fabs(m20) >= 1) {
+        *yaw = 0;
+        double delta = atan2(m21, m22);   /* tf: atan2(m[2].y, m[2].z) */
+        if (m20 < 0) { *pitch = M_PI / 2.0; *roll = delta; }
+        else         { *pitch = -M_PI / 2.0; *roll = delta; }
+        (void)m01;
+    } else {
+        *pitch = -asin(m20);
+        double cp = cos(*pitch);
+        *roll = atan2(m21 / cp, m22 / cp);
+        *yaw = atan2(m10 / cp, m00 / cp);
+    }
+}
+
+static float clampf(float v, float lim)   /* constraintTransformation, common.cpp:285-291 */
+{
+    if (v < -lim) v = -lim;
+    if (v > lim) v = lim;
+    return v;
+}
+
+void orc_transform_update(const lisreg_params* p, const lisreg_imu* imu, float T[6])
+{
+    if (p->use_imu_blend && imu && imu->imu_available) {
+        if (fabsf(imu->imu_pitch_init) < 1.4f) {                 /* std::abs(float) < 1.4 */
+            double w = (double)p->imu_rpy_weight, r, pi, y;
+            quat tq = q_from_rpy((double)T[0], 0, 0), iq = q_from_rpy((double)imu->imu_roll_init, 0, 0);
+            q_get_rpy(q_slerp(tq, iq, w), &r, &pi, &y);
+            T[0] = (float)r;
+            tq = q_from_rpy(0, (double)T[1], 0); iq = q_from_rpy(0, (double)imu->imu_pitch_init, 0);
+            q_get_rpy(q_slerp(tq, iq, w), &r, &pi, &y);
+            T[1] = (float)pi;
+        }
+    }
+    T[0] = clampf(T[0], p->rotation_tol);
+    T[1] = clampf(T[1], p->rotation_tol);
+    T[5] = clampf(T[5], p->z_tol);
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* cloud access                                                                                               */
+/* ------------------------------------------------------------------------------------------------------- */
+static void unpack_cloud(const void* cloud, int n, int stride, int fmt, float* xyz, unsigned short* label)
+{
+    const unsigned char* b = (const unsigned char*)cloud;
+    for (int i = 0; i < n; ++i) {
+        const unsigned char* r = b + (size_t)i * (size_t)stride;
+        memcpy(&xyz[3 * i], r, 12);
+        unsigned short l = 0;
+        if (fmt == LISREG_FMT_XYZIL) memcpy(&l, r + 20, 2);
+        label[i] = l;
+    }
+}
+
+static float label_weight(const lisreg_params* p, unsigned short label)
+{
+    if (!p->use_label_weight) return 1.f;
+    return (float)(2.0 - (double)p->label_score[label & 31]);   /* subMapOptmizationNode.cpp:1671 */
+}
+
+typedef struct {
+    int n; float* xyz; unsigned short* label; orc_kdtree* tree;
+} cloud_t;
+
+static void cloud_init(cloud_t* c, const void* data, int n, int stride, int fmt)
+{
+    c->n = n;
+    c->xyz = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+    c->label = (unsigned short*)malloc(sizeof(unsigned short) * (size_t)(n > 0 ? n : 1));
+    c->tree = NULL;
+    if (n > 0) unpack_cloud(data, n, stride, fmt, c->xyz, c->label);
+}
+static void cloud_free(cloud_t* c) { free(c->xyz); free(c->label); orc_kdtree_free(c->tree); }
+
+static int knn5(const cloud_t* tgt, int use_tree, const float q[3], int idx[5], float sqd[5])
+{
+    if (use_tree && tgt->tree) return orc_kdtree_knn(tgt->tree, q, 5, idx, sqd);
+    return orc_bruteforce_knn(tgt->xyz, tgt->n, q, 5, idx, sqd);
+}
+
+/* one stage (cornerOptimization :633-747 or surfOptimization :749-827) over all source points */
+static void run_stage(int kind, const cloud_t* tgt, const cloud_t* src, const lisreg_params* p,
+                      const float M[12], int use_tree, int n_threads, unsigned char* flags, float* coeffs)
+{
+    (void)n_threads;
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int i = 0; i < src->n; ++i) {
+        float psel[3], nb[15], sqd[5], cf[4];
+        int idx[5];
+        flags[i] = 0;
+        transform_point(M, &src->xyz[3 * i], psel);
+        int found = knn5(tgt, use_tree, psel, idx, sqd);
+        /* copy #1 reads pointSearchSqDis[4] unguarded (UB with < 5 target points); #2/#3 test size()==5.
+         * The restatement defines the <5 case as "no correspondence" for all variants. */
+        if (found < 5 || !(sqd[4] < p->knn_sq_thresh)) continue;
+        for (int j = 0; j < 5; ++j) memcpy(&nb[3 * j], &tgt->xyz[3 * idx[j]], 12);
+        float w = label_weight(p, src->label[i]);
+        int ok = kind == 0 ? orc_corner_coeff(nb, psel, w, p, cf) : orc_surf_coeff(nb, psel, w, p, cf);
+        if (ok) { flags[i] = 1; memcpy(&coeffs[4 * i], cf, 16); }
+    }
+}
+
+void orc_stage_coeffs(int kind, const void* tgt, int n_t, const void* src, int n_s, int stride, int fmt,
+                      const lisreg_params* params, const float T[6], unsigned char* flags, float* coeffs)
+{
+    cloud_t t, s; float M[12];
+    cloud_init(&t, tgt, n_t, stride, fmt);
+    cloud_init(&s, src, n_s, stride, fmt);
+    t.tree = orc_kdtree_build(t.xyz, t.n, 15);
+    orc_pose_to_matrix(T, M);
+    memset(coeffs, 0, sizeof(float) * 4 * (size_t)n_s);
+    run_stage(kind, &t, &s, params, M, 1, 1, flags, coeffs);
+    cloud_free(&t); cloud_free(&s);
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* scan2SubMapOptimization (odomEstimationNode.cpp:596-626) and LMOptimization (:852-974)                    */
+/* ------------------------------------------------------------------------------------------------------- */
+int orc_align(const void* tgt_corner, int n_tc, const void* tgt_surf, int n_ts,
+              const void* src_corner, int n_sc, const void* src_surf, int n_ss,
+              int stride, int fmt, const lisreg_params* p, const lisreg_imu* imu,
+              float T[6], int* degenerate, lisreg_stats* stats,
+              float* trace, int max_trace, int n_threads, int use_kdtree)
+{
+    lisreg_stats st; memset(&st, 0, sizeof st);
+    st.deltaR = 100.f; st.deltaT = 100.f;                     /* member initialisers :70-71 */
+    int isDeg = degenerate ? *degenerate : 0;
+    st.degenerate = isDeg;
+    if (!(n_sc > p->edge_min && n_ss > p->surf_min)) {        /* :598 */
+        st.status = LISREG_NOT_ENOUGH_FEATURES;
+        if (stats) *stats = st;
+        return st.status;
+    }
+    if (n_threads < 1) n_threads = 1;
+    cloud_t tc, ts, sc, ss;
+    cloud_init(&tc, tgt_corner, n_tc, stride, fmt);
+    cloud_init(&ts, tgt_surf, n_ts, stride, fmt);
+    cloud_init(&sc, src_corner, n_sc, stride, fmt);
+    cloud_init(&ss, src_surf, n_ss, stride, fmt);
+    if (use_kdtree) {                                          /* :602-603: two builds per registration */
+        tc.tree = orc_kdtree_build(tc.xyz, tc.n, 15);
+        ts.tree = orc_kdtree_build(ts.xyz, ts.n, 15);
+    }
+    int n_src = n_sc + n_ss;
+    unsigned char* flag_c = (unsigned char*)calloc((size_t)(n_sc > 0 ? n_sc : 1), 1);
+    unsigned char* flag_s = (unsigned char*)calloc((size_t)(n_ss > 0 ? n_ss : 1), 1);
+    float* coef_c = (float*)calloc((size_t)(n_sc > 0 ? n_sc : 1) * 4, sizeof(float));
+    float* coef_s = (float*)calloc((size_t)(n_ss > 0 ? n_ss : 1) * 4, sizeof(float));
+    float* ori = (float*)malloc(sizeof(float) * 3 * (size_t)(n_src > 0 ? n_src : 1));   /* laserCloudOri */
+    float* sel = (float*)malloc(sizeof(float) * 4 * (size_t)(n_src > 0 ? n_src : 1));   /* coeffSel      */
+    float* A = (float*)malloc(sizeof(float) * 6 * (size_t)(n_src > 0 ? n_src : 1));
+    float* B = (float*)malloc(sizeof(float) * (size_t)(n_src > 0 ? n_src : 1));
+    float P[36]; memset(P, 0, sizeof P);
+
+    int bound = p->fixed_iters > 0 ? p->fixed_iters : p->max_iters;
+    int iter = 0, any_solved = 0;
+    for (; iter < bound; ++iter) {
+        float M[12];
+        orc_pose_to_matrix(T, M);                              /* updatePointAssociateToSubMap :628-631 */
+        int do_corner = !(p->skip_empty_target && n_tc == 0);  /* :4505-4509 */
+        int do_surf = !(p->skip_empty_target && n_ts == 0);
+        if (do_corner) run_stage(0, &tc, &sc, p, M, use_kdtree, n_threads, flag_c, coef_c);
+        else memset(flag_c, 0, (size_t)(n_sc > 0 ? n_sc : 1));
+        if (do_surf) run_stage(1, &ts, &ss, p, M, use_kdtree, n_threads, flag_s, coef_s);
+        else memset(flag_s, 0, (size_t)(n_ss > 0 ? n_ss : 1));
+        /* combineOptimizationCoeffs :829-850 — corners in index order, then surfs */
+        int n_sel = 0;
+        for (int i = 0; i < n_sc; ++i) if (flag_c[i]) {
+            memcpy(&ori[3 * n_sel], &sc.xyz[3 * i], 12); memcpy(&sel[4 * n_sel], &coef_c[4 * i], 16); ++n_sel; }
+        for (int i = 0; i < n_ss; ++i) if (flag_s[i]) {
+            memcpy(&ori[3 * n_sel], &ss.xyz[3 * i], 12); memcpy(&sel[4 * n_sel], &coef_s[4 * i], 16); ++n_sel; }
+        st.n_corr_last = n_sel;
+        float* tr = (trace && iter < max_trace) ? &trace[(size_t)iter * LISREG_TRACE_STRIDE] : NULL;
+        if (tr) { memset(tr, 0, sizeof(float) * LISREG_TRACE_STRIDE); tr[0] = (float)n_sel; memcpy(&tr[49], T, 24); }
+        if (n_sel < p->min_corr) continue;                     /* :870-872 return false, pose untouched */
+        any_solved = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+        for (int i = 0; i < n_sel; ++i) orc_jacobian_row(T, &ori[3 * i], &sel[4 * i], &A[6 * i], &B[i]);
+        /* :918-920 matAtA = At*A, matAtB = At*B — cv GEMM on CV_32F accumulates in double */
+        float AtA[36], AtB[6], X[6];
+        for (int r = 0; r < 6; ++r) {
+            for (int c = 0; c < 6; ++c) {
+                double s = 0; for (int i = 0; i < n_sel; ++i) s += (double)A[6 * i + r] * (double)A[6 * i + c];
+                AtA[6 * r + c] = (float)s;
+            }
+            double s = 0; for (int i = 0; i < n_sel; ++i) s += (double)A[6 * i + r] * (double)B[i];
+            AtB[r] = (float)s;
+        }
+        orc_solve6(AtA, AtB, X);                               /* :921 */
+        if (iter == 0) {                                       /* :923-946 */
+            float E[6], V[36], V2[36], Vi[36];
+            orc_eigen_sym(AtA, 6, E, V);
+            memcpy(V2, V, sizeof V2);
+            isDeg = 0;
+            for (int i = 5; i >= 0; --i) {
+                if (E[i] < p->eig_thresh) { for (int j = 0; j < 6; ++j) V2[6 * i + j] = 0; isDeg = 1; }
+                else break;
+            }
+            orc_inv6(V, Vi);
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+                double s = 0; for (int k = 0; k < 6; ++k) s += (double)Vi[6 * r + k] * (double)V2[6 * k + c];
+                P[6 * r + c] = (float)s;
+            }
+        } else if (p->emulate_matp_shadow) {
+            memset(P, 0, sizeof P);                            /* local cv::Mat matP zero-initialised :880 */
+        }
+        if (isDeg) {                                           /* :948-953 */
+            float X2[6]; memcpy(X2, X, sizeof X2);
+            for (int r = 0; r < 6; ++r) {
+                double s = 0; for (int k = 0; k < 6; ++k) s += (double)P[6 * r + k] * (double)X2[k];
+                X[r] = (float)s;
+            }
+        }
+        for (int k = 0; k < 6; ++k) T[k] += X[k];              /* :955-960 */
+        /* :962-967 — pcl::rad2deg(float) is float; pow(float,int) and the sum are double */
+        double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+        double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
+        st.deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+        st.deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+        int conv = (st.deltaR < p->conv_deg && st.deltaT < p->conv_cm);
+        if (tr) {
+            memcpy(&tr[1], AtA, sizeof AtA); memcpy(&tr[37], AtB, sizeof AtB); memcpy(&tr[43], X, sizeof X);
+            memcpy(&tr[49], T, 24); tr[55] = 1.f;
+        }
+        if (conv && p->fixed_iters <= 0) break;                /* :969-972, :617 */
+    }
+    st.iters = iter;
+    orc_transform_update(p, imu, T);                           /* :622 */
+    st.degenerate = isDeg;
+    st.status = any_solved ? LISREG_OK : LISREG_TOO_FEW_CORRESPONDENCES;
+    if (degenerate) *degenerate = isDeg;
+    if (stats) *stats = st;
+    free(flag_c); free(flag_s); free(coef_c); free(coef_s); free(ori); free(sel); free(A); free(B);
+    cloud_free(&tc); cloud_free(&ts); cloud_free(&sc); cloud_free(&ss);
+    return st.status;
+}

@@ -1,0 +1,86 @@
+/*
+ * lisreg_oracle.h — CPU restatement (plain C) of LIS-SLAM's scan-to-submap registration hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library, and only as the checker / the timed CPU baseline.
+ * liblisreg.so never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for this path and cannot be
+ * compiled here (ROS, PCL/FLANN, OpenCV, Eigen absent — SURVEY.md §8c), so this restatement is pinned only by
+ * (a) operation-for-operation fidelity to the cited reference lines, (b) cross-checks against independent
+ * library routines (scipy cKDTree, numpy.linalg) in tests/, and (c) an independent numpy mirror
+ * (oracle/lisreg_numpy.py) whose outputs are committed under tests/golden/.
+ *
+ * Third-party semantics restated from their published algorithms (not under /root/reference; versions implied
+ * by ROS Melodic: PCL 1.8.1, FLANN 1.9.1, OpenCV 3.2.0, Eigen 3.3.4):
+ *   pcl::KdTreeFLANN::nearestKSearch  -> exact k-NN, squared L2 in float, ascending     (orc_kdtree_*)
+ *   cv::eigen (symmetric, CV_32F)     -> Jacobi, eigenvalues descending, eigenvectors in rows (orc_eigen_sym)
+ *   Eigen colPivHouseholderQr().solve -> column-pivoted Householder QR least squares     (orc_lstsq5x3)
+ *   cv::solve(..., DECOMP_QR)         -> Householder QR solve in float                   (orc_solve6)
+ *   cv::Mat::inv() (DECOMP_LU)        -> LU with partial pivoting in float               (orc_inv6)
+ *   cv GEMM for CV_32F                -> float inputs, double accumulation, float result (orc_normal_equations)
+ *   pcl::getTransformation            -> ZYX Euler to affine                             (orc_pose_to_matrix)
+ *   tf::Quaternion setRPY/slerp, tf::Matrix3x3::getRPY                                   (orc_transform_update)
+ */
+#ifndef LISREG_ORACLE_H_
+#define LISREG_ORACLE_H_
+
+#include "../include/lisreg.h"   /* shares the ABI structs (params, imu, stats) so tests read symmetrically */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_kdtree orc_kdtree;
+
+/* common.cpp:54-57 */
+void orc_pose_to_matrix(const float T[6], float M[12]);
+
+/* exact kNN over xyz[n][3] (float). leaf_size 15 mirrors FLANN KDTreeSingleIndexParams(15). */
+orc_kdtree* orc_kdtree_build(const float* xyz, int n, int leaf_size);
+void        orc_kdtree_free(orc_kdtree* t);
+/* returns number found (min(k,n)); idx/sqd ascending by distance */
+int         orc_kdtree_knn(const orc_kdtree* t, const float q[3], int k, int* idx, float* sqd);
+/* brute-force reference for tests */
+int         orc_bruteforce_knn(const float* xyz, int n, const float q[3], int k, int* idx, float* sqd);
+
+/* Jacobi eigen-decomposition of a symmetric n x n float matrix (n <= 6): w descending, V rows = eigenvectors */
+void orc_eigen_sym(const float* A, int n, float* w, float* V);
+/* least squares A(5x3) x = b(5) by column-pivoted Householder QR */
+void orc_lstsq5x3(const float A[15], const float b[5], float x[3]);
+/* 6x6 solve by Householder QR; returns 0 if singular (x zeroed) */
+int  orc_solve6(const float A[36], const float b[6], float x[6]);
+/* 6x6 inverse by LU with partial pivoting; returns 0 if singular (out zeroed, as cv::invert does) */
+int  orc_inv6(const float A[36], float out[36]);
+
+/* cornerOptimization body for one point (odomEstimationNode.cpp:657-742). nb = 5 neighbours xyz, ascending.
+ * psel = transformed point. w = label weight (1 when unused). Returns 1 and coeff[4] if accepted. */
+int  orc_corner_coeff(const float nb[15], const float psel[3], float w, const lisreg_params* p, float coeff[4]);
+/* surfOptimization body for one point (odomEstimationNode.cpp:776-821). */
+int  orc_surf_coeff(const float nb[15], const float psel[3], float w, const lisreg_params* p, float coeff[4]);
+/* one Jacobian row + rhs (LMOptimization :889-915): ori = UNtransformed source point */
+void orc_jacobian_row(const float T[6], const float ori[3], const float coeff[4], float row[6], float* b);
+
+/* transformUpdate (odomEstimationNode.cpp:976-1006) */
+void orc_transform_update(const lisreg_params* p, const lisreg_imu* imu, float T[6]);
+
+/* Whole scan2SubMapOptimization().  Clouds use the ABI's host layouts (LISREG_FMT_XYZI / _XYZIL).
+ * degenerate: in/out isDegenerate member.  trace: NULL or max_trace*LISREG_TRACE_STRIDE floats.
+ * n_threads: OpenMP threads for the three hot loops (1 = the reference as built).
+ * use_kdtree: 1 = kd-tree (the timed baseline, includes the two builds), 0 = brute force (small tests). */
+int  orc_align(const void* tgt_corner, int n_tc, const void* tgt_surf, int n_ts,
+               const void* src_corner, int n_sc, const void* src_surf, int n_ss,
+               int stride_bytes, int fmt,
+               const lisreg_params* params, const lisreg_imu* imu,
+               float T[6], int* degenerate, lisreg_stats* stats,
+               float* trace, int max_trace, int n_threads, int use_kdtree);
+
+/* Single-iteration building block for kernel-level parity: per-point accept flag + coeff for one stage.
+ * kind 0 = corner, 1 = surf.  flags[n_src] (0/1), coeffs[n_src][4]. */
+void orc_stage_coeffs(int kind, const void* tgt, int n_t, const void* src, int n_s, int stride_bytes, int fmt,
+                      const lisreg_params* params, const float T[6], unsigned char* flags, float* coeffs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

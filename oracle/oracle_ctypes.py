@@ -1,0 +1,130 @@
+"""ctypes binding of oracle/liblisreg_oracle.so — TEST INFRASTRUCTURE ONLY (see lisreg_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TRACE_STRIDE = 56
+
+
+class Params(C.Structure):
+    _fields_ = [("max_iters", C.c_int), ("fixed_iters", C.c_int), ("knn_sq_thresh", C.c_float),
+                ("conv_deg", C.c_float), ("conv_cm", C.c_float), ("min_corr", C.c_int),
+                ("eig_thresh", C.c_float), ("edge_min", C.c_int), ("surf_min", C.c_int),
+                ("line_ratio", C.c_float), ("plane_tol", C.c_float), ("accept_s", C.c_float),
+                ("use_label_weight", C.c_int), ("label_score", C.c_float * 32),
+                ("emulate_matp_shadow", C.c_int), ("skip_empty_target", C.c_int), ("use_imu_blend", C.c_int),
+                ("imu_rpy_weight", C.c_float), ("rotation_tol", C.c_float), ("z_tol", C.c_float)]
+
+
+class Imu(C.Structure):
+    _fields_ = [("imu_available", C.c_int), ("imu_roll_init", C.c_float), ("imu_pitch_init", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("deltaR", C.c_float), ("deltaT", C.c_float), ("degenerate", C.c_int),
+                ("n_corr_last", C.c_int), ("status", C.c_int)]
+
+
+LABEL_SCORE = [1.0, 1.0, 0.6, 0.5, 0.8, 0.5, 0.5, 0.5, 0.5, 1.2, 1.2, 1.2, 0.5, 1.0, 0.8, 0.5, 1.3, 0.5, 1.5, 1.5]
+
+
+def default_params(variant: int = 1) -> Params:
+    """Literals of the three reference copies (independent of liblisreg's lisreg_default_params)."""
+    p = Params()
+    p.max_iters, p.knn_sq_thresh, p.conv_deg, p.conv_cm = {1: (15, 1.0, 0.005, 0.05), 2: (20, 2.0, 0.003, 0.03),
+                                                          3: (30, 2.0, 0.002, 0.02)}[variant]
+    p.fixed_iters = 0
+    p.min_corr, p.eig_thresh, p.edge_min, p.surf_min = 50, 100.0, -1, 100
+    p.line_ratio, p.plane_tol, p.accept_s = 3.0, 0.2, 0.1
+    p.use_label_weight = 0 if variant == 1 else 1
+    for i in range(32):
+        p.label_score[i] = LABEL_SCORE[i] if i < 20 else 1.0
+    p.emulate_matp_shadow = 1
+    p.skip_empty_target = 1 if variant == 3 else 0
+    p.use_imu_blend = 0 if variant == 3 else 1
+    p.imu_rpy_weight, p.rotation_tol, p.z_tol = 0.1, 1000.0, 1000.0
+    return p
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_HERE, "liblisreg_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.orc_pose_to_matrix.argtypes = [fp, fp]
+        L.orc_kdtree_build.restype = vp
+        L.orc_kdtree_build.argtypes = [fp, C.c_int, C.c_int]
+        L.orc_kdtree_free.argtypes = [vp]
+        L.orc_kdtree_knn.argtypes = [vp, fp, C.c_int, ip, fp]
+        L.orc_bruteforce_knn.argtypes = [fp, C.c_int, fp, C.c_int, ip, fp]
+        L.orc_eigen_sym.argtypes = [fp, C.c_int, fp, fp]
+        L.orc_lstsq5x3.argtypes = [fp, fp, fp]
+        L.orc_solve6.argtypes = [fp, fp, fp]
+        L.orc_inv6.argtypes = [fp, fp]
+        L.orc_corner_coeff.argtypes = [fp, fp, C.c_float, C.POINTER(Params), fp]
+        L.orc_surf_coeff.argtypes = [fp, fp, C.c_float, C.POINTER(Params), fp]
+        L.orc_jacobian_row.argtypes = [fp, fp, fp, fp, fp]
+        L.orc_transform_update.argtypes = [C.POINTER(Params), C.POINTER(Imu), fp]
+        L.orc_align.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(Params), C.POINTER(Imu), fp, ip, C.POINTER(Stats), fp, C.c_int,
+                                C.c_int, C.c_int]
+        L.orc_stage_coeffs.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Params), fp,
+                                       C.POINTER(C.c_ubyte), fp]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and len(a) else None
+
+
+def align(tgt_corner, tgt_surf, src_corner, src_surf, T_init, params: Params, imu: Imu | None = None,
+          degenerate_in: int = 0, fmt: int = 1, n_threads: int = 1, use_kdtree: bool = True, max_trace: int = 64):
+    """Runs orc_align on PCL-struct arrays (synth.PCL_DTYPE).  Returns (T, stats dict, trace[n,56])."""
+    L = lib()
+    T = np.array(T_init, np.float32).copy()
+    deg = C.c_int(degenerate_in)
+    st = Stats()
+    trace = np.zeros((max_trace, TRACE_STRIDE), np.float32)
+    arrs = [np.ascontiguousarray(a) for a in (tgt_corner, tgt_surf, src_corner, src_surf)]
+    stride = arrs[0].dtype.itemsize
+    L.orc_align(_vp(arrs[0]), len(arrs[0]), _vp(arrs[1]), len(arrs[1]), _vp(arrs[2]), len(arrs[2]),
+                _vp(arrs[3]), len(arrs[3]), stride, fmt, C.byref(params), C.byref(imu) if imu else None,
+                _fp(T), C.byref(deg), C.byref(st), _fp(trace), max_trace, n_threads, 1 if use_kdtree else 0)
+    bound = params.fixed_iters if params.fixed_iters > 0 else params.max_iters
+    n_rec = min(max_trace, min(st.iters + 1, bound))
+    stats = dict(iters=st.iters, deltaR=st.deltaR, deltaT=st.deltaT, degenerate=st.degenerate,
+                 n_corr_last=st.n_corr_last, status=st.status)
+    return T, stats, trace[:n_rec]
+
+
+def stage_coeffs(kind, tgt, src, T, params: Params, fmt: int = 1):
+    L = lib()
+    tgt = np.ascontiguousarray(tgt); src = np.ascontiguousarray(src)
+    flags = np.zeros(len(src), np.uint8)
+    coeffs = np.zeros((len(src), 4), np.float32)
+    Tf = np.array(T, np.float32)
+    L.orc_stage_coeffs(kind, _vp(tgt), len(tgt), _vp(src), len(src), tgt.dtype.itemsize, fmt, C.byref(params),
+                       _fp(Tf), flags.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(coeffs))
+    return flags.astype(bool), coeffs
