@@ -173,6 +173,11 @@ int  lisreg_batch_fetch(lisreg_ctx* ctx, float* T, lisreg_stats* stats);
  * {T[6], iters, deltaR, deltaT, degenerate, n_corr_last, status} — what a multi-GPU host all-gathers. */
 void* lisreg_batch_result_device(const lisreg_ctx* ctx);
 
+/* Options outside the reference's parameter surface: "rebuild_targets_each_run" (0/1: re-run the target index
+ * build inside every lisreg_batch_run, as the reference rebuilds both kd-trees per registration, :602-603),
+ * "trace_cap" (per-item trace records kept on the device for batches; 0 = off). */
+int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
+
 /* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
 int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);
 

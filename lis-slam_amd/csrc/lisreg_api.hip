@@ -1,0 +1,752 @@
+// lisreg_api.hip — C-ABI host layer of liblisreg.so (declared in include/lisreg.h).
+//
+// Creates the seam the reference lacks: each entry point replaces a piece of
+// scan2SubMapOptimization() — /root/reference/src/node/odomEstimationNode.cpp:596-626 and the copies at
+// src/node/subMapOptmizationNode.cpp:1509-1541, 4485-4540.  The GN loop is enqueued in full (index build, source
+// tile sort, `bound` x {correspondence kernel, solve kernel}, finalize) with no host synchronisation inside; a
+// context is single-threaded and owns its stream, so several contexts run concurrently (callers #2/#3).
+// There is deliberately NO CPU fallback: without a HIP device every compute entry point fails with
+// LISREG_ERR_HIP.
+#include "lisreg_internal.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lisreg;
+
+namespace {
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Target {
+    bool      valid = false;
+    int       n[2] = { 0, 0 };
+    int       n_cells[2] = { 1, 1 };
+    GridIndex g[2];
+    DevBuf    raw[2], sorted[2], cell_start[2];
+    bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
+    const float4* raw_ptr[2] = { nullptr, nullptr };
+};
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value, 128 B */, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+};
+
+}  // namespace
+
+struct lisreg_ctx {
+    int          device = 0;
+    hipStream_t  own_stream = nullptr, stream = nullptr;
+    std::string  err;
+    std::vector<Target> targets;
+    DevBuf       grids_dev;
+    bool         grids_dirty = true;
+    // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
+    DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
+    // batch
+    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload;
+    std::vector<BlockDesc> h_blocks;
+    std::vector<Segment>   h_segs;
+    std::vector<ItemState> h_items;
+    std::vector<float>     h_results;
+    int       n_items = 0, n_blocks = 0, n_segs = 0, n_elems = 0, n_buckets = 0, trace_cap = 0;
+    DevParams prm;
+    lisreg_params params;
+    bool      prepared = false;
+    bool      rebuild_targets_each_run = false;
+    std::vector<int> batch_slots;           // target slots used by the prepared batch
+    int       degenerate = 0;               // isDegenerate member (odomEstimationNode.cpp:67)
+    // profiling
+    bool      profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int>        ev_kind;        // kind of the interval STARTING at event i: 0 assoc, 1 solve, 2 index, -1 none
+    double    timing[5] = { 0, 0, 0, 0, 0 };
+    // last align trace (host copy)
+    std::vector<float> last_trace;
+    int       last_trace_n = 0;
+    // RCCL
+    RcclApi   rccl;
+    void*     comm = nullptr;
+    int       comm_nranks = 0;
+};
+
+namespace {
+
+thread_local std::string g_static_err;
+
+int fail(lisreg_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_static_err = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail((c), LISREG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+float env_float(const char* name, float dflt)
+{
+    const char* s = getenv(name);
+    return s ? (float)atof(s) : dflt;
+}
+
+void pose_to_matrix_host(const float T[6], float M[12])
+{
+    // pcl::getTransformation via trans2Affine3f (src/core/common.cpp:54-57)
+    float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
+    float DE = D * E, DF = D * F;
+    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
+    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
+    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
+}
+
+// pack PCL structs (stride/format of common.h:9,25-35) into 16-B device records
+void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* out)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(cloud);
+    for (int i = 0; i < n; ++i) {
+        const unsigned char* r = b + (size_t)i * (size_t)stride;
+        memcpy(&out[i], r, 12);
+        uint16_t lab = 0;
+        if (fmt == LISREG_FMT_XYZIL) memcpy(&lab, r + 20, 2);
+        out[i].payload = lab;
+    }
+}
+
+DevParams make_dev_params(const lisreg_params& p)
+{
+    DevParams d;
+    memset(&d, 0, sizeof d);
+    d.tau = p.knn_sq_thresh; d.line_ratio = p.line_ratio; d.plane_tol = p.plane_tol; d.accept_s = p.accept_s;
+    d.conv_deg = p.conv_deg; d.conv_cm = p.conv_cm; d.eig_thresh = p.eig_thresh;
+    d.min_corr = p.min_corr; d.use_label = p.use_label_weight; d.emulate_shadow = p.emulate_matp_shadow;
+    d.skip_empty = p.skip_empty_target; d.fixed_iters = p.fixed_iters;
+    d.bound = p.fixed_iters > 0 ? p.fixed_iters : p.max_iters;
+    d.edge_min = p.edge_min; d.surf_min = p.surf_min; d.use_imu = p.use_imu_blend;
+    d.imu_w = p.imu_rpy_weight; d.rot_tol = p.rotation_tol; d.z_tol = p.z_tol;
+    for (int i = 0; i < 32; ++i) d.wtab[i] = (float)(2.0 - (double)p.label_score[i]);   // subMapOptmizationNode.cpp:1671
+    return d;
+}
+
+SortBuffers sort_buffers(lisreg_ctx* c)
+{
+    SortBuffers sb;
+    sb.hist = c->hist.as<int>(); sb.bucket_start = c->bucket_start.as<int>(); sb.scan_tmp = c->scan_tmp.as<int>();
+    sb.elem_bucket = c->elem_bucket.as<uint32_t>(); sb.elem_sub = c->elem_sub.as<uint32_t>();
+    sb.tmp_bucket = c->tmp_bucket.as<uint32_t>(); sb.tmp_sub = c->tmp_sub.as<uint32_t>();
+    sb.tmp_idx = c->tmp_idx.as<int>();
+    return sb;
+}
+
+int ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets)
+{
+    HIPCHK(c, c->hist.ensure(sizeof(int) * (n_buckets + 1)));
+    HIPCHK(c, c->bucket_start.ensure(sizeof(int) * (n_buckets + 2)));
+    HIPCHK(c, c->scan_tmp.ensure(sizeof(int) * (n_buckets / 2048 + 4)));
+    HIPCHK(c, c->elem_bucket.ensure(sizeof(uint32_t) * (n_elems + 1)));
+    HIPCHK(c, c->elem_sub.ensure(sizeof(uint32_t) * (n_elems + 1)));
+    HIPCHK(c, c->tmp_bucket.ensure(sizeof(uint32_t) * (n_elems + 1)));
+    HIPCHK(c, c->tmp_sub.ensure(sizeof(uint32_t) * (n_elems + 1)));
+    HIPCHK(c, c->tmp_idx.ensure(sizeof(int) * (n_elems + 1)));
+    return LISREG_OK;
+}
+
+// grid geometry from a bounding box; cell edge grows if the box would need too many cells
+void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells)
+{
+    memset(g, 0, sizeof *g);
+    g->n = n;
+    float cell = env_float("LISREG_CELL", 0.5f);
+    if (n <= 0) { g->cell = cell; g->inv_cell = 1.f / cell; g->nx = g->ny = g->nz = 0; *n_cells = 1; return; }
+    const double max_cells = 1 << 24;
+    for (;;) {
+        double nx = floor((bb[3] - bb[0]) / cell) + 1, ny = floor((bb[4] - bb[1]) / cell) + 1,
+               nz = floor((bb[5] - bb[2]) / cell) + 1;
+        if (nx * ny * nz <= max_cells) { g->nx = (int)nx; g->ny = (int)ny; g->nz = (int)nz; break; }
+        cell *= 1.26f;
+    }
+    g->ox = bb[0]; g->oy = bb[1]; g->oz = bb[2];
+    g->cell = cell; g->inv_cell = 1.f / cell;
+    *n_cells = g->nx * g->ny * g->nz;
+}
+
+int build_target_kind(lisreg_ctx* c, Target& t, int k)
+{
+    const int n = t.n[k];
+    HIPCHK(c, t.cell_start[k].ensure(sizeof(int) * ((size_t)t.n_cells[k] + 2)));
+    HIPCHK(c, t.sorted[k].ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+    int rc = ensure_sort_scratch(c, (size_t)std::max(n, 1), (size_t)t.n_cells[k]);
+    if (rc) return rc;
+    t.g[k].pts = t.sorted[k].as<float4>();
+    t.g[k].cell_start = t.cell_start[k].as<int>();
+    launch_build_target(t.raw_ptr[k], n, t.g[k], t.sorted[k].as<float4>(), t.cell_start[k].as<int>(), t.n_cells[k],
+                        sort_buffers(c), c->stream);
+    HIPCHK(c, hipGetLastError());
+    return LISREG_OK;
+}
+
+int upload_grids(lisreg_ctx* c)
+{
+    std::vector<GridIndex> h(c->targets.size() * 2);
+    for (size_t s = 0; s < c->targets.size(); ++s)
+        for (int k = 0; k < 2; ++k) {
+            if (c->targets[s].valid) h[s * 2 + k] = c->targets[s].g[k];
+            else memset(&h[s * 2 + k], 0, sizeof(GridIndex));
+        }
+    HIPCHK(c, c->grids_dev.ensure(sizeof(GridIndex) * std::max<size_t>(h.size(), 1)));
+    if (!h.empty())
+        HIPCHK(c, hipMemcpyAsync(c->grids_dev.p, h.data(), sizeof(GridIndex) * h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // h is a local
+    c->grids_dirty = false;
+    return LISREG_OK;
+}
+
+void prof_mark(lisreg_ctx* c, int kind_of_next_interval)
+{
+    if (!c->profiling) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, c->stream);
+    c->ev.push_back(e);
+    c->ev_kind.push_back(kind_of_next_interval);
+}
+
+void prof_collect(lisreg_ctx* c)
+{
+    for (int i = 0; i < 5; ++i) c->timing[i] = 0;
+    for (size_t i = 0; i + 1 < c->ev.size(); ++i) {
+        float ms = 0;
+        if (c->ev_kind[i] >= 0 && hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+            if (c->ev_kind[i] == 0) { c->timing[0] += ms; c->timing[1] += 1; }
+            else if (c->ev_kind[i] == 1) { c->timing[2] += ms; c->timing[3] += 1; }
+            else if (c->ev_kind[i] == 2) c->timing[4] += ms;
+        }
+    }
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    c->ev.clear(); c->ev_kind.clear();
+}
+
+}  // namespace
+
+// =============================================================================================================
+extern "C" {
+
+int lisreg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lisreg_create(int device, lisreg_ctx** out)
+{
+    if (!out) return fail(nullptr, LISREG_ERR_ARG, "lisreg_create: out is NULL");
+    *out = nullptr;
+    int n = lisreg_device_count();
+    if (n <= 0) return fail(nullptr, LISREG_ERR_HIP, "lisreg_create: no HIP device visible (liblisreg has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(nullptr, LISREG_ERR_ARG, "lisreg_create: bad device index");
+    lisreg_ctx* c = new (std::nothrow) lisreg_ctx();
+    if (!c) return fail(nullptr, LISREG_ERR_NOMEM, "lisreg_create: out of host memory");
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, LISREG_ERR_HIP, "lisreg_create: hipSetDevice/hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    c->targets.resize(1);
+    lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
+    *out = c;
+    return LISREG_OK;
+}
+
+void lisreg_destroy(lisreg_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    lisreg_comm_destroy(c);
+    for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
+    DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
+                       &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload };
+    for (auto b : bufs) b->release();
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* lisreg_last_error(const lisreg_ctx* c) { return c ? c->err.c_str() : g_static_err.c_str(); }
+
+int lisreg_set_stream(lisreg_ctx* c, void* s)
+{
+    if (!c) return LISREG_ERR_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return LISREG_OK;
+}
+
+void* lisreg_get_stream(const lisreg_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int lisreg_default_params(int variant, lisreg_params* p)
+{
+    if (!p || variant < 1 || variant > 3) return LISREG_ERR_ARG;
+    memset(p, 0, sizeof *p);
+    static const float score[20] = { 1.0f, 1.0f, 0.6f, 0.5f, 0.8f, 0.5f, 0.5f, 0.5f, 0.5f, 1.2f,     // config/label.yaml:214-234
+                                     1.2f, 1.2f, 0.5f, 1.0f, 0.8f, 0.5f, 1.3f, 0.5f, 1.5f, 1.5f };
+    p->max_iters = variant == 1 ? 15 : (variant == 2 ? 20 : 30);
+    p->fixed_iters = 0;
+    p->knn_sq_thresh = variant == 1 ? 1.0f : 2.0f;
+    p->conv_deg = variant == 1 ? 0.005f : (variant == 2 ? 0.003f : 0.002f);
+    p->conv_cm = variant == 1 ? 0.05f : (variant == 2 ? 0.03f : 0.02f);
+    p->min_corr = 50; p->eig_thresh = 100.f; p->edge_min = -1; p->surf_min = 100;
+    p->line_ratio = 3.f; p->plane_tol = 0.2f; p->accept_s = 0.1f;
+    p->use_label_weight = variant == 1 ? 0 : 1;
+    for (int i = 0; i < 32; ++i) p->label_score[i] = i < 20 ? score[i] : 1.0f;
+    p->emulate_matp_shadow = 1;
+    p->skip_empty_target = variant == 3 ? 1 : 0;
+    p->use_imu_blend = variant == 3 ? 0 : 1;
+    p->imu_rpy_weight = 0.1f; p->rotation_tol = 1000.f; p->z_tol = 1000.f;
+    return LISREG_OK;
+}
+
+void lisreg_pose_to_matrix(const float T[6], float M[12]) { pose_to_matrix_host(T, M); }
+
+// transformUpdate, host form (odomEstimationNode.cpp:976-1006): tf's double-precision quaternion slerp of the
+// single-axis roll / pitch rotations, then constraintTransformation (common.cpp:285-291).
+void lisreg_transform_update(const lisreg_params* p, const lisreg_imu* imu, float T[6])
+{
+    auto blend = [](double a, double b, double w, bool is_pitch) {
+        // slerp between two rotations about ONE axis by angles a and b: quaternions (sin(a/2), cos(a/2))
+        double qa_s = sin(a * 0.5), qa_c = cos(a * 0.5), qb_s = sin(b * 0.5), qb_c = cos(b * 0.5);
+        double d = qa_s * qb_s + qa_c * qb_c;
+        double theta = d < 0 ? acos(-d) : acos(d);
+        double rs = qa_s, rc = qa_c;
+        if (theta != 0.0) {
+            double dd = 1.0 / sin(theta), s0 = sin((1.0 - w) * theta), s1 = sin(w * theta), sg = d < 0 ? -1.0 : 1.0;
+            rs = (qa_s * s0 + sg * qb_s * s1) * dd;
+            rc = (qa_c * s0 + sg * qb_c * s1) * dd;
+        }
+        double n2 = rs * rs + rc * rc, s = 2.0 / n2;
+        if (!is_pitch) {                       // rotation about X: m21 = 2wx, m22 = 1 - 2xx ; getRPY roll = atan2(m21, m22)
+            return atan2(rc * rs * s, 1.0 - rs * rs * s);
+        }
+        double m20 = -(rc * rs * s);           // rotation about Y: m20 = xz - wy = -2wy
+        if (fabs(m20) >= 1) return m20 < 0 ? M_PI / 2.0 : -M_PI / 2.0;
+        return -asin(m20);
+    };
+    if (p->use_imu_blend && imu && imu->imu_available && fabsf(imu->imu_pitch_init) < 1.4f) {
+        T[0] = (float)blend((double)T[0], (double)imu->imu_roll_init, (double)p->imu_rpy_weight, false);
+        T[1] = (float)blend((double)T[1], (double)imu->imu_pitch_init, (double)p->imu_rpy_weight, true);
+    }
+    auto clampf = [](float v, float lim) { if (v < -lim) v = -lim; if (v > lim) v = lim; return v; };
+    T[0] = clampf(T[0], p->rotation_tol);
+    T[1] = clampf(T[1], p->rotation_tol);
+    T[5] = clampf(T[5], p->z_tol);
+}
+
+// ---- target -------------------------------------------------------------------------------------------------
+static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const int counts[2], int stride, int fmt)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (slot < 0 || slot > 65535) return fail(c, LISREG_ERR_ARG, "set_target: bad slot");
+    for (int k = 0; k < 2; ++k)
+        if (counts[k] < 0 || (counts[k] > 0 && !clouds[k])) return fail(c, LISREG_ERR_ARG, "set_target: NULL cloud with n > 0");
+    if (fmt != LISREG_FMT_DEVICE && stride < 12) return fail(c, LISREG_ERR_ARG, "set_target: stride < 12");
+    if (fmt == LISREG_FMT_XYZIL && stride < 22) return fail(c, LISREG_ERR_ARG, "set_target: XYZIL needs stride >= 22");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)slot >= c->targets.size()) c->targets.resize((size_t)slot + 1);
+    Target& t = c->targets[(size_t)slot];
+    for (int k = 0; k < 2; ++k) {
+        const int n = counts[k];
+        t.n[k] = n;
+        float bb[6] = { 0, 0, 0, 0, 0, 0 };
+        if (fmt == LISREG_FMT_DEVICE) {
+            t.raw_external[k] = true;
+            t.raw_ptr[k] = static_cast<const float4*>(clouds[k]);
+            if (n > 0) {
+                HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 8));
+                HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
+                launch_bbox(t.raw_ptr[k], n, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), c->stream);
+                HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+        } else {
+            std::vector<lisreg_dpoint> h((size_t)std::max(n, 1));
+            if (n > 0) pack_cloud(clouds[k], n, stride, fmt, h.data());
+            for (int d = 0; d < 3; ++d) { bb[d] = 3.0e38f; bb[3 + d] = -3.0e38f; }
+            for (int i = 0; i < n; ++i) {
+                const float v[3] = { h[(size_t)i].x, h[(size_t)i].y, h[(size_t)i].z };
+                for (int d = 0; d < 3; ++d) { bb[d] = std::min(bb[d], v[d]); bb[3 + d] = std::max(bb[3 + d], v[d]); }
+            }
+            HIPCHK(c, t.raw[k].ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+            if (n > 0) HIPCHK(c, hipMemcpy(t.raw[k].p, h.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
+            t.raw_external[k] = false;
+            t.raw_ptr[k] = t.raw[k].as<float4>();
+        }
+        make_grid(bb, n, &t.g[k], &t.n_cells[k]);
+        prof_mark(c, 2);
+        int rc = build_target_kind(c, t, k);
+        prof_mark(c, -1);
+        if (rc) return rc;
+    }
+    t.valid = true;
+    c->grids_dirty = true;
+    c->prepared = false;
+    return LISREG_OK;
+}
+
+int lisreg_set_target_slot(lisreg_ctx* c, int slot, const void* corner, int n_corner, const void* surf, int n_surf,
+                           int stride, int fmt)
+{
+    const void* clouds[2] = { corner, surf };
+    const int counts[2] = { n_corner, n_surf };
+    return set_target_impl(c, slot, clouds, counts, stride, fmt);
+}
+
+int lisreg_set_target(lisreg_ctx* c, const void* corner, int n_corner, const void* surf, int n_surf, int stride, int fmt)
+{
+    return lisreg_set_target_slot(c, 0, corner, n_corner, surf, n_surf, stride, fmt);
+}
+
+int lisreg_target_from_classes(lisreg_ctx* c, int slot, const void* pole, int n_pole, const void* ground, int n_ground,
+                               const void* building, int n_building, const void* dynamic, int n_dynamic,
+                               int stride, int fmt)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (fmt == LISREG_FMT_DEVICE) return fail(c, LISREG_ERR_ARG, "target_from_classes: host clouds only");
+    if (stride < 12) return fail(c, LISREG_ERR_ARG, "target_from_classes: stride < 12");
+    // surf = ground + building + dynamic, the concat order of extractSlidingCloud (subMapOptmizationNode.cpp:1408-1419)
+    const void* parts[3] = { ground, building, dynamic };
+    const int cnt[3] = { std::max(n_ground, 0), std::max(n_building, 0), std::max(n_dynamic, 0) };
+    std::vector<unsigned char> surf((size_t)(cnt[0] + cnt[1] + cnt[2]) * (size_t)stride + 1);
+    size_t off = 0;
+    for (int i = 0; i < 3; ++i) if (cnt[i] > 0 && parts[i]) {
+        memcpy(surf.data() + off, parts[i], (size_t)cnt[i] * (size_t)stride);
+        off += (size_t)cnt[i] * (size_t)stride;
+    }
+    return lisreg_set_target_slot(c, slot, pole, pole ? std::max(n_pole, 0) : 0, surf.data(), (int)(off / (size_t)stride), stride, fmt);
+}
+
+// ---- batch --------------------------------------------------------------------------------------------------
+int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, const lisreg_params* params,
+                         const float* T_init)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n_items < 0 || (n_items > 0 && (!items || !T_init)) || !params) return fail(c, LISREG_ERR_ARG, "batch_prepare: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prepared = false;
+    c->params = *params;
+    c->prm = make_dev_params(*params);
+    c->n_items = n_items;
+    c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
+    c->batch_slots.clear();
+    const float tile = env_float("LISREG_TILE", 2.0f);
+    int flat = 0, bucket = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const lisreg_item& in = items[i];
+        if (in.fmt != LISREG_FMT_DEVICE) return fail(c, LISREG_ERR_ARG, "batch_prepare: items must be LISREG_FMT_DEVICE (use lisreg_align_batch for host clouds)");
+        if (in.n_corner < 0 || in.n_surf < 0 || (in.n_corner > 0 && !in.src_corner) || (in.n_surf > 0 && !in.src_surf))
+            return fail(c, LISREG_ERR_ARG, "batch_prepare: NULL source cloud with n > 0");
+        if (in.target < 0 || (size_t)in.target >= c->targets.size() || !c->targets[(size_t)in.target].valid)
+            return fail(c, LISREG_ERR_NO_TARGET, "batch_prepare: item refers to a target slot that was never set");
+        if (std::find(c->batch_slots.begin(), c->batch_slots.end(), in.target) == c->batch_slots.end()) c->batch_slots.push_back(in.target);
+        const Target& t = c->targets[(size_t)in.target];
+        ItemState& st = c->h_items[(size_t)i];
+        memset(&st, 0, sizeof st);
+        memcpy(st.T_init, T_init + 6 * (size_t)i, 24);
+        memcpy(st.T, st.T_init, 24);
+        st.degenerate_in = in.degenerate_in;
+        st.imu = in.imu;
+        st.n_sc = in.n_corner; st.n_ss = in.n_surf;
+        st.blk_begin = (int)c->h_blocks.size();
+        for (int k = 0; k < 2; ++k) {
+            Segment sg;
+            memset(&sg, 0, sizeof sg);
+            sg.src = static_cast<const float4*>(k == 0 ? in.src_corner : in.src_surf);
+            sg.n = k == 0 ? in.n_corner : in.n_surf;
+            sg.item = i; sg.kind = k; sg.target = in.target * 2 + k;
+            sg.flat_base = flat; sg.bucket_base = bucket;
+            const GridIndex& g = t.g[k];
+            sg.tox = g.ox; sg.toy = g.oy; sg.toz = g.oz;
+            sg.inv_tile = 1.f / tile;
+            sg.tnx = std::max(1, (int)ceilf(g.nx * g.cell / tile));
+            sg.tny = std::max(1, (int)ceilf(g.ny * g.cell / tile));
+            sg.tnz = std::max(1, (int)ceilf(g.nz * g.cell / tile));
+            const int seg_id = (int)c->h_segs.size();
+            c->h_segs.push_back(sg);
+            for (int s = 0; s < sg.n; s += kBlockQ)
+                c->h_blocks.push_back(BlockDesc{ seg_id, s, std::min(kBlockQ, sg.n - s), i });
+            flat += sg.n;
+            bucket += sg.tnx * sg.tny * sg.tnz;
+        }
+        st.blk_count = (int)c->h_blocks.size() - st.blk_begin;
+    }
+    c->n_blocks = (int)c->h_blocks.size();
+    c->n_segs = (int)c->h_segs.size();
+    c->n_elems = flat;
+    c->n_buckets = std::max(bucket, 1);
+    int rc = ensure_sort_scratch(c, (size_t)std::max(flat, 1), (size_t)c->n_buckets);
+    if (rc) return rc;
+    HIPCHK(c, c->blocks.ensure(sizeof(BlockDesc) * (size_t)std::max(c->n_blocks, 1)));
+    HIPCHK(c, c->segs.ensure(sizeof(Segment) * (size_t)std::max(c->n_segs, 1)));
+    HIPCHK(c, c->items.ensure(sizeof(ItemState) * (size_t)std::max(n_items, 1)));
+    HIPCHK(c, c->sorted_all.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
+    HIPCHK(c, c->order_all.ensure(sizeof(int) * (size_t)std::max(flat, 1)));
+    HIPCHK(c, c->partials.ensure(sizeof(double) * kNumAcc * (size_t)std::max(c->n_blocks, 1)));
+    HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * (size_t)std::max(n_items, 1)));
+    if (c->trace_cap > 0) HIPCHK(c, c->trace.ensure(sizeof(float) * kTraceStride * (size_t)c->trace_cap * (size_t)std::max(n_items, 1)));
+    if (c->n_blocks) HIPCHK(c, hipMemcpyAsync(c->blocks.p, c->h_blocks.data(), sizeof(BlockDesc) * (size_t)c->n_blocks, hipMemcpyHostToDevice, c->stream));
+    if (c->n_segs) HIPCHK(c, hipMemcpyAsync(c->segs.p, c->h_segs.data(), sizeof(Segment) * (size_t)c->n_segs, hipMemcpyHostToDevice, c->stream));
+    if (n_items) HIPCHK(c, hipMemcpyAsync(c->items.p, c->h_items.data(), sizeof(ItemState) * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
+    if (c->grids_dirty) { rc = upload_grids(c); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->prepared = true;
+    return LISREG_OK;
+}
+
+int lisreg_batch_run(lisreg_ctx* c)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!c->prepared) return fail(c, LISREG_ERR_ARG, "batch_run: no prepared batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
+        prof_mark(c, 2);
+        for (int slot : c->batch_slots)
+            for (int k = 0; k < 2; ++k) { int rc = build_target_kind(c, c->targets[(size_t)slot], k); if (rc) return rc; }
+        prof_mark(c, -1);
+    }
+    launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, st);
+    prof_mark(c, 2);
+    launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
+                        c->n_elems, c->n_buckets, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
+    prof_mark(c, -1);
+    for (int it = 0; it < c->prm.bound; ++it) {
+        prof_mark(c, 0);
+        launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
+                     c->items.as<ItemState>(), c->prm, c->sorted_all.as<float4>(), c->partials.as<double>(), st);
+        prof_mark(c, 1);
+        launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
+                     c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, st);
+        prof_mark(c, -1);
+    }
+    launch_finalize(c->items.as<ItemState>(), c->n_items, c->prm, c->results.as<float>(), st);
+    HIPCHK(c, hipGetLastError());
+    return LISREG_OK;
+}
+
+int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!c->prepared) return fail(c, LISREG_ERR_ARG, "batch_fetch: no prepared batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->h_results.resize((size_t)std::max(c->n_items, 1) * kResultSize);
+    if (c->n_items) HIPCHK(c, hipMemcpyAsync(c->h_results.data(), c->results.p, sizeof(float) * kResultSize * (size_t)c->n_items, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) prof_collect(c);
+    for (int i = 0; i < c->n_items; ++i) {
+        const float* r = &c->h_results[(size_t)i * kResultSize];
+        if (T) memcpy(T + 6 * (size_t)i, r, 24);
+        if (stats) {
+            stats[i].iters = (int)r[6]; stats[i].deltaR = r[7]; stats[i].deltaT = r[8];
+            stats[i].degenerate = (int)r[9]; stats[i].n_corr_last = (int)r[10]; stats[i].status = (int)r[11];
+        }
+    }
+    return LISREG_OK;
+}
+
+void* lisreg_batch_result_device(const lisreg_ctx* c) { return c ? c->results.p : nullptr; }
+
+// Options that are not part of the reference's parameter surface (kept out of lisreg_params on purpose).
+int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return LISREG_ERR_ARG;
+    if (!strcmp(name, "rebuild_targets_each_run")) { c->rebuild_targets_each_run = value != 0; return LISREG_OK; }
+    if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
+    return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
+}
+
+int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, const lisreg_params* params, float* T,
+                       lisreg_stats* stats)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n_items < 0 || (n_items > 0 && (!items || !T)) || !params) return fail(c, LISREG_ERR_ARG, "align_batch: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    // stage host clouds into one device buffer of 16-B records; device items pass through
+    size_t total = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const lisreg_item& in = items[i];
+        if (in.n_corner < 0 || in.n_surf < 0) return fail(c, LISREG_ERR_ARG, "align_batch: negative count");
+        if (in.fmt != LISREG_FMT_DEVICE) {
+            if (in.stride_bytes < 12 || (in.fmt == LISREG_FMT_XYZIL && in.stride_bytes < 22)) return fail(c, LISREG_ERR_ARG, "align_batch: bad stride");
+            if ((in.n_corner > 0 && !in.src_corner) || (in.n_surf > 0 && !in.src_surf)) return fail(c, LISREG_ERR_ARG, "align_batch: NULL cloud");
+            total += (size_t)in.n_corner + (size_t)in.n_surf;
+        }
+    }
+    std::vector<lisreg_dpoint> h(std::max<size_t>(total, 1));
+    std::vector<lisreg_item> dev_items((size_t)n_items);
+    HIPCHK(c, c->src_upload.ensure(sizeof(lisreg_dpoint) * std::max<size_t>(total, 1)));
+    size_t off = 0;
+    for (int i = 0; i < n_items; ++i) {
+        dev_items[(size_t)i] = items[i];
+        const lisreg_item& in = items[i];
+        if (in.fmt == LISREG_FMT_DEVICE) continue;
+        lisreg_item& d = dev_items[(size_t)i];
+        if (in.n_corner > 0) pack_cloud(in.src_corner, in.n_corner, in.stride_bytes, in.fmt, &h[off]);
+        d.src_corner = c->src_upload.as<lisreg_dpoint>() + off; off += (size_t)in.n_corner;
+        if (in.n_surf > 0) pack_cloud(in.src_surf, in.n_surf, in.stride_bytes, in.fmt, &h[off]);
+        d.src_surf = c->src_upload.as<lisreg_dpoint>() + off; off += (size_t)in.n_surf;
+        d.fmt = LISREG_FMT_DEVICE;
+    }
+    if (total) HIPCHK(c, hipMemcpy(c->src_upload.p, h.data(), sizeof(lisreg_dpoint) * total, hipMemcpyHostToDevice));
+    int rc = lisreg_batch_prepare(c, n_items, dev_items.data(), params, T);
+    if (rc) return rc;
+    rc = lisreg_batch_run(c);
+    if (rc) return rc;
+    return lisreg_batch_fetch(c, T, stats);
+}
+
+int lisreg_align(lisreg_ctx* c, const void* src_corner, int n_corner, const void* src_surf, int n_surf, int stride,
+                 int fmt, const lisreg_params* params, const lisreg_imu* imu, float T[6], lisreg_stats* stats)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!params || !T) return fail(c, LISREG_ERR_ARG, "align: params/T NULL");
+    if (c->targets.empty() || !c->targets[0].valid) return fail(c, LISREG_ERR_NO_TARGET, "align: call lisreg_set_target first");
+    lisreg_item item;
+    memset(&item, 0, sizeof item);
+    item.src_corner = src_corner; item.n_corner = n_corner;
+    item.src_surf = src_surf; item.n_surf = n_surf;
+    item.stride_bytes = stride; item.fmt = fmt; item.target = 0;
+    item.degenerate_in = c->degenerate;
+    if (imu) item.imu = *imu;
+    const int bound = params->fixed_iters > 0 ? params->fixed_iters : params->max_iters;
+    const int saved_cap = c->trace_cap;
+    c->trace_cap = std::max(bound, 1);
+    lisreg_stats st;
+    memset(&st, 0, sizeof st);
+    int rc = lisreg_align_batch(c, 1, &item, params, T, &st);
+    if (rc == LISREG_OK) {
+        c->degenerate = st.degenerate;
+        c->last_trace_n = std::min(bound, st.iters + 1);
+        if (st.status == LISREG_NOT_ENOUGH_FEATURES) c->last_trace_n = 0;
+        c->last_trace.assign((size_t)kTraceStride * (size_t)std::max(c->last_trace_n, 1), 0.f);
+        if (c->last_trace_n > 0) {
+            hipError_t e = hipMemcpy(c->last_trace.data(), c->trace.p, sizeof(float) * kTraceStride * (size_t)c->last_trace_n, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { c->trace_cap = saved_cap; return fail(c, LISREG_ERR_HIP, "align: trace copy failed"); }
+        }
+        if (stats) *stats = st;
+        rc = st.status;
+    }
+    c->trace_cap = saved_cap;
+    c->prepared = false;
+    return rc;
+}
+
+int lisreg_get_trace(lisreg_ctx* c, float* buf, int max_iters)
+{
+    if (!c || !buf || max_iters <= 0) return 0;
+    const int n = std::min(max_iters, c->last_trace_n);
+    if (n > 0) memcpy(buf, c->last_trace.data(), sizeof(float) * kTraceStride * (size_t)n);
+    return n;
+}
+
+int lisreg_set_profiling(lisreg_ctx* c, int enable)
+{
+    if (!c) return LISREG_ERR_ARG;
+    c->profiling = enable != 0;
+    return LISREG_OK;
+}
+
+int lisreg_get_timing(lisreg_ctx* c, double out[5])
+{
+    if (!c || !out) return LISREG_ERR_ARG;
+    for (int i = 0; i < 5; ++i) out[i] = c->timing[i];
+    return LISREG_OK;
+}
+
+// ---- RCCL pose gather: librccl is loaded lazily so single-GPU users never pay for it ------------
+static int rccl_load(lisreg_ctx* c)
+{
+    if (c->rccl.handle) return LISREG_OK;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(c, LISREG_ERR_COMM, std::string("dlopen(librccl.so): ") + dlerror());
+    c->rccl.handle = h;
+    c->rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    c->rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    c->rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    if (!c->rccl.GetUniqueId || !c->rccl.AllGather || !c->rccl.CommDestroy || !dlsym(h, "ncclCommInitRank"))
+        return fail(c, LISREG_ERR_COMM, "librccl.so lacks the expected nccl* symbols");
+    return LISREG_OK;
+}
+
+int lisreg_comm_unique_id(unsigned char id[128])
+{
+    if (!id) return LISREG_ERR_ARG;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(nullptr, LISREG_ERR_COMM, "dlopen(librccl.so) failed");
+    auto f = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    if (!f || f(id) != 0) return fail(nullptr, LISREG_ERR_COMM, "ncclGetUniqueId failed");
+    return LISREG_OK;
+}
+
+namespace { struct UniqueId128 { char b[128]; }; }
+
+int lisreg_comm_init(lisreg_ctx* c, int rank, int nranks, const unsigned char id[128])
+{
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return LISREG_ERR_ARG;
+    int rc = rccl_load(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    UniqueId128 uid;
+    memcpy(uid.b, id, 128);
+    auto init = (int (*)(void**, int, UniqueId128, int))dlsym(c->rccl.handle, "ncclCommInitRank");
+    if (init(&c->comm, nranks, uid, rank) != 0) return fail(c, LISREG_ERR_COMM, "ncclCommInitRank failed");
+    c->comm_nranks = nranks;
+    return LISREG_OK;
+}
+
+int lisreg_gather_results(lisreg_ctx* c, const void* local_device, int n_local, void* out_device)
+{
+    if (!c || !local_device || !out_device || n_local < 0) return LISREG_ERR_ARG;
+    if (!c->comm) return fail(c, LISREG_ERR_COMM, "gather_results: call lisreg_comm_init first");
+    const int ncclFloat32 = 7;
+    if (c->rccl.AllGather(local_device, out_device, (size_t)n_local * kResultSize, ncclFloat32, c->comm, c->stream) != 0)
+        return fail(c, LISREG_ERR_COMM, "ncclAllGather failed");
+    return LISREG_OK;
+}
+
+void lisreg_comm_destroy(lisreg_ctx* c)
+{
+    if (!c || !c->comm) return;
+    if (c->rccl.CommDestroy) c->rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,467 @@
+// lisreg_assoc.hip — the hot kernel: fused correspondence search + residual model + normal-equation partials.
+//
+// One launch = one Gauss-Newton iteration's cornerOptimization + surfOptimization + combineOptimizationCoeffs +
+// the Jacobian / AtA / AtB build of LMOptimization for EVERY registration of the batch:
+//   /root/reference/src/node/odomEstimationNode.cpp:633-747 (point-to-line), :749-827 (point-to-plane),
+//   :829-850 (compaction — fused away: accepted rows go straight into the reduction), :862-920 (J rows, AtA, AtB)
+// and the label-weighted copies src/node/subMapOptmizationNode.cpp:1557-1917, 4556-4916.
+//
+// gfx950 mapping
+//   * a workgroup = 256 spatially compact queries (tile-sorted by lisreg_index.hip) of one (item, stage);
+//   * pcl::KdTreeFLANN::nearestKSearch(k=5) + `sqDist[4] < tau` is replaced by an exact fixed-radius 5-NN:
+//     the workgroup takes the bounding box of its transformed queries, grows it by r = sqrt(tau), stages every
+//     target point of the covered grid cells through LDS (coalesced 16-B loads of contiguous cell runs), and all
+//     lanes scan the staged points (LDS broadcast reads) keeping a sorted top-5 in registers initialised at tau.
+//     Any target point closer than r to a query lies in a staged cell, so the 5 nearest within r are exact;
+//   * the 5 neighbours are gathered once (5 x 16 B), the 3x3 eigen / 5x3 QR fit, weights and the Jacobian row
+//     stay in registers, and 28 normal-equation scalars are reduced in fp64 by wave shuffles -> LDS -> one
+//     partial row per workgroup (fixed order, no float atomics: reproducible).
+// No dense contraction exists here (K = n_corr, M = N = 6), so MFMA is not used; the kernel is bound by VALU
+// issue and LDS broadcast bandwidth, with the submap resident in L2 / Infinity Cache.
+#include "lisreg_internal.hpp"
+
+namespace lisreg {
+
+namespace {
+
+__device__ __forceinline__ void pose_matrix(const float* T, float M[12])
+{
+    // pcl::getTransformation via trans2Affine3f (src/core/common.cpp:54-57), float
+    const float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
+    const float DE = D * E, DF = D * F;
+    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
+    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
+    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
+}
+
+__device__ __forceinline__ float hypot_f(float a, float b)
+{
+    a = fabsf(a); b = fabsf(b);
+    const float mx = fmaxf(a, b), mn = fminf(a, b);
+    const float r = mn / mx;
+    return mx > 0.f ? mx * sqrtf(1.f + r * r) : 0.f;
+}
+
+// one Jacobi rotation annihilating A[k][l] of a symmetric 3x3 held in registers (cv::eigen's rotation formulas)
+#define LISREG_ROT(v0, v1) do { const float a0_ = (v0), b0_ = (v1); (v0) = a0_ * c - b0_ * s; (v1) = a0_ * s + b0_ * c; } while (0)
+
+// Largest eigenvector and the two largest eigenvalues of the symmetric 3x3 {a11..a33} by cyclic Jacobi.
+__device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, float a22, float a23, float a33,
+                                           float& l0, float& l1, float v0[3])
+{
+    float w0 = a11, w1 = a22, w2 = a33;
+    float v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;   // rows = vectors
+#pragma unroll 1
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        if (fabsf(a12) + fabsf(a13) + fabsf(a23) <= 1e-30f) break;
+        {   // (k,l) = (0,1)
+            const float p = a12;
+            if (fabsf(p) > 0.f) {
+                const float y = (w1 - w0) * 0.5f;
+                float t = fabsf(y) + hypot_f(p, y);
+                float s = hypot_f(p, t);
+                const float c = t / s;
+                s = p / s; t = (p / t) * p;
+                if (y < 0.f) { s = -s; t = -t; }
+                a12 = 0.f; w0 -= t; w1 += t;
+                LISREG_ROT(a13, a23);
+                LISREG_ROT(v00, v10); LISREG_ROT(v01, v11); LISREG_ROT(v02, v12);
+            }
+        }
+        {   // (0,2)
+            const float p = a13;
+            if (fabsf(p) > 0.f) {
+                const float y = (w2 - w0) * 0.5f;
+                float t = fabsf(y) + hypot_f(p, y);
+                float s = hypot_f(p, t);
+                const float c = t / s;
+                s = p / s; t = (p / t) * p;
+                if (y < 0.f) { s = -s; t = -t; }
+                a13 = 0.f; w0 -= t; w2 += t;
+                LISREG_ROT(a12, a23);
+                LISREG_ROT(v00, v20); LISREG_ROT(v01, v21); LISREG_ROT(v02, v22);
+            }
+        }
+        {   // (1,2)
+            const float p = a23;
+            if (fabsf(p) > 0.f) {
+                const float y = (w2 - w1) * 0.5f;
+                float t = fabsf(y) + hypot_f(p, y);
+                float s = hypot_f(p, t);
+                const float c = t / s;
+                s = p / s; t = (p / t) * p;
+                if (y < 0.f) { s = -s; t = -t; }
+                a23 = 0.f; w1 -= t; w2 += t;
+                // rows 1,2 rotate: elements A[0][1], A[0][2]
+                LISREG_ROT(a12, a13);
+                LISREG_ROT(v10, v20); LISREG_ROT(v11, v21); LISREG_ROT(v12, v22);
+            }
+        }
+    }
+    // descending order; only the top vector is needed (odomEstimationNode.cpp:692-702 read D[0], D[1], V row 0)
+    float e0 = w0, e1 = w1, e2 = w2;
+    float x = v00, y = v01, z = v02;
+    if (e1 > e0) { float t = e0; e0 = e1; e1 = t; x = v10; y = v11; z = v12; }
+    if (e2 > e0) { float t = e0; e0 = e2; e2 = t; x = v20; y = v21; z = v22; }
+    l0 = e0; l1 = fmaxf(e1, e2);
+    v0[0] = x; v0[1] = y; v0[2] = z;
+}
+
+// cornerOptimization body for one point (odomEstimationNode.cpp:658-742)
+__device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float y0, float z0, float w,
+                                             const DevParams& P, float cf[4])
+{
+    float cx = 0, cy = 0, cz = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { cx += nb[j].x; cy += nb[j].y; cz += nb[j].z; }
+    cx /= 5; cy /= 5; cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float ax = nb[j].x - cx, ay = nb[j].y - cy, az = nb[j].z - cz;
+        a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
+    }
+    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    float l0, l1, v[3];
+    eigen_sym3(a11, a12, a13, a22, a23, a33, l0, l1, v);
+    if (!(l0 > P.line_ratio * l1)) return false;
+    // `cx + 0.1 * v` is double arithmetic in the reference (:697-702)
+    const float x1 = (float)((double)cx + 0.1 * (double)v[0]);
+    const float y1 = (float)((double)cy + 0.1 * (double)v[1]);
+    const float z1 = (float)((double)cz + 0.1 * (double)v[2]);
+    const float x2 = (float)((double)cx - 0.1 * (double)v[0]);
+    const float y2 = (float)((double)cy - 0.1 * (double)v[1]);
+    const float z2 = (float)((double)cz - 0.1 * (double)v[2]);
+    const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+    const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+    const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+    const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+    const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+    const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+    const float ld2 = a012 / l12;
+    const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));
+    const float ws = w * s;
+    cf[0] = ws * la; cf[1] = ws * lb; cf[2] = ws * lc; cf[3] = ws * ld2;
+    return s > P.accept_s;
+}
+
+// Column-pivoted Householder QR least squares  [p_j] n = -1  (Eigen colPivHouseholderQr().solve, :783), all in
+// registers: column swaps are branch-free selects so nothing is dynamically indexed.
+__device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
+{
+    float a[5][3], c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { a[i][0] = nb[i].x; a[i][1] = nb[i].y; a[i][2] = nb[i].z; c[i] = -1.f; }
+    float n0 = 0, n1 = 0, n2 = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { n0 += a[i][0] * a[i][0]; n1 += a[i][1] * a[i][1]; n2 += a[i][2] * a[i][2]; }
+    const float maxn = sqrtf(fmaxf(n0, fmaxf(n1, n2)));
+    const float thr = (maxn * 1.1920929e-7f) * (maxn * 1.1920929e-7f) / 5.f;
+    int p0 = 0, p1 = 1, p2 = 2;        // perm: column k of the working matrix is original column p_k
+    int rank = 3;
+    float y[3] = { 0.f, 0.f, 0.f };
+
+#define LISREG_SWAPCOL(ca, cb, pa, pb) do { \
+        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) { const float t_ = a[i_][ca]; a[i_][ca] = a[i_][cb]; a[i_][cb] = t_; } \
+        const int tp_ = pa; pa = pb; pb = tp_; } while (0)
+
+#define LISREG_HOUSEHOLDER(k) do { \
+        const float c0_ = a[k][k]; float tail_ = 0.f; \
+        _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) tail_ += a[i_][k] * a[i_][k]; \
+        float beta_, tau_, v_[5]; \
+        if (tail_ <= 1.17549435e-38f) { tau_ = 0.f; beta_ = c0_; _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = 0.f; } \
+        else { beta_ = sqrtf(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
+               _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? a[i_][k] / (c0_ - beta_) : 0.f; \
+               tau_ = (beta_ - c0_) / beta_; } \
+        a[k][k] = beta_; \
+        _Pragma("unroll") for (int j_ = k + 1; j_ < 3; ++j_) { \
+            float dot_ = a[k][j_]; \
+            _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) dot_ += v_[i_] * a[i_][j_]; \
+            dot_ *= tau_; a[k][j_] -= dot_; \
+            _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) a[i_][j_] -= dot_ * v_[i_]; } \
+        { float dot_ = c[k]; \
+          _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) dot_ += v_[i_] * c[i_]; \
+          dot_ *= tau_; c[k] -= dot_; \
+          _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) c[i_] -= dot_ * v_[i_]; } \
+    } while (0)
+
+    // k = 0
+    {
+        if (n1 > n0 && n1 >= n2) LISREG_SWAPCOL(0, 1, p0, p1);
+        else if (n2 > n0 && n2 > n1) LISREG_SWAPCOL(0, 2, p0, p2);
+        const float big = fmaxf(n0, fmaxf(n1, n2));
+        if (big < thr * 5.f) rank = 0;
+        else LISREG_HOUSEHOLDER(0);
+    }
+    if (rank == 3) {   // k = 1
+        float m1 = 0, m2 = 0;
+#pragma unroll
+        for (int i = 1; i < 5; ++i) { m1 += a[i][1] * a[i][1]; m2 += a[i][2] * a[i][2]; }
+        if (m2 > m1) LISREG_SWAPCOL(1, 2, p1, p2);
+        if (fmaxf(m1, m2) < thr * 4.f) rank = 1;
+        else LISREG_HOUSEHOLDER(1);
+    }
+    if (rank == 3) {   // k = 2
+        float m2 = 0;
+#pragma unroll
+        for (int i = 2; i < 5; ++i) m2 += a[i][2] * a[i][2];
+        if (m2 < thr * 3.f) rank = 2;
+        else LISREG_HOUSEHOLDER(2);
+    }
+    if (rank == 3) {
+        y[2] = c[2] / a[2][2];
+        y[1] = (c[1] - a[1][2] * y[2]) / a[1][1];
+        y[0] = (c[0] - a[0][1] * y[1] - a[0][2] * y[2]) / a[0][0];
+    } else if (rank == 2) {
+        y[1] = c[1] / a[1][1];
+        y[0] = (c[0] - a[0][1] * y[1]) / a[0][0];
+    } else if (rank == 1) {
+        y[0] = c[0] / a[0][0];
+    }
+    X[0] = X[1] = X[2] = 0.f;
+    // x[perm[i]] = y[i]
+    X[0] = (p0 == 0) ? y[0] : ((p1 == 0) ? y[1] : y[2]);
+    X[1] = (p0 == 1) ? y[0] : ((p1 == 1) ? y[1] : y[2]);
+    X[2] = (p0 == 2) ? y[0] : ((p1 == 2) ? y[1] : y[2]);
+#undef LISREG_SWAPCOL
+#undef LISREG_HOUSEHOLDER
+}
+
+// surfOptimization body for one point (odomEstimationNode.cpp:776-821)
+__device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y0, float z0, float w,
+                                           const DevParams& P, float cf[4])
+{
+    float X[3];
+    lstsq5x3(nb, X);
+    float pa = X[0], pb = X[1], pc = X[2], pd = 1.f;
+    const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+    pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+    bool valid = true;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        valid = valid && !(fabsf(pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd) > P.plane_tol);
+    const float pd2 = pa * x0 + pb * y0 + pc * z0 + pd;
+    const float rng = sqrtf(sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
+    const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)rng);
+    const float ws = w * s;
+    cf[0] = ws * pa; cf[1] = ws * pb; cf[2] = ws * pc; cf[3] = ws * pd2;
+    return valid && (s > P.accept_s);
+}
+
+// LMOptimization row (odomEstimationNode.cpp:862-915); (ox,oy,oz) is the UNtransformed source point
+__device__ __forceinline__ void jacobian_row(const float* T, float ox, float oy, float oz, const float cf[4],
+                                             float row[6], float& b)
+{
+    const float srx = sinf(T[1]), crx = cosf(T[1]);
+    const float sry = sinf(T[2]), cry = cosf(T[2]);
+    const float srz = sinf(T[0]), crz = cosf(T[0]);
+    const float px = oy, py = oz, pz = ox;
+    const float cx = cf[1], cy = cf[2], cz = cf[0];
+    const float arx = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cx +
+                      (-srx * srz * px - crz * srx * py - crx * pz) * cy +
+                      (crx * cry * srz * px + crx * cry * crz * py - cry * srx * pz) * cz;
+    const float ary = ((cry * srx * srz - crz * sry) * px + (sry * srz + cry * crz * srx) * py + crx * cry * pz) * cx +
+                      ((-cry * crz - srx * sry * srz) * px + (cry * srz - crz * srx * sry) * py - crx * sry * pz) * cz;
+    const float arz = ((crz * srx * sry - cry * srz) * px + (-cry * crz - srx * sry * srz) * py) * cx +
+                      (crx * crz * px - crx * srz * py) * cy +
+                      ((sry * srz + cry * crz * srx) * px + (crz * sry - cry * srx * srz) * py) * cz;
+    row[0] = arz; row[1] = arx; row[2] = ary; row[3] = cz; row[4] = cx; row[5] = cy;
+    b = -cf[3];
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask); hi = __shfl_xor(hi, mask);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
+{
+    return (int)floorf((v - origin) * inv_cell);
+}
+
+__global__ __launch_bounds__(kBlockQ) void k_assoc(const BlockDesc* __restrict__ blocks,
+                                                   const Segment* __restrict__ segs,
+                                                   const GridIndex* __restrict__ grids,
+                                                   const ItemState* __restrict__ items, const DevParams P,
+                                                   const float4* __restrict__ sorted_all,
+                                                   double* __restrict__ partials)
+{
+    __shared__ float4 s_pts[kStageCap];
+    __shared__ int    s_run_start[kBlockQ];
+    __shared__ int    s_run_off[kBlockQ + 1];
+    __shared__ int    s_wave[4];
+    __shared__ float  s_bb[4][6];
+    __shared__ double s_acc[4][kNumAcc];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ItemState* it = &items[bd.item];
+    if (it->done) return;                       // converged / guarded-out item: solve kernel skips it too
+    const Segment sg = segs[bd.seg];
+    const GridIndex g = grids[sg.target];
+    double* out = partials + (size_t)blockIdx.x * kNumAcc;
+    if (g.n < 5) {                              // nearestKSearch cannot return 5 neighbours: no correspondences
+        if (tid < kNumAcc) out[tid] = 0.0;
+        return;
+    }
+
+    float T[6], M[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) T[k] = it->T[k];
+    pose_matrix(T, M);
+
+    const bool valid = tid < bd.count;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) q4 = sorted_all[sg.flat_base + bd.start + tid];
+    // pointAssociateToMap (:243-258)
+    float qx = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
+    float qy = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
+    float qz = M[8] * q4.x + M[9] * q4.y + M[10] * q4.z + M[11];
+
+    // ---- workgroup bounding box of the transformed queries --------------------------------------------------
+    float lo[3] = { valid ? qx : 3.0e38f, valid ? qy : 3.0e38f, valid ? qz : 3.0e38f };
+    float hi[3] = { valid ? qx : -3.0e38f, valid ? qy : -3.0e38f, valid ? qz : -3.0e38f };
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], d));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d));
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_bb[wave][k] = lo[k]; s_bb[wave][3 + k] = hi[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(s_bb[0][k], s_bb[1][k]), fminf(s_bb[2][k], s_bb[3][k]));
+        hi[k] = fmaxf(fmaxf(s_bb[0][3 + k], s_bb[1][3 + k]), fmaxf(s_bb[2][3 + k], s_bb[3][3 + k]));
+    }
+    if (!valid) { qx = qy = qz = 3.0e18f; }     // never closer than tau to anything
+
+    // ---- covered cell range: every target point with |p - q|_inf <= margin lies inside ----------------------
+    const float margin = sqrtf(P.tau) * 1.0005f + 1e-3f;
+    int ix0 = grid_coord(lo[0] - margin, g.ox, g.inv_cell), ix1 = grid_coord(hi[0] + margin, g.ox, g.inv_cell);
+    int iy0 = grid_coord(lo[1] - margin, g.oy, g.inv_cell), iy1 = grid_coord(hi[1] + margin, g.oy, g.inv_cell);
+    int iz0 = grid_coord(lo[2] - margin, g.oz, g.inv_cell), iz1 = grid_coord(hi[2] + margin, g.oz, g.inv_cell);
+    ix0 = max(ix0, 0); iy0 = max(iy0, 0); iz0 = max(iz0, 0);
+    ix1 = min(ix1, g.nx - 1); iy1 = min(iy1, g.ny - 1); iz1 = min(iz1, g.nz - 1);
+    const int nrx = ix1 - ix0 + 1, nry = iy1 - iy0 + 1;
+    const int nruns = (nrx > 0 && nry > 0 && iz1 >= iz0) ? nrx * nry : 0;
+
+    // ---- exact fixed-radius 5-NN: sorted top-5 in registers, initialised at tau ------------------------------
+    float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau;
+    int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
+
+    for (int rb = 0; rb < nruns; rb += kBlockQ) {
+        const int r = rb + tid;
+        int rs = 0, rl = 0;
+        if (r < nruns) {
+            const int ix = ix0 + r / nry, iy = iy0 + r % nry;
+            const int base = (ix * g.ny + iy) * g.nz;
+            rs = g.cell_start[base + iz0];
+            rl = g.cell_start[base + iz1 + 1] - rs;
+        }
+        // workgroup exclusive scan of run lengths
+        int inc = rl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int s = s_wave[w]; if (w < wave) wbase += s; total += s; }
+        s_run_start[tid] = rs;
+        s_run_off[tid] = wbase + inc - rl;
+        if (tid == 0) s_run_off[kBlockQ] = total;
+        __syncthreads();
+
+        for (int chunk = 0; chunk < total; chunk += kStageCap) {
+            const int cnt = min(kStageCap, total - chunk);
+            // stage: flat candidate id -> (run, offset) by binary search over the run offsets
+            for (int j = tid; j < cnt; j += kBlockQ) {
+                const int gidx = chunk + j;
+                int l = 0, h = kBlockQ - 1;
+                while (l < h) {
+                    const int mid = (l + h + 1) >> 1;
+                    if (s_run_off[mid] <= gidx) l = mid; else h = mid - 1;
+                }
+                const int src = s_run_start[l] + (gidx - s_run_off[l]);
+                float4 v = g.pts[src];
+                v.w = __int_as_float(src);                 // position in the sorted target array
+                s_pts[j] = v;
+            }
+            __syncthreads();
+            // scan: every lane tests every staged point (LDS broadcast read)
+#pragma unroll 4
+            for (int j = 0; j < cnt; ++j) {
+                const float4 c = s_pts[j];
+                const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;     // flann::L2_Simple order
+                if (d2 < b4) {
+                    const int id = __float_as_int(c.w);
+                    const bool c3 = d2 < b3, c2 = d2 < b2, c1 = d2 < b1, c0 = d2 < b0;
+                    b4 = c3 ? b3 : d2;               i4 = c3 ? i3 : id;
+                    b3 = c3 ? (c2 ? b2 : d2) : b3;   i3 = c3 ? (c2 ? i2 : id) : i3;
+                    b2 = c2 ? (c1 ? b1 : d2) : b2;   i2 = c2 ? (c1 ? i1 : id) : i2;
+                    b1 = c1 ? (c0 ? b0 : d2) : b1;   i1 = c1 ? (c0 ? i0 : id) : i1;
+                    b0 = c0 ? d2 : b0;               i0 = c0 ? id : i0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- residual model + Jacobian row -----------------------------------------------------------------------
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+    const bool found = valid && (i4 >= 0);          // five neighbours with sqDist < tau  (:657 / :776)
+    if (found) {
+        float4 nb[5];
+        nb[0] = g.pts[i0]; nb[1] = g.pts[i1]; nb[2] = g.pts[i2]; nb[3] = g.pts[i3]; nb[4] = g.pts[i4];
+        float w = 1.f;
+        if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
+        float cf[4];
+        const bool ok = (sg.kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
+        if (ok) {
+            float row[6], b;
+            jacobian_row(T, q4.x, q4.y, q4.z, cf, row, b);
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) acc[k++] = (double)row[r] * (double)row[c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[21 + r] = (double)row[r] * (double)b;
+            acc[27] = 1.0;
+        }
+    }
+    // ---- fixed-order fp64 reduction: wave shuffles -> LDS -> one partial row ---------------------------------
+#pragma unroll
+    for (int k = 0; k < kNumAcc; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += shfl_xor_d(v, d);
+        if (lane == 0) s_acc[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < kNumAcc) out[tid] = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
+}
+
+}  // namespace
+
+void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
+                  const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
+                  hipStream_t st)
+{
+    if (n_blocks <= 0) return;
+    k_assoc<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
+}
+
+}  // namespace lisreg

@@ -1,0 +1,320 @@
+// lisreg_index.hip — device search-index construction for gfx950.
+//
+// Replaces the two pcl::KdTreeFLANN::setInputCloud calls of every registration
+// (/root/reference/src/node/odomEstimationNode.cpp:602-603; subMapOptmizationNode.cpp:1516-1517, 4496-4497) with a
+// uniform-grid bucket sort of the target cloud, and tile-sorts the source features of a whole batch so that a
+// workgroup's 256 queries are spatially compact (small LDS staging footprint in lisreg_assoc.hip).
+//
+// One deterministic bucket sort serves both: histogram (integer atomics, order-independent counts) ->
+// exclusive scan -> scatter (atomic cursor, arbitrary order inside a bucket) -> rank pass that orders every
+// bucket by (sub-key, original index).  The result is bit-reproducible run to run.  All passes are HBM-bound
+// streaming/gather passes with coalesced 16-byte records; nothing here is GEMM-shaped.
+#include "lisreg_internal.hpp"
+
+namespace lisreg {
+
+namespace {
+
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile  = kScanBlock * kScanItems;   // 2048 buckets per workgroup
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread workgroup; *total = workgroup sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* s_wave /* [4] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = wave_incl_scan(v, lane);
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int s = s_wave[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const int* __restrict__ in, int* __restrict__ out,
+                                                           int* __restrict__ block_sums, int n)
+{
+    __shared__ int s_wave[4];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    int v[kScanItems], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; sum += v[i]; }
+    int total;
+    int ex = block_excl_scan(sum, &total, s_wave);
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of the per-tile sums in place, grand total appended at [nb]
+__global__ __launch_bounds__(kScanBlock) void k_scan_tops(int* __restrict__ block_sums, int nb)
+{
+    __shared__ int s_wave[4];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += kScanBlock) {
+        int i = b0 + threadIdx.x;
+        int v = i < nb ? block_sums[i] : 0;
+        int total;
+        int ex = block_excl_scan(v, &total, s_wave);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_add(int* __restrict__ out, const int* __restrict__ block_sums,
+                                                         int n, int nb)
+{
+    const int off = block_sums[blockIdx.x];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] += off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
+}
+
+void exclusive_scan(const int* in, int* out /* [n+1] */, int* tmp, int n, hipStream_t st)
+{
+    const int nb = (n + kScanTile - 1) / kScanTile;
+    k_scan_local<<<nb, kScanBlock, 0, st>>>(in, out, tmp, n);
+    k_scan_tops<<<1, kScanBlock, 0, st>>>(tmp, nb);
+    k_scan_add<<<nb, kScanBlock, 0, st>>>(out, tmp, n, nb);
+}
+
+// ---- bounding box ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__ pts, int n, float* __restrict__ part)
+{
+    __shared__ float s[4][6];
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float4 p = pts[i];
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], d));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 3; ++k) { s[wave][k] = lo[k]; s[wave][3 + k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_bbox_final(const float* __restrict__ part, int nb, float* __restrict__ bbox6)
+{
+    const int k = threadIdx.x;
+    if (k >= 6) return;
+    float v = part[k];
+    for (int b = 1; b < nb; ++b) v = k < 3 ? fminf(v, part[b * 6 + k]) : fmaxf(v, part[b * 6 + k]);
+    bbox6[k] = v;
+}
+
+// ---- target keys -------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_coord(float v, float origin, float inv_cell, int n)
+{
+    int c = (int)floorf((v - origin) * inv_cell);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+__global__ __launch_bounds__(256) void k_target_keys(const float4* __restrict__ pts, int n, GridIndex g,
+                                                     uint32_t* __restrict__ elem_bucket,
+                                                     uint32_t* __restrict__ elem_sub, int* __restrict__ hist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const int ix = cell_coord(p.x, g.ox, g.inv_cell, g.nx);
+    const int iy = cell_coord(p.y, g.oy, g.inv_cell, g.ny);
+    const int iz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
+    const uint32_t b = (uint32_t)((ix * g.ny + iy) * g.nz + iz);
+    elem_bucket[i] = b;
+    elem_sub[i] = 0u;
+    atomicAdd(&hist[b], 1);
+}
+
+// ---- source keys: tile of the point under the item's INITIAL pose (pcl::getTransformation, common.cpp:54-57) --
+__device__ __forceinline__ void pose_matrix(const float* T, float M[12])
+{
+    const float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
+    const float DE = D * E, DF = D * F;
+    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
+    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
+    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v)   // 3 bits -> every third bit
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
+}
+
+__global__ __launch_bounds__(kBlockQ) void k_source_keys(const BlockDesc* __restrict__ blocks,
+                                                         const Segment* __restrict__ segs,
+                                                         const ItemState* __restrict__ items,
+                                                         uint32_t* __restrict__ elem_bucket,
+                                                         uint32_t* __restrict__ elem_sub, int* __restrict__ hist)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    if ((int)threadIdx.x >= bd.count) return;
+    const Segment sg = segs[bd.seg];
+    float M[12];
+    pose_matrix(items[bd.item].T_init, M);
+    const int e = bd.start + threadIdx.x;
+    const float4 p = sg.src[e];
+    const float x = M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3];
+    const float y = M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7];
+    const float z = M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11];
+    // tile coordinate and 1/8-tile sub-cell (9-bit Morton) — sort keys only, clamping is harmless
+    const float fx = (x - sg.tox) * sg.inv_tile, fy = (y - sg.toy) * sg.inv_tile, fz = (z - sg.toz) * sg.inv_tile;
+    int tx = (int)floorf(fx), ty = (int)floorf(fy), tz = (int)floorf(fz);
+    uint32_t sx = (uint32_t)(int)((fx - floorf(fx)) * 8.f) & 7u;
+    uint32_t sy = (uint32_t)(int)((fy - floorf(fy)) * 8.f) & 7u;
+    uint32_t sz = (uint32_t)(int)((fz - floorf(fz)) * 8.f) & 7u;
+    tx = tx < 0 ? 0 : (tx >= sg.tnx ? sg.tnx - 1 : tx);
+    ty = ty < 0 ? 0 : (ty >= sg.tny ? sg.tny - 1 : ty);
+    tz = tz < 0 ? 0 : (tz >= sg.tnz ? sg.tnz - 1 : tz);
+    const uint32_t b = (uint32_t)(sg.bucket_base + (tx * sg.tny + ty) * sg.tnz + tz);
+    const int flat = sg.flat_base + e;
+    elem_bucket[flat] = b;
+    elem_sub[flat] = (spread3(sx) << 2) | (spread3(sy) << 1) | spread3(sz);
+    atomicAdd(&hist[b], 1);
+}
+
+// ---- scatter + rank ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ elem_bucket,
+                                                 const uint32_t* __restrict__ elem_sub, int n,
+                                                 const int* __restrict__ bucket_start, int* __restrict__ hist,
+                                                 uint32_t* __restrict__ tmp_bucket, uint32_t* __restrict__ tmp_sub,
+                                                 int* __restrict__ tmp_idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = elem_bucket[i];
+    const int pos = bucket_start[b] + atomicSub(&hist[b], 1) - 1;
+    tmp_bucket[pos] = b;
+    tmp_sub[pos] = elem_sub[i];
+    tmp_idx[pos] = i;
+}
+
+// final position of scattered slot p inside its bucket: rank by (sub-key, original index)
+__device__ __forceinline__ int rank_in_bucket(int p, const uint32_t* __restrict__ tmp_bucket,
+                                              const uint32_t* __restrict__ tmp_sub, const int* __restrict__ tmp_idx,
+                                              const int* __restrict__ bucket_start, int* idx_out)
+{
+    const uint32_t b = tmp_bucket[p];
+    const int s = bucket_start[b], e = bucket_start[b + 1];
+    const uint32_t sub = tmp_sub[p];
+    const int idx = tmp_idx[p];
+    int rank = 0;
+    for (int j = s; j < e; ++j) {
+        const uint32_t sj = tmp_sub[j];
+        const int ij = tmp_idx[j];
+        rank += (sj < sub || (sj == sub && ij < idx)) ? 1 : 0;
+    }
+    *idx_out = idx;
+    return s + rank;
+}
+
+__global__ __launch_bounds__(256) void k_rank_target(const float4* __restrict__ pts, int n,
+                                                     const uint32_t* __restrict__ tmp_bucket,
+                                                     const uint32_t* __restrict__ tmp_sub,
+                                                     const int* __restrict__ tmp_idx,
+                                                     const int* __restrict__ bucket_start,
+                                                     float4* __restrict__ sorted_out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int idx;
+    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &idx);
+    float4 v = pts[idx];
+    v.w = __int_as_float(idx);
+    sorted_out[dst] = v;
+}
+
+__global__ __launch_bounds__(256) void k_rank_source(const Segment* __restrict__ segs, int n_segs, int n,
+                                                     const uint32_t* __restrict__ tmp_bucket,
+                                                     const uint32_t* __restrict__ tmp_sub,
+                                                     const int* __restrict__ tmp_idx,
+                                                     const int* __restrict__ bucket_start,
+                                                     float4* __restrict__ sorted_all, int* __restrict__ order_all)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int flat;
+    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &flat);
+    int lo = 0, hi = n_segs - 1;           // last segment with flat_base <= flat
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].flat_base <= flat) lo = mid; else hi = mid - 1;
+    }
+    const int e = flat - segs[lo].flat_base;
+    sorted_all[dst] = segs[lo].src[e];
+    order_all[dst] = e;
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------------------------------------
+void launch_bbox(const float4* pts, int n, float* bbox6, float* scratch /* >= 6*256 floats */, hipStream_t st)
+{
+    int nb = (n + 255) / 256;
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    k_bbox_partial<<<nb, 256, 0, st>>>(pts, n, scratch);
+    k_bbox_final<<<1, 64, 0, st>>>(scratch, nb, bbox6);
+}
+
+void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_out, int* cell_start_out,
+                         int n_cells, SortBuffers sb, hipStream_t st)
+{
+    (void)hipMemsetAsync(sb.hist, 0, sizeof(int) * (size_t)n_cells, st);
+    if (n > 0) k_target_keys<<<(n + 255) / 256, 256, 0, st>>>(pts, n, g, sb.elem_bucket, sb.elem_sub, sb.hist);
+    exclusive_scan(sb.hist, cell_start_out, sb.scan_tmp, n_cells, st);
+    if (n > 0) {
+        k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, cell_start_out, sb.hist,
+                                                   sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
+        k_rank_target<<<(n + 255) / 256, 256, 0, st>>>(pts, n, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx,
+                                                       cell_start_out, sorted_out);
+    }
+}
+
+void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
+                         const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all,
+                         int* order_all, hipStream_t st)
+{
+    (void)hipMemsetAsync(sb.hist, 0, sizeof(int) * (size_t)n_buckets, st);
+    if (n_blocks > 0)
+        k_source_keys<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, items, sb.elem_bucket, sb.elem_sub, sb.hist);
+    exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
+    if (n_elems > 0) {
+        k_scatter<<<(n_elems + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n_elems, sb.bucket_start,
+                                                         sb.hist, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
+        k_rank_source<<<(n_elems + 255) / 256, 256, 0, st>>>(segs, n_segs, n_elems, sb.tmp_bucket, sb.tmp_sub,
+                                                             sb.tmp_idx, sb.bucket_start, sorted_all, order_all);
+    }
+}
+
+}  // namespace lisreg

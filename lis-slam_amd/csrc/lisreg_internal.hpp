@@ -1,0 +1,106 @@
+// lisreg_internal.hpp — device-side data contract shared by the HIP kernels and the C-ABI host layer.
+// gfx950 only (wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs). Not a public header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lisreg.h"
+
+namespace lisreg {
+
+constexpr int kBlockQ     = 256;   // queries per workgroup in the correspondence kernel (4 waves)
+constexpr int kStageCap   = 1024;  // target points staged in LDS per chunk (16 KiB)
+constexpr int kNumAcc     = 28;    // 21 upper-tri AtA + 6 AtB + 1 count
+constexpr int kResultSize = 12;    // floats per item in the result block
+constexpr int kTraceStride = LISREG_TRACE_STRIDE;
+
+// Uniform-grid index over one target cloud (replaces one pcl::KdTreeFLANN, odomEstimationNode.cpp:602-603).
+// Points are bucket-sorted by cell; linear cell id = (ix*ny + iy)*nz + iz (z fastest), so a z-range of one
+// (ix,iy) column is one contiguous run of the sorted array.
+struct GridIndex {
+    const float4* pts;         // [n] sorted; .w = bit-cast ORIGINAL index in the caller's cloud
+    const int*    cell_start;  // [nx*ny*nz + 1]
+    int   n;
+    float ox, oy, oz;          // grid origin (min corner)
+    float cell, inv_cell;
+    int   nx, ny, nz;
+};
+
+// One (item, kind) source segment; kind 0 = edge features vs corner target, 1 = planar features vs surf target.
+struct Segment {
+    const float4* src;         // caller's device records (x,y,z,payload), original order
+    int   n;
+    int   item;
+    int   kind;
+    int   target;              // index into the GridIndex array (slot*2 + kind)
+    int   flat_base;           // first position of this segment in the batch-wide sorted arrays
+    int   bucket_base;         // first sort bucket of this segment
+    int   tnx, tny, tnz;       // sort-tile grid dims
+    float tox, toy, toz;       // sort-tile grid origin
+    float inv_tile;
+};
+
+// One workgroup of the correspondence kernel (also the unit of the source-key kernel).
+struct BlockDesc {
+    int seg;                   // segment id
+    int start;                 // first query of the block, relative to the segment
+    int count;                 // <= kBlockQ
+    int item;
+};
+
+// Literals of lisreg_params in the form the kernels want (passed by value as a kernel argument).
+struct DevParams {
+    float tau, line_ratio, plane_tol, accept_s, conv_deg, conv_cm, eig_thresh;
+    int   min_corr, use_label, emulate_shadow, skip_empty, fixed_iters, bound, edge_min, surf_min, use_imu;
+    float imu_w, rot_tol, z_tol;
+    float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
+};
+
+// Mutable per-registration state (device resident for the whole GN loop — no host sync per iteration).
+struct ItemState {
+    float T[6];                // transformTobeMapped
+    float T_init[6];
+    float P[36];               // matP
+    int   iter;                // iterations started so far
+    int   done;                // converged / exhausted: all later launches skip this item
+    int   iters_out;           // iterCount as the reference reports it
+    float deltaR, deltaT;
+    int   degenerate;          // isDegenerate
+    int   degenerate_in;
+    int   n_corr;
+    int   any_solved;
+    int   guard_failed;        // NOT_ENOUGH_FEATURES
+    int   blk_begin, blk_count;// this item's range in the partials array (corner blocks first, then surf)
+    int   n_sc, n_ss;          // source sizes (guard)
+    lisreg_imu imu;
+};
+
+// ---- launchers (lisreg_kernels.hip); all enqueue on `st`, none synchronise --------------------------------
+struct SortBuffers {           // scratch for one deterministic bucket sort
+    int*      hist;            // [n_buckets] counts (consumed by the scatter)
+    int*      bucket_start;    // [n_buckets + 1]
+    int*      scan_tmp;        // [ceil(n_buckets / 2048) + 1]
+    uint32_t* elem_bucket;     // [n_elems] bucket of each ORIGINAL element
+    uint32_t* elem_sub;        // [n_elems] sub-key of each original element
+    uint32_t* tmp_bucket;      // [n_elems] by scattered position
+    uint32_t* tmp_sub;
+    int*      tmp_idx;
+};
+
+// bounding box of device records -> bbox6 = {minx,miny,minz,maxx,maxy,maxz} (device)
+void launch_bbox(const float4* pts, int n, float* bbox6, float* scratch /* >= 6*256 floats */, hipStream_t st);
+// target index: sorted_out / cell_start_out for the grid described by `g` (g.pts / g.cell_start ignored)
+void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_out, int* cell_start_out,
+                         int n_cells, SortBuffers sb, hipStream_t st);
+// sources of a whole batch: tile-sort every segment under its item's initial pose
+void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
+                         const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
+                         hipStream_t st);
+void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_t st);
+void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
+                  const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
+                  hipStream_t st);
+void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
+                  int trace_cap, hipStream_t st);
+void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);
+
+}  // namespace lisreg

@@ -1,0 +1,356 @@
+// lisreg_solve.hip — per-registration Gauss-Newton step, kept on the device so the GN loop never syncs the host.
+//
+// One 64-lane workgroup per registration:
+//   * fixed-order fp64 sum of the workgroup partials written by lisreg_assoc.hip -> AtA, AtB (rounded to float
+//     exactly once, like cv's CV_32F GEMM with double accumulators), n_corr;
+//   * LMOptimization's tail: /root/reference/src/node/odomEstimationNode.cpp:869-872 (`< 50` no-op), :921
+//     cv::solve(DECOMP_QR), :923-946 iteration-0 degeneracy analysis (cv::eigen 6x6, matV.inv()*matV2),
+//     :948-953 projection incl. the local-matP shadowing quirk, :955-973 update + convergence;
+//   * finalize: transformUpdate (:976-1006) and the 12-float result record.
+// 6x6 algebra is tiny and strictly sequential: lane 0 runs it on LDS-resident matrices.
+#include "lisreg_internal.hpp"
+
+namespace lisreg {
+
+namespace {
+
+__device__ float hyp(float a, float b)
+{
+    a = fabsf(a); b = fabsf(b);
+    if (a > b) { b /= a; return a * sqrtf(1.f + b * b); }
+    if (b > 0.f) { a /= b; return b * sqrtf(1.f + a * a); }
+    return 0.f;
+}
+
+// cv::eigen on a symmetric 6x6 float matrix: classical Jacobi (largest off-diagonal pivot), eigenvalues
+// descending, eigenvectors in rows.  A is destroyed.
+__device__ void eigen_sym6(float* A, float* W, float* V, int* indR, int* indC)
+{
+    const int n = 6;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.f : 0.f;
+    for (int k = 0; k < n; ++k) {
+        W[k] = A[k * n + k];
+        if (k < n - 1) {
+            int m = k + 1; float mv = fabsf(A[k * n + m]);
+            for (int i = k + 2; i < n; ++i) { float v = fabsf(A[k * n + i]); if (mv < v) { mv = v; m = i; } }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            int m = 0; float mv = fabsf(A[k]);
+            for (int i = 1; i < k; ++i) { float v = fabsf(A[i * n + k]); if (mv < v) { mv = v; m = i; } }
+            indC[k] = m;
+        }
+    }
+    for (int it = 0; it < n * n * 30; ++it) {
+        int k = 0, l; float mv = fabsf(A[indR[0]]);
+        for (int i = 1; i < n - 1; ++i) { float v = fabsf(A[i * n + indR[i]]); if (mv < v) { mv = v; k = i; } }
+        l = indR[k];
+        for (int i = 1; i < n; ++i) { float v = fabsf(A[indC[i] * n + i]); if (mv < v) { mv = v; k = indC[i]; l = i; } }
+        const float p = A[k * n + l];
+        if (fabsf(p) <= 1.1920929e-7f) break;
+        const float y = (W[l] - W[k]) * 0.5f;
+        float t = fabsf(y) + hyp(p, y);
+        float s = hyp(p, t);
+        const float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0.f) { s = -s; t = -t; }
+        A[k * n + l] = 0.f;
+        W[k] -= t; W[l] += t;
+#define LR(v0, v1) do { const float a0_ = (v0), b0_ = (v1); (v0) = a0_ * c - b0_ * s; (v1) = a0_ * s + b0_ * c; } while (0)
+        for (int i = 0; i < k; ++i)      LR(A[i * n + k], A[i * n + l]);
+        for (int i = k + 1; i < l; ++i)  LR(A[k * n + i], A[i * n + l]);
+        for (int i = l + 1; i < n; ++i)  LR(A[k * n + i], A[l * n + i]);
+        for (int i = 0; i < n; ++i)      LR(V[k * n + i], V[l * n + i]);
+#undef LR
+        for (int j = 0; j < 2; ++j) {
+            const int idx = j == 0 ? k : l;
+            if (idx < n - 1) {
+                int m = idx + 1; float mv2 = fabsf(A[idx * n + m]);
+                for (int i = idx + 2; i < n; ++i) { float v = fabsf(A[idx * n + i]); if (mv2 < v) { mv2 = v; m = i; } }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                int m = 0; float mv2 = fabsf(A[idx]);
+                for (int i = 1; i < idx; ++i) { float v = fabsf(A[i * n + idx]); if (mv2 < v) { mv2 = v; m = i; } }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        int m = k;
+        for (int i = k + 1; i < n; ++i) if (W[m] < W[i]) m = i;
+        if (m != k) {
+            float tw = W[m]; W[m] = W[k]; W[k] = tw;
+            for (int i = 0; i < n; ++i) { float tv = V[m * n + i]; V[m * n + i] = V[k * n + i]; V[k * n + i] = tv; }
+        }
+    }
+}
+
+// cv::solve(AtA, AtB, X, DECOMP_QR): Householder QR.  A (6x6) and c (6) are destroyed.  false if singular.
+__device__ bool solve6_qr(float* A, float* c, float* x, float* v)
+{
+    const int N = 6;
+    for (int k = 0; k < N; ++k) {
+        const float c0 = A[k * N + k];
+        float tail = 0.f;
+        for (int i = k + 1; i < N; ++i) tail += A[i * N + k] * A[i * N + k];
+        float beta, tau;
+        if (tail <= 1.17549435e-38f) { tau = 0.f; beta = c0; for (int i = k + 1; i < N; ++i) v[i] = 0.f; }
+        else {
+            beta = sqrtf(c0 * c0 + tail);
+            if (c0 >= 0.f) beta = -beta;
+            for (int i = k + 1; i < N; ++i) v[i] = A[i * N + k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        A[k * N + k] = beta;
+        if (tau != 0.f) {
+            for (int j = k + 1; j < N; ++j) {
+                float dot = A[k * N + j];
+                for (int i = k + 1; i < N; ++i) dot += v[i] * A[i * N + j];
+                dot *= tau;
+                A[k * N + j] -= dot;
+                for (int i = k + 1; i < N; ++i) A[i * N + j] -= dot * v[i];
+            }
+            float dot = c[k];
+            for (int i = k + 1; i < N; ++i) dot += v[i] * c[i];
+            dot *= tau;
+            c[k] -= dot;
+            for (int i = k + 1; i < N; ++i) c[i] -= dot * v[i];
+        }
+    }
+    for (int i = 0; i < N; ++i) if (fabsf(A[i * N + i]) <= 1.17549435e-38f) { for (int j = 0; j < N; ++j) x[j] = 0.f; return false; }
+    for (int i = N - 1; i >= 0; --i) {
+        float s = c[i];
+        for (int j = i + 1; j < N; ++j) s -= A[i * N + j] * x[j];
+        x[i] = s / A[i * N + i];
+    }
+    return true;
+}
+
+// cv::Mat::inv() (DECOMP_LU): LU with partial pivoting.  A destroyed, B receives the inverse (zeros if singular).
+__device__ void inv6_lu(float* A, float* B)
+{
+    const int N = 6;
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) B[i * N + j] = (i == j) ? 1.f : 0.f;
+    for (int i = 0; i < N; ++i) {
+        int k = i;
+        for (int j = i + 1; j < N; ++j) if (fabsf(A[j * N + i]) > fabsf(A[k * N + i])) k = j;
+        if (fabsf(A[k * N + i]) < 1.1920929e-7f * 100) { for (int j = 0; j < N * N; ++j) B[j] = 0.f; return; }
+        if (k != i) for (int j = 0; j < N; ++j) {
+            float t = A[i * N + j]; A[i * N + j] = A[k * N + j]; A[k * N + j] = t;
+            t = B[i * N + j]; B[i * N + j] = B[k * N + j]; B[k * N + j] = t;
+        }
+        const float d = -1.f / A[i * N + i];
+        for (int j = i + 1; j < N; ++j) {
+            const float alpha = A[j * N + i] * d;
+            for (int m = i + 1; m < N; ++m) A[j * N + m] += alpha * A[i * N + m];
+            for (int m = 0; m < N; ++m) B[j * N + m] += alpha * B[i * N + m];
+        }
+    }
+    for (int i = N - 1; i >= 0; --i)
+        for (int j = 0; j < N; ++j) {
+            float s = B[i * N + j];
+            for (int k = i + 1; k < N; ++k) s -= A[i * N + k] * B[k * N + j];
+            B[i * N + j] = s / A[i * N + i];
+        }
+}
+
+__global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_items) return;
+    ItemState* it = &items[i];
+    for (int k = 0; k < 6; ++k) it->T[k] = it->T_init[k];
+    for (int k = 0; k < 36; ++k) it->P[k] = 0.f;
+    const bool guard_ok = (it->n_sc > P.edge_min) && (it->n_ss > P.surf_min);   // odomEstimationNode.cpp:598
+    it->iter = 0;
+    it->guard_failed = guard_ok ? 0 : 1;
+    it->done = guard_ok ? 0 : 1;
+    it->iters_out = 0;
+    it->deltaR = 100.f; it->deltaT = 100.f;                                      // member initialisers :70-71
+    it->degenerate = it->degenerate_in;
+    it->n_corr = 0;
+    it->any_solved = 0;
+}
+
+__global__ __launch_bounds__(64) void k_solve(ItemState* __restrict__ items, const DevParams P,
+                                              const double* __restrict__ partials, float* __restrict__ trace,
+                                              int trace_cap)
+{
+    __shared__ float s_AtA[36], s_AtB[6], s_X[6], s_A[36], s_c[6], s_v[6];
+    __shared__ float s_E[6], s_V[36], s_V2[36], s_Vi[36];
+    __shared__ int   s_ind[12];
+    __shared__ double s_sum[kNumAcc];
+
+    ItemState* it = &items[blockIdx.x];
+    if (it->done) return;
+    const int lane = threadIdx.x;
+    if (lane < kNumAcc) {
+        double s = 0.0;
+        const double* p = partials + (size_t)it->blk_begin * kNumAcc + lane;
+        for (int b = 0; b < it->blk_count; ++b) s += p[(size_t)b * kNumAcc];   // fixed order
+        s_sum[lane] = s;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+
+    const int iter = it->iter;
+    const int n_sel = (int)(s_sum[27] + 0.5);
+    it->n_corr = n_sel;
+    float* tr = (trace && iter < trace_cap) ? trace + ((size_t)blockIdx.x * trace_cap + iter) * kTraceStride : nullptr;
+    if (tr) {
+        for (int k = 0; k < kTraceStride; ++k) tr[k] = 0.f;
+        tr[0] = (float)n_sel;
+        for (int k = 0; k < 6; ++k) tr[49 + k] = it->T[k];
+    }
+    bool finished = false;
+    if (n_sel >= P.min_corr) {                                   // :870-872
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) { const float v = (float)s_sum[k++]; s_AtA[r * 6 + c] = v; s_AtA[c * 6 + r] = v; }
+        for (int r = 0; r < 6; ++r) s_AtB[r] = (float)s_sum[21 + r];
+        for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
+        for (int i = 0; i < 6; ++i) s_c[i] = s_AtB[i];
+        solve6_qr(s_A, s_c, s_X, s_v);                           // :921
+        int isDeg = it->degenerate;
+        if (iter == 0) {                                         // :923-946
+            for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
+            eigen_sym6(s_A, s_E, s_V, s_ind, s_ind + 6);
+            for (int i = 0; i < 36; ++i) s_V2[i] = s_V[i];
+            isDeg = 0;
+            for (int i = 5; i >= 0; --i) {
+                if (s_E[i] < P.eig_thresh) { for (int j = 0; j < 6; ++j) s_V2[i * 6 + j] = 0.f; isDeg = 1; }
+                else break;
+            }
+            for (int i = 0; i < 36; ++i) s_A[i] = s_V[i];
+            inv6_lu(s_A, s_Vi);
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+                double s = 0; for (int m = 0; m < 6; ++m) s += (double)s_Vi[r * 6 + m] * (double)s_V2[m * 6 + c];
+                it->P[r * 6 + c] = (float)s;
+            }
+        } else if (P.emulate_shadow) {
+            for (int i = 0; i < 36; ++i) it->P[i] = 0.f;         // local zero cv::Mat matP (:880)
+        }
+        if (isDeg) {                                             // :948-953
+            float X2[6];
+            for (int r = 0; r < 6; ++r) X2[r] = s_X[r];
+            for (int r = 0; r < 6; ++r) {
+                double s = 0; for (int m = 0; m < 6; ++m) s += (double)it->P[r * 6 + m] * (double)X2[m];
+                s_X[r] = (float)s;
+            }
+        }
+        for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];          // :955-960
+        const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
+        const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
+        const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+        const float dT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+        it->deltaR = dR; it->deltaT = dT;
+        it->degenerate = isDeg;
+        it->any_solved = 1;
+        if (tr) {
+            for (int i = 0; i < 36; ++i) tr[1 + i] = s_AtA[i];
+            for (int i = 0; i < 6; ++i) { tr[37 + i] = s_AtB[i]; tr[43 + i] = s_X[i]; tr[49 + i] = it->T[i]; }
+            tr[55] = 1.f;
+        }
+        if (dR < P.conv_deg && dT < P.conv_cm && P.fixed_iters <= 0) {   // :969-972 -> break at :617
+            it->iters_out = iter;
+            finished = true;
+        }
+    }
+    it->iter = iter + 1;
+    if (!finished && iter + 1 >= P.bound) { it->iters_out = P.bound; finished = true; }
+    if (finished) it->done = 1;
+}
+
+// tf::Quaternion / tf::Matrix3x3 pieces of transformUpdate (odomEstimationNode.cpp:976-1006), double like tf
+struct Quat { double x, y, z, w; };
+__device__ Quat q_rpy(double roll, double pitch, double yaw)
+{
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+    return Quat{ sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+                 cr * cp * cy + sr * sp * sy };
+}
+__device__ double q_dot(Quat a, Quat b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ Quat q_slerp(Quat a, Quat b, double t)
+{
+    const double s = sqrt(q_dot(a, a) * q_dot(b, b));
+    const double d = q_dot(a, b);
+    const double theta = (d < 0 ? acos(-d / s) * 2.0 : acos(d / s) * 2.0) / 2.0;
+    if (theta != 0.0) {
+        const double dd = 1.0 / sin(theta), s0 = sin((1.0 - t) * theta), s1 = sin(t * theta);
+        const double sg = d < 0 ? -1.0 : 1.0;
+        return Quat{ (a.x * s0 + sg * b.x * s1) * dd, (a.y * s0 + sg * b.y * s1) * dd,
+                     (a.z * s0 + sg * b.z * s1) * dd, (a.w * s0 + sg * b.w * s1) * dd };
+    }
+    return a;
+}
+__device__ void q_get_rpy(Quat q, double& roll, double& pitch, double& yaw)
+{
+    const double d = q_dot(q, q), s = 2.0 / d;
+    const double xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    const double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    const double xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+    if (fabs(m20) >= 1) {
+        yaw = 0;
+        roll = atan2(m21, m22);
+        pitch = m20 < 0 ? 1.5707963267948966 : -1.5707963267948966;
+    } else {
+        pitch = -asin(m20);
+        const double cp = cos(pitch);
+        roll = atan2(m21 / cp, m22 / cp);
+        yaw = atan2(m10 / cp, m00 / cp);
+    }
+}
+__device__ float clampf(float v, float lim) { v = v < -lim ? -lim : v; return v > lim ? lim : v; }
+
+__global__ __launch_bounds__(64) void k_finalize(ItemState* __restrict__ items, int n_items, const DevParams P,
+                                                 float* __restrict__ results)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_items) return;
+    ItemState* it = &items[i];
+    float T[6];
+    for (int k = 0; k < 6; ++k) T[k] = it->T[k];
+    int status = LISREG_OK;
+    if (it->guard_failed) status = LISREG_NOT_ENOUGH_FEATURES;          // :623-625, T untouched
+    else {
+        if (P.use_imu && it->imu.imu_available && fabsf(it->imu.imu_pitch_init) < 1.4f) {
+            const double w = (double)P.imu_w;
+            double r, p, y;
+            q_get_rpy(q_slerp(q_rpy((double)T[0], 0, 0), q_rpy((double)it->imu.imu_roll_init, 0, 0), w), r, p, y);
+            T[0] = (float)r;
+            q_get_rpy(q_slerp(q_rpy(0, (double)T[1], 0), q_rpy(0, (double)it->imu.imu_pitch_init, 0), w), r, p, y);
+            T[1] = (float)p;
+        }
+        T[0] = clampf(T[0], P.rot_tol);                                   // constraintTransformation, common.cpp:285
+        T[1] = clampf(T[1], P.rot_tol);
+        T[5] = clampf(T[5], P.z_tol);
+        if (!it->any_solved) status = LISREG_TOO_FEW_CORRESPONDENCES;
+    }
+    float* r = results + (size_t)i * kResultSize;
+    for (int k = 0; k < 6; ++k) r[k] = T[k];
+    r[6] = (float)it->iters_out; r[7] = it->deltaR; r[8] = it->deltaT;
+    r[9] = (float)it->degenerate; r[10] = (float)it->n_corr; r[11] = (float)status;
+}
+
+}  // namespace
+
+void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_t st)
+{
+    if (n_items > 0) k_reset_items<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm);
+}
+
+void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
+                  int trace_cap, hipStream_t st)
+{
+    if (n_items > 0) k_solve<<<n_items, 64, 0, st>>>(items, prm, partials, trace, trace_cap);
+}
+
+void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st)
+{
+    if (n_items > 0) k_finalize<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, results);
+}
+
+}  // namespace lisreg

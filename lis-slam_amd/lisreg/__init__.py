@@ -1,0 +1,302 @@
+"""lisreg — thin ctypes binding of liblisreg.so (include/lisreg.h), used by tests/, bench.py and smoke().
+
+The product is the C-ABI shared library built from lis-slam_amd/csrc (hand-written HIP for gfx950); this module
+only marshals numpy arrays of PCL point structs (the reference's host layout, src/include/common.h:9,25-35)
+and device pointers across that boundary.  It has NO compute of its own and NO CPU fallback: if the shared
+library is missing or no HIP device is visible, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "liblisreg.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES = 0, 1, 2
+ERR_ARG, ERR_HIP, ERR_NO_TARGET, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5
+FMT_XYZI, FMT_XYZIL, FMT_DEVICE = 0, 1, 2
+VARIANT_ODOM, VARIANT_KEYFRAME, VARIANT_SUBMAP = 1, 2, 3
+TRACE_STRIDE = 56
+RESULT_SIZE = 12
+
+# every symbol include/lisreg.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
+    "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
+    "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_trace",
+    "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
+    "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("max_iters", C.c_int), ("fixed_iters", C.c_int), ("knn_sq_thresh", C.c_float),
+                ("conv_deg", C.c_float), ("conv_cm", C.c_float), ("min_corr", C.c_int),
+                ("eig_thresh", C.c_float), ("edge_min", C.c_int), ("surf_min", C.c_int),
+                ("line_ratio", C.c_float), ("plane_tol", C.c_float), ("accept_s", C.c_float),
+                ("use_label_weight", C.c_int), ("label_score", C.c_float * 32),
+                ("emulate_matp_shadow", C.c_int), ("skip_empty_target", C.c_int), ("use_imu_blend", C.c_int),
+                ("imu_rpy_weight", C.c_float), ("rotation_tol", C.c_float), ("z_tol", C.c_float)]
+
+
+class Imu(C.Structure):
+    _fields_ = [("imu_available", C.c_int), ("imu_roll_init", C.c_float), ("imu_pitch_init", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("deltaR", C.c_float), ("deltaT", C.c_float), ("degenerate", C.c_int),
+                ("n_corr_last", C.c_int), ("status", C.c_int)]
+
+
+class Item(C.Structure):
+    _fields_ = [("src_corner", C.c_void_p), ("n_corner", C.c_int), ("src_surf", C.c_void_p), ("n_surf", C.c_int),
+                ("stride_bytes", C.c_int), ("fmt", C.c_int), ("target", C.c_int), ("degenerate_in", C.c_int),
+                ("imu", Imu)]
+
+
+class LisregError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lisreg error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> str:
+    """Compile liblisreg.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC] + ([] if verbose else ["-s"]))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built — run `make -C {CSRC}` (there is no fallback path)")
+        L = C.CDLL(LIB_PATH)
+        vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.lisreg_device_count.restype = C.c_int
+        L.lisreg_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.lisreg_destroy.argtypes = [vp]
+        L.lisreg_destroy.restype = None
+        L.lisreg_last_error.argtypes = [vp]
+        L.lisreg_last_error.restype = C.c_char_p
+        L.lisreg_set_stream.argtypes = [vp, vp]
+        L.lisreg_get_stream.argtypes = [vp]
+        L.lisreg_get_stream.restype = vp
+        L.lisreg_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+        L.lisreg_set_target.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.lisreg_set_target_slot.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.lisreg_target_from_classes.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
+                                                 C.c_int, C.c_int]
+        L.lisreg_align.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Params),
+                                   C.POINTER(Imu), fp, C.POINTER(Stats)]
+        L.lisreg_align_batch.argtypes = [vp, C.c_int, C.POINTER(Item), C.POINTER(Params), fp, C.POINTER(Stats)]
+        L.lisreg_batch_prepare.argtypes = [vp, C.c_int, C.POINTER(Item), C.POINTER(Params), fp]
+        L.lisreg_batch_run.argtypes = [vp]
+        L.lisreg_batch_fetch.argtypes = [vp, fp, C.POINTER(Stats)]
+        L.lisreg_batch_result_device.argtypes = [vp]
+        L.lisreg_batch_result_device.restype = vp
+        L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
+        L.lisreg_set_profiling.argtypes = [vp, C.c_int]
+        L.lisreg_get_timing.argtypes = [vp, C.POINTER(C.c_double)]
+        L.lisreg_pose_to_matrix.argtypes = [fp, fp]
+        L.lisreg_pose_to_matrix.restype = None
+        L.lisreg_transform_update.argtypes = [C.POINTER(Params), C.POINTER(Imu), fp]
+        L.lisreg_transform_update.restype = None
+        L.lisreg_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+        L.lisreg_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
+        L.lisreg_gather_results.argtypes = [vp, vp, C.c_int, vp]
+        L.lisreg_comm_destroy.argtypes = [vp]
+        L.lisreg_comm_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def default_params(variant: int = VARIANT_ODOM) -> Params:
+    p = Params()
+    rc = lib().lisreg_default_params(variant, C.byref(p))
+    if rc:
+        raise LisregError(rc, "lisreg_default_params")
+    return p
+
+
+def pose_to_matrix(T) -> np.ndarray:
+    T = np.ascontiguousarray(T, np.float32)
+    M = np.zeros(12, np.float32)
+    lib().lisreg_pose_to_matrix(T.ctypes.data_as(C.POINTER(C.c_float)), M.ctypes.data_as(C.POINTER(C.c_float)))
+    return M.reshape(3, 4)
+
+
+def transform_update(params: Params, imu: Imu | None, T) -> np.ndarray:
+    T = np.array(T, np.float32)
+    lib().lisreg_transform_update(C.byref(params), C.byref(imu) if imu is not None else None,
+                                  T.ctypes.data_as(C.POINTER(C.c_float)))
+    return T
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and len(a) else None
+
+
+def _fmt_of(cloud) -> int:
+    return FMT_XYZIL if (cloud.dtype.names and "label" in cloud.dtype.names) else FMT_XYZI
+
+
+def stats_dict(s: Stats) -> dict:
+    return dict(iters=s.iters, deltaR=s.deltaR, deltaT=s.deltaT, degenerate=s.degenerate,
+                n_corr_last=s.n_corr_last, status=s.status)
+
+
+class Context:
+    """One lisreg_ctx (single-threaded; one per caller, like the three reference node classes)."""
+
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.lisreg_create(device, C.byref(h))
+        if rc:
+            raise LisregError(rc, self._L.lisreg_last_error(None).decode())
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._L.lisreg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=(OK,)):
+        if rc not in allow:
+            raise LisregError(rc, self._L.lisreg_last_error(self._h).decode())
+        return rc
+
+    @property
+    def stream(self) -> int:
+        return self._L.lisreg_get_stream(self._h) or 0
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self._L.lisreg_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_option(self, name: str, value: int):
+        self._chk(self._L.lisreg_set_option(self._h, name.encode(), int(value)))
+
+    # -- target ------------------------------------------------------------------------------------------
+    def set_target(self, corner: np.ndarray, surf: np.ndarray, slot: int = 0):
+        """corner/surf: numpy arrays of PCL point structs (itemsize = stride)."""
+        corner = np.ascontiguousarray(corner); surf = np.ascontiguousarray(surf)
+        self._chk(self._L.lisreg_set_target_slot(self._h, slot, _vp(corner), len(corner), _vp(surf), len(surf),
+                                                 corner.dtype.itemsize, _fmt_of(corner)))
+
+    def set_target_device(self, corner_ptr: int, n_corner: int, surf_ptr: int, n_surf: int, slot: int = 0):
+        self._chk(self._L.lisreg_set_target_slot(self._h, slot, C.c_void_p(corner_ptr), n_corner,
+                                                 C.c_void_p(surf_ptr), n_surf, 16, FMT_DEVICE))
+
+    def target_from_classes(self, pole, ground, building, dynamic, slot: int = 0):
+        arrs = [np.ascontiguousarray(a) for a in (pole, ground, building, dynamic)]
+        self._chk(self._L.lisreg_target_from_classes(self._h, slot, _vp(arrs[0]), len(arrs[0]), _vp(arrs[1]),
+                                                     len(arrs[1]), _vp(arrs[2]), len(arrs[2]), _vp(arrs[3]),
+                                                     len(arrs[3]), arrs[0].dtype.itemsize, _fmt_of(arrs[0])))
+
+    # -- single registration ---------------------------------------------------------------------------------
+    def align(self, src_corner: np.ndarray, src_surf: np.ndarray, T_init, params: Params, imu: Imu | None = None):
+        """lisreg_align.  Returns (T, stats dict, trace[n,56])."""
+        sc = np.ascontiguousarray(src_corner); ss = np.ascontiguousarray(src_surf)
+        T = np.array(T_init, np.float32).copy()
+        st = Stats()
+        rc = self._L.lisreg_align(self._h, _vp(sc), len(sc), _vp(ss), len(ss), sc.dtype.itemsize, _fmt_of(sc),
+                                  C.byref(params), C.byref(imu) if imu is not None else None,
+                                  T.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
+        self._chk(rc, allow=(OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES))
+        bound = params.fixed_iters if params.fixed_iters > 0 else params.max_iters
+        buf = np.zeros((max(bound, 1), TRACE_STRIDE), np.float32)
+        n = self._L.lisreg_get_trace(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), max(bound, 1))
+        d = stats_dict(st)
+        if rc == NOT_ENOUGH_FEATURES:
+            d["status"] = NOT_ENOUGH_FEATURES
+        return T, d, buf[:n]
+
+    # -- batches ---------------------------------------------------------------------------------------------
+    def align_batch(self, items: list[dict], T_init: np.ndarray, params: Params):
+        """items: dicts with src_corner, src_surf (PCL struct arrays), optional target, degenerate_in, imu."""
+        n = len(items)
+        arr = (Item * max(n, 1))()
+        keep = []
+        for i, it in enumerate(items):
+            sc = np.ascontiguousarray(it["src_corner"]); ss = np.ascontiguousarray(it["src_surf"])
+            keep += [sc, ss]
+            arr[i].src_corner = _vp(sc); arr[i].n_corner = len(sc)
+            arr[i].src_surf = _vp(ss); arr[i].n_surf = len(ss)
+            arr[i].stride_bytes = sc.dtype.itemsize; arr[i].fmt = _fmt_of(sc)
+            arr[i].target = it.get("target", 0); arr[i].degenerate_in = it.get("degenerate_in", 0)
+            if it.get("imu") is not None:
+                arr[i].imu = it["imu"]
+        T = np.ascontiguousarray(T_init, np.float32).reshape(n, 6).copy()
+        st = (Stats * max(n, 1))()
+        self._chk(self._L.lisreg_align_batch(self._h, n, arr, C.byref(params),
+                                             T.ctypes.data_as(C.POINTER(C.c_float)), st))
+        return T, [stats_dict(st[i]) for i in range(n)]
+
+    def batch_prepare_device(self, items: list[dict], T_init: np.ndarray, params: Params):
+        """items: dicts with corner_ptr, n_corner, surf_ptr, n_surf (device pointers to 16-B records), target."""
+        n = len(items)
+        arr = (Item * max(n, 1))()
+        for i, it in enumerate(items):
+            arr[i].src_corner = C.c_void_p(it["corner_ptr"]) if it["n_corner"] else None
+            arr[i].n_corner = it["n_corner"]
+            arr[i].src_surf = C.c_void_p(it["surf_ptr"]) if it["n_surf"] else None
+            arr[i].n_surf = it["n_surf"]
+            arr[i].stride_bytes = 16; arr[i].fmt = FMT_DEVICE
+            arr[i].target = it.get("target", 0); arr[i].degenerate_in = it.get("degenerate_in", 0)
+            if it.get("imu") is not None:
+                arr[i].imu = it["imu"]
+        T = np.ascontiguousarray(T_init, np.float32).reshape(n, 6)
+        self._n_items = n
+        self._chk(self._L.lisreg_batch_prepare(self._h, n, arr, C.byref(params),
+                                               T.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def batch_run(self):
+        self._chk(self._L.lisreg_batch_run(self._h))
+
+    def batch_fetch(self):
+        n = self._n_items
+        T = np.zeros((n, 6), np.float32)
+        st = (Stats * max(n, 1))()
+        self._chk(self._L.lisreg_batch_fetch(self._h, T.ctypes.data_as(C.POINTER(C.c_float)), st))
+        return T, [stats_dict(st[i]) for i in range(n)]
+
+    @property
+    def result_device_ptr(self) -> int:
+        return self._L.lisreg_batch_result_device(self._h) or 0
+
+    def set_profiling(self, on: bool):
+        self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))
+
+    def timing(self) -> dict:
+        out = (C.c_double * 5)()
+        self._chk(self._L.lisreg_get_timing(self._h, out))
+        return dict(assoc_ms=out[0], assoc_launches=int(out[1]), solve_ms=out[2], solve_launches=int(out[3]),
+                    index_ms=out[4])
+
+
+def pack_device_records(cloud: np.ndarray) -> np.ndarray:
+    """PCL struct array -> contiguous [n,4] float32 view of lisreg_dpoint records (payload = label bits)."""
+    n = len(cloud)
+    out = np.zeros((n, 4), np.float32)
+    out[:, 0], out[:, 1], out[:, 2] = cloud["x"], cloud["y"], cloud["z"]
+    if cloud.dtype.names and "label" in cloud.dtype.names:
+        out[:, 3] = cloud["label"].astype(np.uint32).view(np.float32)
+    return out
