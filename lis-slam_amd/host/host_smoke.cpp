@@ -1,0 +1,50 @@
+// host_smoke.cpp — C++ caller of liblisreg through the reference-shaped host mirror (plain g++, no HIP headers).
+// With a GPU: registers a small synthetic scene (two walls + floor + poles) and checks the pose moved toward truth.
+// Without a GPU: verifies the loud failure path (no CPU fallback) and exits 0.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "lis_slam_registration.hpp"
+
+using namespace lis_slam;
+
+static void add(PointCloud<PointType>& c, float x, float y, float z) { PointType p{}; p.x = x; p.y = y; p.z = z; c.push_back(p); }
+
+int main()
+{
+    if (lisreg_device_count() == 0) {
+        try { Scan2SubMapRegistration<> reg(Variant::Odom); }
+        catch (const RegistrationError& e) { std::printf("no HIP device: constructor failed loudly as designed (%d: %s)\n", e.code, e.what()); return 0; }
+        std::printf("ERROR: context creation succeeded without a device\n");
+        return 1;
+    }
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    std::normal_distribution<float> N(0.f, 0.01f);
+    PointCloud<PointType> mapCorner, mapSurf, corner, surf;
+    for (int i = 0; i < 40000; ++i) {            // floor z=0, wall x=10, wall y=-8
+        float u = U(rng) * 40 - 20, v = U(rng) * 40 - 20, h = U(rng) * 6;
+        add(mapSurf, u + N(rng), v + N(rng), N(rng));
+        if (i % 2 == 0) add(mapSurf, 10 + N(rng), v + N(rng), h);
+        else add(mapSurf, u + N(rng), -8 + N(rng), h);
+    }
+    const float poles[6][2] = { { 3, 4 }, { -5, 6 }, { 7, -3 }, { -6, -4 }, { 1, -6 }, { -2, 9 } };
+    for (int i = 0; i < 6000; ++i) { int k = i % 6; float a = U(rng) * 6.2831853f; add(mapCorner, poles[k][0] + 0.1f * std::cos(a) + N(rng), poles[k][1] + 0.1f * std::sin(a) + N(rng), U(rng) * 5); }
+    // source = subsample of the map moved by the inverse of a known pose (yaw 0.03, t = (0.2,-0.15,0.05))
+    const float yaw = 0.03f, tx = 0.2f, ty = -0.15f, tz = 0.05f, cy = std::cos(yaw), sy = std::sin(yaw);
+    auto inv = [&](const PointType& p) { PointType q{}; float x = p.x - tx, y = p.y - ty; q.x = cy * x + sy * y; q.y = -sy * x + cy * y; q.z = p.z - tz; return q; };
+    for (size_t i = 0; i < mapSurf.size(); i += 7) surf.push_back(inv(mapSurf.points[i]));
+    for (size_t i = 0; i < mapCorner.size(); i += 5) corner.push_back(inv(mapCorner.points[i]));
+
+    Scan2SubMapRegistration<> reg(Variant::Odom);
+    reg.setInputTarget(mapCorner, mapSurf);
+    cloud_info info;
+    int rc = reg.scan2SubMapOptimization(corner, surf, info);
+    const float* T = reg.transformTobeMapped;
+    std::printf("rc=%d iterCount=%d deltaR=%g deltaT=%g isDegenerate=%d nSel=%d T=[%g %g %g %g %g %g]\n", rc, reg.iterCount, reg.deltaR,
+                reg.deltaT, (int)reg.isDegenerate, reg.laserCloudSelNum, T[0], T[1], T[2], T[3], T[4], T[5]);
+    bool ok = rc == LISREG_OK && std::fabs(T[2] - yaw) < 5e-3f && std::fabs(T[3] - tx) < 2e-2f && std::fabs(T[4] - ty) < 2e-2f && std::fabs(T[5] - tz) < 2e-2f;
+    std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
+    return ok ? 0 : 1;
+}

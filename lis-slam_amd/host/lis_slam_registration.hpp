@@ -1,0 +1,133 @@
+// lis_slam_registration.hpp — C++ host-side mirror of the reference's scan-to-submap interface, above the C ABI.
+//
+// The reference has no library seam for this path: three node classes each own a private
+// scan2SubMapOptimization() that talks to ~15 member variables.  This header keeps their names
+// and meaning so a maintainer can swap each body for one call:
+//   OdomEstimationNode      /root/reference/src/node/odomEstimationNode.cpp:29-97 (members), :596-626 (driver)
+//   SubMapOdometryNode      src/node/subMapOptmizationNode.cpp:151-203, :1509-1541
+//   SubMapOptmizationNode   src/node/subMapOptmizationNode.cpp:3302-3333, :4485-4540
+// plus POD mirrors of the message surface (msg/cloud_info.msg, msg/semantic_info.msg) and a PointCloud2
+// byte-layout view, because ROS/PCL are not part of this build.  Header-only, C++17, no dependencies.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lisreg.h"
+
+namespace lis_slam {
+
+// ---- point types (src/include/common.h:9,25-35): 32 bytes, 16-byte aligned, PCL_ADD_POINT4D + intensity -------
+struct alignas(16) PointXYZI  { float x, y, z, _pad0; float intensity; float _pad1[3]; };
+struct alignas(16) PointXYZIL { float x, y, z, _pad0; float intensity; uint16_t label; uint16_t _pad1; float _pad2[2]; };
+static_assert(sizeof(PointXYZI) == 32 && sizeof(PointXYZIL) == 32, "PCL point layout");
+using PointType = PointXYZI;                       // typedef pcl::PointXYZI PointType (common.h:9)
+
+template <class P> struct PointCloud {             // the slice of pcl::PointCloud<P> the path touches
+    std::vector<P> points;
+    size_t size() const { return points.size(); }
+    void clear() { points.clear(); }
+    void push_back(const P& p) { points.push_back(p); }
+};
+
+// ---- sensor_msgs/PointCloud2 byte-layout view: pass a ROS message buffer straight through ---------------------
+struct PointCloud2View {
+    const uint8_t* data = nullptr;
+    uint32_t width = 0, height = 1, point_step = 32;
+    int off_x = 0, off_y = 4, off_z = 8, off_intensity = 16, off_label = -1;   // field offsets by name
+    size_t size() const { return (size_t)width * height; }
+    int fmt() const { return off_label >= 0 ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI; }
+};
+
+// ---- msg/cloud_info.msg:1-25 and msg/semantic_info.msg:1-34 (scalars + the clouds the path reads) --------------
+struct cloud_info {
+    bool  imuAvailable = false, odomAvailable = false;
+    float imuRollInit = 0, imuPitchInit = 0, imuYawInit = 0;
+    float initialGuessX = 0, initialGuessY = 0, initialGuessZ = 0;
+    float initialGuessRoll = 0, initialGuessPitch = 0, initialGuessYaw = 0;
+    PointCloud2View cloud_deskewed, cloud_corner, cloud_surface, cloud_corner_sharp, cloud_surface_sharp;
+};
+struct semantic_info : cloud_info {
+    PointCloud2View semantic_raw, semantic_dynamic, semantic_pole, semantic_ground, semantic_building, semantic_outlier;
+};
+
+enum class Variant { Odom = LISREG_VARIANT_ODOM, KeyFrame = LISREG_VARIANT_KEYFRAME, SubMap = LISREG_VARIANT_SUBMAP };
+
+class RegistrationError : public std::runtime_error { public: int code; RegistrationError(int c, const std::string& m) : std::runtime_error(m), code(c) {} };
+
+// One instance per reference node class (each owns a lisreg context = its own HIP stream; #2 and #3 run
+// concurrently in one process, subMapOptmizationNode.cpp:5188-5195).
+template <class PointT = PointType>
+class Scan2SubMapRegistration {
+public:
+    // members the reference's callers read after the call (odomEstimationNode.cpp:66-71)
+    float transformTobeMapped[6] = { 0, 0, 0, 0, 0, 0 };
+    bool  isDegenerate = false;
+    float deltaR = 100, deltaT = 100;
+    int   iterCount = 0;
+    int   laserCloudSelNum = 0;
+    lisreg_params params;
+
+    explicit Scan2SubMapRegistration(Variant v, int device = 0) {
+        lisreg_default_params((int)v, &params);
+        int rc = lisreg_create(device, &ctx_);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(nullptr));
+    }
+    ~Scan2SubMapRegistration() { lisreg_destroy(ctx_); }
+    Scan2SubMapRegistration(const Scan2SubMapRegistration&) = delete;
+    Scan2SubMapRegistration& operator=(const Scan2SubMapRegistration&) = delete;
+
+    // kdtreeCornerFromMap->setInputCloud(...); kdtreeSurfFromMap->setInputCloud(...)   (:602-603)
+    void setInputTarget(const PointCloud<PointT>& laserCloudCornerFromMapDS, const PointCloud<PointT>& laserCloudSurfFromMapDS) {
+        check(lisreg_set_target(ctx_, laserCloudCornerFromMapDS.points.data(), (int)laserCloudCornerFromMapDS.size(),
+                                laserCloudSurfFromMapDS.points.data(), (int)laserCloudSurfFromMapDS.size(),
+                                (int)sizeof(PointT), fmt()));
+    }
+    // submap API (subMap.h:435-777): corner = pole; surf = ground + building + dynamic (:1408-1419)
+    void setInputTargetFromClasses(const PointCloud<PointT>& pole, const PointCloud<PointT>& ground,
+                                   const PointCloud<PointT>& building, const PointCloud<PointT>& dynamic) {
+        check(lisreg_target_from_classes(ctx_, 0, pole.points.data(), (int)pole.size(), ground.points.data(), (int)ground.size(),
+                                         building.points.data(), (int)building.size(), dynamic.points.data(), (int)dynamic.size(),
+                                         (int)sizeof(PointT), fmt()));
+    }
+
+    // The body of scan2SubMapOptimization() (:596-626): guard, GN loop, transformUpdate.  Returns the lisreg
+    // status: LISREG_OK, LISREG_NOT_ENOUGH_FEATURES (the reference's ROS_WARN branch, pose untouched) or
+    // LISREG_TOO_FEW_CORRESPONDENCES.  transformTobeMapped is in/out exactly like the member.
+    int scan2SubMapOptimization(const PointCloud<PointT>& laserCloudCornerLastDS, const PointCloud<PointT>& laserCloudSurfLastDS,
+                                const cloud_info& cloudInfo) {
+        lisreg_imu imu{ cloudInfo.imuAvailable ? 1 : 0, cloudInfo.imuRollInit, cloudInfo.imuPitchInit };
+        lisreg_stats st{};
+        int rc = lisreg_align(ctx_, laserCloudCornerLastDS.points.data(), (int)laserCloudCornerLastDS.size(),
+                              laserCloudSurfLastDS.points.data(), (int)laserCloudSurfLastDS.size(), (int)sizeof(PointT), fmt(),
+                              &params, &imu, transformTobeMapped, &st);
+        if (rc < 0) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        iterCount = st.iters; laserCloudSelNum = st.n_corr_last;
+        if (rc != LISREG_NOT_ENOUGH_FEATURES) { isDegenerate = st.degenerate != 0; deltaR = st.deltaR; deltaT = st.deltaT; }
+        return rc;
+    }
+    // same, reading the feature clouds straight out of PointCloud2 message buffers
+    int scan2SubMapOptimization(const PointCloud2View& corner, const PointCloud2View& surf, const cloud_info& cloudInfo) {
+        lisreg_imu imu{ cloudInfo.imuAvailable ? 1 : 0, cloudInfo.imuRollInit, cloudInfo.imuPitchInit };
+        lisreg_stats st{};
+        int rc = lisreg_align(ctx_, corner.data, (int)corner.size(), surf.data, (int)surf.size(), (int)corner.point_step, corner.fmt(),
+                              &params, &imu, transformTobeMapped, &st);
+        if (rc < 0) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        iterCount = st.iters; laserCloudSelNum = st.n_corr_last;
+        if (rc != LISREG_NOT_ENOUGH_FEATURES) { isDegenerate = st.degenerate != 0; deltaR = st.deltaR; deltaT = st.deltaT; }
+        return rc;
+    }
+    // subMap2SubMapOptimization() of SubMapOptmizationNode is the same call with Variant::SubMap (:4485-4540)
+    int subMap2SubMapOptimization(const PointCloud<PointT>& c, const PointCloud<PointT>& s, const cloud_info& ci) { return scan2SubMapOptimization(c, s, ci); }
+
+    lisreg_ctx* handle() { return ctx_; }
+
+private:
+    static constexpr int fmt() { return std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI; }
+    void check(int rc) { if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_)); }
+    lisreg_ctx* ctx_ = nullptr;
+};
+
+}  // namespace lis_slam
