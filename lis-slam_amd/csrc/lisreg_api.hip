@@ -70,7 +70,9 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
     // batch
-    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload;
+    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn;
+    int       search_mode = 1;
+    float     first_pass_r = 0.45f;
     std::vector<BlockDesc> h_blocks;
     std::vector<Segment>   h_segs;
     std::vector<ItemState> h_items;
@@ -280,6 +282,8 @@ int lisreg_create(int device, lisreg_ctx** out)
     c->stream = c->own_stream;
     c->targets.resize(1);
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
+    if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
+    if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     *out = c;
     return LISREG_OK;
 }
@@ -293,7 +297,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload };
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn };
     for (auto b : bufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -465,7 +469,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
-    const float tile = env_float("LISREG_TILE", 2.0f);
+    const float tile = env_float("LISREG_TILE", 0.25f);   // 2-D sort columns
     int flat = 0, bucket = 0;
     for (int i = 0; i < n_items; ++i) {
         const lisreg_item& in = items[i];
@@ -496,13 +500,13 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             sg.inv_tile = 1.f / tile;
             sg.tnx = std::max(1, (int)ceilf(g.nx * g.cell / tile));
             sg.tny = std::max(1, (int)ceilf(g.ny * g.cell / tile));
-            sg.tnz = std::max(1, (int)ceilf(g.nz * g.cell / tile));
+            sg.tnz = 1;
             const int seg_id = (int)c->h_segs.size();
             c->h_segs.push_back(sg);
             for (int s = 0; s < sg.n; s += kBlockQ)
                 c->h_blocks.push_back(BlockDesc{ seg_id, s, std::min(kBlockQ, sg.n - s), i });
             flat += sg.n;
-            bucket += sg.tnx * sg.tny * sg.tnz;
+            bucket += sg.tnx * sg.tny;
         }
         st.blk_count = (int)c->h_blocks.size() - st.blk_begin;
     }
@@ -517,6 +521,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     HIPCHK(c, c->items.ensure(sizeof(ItemState) * (size_t)std::max(n_items, 1)));
     HIPCHK(c, c->sorted_all.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->order_all.ensure(sizeof(int) * (size_t)std::max(flat, 1)));
+    HIPCHK(c, c->nn.ensure(sizeof(int) * 5 * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->partials.ensure(sizeof(double) * kNumAcc * (size_t)std::max(c->n_blocks, 1)));
     HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * (size_t)std::max(n_items, 1)));
     if (c->trace_cap > 0) HIPCHK(c, c->trace.ensure(sizeof(float) * kTraceStride * (size_t)c->trace_cap * (size_t)std::max(n_items, 1)));
@@ -549,7 +554,8 @@ int lisreg_batch_run(lisreg_ctx* c)
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
         launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
-                     c->items.as<ItemState>(), c->prm, c->sorted_all.as<float4>(), c->partials.as<double>(), st);
+                     c->items.as<ItemState>(), c->prm, c->sorted_all.as<float4>(), c->partials.as<double>(),
+                     c->search_mode, c->nn.as<int>(), c->n_elems, c->first_pass_r * c->first_pass_r, st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, st);
@@ -587,6 +593,8 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
 {
     if (!c || !name) return LISREG_ERR_ARG;
     if (!strcmp(name, "rebuild_targets_each_run")) { c->rebuild_targets_each_run = value != 0; return LISREG_OK; }
+    if (!strcmp(name, "search_mode")) { c->search_mode = value; return LISREG_OK; }
+    if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
 }

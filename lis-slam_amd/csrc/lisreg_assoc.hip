@@ -24,16 +24,6 @@ namespace lisreg {
 
 namespace {
 
-__device__ __forceinline__ void pose_matrix(const float* T, float M[12])
-{
-    // pcl::getTransformation via trans2Affine3f (src/core/common.cpp:54-57), float
-    const float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
-    const float DE = D * E, DF = D * F;
-    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
-    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
-    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
-}
-
 __device__ __forceinline__ float hypot_f(float a, float b)
 {
     a = fabsf(a); b = fabsf(b);
@@ -251,12 +241,10 @@ __device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y
 }
 
 // LMOptimization row (odomEstimationNode.cpp:862-915); (ox,oy,oz) is the UNtransformed source point
-__device__ __forceinline__ void jacobian_row(const float* T, float ox, float oy, float oz, const float cf[4],
+__device__ __forceinline__ void jacobian_row(const float* sc, float ox, float oy, float oz, const float cf[4],
                                              float row[6], float& b)
 {
-    const float srx = sinf(T[1]), crx = cosf(T[1]);
-    const float sry = sinf(T[2]), cry = cosf(T[2]);
-    const float srz = sinf(T[0]), crz = cosf(T[0]);
+    const float srx = sc[0], crx = sc[1], sry = sc[2], cry = sc[3], srz = sc[4], crz = sc[5];   // ItemState::sc
     const float px = oy, py = oz, pz = ox;
     const float cx = cf[1], cy = cf[2], cz = cf[0];
     const float arx = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cx +
@@ -283,7 +271,52 @@ __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
     return (int)floorf((v - origin) * inv_cell);
 }
 
-__global__ __launch_bounds__(kBlockQ) void k_assoc(const BlockDesc* __restrict__ blocks,
+// Residual model + Jacobian row + fixed-order fp64 reduction shared by both search front-ends.
+// (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
+__device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
+                                                    const GridIndex& g, const float4 q4, float qx, float qy, float qz,
+                                                    const float* sc, const DevParams& P, int kind,
+                                                    double (*s_acc)[kNumAcc], double* __restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+    const bool found = valid && (i4 >= 0);          // five neighbours with sqDist < tau  (:657 / :776)
+    if (found) {
+        float4 nb[5];
+        nb[0] = g.pts[i0]; nb[1] = g.pts[i1]; nb[2] = g.pts[i2]; nb[3] = g.pts[i3]; nb[4] = g.pts[i4];
+        float w = 1.f;
+        if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
+        float cf[4];
+        const bool ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
+        if (ok) {
+            float row[6], b;
+            jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, b);
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) acc[k++] = (double)row[r] * (double)row[c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[21 + r] = (double)row[r] * (double)b;
+            acc[27] = 1.0;
+        }
+    }
+    // ---- fixed-order fp64 reduction: wave shuffles -> LDS -> one partial row ---------------------------------
+#pragma unroll
+    for (int k = 0; k < kNumAcc; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += shfl_xor_d(v, d);
+        if (lane == 0) s_acc[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < kNumAcc) out[tid] = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
+}
+
+
+__global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __restrict__ blocks,
                                                    const Segment* __restrict__ segs,
                                                    const GridIndex* __restrict__ grids,
                                                    const ItemState* __restrict__ items, const DevParams P,
@@ -309,10 +342,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc(const BlockDesc* __restrict__
         return;
     }
 
-    float T[6], M[12];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) T[k] = it->T[k];
-    pose_matrix(T, M);
+    const float* M = it->M;            // trans2Affine3f(T), cached by the solve kernel (uniform -> SGPRs)
 
     const bool valid = tid < bd.count;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -417,51 +447,130 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc(const BlockDesc* __restrict__
         }
     }
 
-    // ---- residual model + Jacobian row -----------------------------------------------------------------------
-    double acc[kNumAcc];
-#pragma unroll
-    for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
-    const bool found = valid && (i4 >= 0);          // five neighbours with sqDist < tau  (:657 / :776)
-    if (found) {
-        float4 nb[5];
-        nb[0] = g.pts[i0]; nb[1] = g.pts[i1]; nb[2] = g.pts[i2]; nb[3] = g.pts[i3]; nb[4] = g.pts[i4];
-        float w = 1.f;
-        if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
-        float cf[4];
-        const bool ok = (sg.kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
-        if (ok) {
-            float row[6], b;
-            jacobian_row(T, q4.x, q4.y, q4.z, cf, row, b);
-            int k = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = r; c < 6; ++c) acc[k++] = (double)row[r] * (double)row[c];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[21 + r] = (double)row[r] * (double)b;
-            acc[27] = 1.0;
-        }
-    }
-    // ---- fixed-order fp64 reduction: wave shuffles -> LDS -> one partial row ---------------------------------
-#pragma unroll
-    for (int k = 0; k < kNumAcc; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += shfl_xor_d(v, d);
-        if (lane == 0) s_acc[wave][k] = v;
-    }
-    __syncthreads();
-    if (tid < kNumAcc) out[tid] = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
+    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
 }
 
+// sorted top-5 insertion (ascending); `id` must not already be in the list
+#define LISREG_INSERT(d2, id) do { \
+        const bool c3_ = (d2) < b3, c2_ = (d2) < b2, c1_ = (d2) < b1, c0_ = (d2) < b0; \
+        b4 = c3_ ? b3 : (d2);               i4 = c3_ ? i3 : (id); \
+        b3 = c3_ ? (c2_ ? b2 : (d2)) : b3;  i3 = c3_ ? (c2_ ? i2 : (id)) : i3; \
+        b2 = c2_ ? (c1_ ? b1 : (d2)) : b2;  i2 = c2_ ? (c1_ ? i1 : (id)) : i2; \
+        b1 = c1_ ? (c0_ ? b0 : (d2)) : b1;  i1 = c1_ ? (c0_ ? i0 : (id)) : i1; \
+        b0 = c0_ ? (d2) : b0;               i0 = c0_ ? (id) : i0; } while (0)
+
+// Per-lane grid walk: every lane visits only the cells that can hold a point closer than its current 5th-best
+// distance (pruned per x-slab, per (x,y) column and per z-range), reading candidates straight from the
+// cell-sorted target through L1/L2.  `lim2` caps the search radius of this pass (squared).
+#define LISREG_WALK(lim2_expr) do { \
+        const float rad_ = sqrtf(fminf(b4, (lim2_expr))) + kEps; \
+        const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
+        const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
+        for (int ix_ = cx0_; ix_ <= cx1_; ++ix_) { \
+            const float xl_ = g.ox + (float)ix_ * g.cell; \
+            const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
+            if (dx_ * dx_ >= fminf(b4, (lim2_expr))) continue; \
+            for (int iy_ = cy0_; iy_ <= cy1_; ++iy_) { \
+                const float yl_ = g.oy + (float)iy_ * g.cell; \
+                const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
+                const float rem_ = fminf(b4, (lim2_expr)) - (dx_ * dx_ + dy_ * dy_); \
+                if (rem_ <= 0.f) continue; \
+                const float rz_ = sqrtf(rem_) + kEps; \
+                const int cz0_ = max(grid_coord(qz - rz_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rz_, g.oz, g.inv_cell), g.nz - 1); \
+                if (cz0_ > cz1_) continue; \
+                const int base_ = (ix_ * g.ny + iy_) * g.nz; \
+                const int js_ = g.cell_start[base_ + cz0_], je_ = g.cell_start[base_ + cz1_ + 1]; \
+                for (int j_ = js_; j_ < je_; ++j_) { \
+                    const float4 c_ = g.pts[j_]; \
+                    const float ex_ = qx - c_.x, ey_ = qy - c_.y, ez_ = qz - c_.z; \
+                    const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
+                    if (d2_ < b4 && j_ != i0 && j_ != i1 && j_ != i2 && j_ != i3 && j_ != i4) LISREG_INSERT(d2_, j_); \
+                } \
+            } \
+        } } while (0)
+
+__global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
+                                                        const Segment* __restrict__ segs,
+                                                        const GridIndex* __restrict__ grids,
+                                                        const ItemState* __restrict__ items, const DevParams P,
+                                                        const float4* __restrict__ sorted_all,
+                                                        int* __restrict__ nn, int n_elems, float first_pass_r2,
+                                                        double* __restrict__ partials)
+{
+    __shared__ double s_acc[4][kNumAcc];
+    constexpr float kEps = 1e-3f;
+
+    const int tid = threadIdx.x;
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ItemState* it = &items[bd.item];
+    if (it->done) return;
+    const Segment sg = segs[bd.seg];
+    const GridIndex g = grids[sg.target];
+    double* out = partials + (size_t)blockIdx.x * kNumAcc;
+    if (g.n < 5) {
+        if (tid < kNumAcc) out[tid] = 0.0;
+        return;
+    }
+    const float* M = it->M;            // trans2Affine3f(T), cached by the solve kernel (uniform -> SGPRs)
+
+    const bool valid = tid < bd.count;
+    const int qflat = sg.flat_base + bd.start + tid;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) q4 = sorted_all[qflat];
+    const float qx = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
+    const float qy = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
+    const float qz = M[8] * q4.x + M[9] * q4.y + M[10] * q4.z + M[11];
+
+    float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau;
+    int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
+    if (valid) {
+        bool seeded = false;
+        if (it->iter > 0) {
+            // seeds: last iteration's neighbours bound the new 5th-nearest distance (any 5 points do), so the walk
+            // below only has to look inside that radius.  Exactness does not depend on the seeds being right.
+            const int s4 = nn[4 * (size_t)n_elems + qflat];
+            if (s4 >= 0) {
+                int sid[5];
+                sid[4] = s4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sid[k] = nn[(size_t)k * n_elems + qflat];
+                float4 sp[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sp[k] = g.pts[sid[k]];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float ex = qx - sp[k].x, ey = qy - sp[k].y, ez = qz - sp[k].z;
+                    const float d2 = ex * ex + ey * ey + ez * ez;
+                    if (d2 < b4) LISREG_INSERT(d2, sid[k]);
+                }
+                seeded = true;
+            }
+        }
+        if (!seeded) {
+            LISREG_WALK(first_pass_r2);                    // tight first pass establishes a bound cheaply
+            if (!(b4 <= first_pass_r2)) LISREG_WALK(3.0e38f);
+        } else {
+            LISREG_WALK(3.0e38f);
+        }
+        // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set")
+        nn[0 * (size_t)n_elems + qflat] = i0; nn[1 * (size_t)n_elems + qflat] = i1;
+        nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
+        nn[4 * (size_t)n_elems + qflat] = i4;
+    }
+    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
+}
 }  // namespace
 
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                  hipStream_t st)
+                  int mode, int* nn, int n_elems, float first_pass_r2, hipStream_t st)
 {
     if (n_blocks <= 0) return;
-    k_assoc<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
+    if (mode == 0)
+        k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
+    else
+        k_assoc_walk<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                   first_pass_r2, partials);
 }
 
 }  // namespace lisreg

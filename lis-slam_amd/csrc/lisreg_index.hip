@@ -156,21 +156,8 @@ __global__ __launch_bounds__(256) void k_target_keys(const float4* __restrict__ 
     atomicAdd(&hist[b], 1);
 }
 
-// ---- source keys: tile of the point under the item's INITIAL pose (pcl::getTransformation, common.cpp:54-57) --
-__device__ __forceinline__ void pose_matrix(const float* T, float M[12])
-{
-    const float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
-    const float DE = D * E, DF = D * F;
-    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
-    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
-    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
-}
-
-__device__ __forceinline__ uint32_t spread3(uint32_t v)   // 3 bits -> every third bit
-{
-    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
-}
-
+// ---- source keys: (x,y) sort column of the point under the item's INITIAL pose (ItemState::M, written by the
+// reset kernel = pcl::getTransformation of T_init, common.cpp:54-57) ---------------------------------------------
 __global__ __launch_bounds__(kBlockQ) void k_source_keys(const BlockDesc* __restrict__ blocks,
                                                          const Segment* __restrict__ segs,
                                                          const ItemState* __restrict__ items,
@@ -180,26 +167,23 @@ __global__ __launch_bounds__(kBlockQ) void k_source_keys(const BlockDesc* __rest
     const BlockDesc bd = blocks[blockIdx.x];
     if ((int)threadIdx.x >= bd.count) return;
     const Segment sg = segs[bd.seg];
-    float M[12];
-    pose_matrix(items[bd.item].T_init, M);
+    const float* M = items[bd.item].M;      // uniform: scalar loads
     const int e = bd.start + threadIdx.x;
     const float4 p = sg.src[e];
     const float x = M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3];
     const float y = M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7];
     const float z = M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11];
-    // tile coordinate and 1/8-tile sub-cell (9-bit Morton) — sort keys only, clamping is harmless
-    const float fx = (x - sg.tox) * sg.inv_tile, fy = (y - sg.toy) * sg.inv_tile, fz = (z - sg.toz) * sg.inv_tile;
-    int tx = (int)floorf(fx), ty = (int)floorf(fy), tz = (int)floorf(fz);
-    uint32_t sx = (uint32_t)(int)((fx - floorf(fx)) * 8.f) & 7u;
-    uint32_t sy = (uint32_t)(int)((fy - floorf(fy)) * 8.f) & 7u;
-    uint32_t sz = (uint32_t)(int)((fz - floorf(fz)) * 8.f) & 7u;
+    // sort key = (x,y) column of the point under the initial pose; sub-key = height bin.  Keys only order the
+    // queries (wave-level locality for the cell walk); clamping is harmless.
+    int tx = (int)floorf((x - sg.tox) * sg.inv_tile), ty = (int)floorf((y - sg.toy) * sg.inv_tile);
+    int tz = (int)floorf((z - sg.toz) * sg.inv_tile);
     tx = tx < 0 ? 0 : (tx >= sg.tnx ? sg.tnx - 1 : tx);
     ty = ty < 0 ? 0 : (ty >= sg.tny ? sg.tny - 1 : ty);
-    tz = tz < 0 ? 0 : (tz >= sg.tnz ? sg.tnz - 1 : tz);
-    const uint32_t b = (uint32_t)(sg.bucket_base + (tx * sg.tny + ty) * sg.tnz + tz);
+    tz = tz < 0 ? 0 : (tz > 4095 ? 4095 : tz);
+    const uint32_t b = (uint32_t)(sg.bucket_base + tx * sg.tny + ty);
     const int flat = sg.flat_base + e;
     elem_bucket[flat] = b;
-    elem_sub[flat] = (spread3(sx) << 2) | (spread3(sy) << 1) | spread3(sz);
+    elem_sub[flat] = (uint32_t)tz;
     atomicAdd(&hist[b], 1);
 }
 

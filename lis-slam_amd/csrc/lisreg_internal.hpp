@@ -60,6 +60,8 @@ struct ItemState {
     float T[6];                // transformTobeMapped
     float T_init[6];
     float P[36];               // matP
+    float M[12];               // trans2Affine3f(T) for the NEXT correspondence launch (uniform -> scalar loads)
+    float sc[6];               // srx, crx, sry, cry, srz, crz of LMOptimization (:862-867) for the same T
     int   iter;                // iterations started so far
     int   done;                // converged / exhausted: all later launches skip this item
     int   iters_out;           // iterCount as the reference reports it
@@ -98,7 +100,8 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
 void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_t st);
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                  hipStream_t st);
+                  int mode /* 0 = LDS-staged workgroup box, 1 = per-lane grid walk */, int* nn, int n_elems,
+                  float first_pass_r2, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);

@@ -155,6 +155,22 @@ __device__ void inv6_lu(float* A, float* B)
         }
 }
 
+// pcl::getTransformation via trans2Affine3f (common.cpp:54-57) and LMOptimization's sin/cos (:862-867), computed
+// once per registration per iteration here instead of once per thread in the correspondence kernel.
+__device__ void write_pose_cache(ItemState* it)
+{
+    const float* T = it->T;
+    const float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
+    const float DE = D * E, DF = D * F;
+    float* M = it->M;
+    M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
+    M[4] = B * C;  M[5] = A * E + B * DF;  M[6]  = B * DE - A * F;  M[7]  = T[4];
+    M[8] = -D;     M[9] = C * F;           M[10] = C * E;           M[11] = T[5];
+    it->sc[0] = D; it->sc[1] = C;      // srx = sin(pitch), crx = cos(pitch)
+    it->sc[2] = B; it->sc[3] = A;      // sry = sin(yaw),   cry = cos(yaw)
+    it->sc[4] = F; it->sc[5] = E;      // srz = sin(roll),  crz = cos(roll)
+}
+
 __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -171,28 +187,45 @@ __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ item
     it->degenerate = it->degenerate_in;
     it->n_corr = 0;
     it->any_solved = 0;
+    write_pose_cache(it);
 }
 
-__global__ __launch_bounds__(64) void k_solve(ItemState* __restrict__ items, const DevParams P,
-                                              const double* __restrict__ partials, float* __restrict__ trace,
-                                              int trace_cap)
+constexpr int kSolveThreads = 256;
+
+__global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__ items, const DevParams P,
+                                                         const double* __restrict__ partials,
+                                                         float* __restrict__ trace, int trace_cap)
 {
     __shared__ float s_AtA[36], s_AtB[6], s_X[6], s_A[36], s_c[6], s_v[6];
     __shared__ float s_E[6], s_V[36], s_V2[36], s_Vi[36];
     __shared__ int   s_ind[12];
+    __shared__ double s_part[kSolveThreads / 32][32];
     __shared__ double s_sum[kNumAcc];
 
     ItemState* it = &items[blockIdx.x];
     if (it->done) return;
-    const int lane = threadIdx.x;
-    if (lane < kNumAcc) {
+    // fixed-order fp64 sum of this registration's workgroup partials: 8 row groups x 28 columns in parallel,
+    // group g takes rows g, g+8, ... ; groups are then combined in index order (deterministic).
+    {
+        const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
         double s = 0.0;
-        const double* p = partials + (size_t)it->blk_begin * kNumAcc + lane;
-        for (int b = 0; b < it->blk_count; ++b) s += p[(size_t)b * kNumAcc];   // fixed order
-        s_sum[lane] = s;
+        if (col < kNumAcc) {
+            const double* p = partials + (size_t)it->blk_begin * kNumAcc + col;
+            const int nb = it->blk_count;
+#pragma unroll 4
+            for (int b = grp; b < nb; b += kSolveThreads / 32) s += p[(size_t)b * kNumAcc];
+        }
+        s_part[grp][col] = s;
     }
     __syncthreads();
-    if (lane != 0) return;
+    if (threadIdx.x < kNumAcc) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < kSolveThreads / 32; ++g) s += s_part[g][threadIdx.x];
+        s_sum[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
 
     const int iter = it->iter;
     const int n_sel = (int)(s_sum[27] + 0.5);
@@ -240,6 +273,7 @@ __global__ __launch_bounds__(64) void k_solve(ItemState* __restrict__ items, con
             }
         }
         for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];          // :955-960
+        write_pose_cache(it);
         const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
         const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
         const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
@@ -345,7 +379,7 @@ void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, hipStream_t st)
 {
-    if (n_items > 0) k_solve<<<n_items, 64, 0, st>>>(items, prm, partials, trace, trace_cap);
+    if (n_items > 0) k_solve<<<n_items, kSolveThreads, 0, st>>>(items, prm, partials, trace, trace_cap);
 }
 
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st)
