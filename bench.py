@@ -5,8 +5,8 @@ Workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): per GPU a batch of 64
 valid pixel a feature: ~4.4 k edge + ~110.8 k planar points) against one shared 200 k-point submap, semantic mask
 off, fixed 10 Gauss-Newton iterations.  A "step" = one pass of the hot path over that batch with the inputs
 already resident in HBM: target index build (the reference rebuilds both kd-trees per registration,
-odomEstimationNode.cpp:602-603; here once per batch because the submap is shared), source tile sort, 10 x
-{correspondence + normal-equation kernel, solve kernel}, finalize.  Multi-GPU: one process per GPU, independent
+odomEstimationNode.cpp:602-603; here once per batch because the submap is shared), 10 x {correspondence +
+normal-equation kernel, solve kernel}, finalize (sources stay in caller order: scan order is already coherent).  Multi-GPU: one process per GPU, independent
 batches per rank (weak scaling), one RCCL all-gather of the 64 x 12-float result blocks per step.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch of the dominant kernel
@@ -138,7 +138,7 @@ def main():
                 traffic = json.load(open(tpath)).get("k_assoc_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = dict(bound="hbm", kernel="k_assoc", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+        roof = dict(bound="hbm", kernel="k_assoc_walk", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     avg_launch_ms=round(avg_ms, 4), launches=timing["assoc_launches"],
                     algorithmic_bytes_per_launch=alg_bytes,
@@ -180,7 +180,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch=64 synthetic 64x1800 scans vs one shared 200k-pt submap per GPU, "
-                                   "semantic mask off, 10 fixed GN iterations, index build + source sort inside the step",
+                                   "semantic mask off, 10 fixed GN iterations, target index build inside the step",
                        "batch_per_gpu": args.batch, "scan": [H, W], "submap_points": M_SUBMAP, "gn_iters": ITERS,
                        "source_points_per_batch": int(n_src), "parallelism": f"independent batches x{n_gpus} + RCCL all-gather of results"},
             "roofline": roof, "cpu_baseline": cpu,

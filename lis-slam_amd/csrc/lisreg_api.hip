@@ -72,6 +72,7 @@ struct lisreg_ctx {
     // batch
     DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn;
     int       search_mode = 1;
+    int       sort_sources = 0;          // 0: keep the caller order (scan/voxel order is already coherent), 1: 2-D column sort
     float     first_pass_r = 0.45f;
     std::vector<BlockDesc> h_blocks;
     std::vector<Segment>   h_segs;
@@ -241,9 +242,11 @@ void prof_mark(lisreg_ctx* c, int kind_of_next_interval)
 void prof_collect(lisreg_ctx* c)
 {
     for (int i = 0; i < 5; ++i) c->timing[i] = 0;
+    const bool dump = getenv("LISREG_PROF_DUMP") != nullptr;
     for (size_t i = 0; i + 1 < c->ev.size(); ++i) {
         float ms = 0;
         if (c->ev_kind[i] >= 0 && hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+            if (dump) fprintf(stderr, "[lisreg prof] interval %zu kind %d: %.4f ms\n", i, c->ev_kind[i], ms);
             if (c->ev_kind[i] == 0) { c->timing[0] += ms; c->timing[1] += 1; }
             else if (c->ev_kind[i] == 1) { c->timing[2] += ms; c->timing[3] += 1; }
             else if (c->ev_kind[i] == 2) c->timing[4] += ms;
@@ -283,6 +286,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     c->targets.resize(1);
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
     if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
+    if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     *out = c;
     return LISREG_OK;
@@ -549,7 +553,7 @@ int lisreg_batch_run(lisreg_ctx* c)
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, st);
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
-                        c->n_elems, c->n_buckets, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
+                        c->n_elems, c->sort_sources ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
@@ -593,6 +597,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
 {
     if (!c || !name) return LISREG_ERR_ARG;
     if (!strcmp(name, "rebuild_targets_each_run")) { c->rebuild_targets_each_run = value != 0; return LISREG_OK; }
+    if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
     if (!strcmp(name, "search_mode")) { c->search_mode = value; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }

@@ -104,14 +104,14 @@ __device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float
     float cx = 0, cy = 0, cz = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) { cx += nb[j].x; cy += nb[j].y; cz += nb[j].z; }
-    cx /= 5; cy /= 5; cz /= 5;
+    cx *= 0.2f; cy *= 0.2f; cz *= 0.2f;          // /5 (reciprocal multiply: <= 1 ulp from the reference's division)
     float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const float ax = nb[j].x - cx, ay = nb[j].y - cy, az = nb[j].z - cz;
         a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
     }
-    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    a11 *= 0.2f; a12 *= 0.2f; a13 *= 0.2f; a22 *= 0.2f; a23 *= 0.2f; a33 *= 0.2f;
     float l0, l1, v[3];
     eigen_sym3(a11, a12, a13, a22, a23, a33, l0, l1, v);
     if (!(l0 > P.line_ratio * l1)) return false;
@@ -127,9 +127,10 @@ __device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float
     const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
     const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
     const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
-    const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
-    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
-    const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+    const float inv_al = 1.f / (a012 * l12);     // one reciprocal for the three `/ a012 / l12` (:713-723)
+    const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) * inv_al;
+    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) * inv_al;
+    const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) * inv_al;
     const float ld2 = a012 / l12;
     const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));
     const float ws = w * s;
@@ -163,7 +164,8 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         float beta_, tau_, v_[5]; \
         if (tail_ <= 1.17549435e-38f) { tau_ = 0.f; beta_ = c0_; _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = 0.f; } \
         else { beta_ = sqrtf(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
-               _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? a[i_][k] / (c0_ - beta_) : 0.f; \
+               const float invd_ = 1.f / (c0_ - beta_); \
+               _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? a[i_][k] * invd_ : 0.f; \
                tau_ = (beta_ - c0_) / beta_; } \
         a[k][k] = beta_; \
         _Pragma("unroll") for (int j_ = k + 1; j_ < 3; ++j_) { \
@@ -227,7 +229,8 @@ __device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y
     lstsq5x3(nb, X);
     float pa = X[0], pb = X[1], pc = X[2], pd = 1.f;
     const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
-    pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+    const float ips = 1.f / ps;
+    pa *= ips; pb *= ips; pc *= ips; pd = ips;
     bool valid = true;
 #pragma unroll
     for (int j = 0; j < 5; ++j)
@@ -266,6 +269,13 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
     return __hiloint2double(hi, lo);
 }
 
+// The index arrays are reached through pointers stored in device structs, which the compiler can only treat as
+// generic (flat_load).  They are always global memory: say so, and get global_load with a scalar base.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const v4f* gptr_f4;
+typedef __attribute__((address_space(1))) const int* gptr_i32;
+typedef __attribute__((address_space(1))) int*       gptr_i32w;
+
 __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
 {
     return (int)floorf((v - origin) * inv_cell);
@@ -279,37 +289,69 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
                                                     double (*s_acc)[kNumAcc], double* __restrict__ out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double acc[kNumAcc];
-#pragma unroll
-    for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+    float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
     const bool found = valid && (i4 >= 0);          // five neighbours with sqDist < tau  (:657 / :776)
     if (found) {
         float4 nb[5];
-        nb[0] = g.pts[i0]; nb[1] = g.pts[i1]; nb[2] = g.pts[i2]; nb[3] = g.pts[i3]; nb[4] = g.pts[i4];
+        const gptr_f4 gp = (gptr_f4)g.pts;
+        const v4f n0 = gp[i0], n1 = gp[i1], n2 = gp[i2], n3 = gp[i3], n4 = gp[i4];
+        nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
+        nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
+        nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
         float w = 1.f;
         if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
         float cf[4];
         const bool ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
-        if (ok) {
-            float row[6], b;
-            jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, b);
-            int k = 0;
+        if (ok) { jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
+    }
+    // the 28 normal-equation terms of this row, produced on demand (float x float is exact in double):
+    //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
+    auto term = [&](int k) -> double {
+        constexpr int R[21] = { 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5 };
+        constexpr int C[21] = { 0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5 };
+        if (k < 21) return (double)row[R[k]] * (double)row[C[k]];
+        if (k < 27) return (double)row[k - 21] * (double)rb;
+        if (k == 27) return (double)one;
+        return 0.0;
+    };
+    // ---- fixed-order fp64 reduction: halving butterfly across the wave -> LDS -> one partial row ---------------
+    // Each step exchanges HALF of the values with the partner lane (xor 32, 16, 8, 4, 2), so 32 values need
+    // 16+8+4+2+1(+1) 64-bit shuffles instead of 32 x 6; after five steps lane l holds the 32-lane sum of value
+    // index bits(l)[5:1] and one last xor-1 step completes it.  Deterministic: the pairing is fixed.
+    double v16[16];
+    {
+        const bool up = (lane & 32) != 0;
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = r; c < 6; ++c) acc[k++] = (double)row[r] * (double)row[c];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[21 + r] = (double)row[r] * (double)b;
-            acc[27] = 1.0;
+        for (int i = 0; i < 16; ++i) {
+            const double a = term(i), b = term(i + 16);
+            v16[i] = (up ? b : a) + shfl_xor_d(up ? a : b, 32);
         }
     }
-    // ---- fixed-order fp64 reduction: wave shuffles -> LDS -> one partial row ---------------------------------
+    double v8[8], v4[4], v2[2], v1;
+    {
+        const bool up = (lane & 16) != 0;
 #pragma unroll
-    for (int k = 0; k < kNumAcc; ++k) {
-        double v = acc[k];
+        for (int i = 0; i < 8; ++i) v8[i] = (up ? v16[i + 8] : v16[i]) + shfl_xor_d(up ? v16[i] : v16[i + 8], 16);
+    }
+    {
+        const bool up = (lane & 8) != 0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += shfl_xor_d(v, d);
-        if (lane == 0) s_acc[wave][k] = v;
+        for (int i = 0; i < 4; ++i) v4[i] = (up ? v8[i + 4] : v8[i]) + shfl_xor_d(up ? v8[i] : v8[i + 4], 8);
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v2[i] = (up ? v4[i + 2] : v4[i]) + shfl_xor_d(up ? v4[i] : v4[i + 2], 4);
+    }
+    {
+        const bool up = (lane & 2) != 0;
+        v1 = (up ? v2[1] : v2[0]) + shfl_xor_d(up ? v2[0] : v2[1], 2);
+    }
+    v1 += shfl_xor_d(v1, 1);
+    {
+        // value index held by this lane: bit5 -> +16, bit4 -> +8, bit3 -> +4, bit2 -> +2, bit1 -> +1
+        const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        if ((lane & 1) == 0 && idx < kNumAcc) s_acc[wave][idx] = v1;
     }
     __syncthreads();
     if (tid < kNumAcc) out[tid] = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
@@ -461,7 +503,13 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 
 // Per-lane grid walk: every lane visits only the cells that can hold a point closer than its current 5th-best
 // distance (pruned per x-slab, per (x,y) column and per z-range), reading candidates straight from the
-// cell-sorted target through L1/L2.  `lim2` caps the search radius of this pass (squared).
+// cell-sorted target through L1/L2 (16-B records, contiguous per cell run, 4 loads in flight per lane).
+// `lim2` caps the search radius of this pass (squared).
+#define LISREG_TEST(c_, j_) do { \
+        const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
+        const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
+        if (d2_ < b4 && (j_) != i0 && (j_) != i1 && (j_) != i2 && (j_) != i3 && (j_) != i4) LISREG_INSERT(d2_, (j_)); } while (0)
+
 #define LISREG_WALK(lim2_expr) do { \
         const float rad_ = sqrtf(fminf(b4, (lim2_expr))) + kEps; \
         const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
@@ -479,12 +527,14 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
                 const int cz0_ = max(grid_coord(qz - rz_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rz_, g.oz, g.inv_cell), g.nz - 1); \
                 if (cz0_ > cz1_) continue; \
                 const int base_ = (ix_ * g.ny + iy_) * g.nz; \
-                const int js_ = g.cell_start[base_ + cz0_], je_ = g.cell_start[base_ + cz1_ + 1]; \
-                for (int j_ = js_; j_ < je_; ++j_) { \
-                    const float4 c_ = g.pts[j_]; \
-                    const float ex_ = qx - c_.x, ey_ = qy - c_.y, ez_ = qz - c_.z; \
-                    const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
-                    if (d2_ < b4 && j_ != i0 && j_ != i1 && j_ != i2 && j_ != i3 && j_ != i4) LISREG_INSERT(d2_, j_); \
+                const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
+                for (int j_ = js_; j_ < je_; j_ += 4) { \
+                    const int l_ = je_ - 1; \
+                    const v4f c0_ = pts[j_], c1_ = pts[min(j_ + 1, l_)], c2_ = pts[min(j_ + 2, l_)], c3_ = pts[min(j_ + 3, l_)]; \
+                    LISREG_TEST(c0_, j_); \
+                    if (j_ + 1 <= l_) LISREG_TEST(c1_, j_ + 1); \
+                    if (j_ + 2 <= l_) LISREG_TEST(c2_, j_ + 2); \
+                    if (j_ + 3 <= l_) LISREG_TEST(c3_, j_ + 3); \
                 } \
             } \
         } } while (0)
@@ -494,7 +544,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
                                                         const GridIndex* __restrict__ grids,
                                                         const ItemState* __restrict__ items, const DevParams P,
                                                         const float4* __restrict__ sorted_all,
-                                                        int* __restrict__ nn, int n_elems, float first_pass_r2,
+                                                        int* __restrict__ nn_, int n_elems, float first_pass_r2,
                                                         double* __restrict__ partials)
 {
     __shared__ double s_acc[4][kNumAcc];
@@ -511,6 +561,9 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
         if (tid < kNumAcc) out[tid] = 0.0;
         return;
     }
+    const gptr_f4 pts = (gptr_f4)g.pts;
+    const gptr_i32 cells = (gptr_i32)g.cell_start;
+    const gptr_i32w nn = (gptr_i32w)nn_;
     const float* M = it->M;            // trans2Affine3f(T), cached by the solve kernel (uniform -> SGPRs)
 
     const bool valid = tid < bd.count;
@@ -534,9 +587,9 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
                 sid[4] = s4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sid[k] = nn[(size_t)k * n_elems + qflat];
-                float4 sp[5];
+                v4f sp[5];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) sp[k] = g.pts[sid[k]];
+                for (int k = 0; k < 5; ++k) sp[k] = pts[sid[k]];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const float ex = qx - sp[k].x, ey = qy - sp[k].y, ez = qz - sp[k].z;
@@ -559,6 +612,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
     }
     residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
 }
+
 }  // namespace
 
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
