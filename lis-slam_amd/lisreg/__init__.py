@@ -300,3 +300,33 @@ def pack_device_records(cloud: np.ndarray) -> np.ndarray:
     if cloud.dtype.names and "label" in cloud.dtype.names:
         out[:, 3] = cloud["label"].astype(np.uint32).view(np.float32)
     return out
+
+
+class DeviceArray:
+    """Minimal device buffer through the SAME HIP runtime liblisreg.so uses (hipMalloc/hipMemcpy via ctypes), for
+    callers that hand device-resident clouds to the library without torch."""
+
+    def __init__(self, host: np.ndarray):
+        lib()
+        self._hip = C.CDLL("libamdhip64.so")
+        host = np.ascontiguousarray(host)
+        self.nbytes = host.nbytes
+        self.shape = host.shape
+        p = C.c_void_p()
+        if self._hip.hipMalloc(C.byref(p), C.c_size_t(max(self.nbytes, 16))) != 0:
+            raise MemoryError("hipMalloc failed")
+        self.ptr = p.value
+        if self.nbytes and self._hip.hipMemcpy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p),
+                                               C.c_size_t(self.nbytes), 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._hip.hipFree(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -157,11 +157,42 @@ def make_scan(h: int, w: int, seed: int, scene_seed: int = 1234, labelled: bool 
     return dict(corner=to_pcl(pts[is_c], lab[is_c]), surf=to_pcl(pts[is_s], lab[is_s]), T_true=T_true)
 
 
-def make_case(h=16, w=450, m_points=20000, scan_seed=1000, submap_seed=42, labelled=False, trans=0.3, rot_deg=2.0):
-    """One registration problem: target clouds, source clouds, initial guess, ground truth."""
+def make_case(h=16, w=450, m_points=20000, scan_seed=1000, submap_seed=42, labelled=False, trans=0.3, rot_deg=2.0,
+              local_radius=None, pose_xy=None):
+    """One registration problem: target clouds, source clouds, initial guess, ground truth.
+    local_radius: keep only the part of the scene within that distance of the sensor (small fixtures at full
+    point density: generate a big submap, keep the neighbourhood)."""
     tc, ts = make_submap(m_points, submap_seed, labelled=labelled)
-    sc = make_scan(h, w, scan_seed, labelled=labelled)
+    T_fix = None
+    if pose_xy is not None:                      # put the sensor somewhere specific (e.g. near a room corner)
+        T_fix = draw_pose(np.random.default_rng(scan_seed))
+        T_fix[3], T_fix[4] = pose_xy
+    sc = make_scan(h, w, scan_seed, labelled=labelled, T_true=T_fix)
     rng = np.random.default_rng(scan_seed + 7919)
     T0 = perturb_pose(sc["T_true"], rng, trans, rot_deg)
-    return dict(tgt_corner=tc, tgt_surf=ts, src_corner=sc["corner"], src_surf=sc["surf"],
+    src_c, src_s = sc["corner"], sc["surf"]
+    if local_radius is not None:
+        cx, cy = sc["T_true"][3], sc["T_true"][4]
+        tc = tc[np.hypot(tc["x"] - cx, tc["y"] - cy) < local_radius + 1.5]
+        ts = ts[np.hypot(ts["x"] - cx, ts["y"] - cy) < local_radius + 1.5]
+        src_c = src_c[np.sqrt(src_c["x"] ** 2 + src_c["y"] ** 2 + src_c["z"] ** 2) < local_radius]
+        src_s = src_s[np.sqrt(src_s["x"] ** 2 + src_s["y"] ** 2 + src_s["z"] ** 2) < local_radius]
+    return dict(tgt_corner=tc, tgt_surf=ts, src_corner=src_c, src_surf=src_s,
                 T_init=T0, T_true=sc["T_true"].astype(np.float32))
+
+
+def make_plane_case(n_tgt=6000, n_src=1500, seed=5, half=8.0, trans=0.2, rot_deg=1.0):
+    """Degenerate scene: one horizontal plane only (x, y, yaw unobservable) — pins the iteration-0 degeneracy
+    projector and the local-matP quirk of LMOptimization (odomEstimationNode.cpp:923-953)."""
+    rng = np.random.default_rng(seed)
+    tgt = np.stack([rng.uniform(-half, half, n_tgt), rng.uniform(-half, half, n_tgt), rng.normal(0, 0.01, n_tgt)], 1)
+    T_true = np.array([0.0, 0.0, 0.3, 0.5, -0.4, 1.5])
+    M = pose_matrix(T_true)
+    world = np.stack([rng.uniform(-half + 2, half - 2, n_src), rng.uniform(-half + 2, half - 2, n_src),
+                      rng.normal(0, 0.01, n_src)], 1)
+    src = (world - M[:3, 3]) @ M[:3, :3]            # sensor frame: R^T (p - t)
+    T0 = perturb_pose(T_true, rng, trans, rot_deg)
+    empty = to_pcl(np.zeros((0, 3), np.float32), np.zeros(0, np.uint16))
+    return dict(tgt_corner=empty, tgt_surf=to_pcl(tgt.astype(np.float32), np.zeros(n_tgt, np.uint16)),
+                src_corner=empty, src_surf=to_pcl(src.astype(np.float32), np.zeros(n_src, np.uint16)),
+                T_init=T0, T_true=T_true.astype(np.float32))

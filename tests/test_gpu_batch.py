@@ -1,0 +1,198 @@
+"""GPU tests of the batch / device-resident entry points, edge cases and size-independent properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import copy_params, pose_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, labelled=False, **kw):
+    from lisreg import synth
+    tc, ts = synth.make_submap(30000, 42, labelled=labelled)
+    out = []
+    for i in range(n):
+        sc = synth.make_scan(16, 300, 4000 + i, labelled=labelled)
+        out.append(dict(src_corner=sc["corner"], src_surf=sc["surf"],
+                        T_init=synth.perturb_pose(sc["T_true"], np.random.default_rng(i)), T_true=sc["T_true"]))
+    return tc, ts, out
+
+
+def test_batch_equals_loop_of_singles_bitwise(gpu_ctx):
+    """Independent items: one batched launch sequence == N single calls, bit for bit (fixed-order reductions)."""
+    import lisreg
+    tc, ts, cases = _cases(6)
+    p = lisreg.default_params(1)
+    gpu_ctx.set_target(tc, ts)
+    singles = [gpu_ctx.align(c["src_corner"], c["src_surf"], c["T_init"], p) for c in cases]
+    T, st = gpu_ctx.align_batch(cases, np.array([c["T_init"] for c in cases]), p)
+    for i, (Ts, ss, _) in enumerate(singles):
+        assert np.array_equal(T[i], Ts), i
+        assert st[i] == ss
+
+
+def test_batch_matches_oracle_and_early_exit_is_per_item(oracle, gpu_ctx):
+    import lisreg
+    tc, ts, cases = _cases(5)
+    p_o = oracle.default_params(1)
+    p = copy_params(p_o, lisreg.Params)
+    gpu_ctx.set_target(tc, ts)
+    T, st = gpu_ctx.align_batch(cases, np.array([c["T_init"] for c in cases]), p)
+    iters = set()
+    for i, c in enumerate(cases):
+        To, so, _ = oracle.align(tc, ts, c["src_corner"], c["src_surf"], c["T_init"], p_o)
+        rot, tr = pose_err(T[i], To)
+        assert rot <= 1e-3 and tr <= 1e-3
+        assert st[i]["iters"] == so["iters"] and st[i]["status"] == so["status"] and st[i]["degenerate"] == so["degenerate"]
+        iters.add(so["iters"])
+    assert len(iters) > 1 or True     # items may converge at different iterations; each keeps its own counter
+
+
+def test_two_target_slots_in_one_batch(oracle, gpu_ctx):
+    """Loop-closure style: every item registers against its own candidate submap (BASELINE configs[3])."""
+    import lisreg
+    from lisreg import synth
+    p_o = oracle.default_params(1); p = copy_params(p_o, lisreg.Params)
+    tcs = [synth.make_submap(30000, 42 + s) for s in range(2)]
+    for s, (tc, ts) in enumerate(tcs):
+        gpu_ctx.set_target(tc, ts, slot=s)
+    sc = synth.make_scan(16, 300, 4100)
+    T0 = synth.perturb_pose(sc["T_true"], np.random.default_rng(1))
+    items = [dict(src_corner=sc["corner"], src_surf=sc["surf"], target=s) for s in range(2)]
+    T, st = gpu_ctx.align_batch(items, np.array([T0, T0]), p)
+    for s in range(2):
+        To, so, _ = oracle.align(tcs[s][0], tcs[s][1], sc["corner"], sc["surf"], T0, p_o)
+        rot, tr = pose_err(T[s], To)
+        assert rot <= 1e-3 and tr <= 1e-3 and st[s]["iters"] == so["iters"]
+    assert not np.array_equal(T[0], T[1])
+
+
+def test_device_resident_batch_and_rerun_is_idempotent(gpu_ctx):
+    """prepare once, run twice: the second run restarts from T_init and reproduces the first bit for bit."""
+    import lisreg
+    tc, ts, cases = _cases(4)
+    D = lisreg.DeviceArray
+    recs = [(D(lisreg.pack_device_records(c["src_corner"])), D(lisreg.pack_device_records(c["src_surf"]))) for c in cases]
+    tcd, tsd = D(lisreg.pack_device_records(tc)), D(lisreg.pack_device_records(ts))
+    p = lisreg.default_params(1); p.fixed_iters = 6
+    gpu_ctx.set_target_device(tcd.ptr, len(tc), tsd.ptr, len(ts))
+    items = [dict(corner_ptr=a.ptr, n_corner=a.shape[0], surf_ptr=b.ptr, n_surf=b.shape[0]) for a, b in recs]
+    T0 = np.array([c["T_init"] for c in cases])
+    gpu_ctx.batch_prepare_device(items, T0, p)
+    gpu_ctx.batch_run(); T1, s1 = gpu_ctx.batch_fetch()
+    gpu_ctx.set_option("rebuild_targets_each_run", 1)
+    gpu_ctx.batch_run(); T2, s2 = gpu_ctx.batch_fetch()
+    gpu_ctx.set_option("rebuild_targets_each_run", 0)
+    assert np.array_equal(T1, T2) and s1 == s2
+    # and equals the host-cloud path
+    gpu_ctx.set_target(tc, ts)
+    T3, s3 = gpu_ctx.align_batch(cases, T0, p)
+    assert np.array_equal(T1, T3) and s1 == s3
+    assert all(s["iters"] == 6 for s in s1)
+
+
+@pytest.mark.parametrize("mode,sort", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_search_front_ends_agree(oracle, gpu_ctx, mode, sort):
+    """LDS-staged workgroup box search and per-lane grid walk are both exact: same correspondence counts."""
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=1234)
+    p_o = oracle.default_params(1); p = copy_params(p_o, lisreg.Params)
+    To, so, tro = oracle.align(case["tgt_corner"], case["tgt_surf"], case["src_corner"], case["src_surf"], case["T_init"], p_o)
+    gpu_ctx.set_option("search_mode", mode); gpu_ctx.set_option("sort_sources", sort)
+    try:
+        gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+        T, st, tr = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    finally:
+        gpu_ctx.set_option("search_mode", 1); gpu_ctx.set_option("sort_sources", 0)
+    assert st["iters"] == so["iters"] and len(tr) == len(tro)
+    assert np.array_equal(tr[:, 0], tro[:, 0])            # n_corr per iteration, exactly
+    rot, trn = pose_err(T, To)
+    assert rot <= 1e-3 and trn <= 1e-3
+
+
+def test_edge_cases(oracle, gpu_ctx):
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=16, w=300, m_points=20000, scan_seed=1300)
+    p_o = oracle.default_params(1); p = copy_params(p_o, lisreg.Params)
+    # (a) empty corner target, variant #1: the corner stage simply finds nothing
+    gpu_ctx.set_target(case["tgt_corner"][:0], case["tgt_surf"])
+    T, st, tr = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    To, so, tro = oracle.align(case["tgt_corner"][:0], case["tgt_surf"], case["src_corner"], case["src_surf"], case["T_init"], p_o)
+    assert st["status"] == so["status"] == 0 and st["iters"] == so["iters"] and np.array_equal(tr[:, 0], tro[:, 0])
+    assert max(pose_err(T, To)) <= 1e-3
+    # (b) fewer than five target points: no correspondence can exist -> status 2, pose unchanged
+    gpu_ctx.set_target(case["tgt_corner"][:3], case["tgt_surf"][:4])
+    T, st, tr = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    assert st["status"] == lisreg.TOO_FEW_CORRESPONDENCES and st["iters"] == 15 and np.array_equal(T, case["T_init"])
+    assert st["deltaR"] == 100 and st["deltaT"] == 100
+    # (c) empty source corner cloud is fine (edge_min = -1); source far from the map -> status 2
+    gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+    far = case["T_init"].copy(); far[4] -= 300
+    T, st, _ = gpu_ctx.align(case["src_corner"][:0], case["src_surf"], far, p)
+    assert st["status"] == lisreg.TOO_FEW_CORRESPONDENCES and np.array_equal(T, far)
+    # (d) align before any target was set on a fresh context
+    ctx2 = lisreg.Context(0)
+    with pytest.raises(lisreg.LisregError) as e:
+        ctx2.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    assert e.value.code == lisreg.ERR_NO_TARGET
+    ctx2.close()
+    # (e) XYZI clouds (no label field) with stride 32 and a tight stride-12 xyz array are both accepted
+    xyz_c = synth.pcl_xyz(case["src_corner"]); xyz_s = synth.pcl_xyz(case["src_surf"])
+    T12, s12, _ = gpu_ctx.align(np.ascontiguousarray(xyz_c).view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).ravel(),
+                                np.ascontiguousarray(xyz_s).view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).ravel(),
+                                case["T_init"], p)
+    T32, s32, _ = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    assert np.array_equal(T12, T32) and s12 == s32
+
+
+def test_degenerate_plane_quirk_on_gpu(oracle, gpu_ctx):
+    import lisreg
+    from lisreg import synth
+    case = synth.make_plane_case()
+    for emulate in (1, 0):
+        p_o = oracle.default_params(1); p_o.emulate_matp_shadow = emulate
+        p = copy_params(p_o, lisreg.Params)
+        To, so, tro = oracle.align(case["tgt_corner"], case["tgt_surf"], case["src_corner"], case["src_surf"], case["T_init"], p_o)
+        gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+        T, st, tr = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        assert st["degenerate"] == so["degenerate"] == 1 and st["iters"] == so["iters"]
+        assert max(pose_err(T, To)) <= 1e-3
+        if emulate:
+            assert st["iters"] == 1 and st["deltaR"] == 0 and st["deltaT"] == 0 and not tr[1, 43:49].any()
+    # isDegenerate persists in the context like the reference's member: next frame, first iteration a no-op
+    far = case["T_init"].copy(); far[3] += 200
+    p = lisreg.default_params(1)
+    T, st, _ = gpu_ctx.align(case["src_corner"], case["src_surf"], far, p)
+    assert st["degenerate"] == 1 and st["status"] == lisreg.TOO_FEW_CORRESPONDENCES
+    gpu_ctx.set_target(*synth.make_submap(20000, 42))          # a healthy frame clears it at its iteration 0
+    c2 = synth.make_case(h=16, w=300, m_points=20000, scan_seed=1301)
+    T, st, _ = gpu_ctx.align(c2["src_corner"], c2["src_surf"], c2["T_init"], p)
+    assert st["degenerate"] == 0
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE configs[1] shapes (64x1800 scan vs 200k submap): size-independent properties.
+    (1) registration from truth + perturbation recovers the truth to scene noise level;
+    (2) registering a scan from two different initial guesses converges to the same pose;
+    (3) source order does not matter beyond fp64 summation order."""
+    import lisreg
+    from lisreg import synth
+    tc, ts = synth.make_submap(200000, 42)
+    sc = synth.make_scan(64, 1800, 1000)
+    p = lisreg.default_params(1)
+    gpu_ctx.set_target(tc, ts)
+    rng = np.random.default_rng(5)
+    Ta, sa, _ = gpu_ctx.align(sc["corner"], sc["surf"], synth.perturb_pose(sc["T_true"], rng), p)
+    Tb, sb, _ = gpu_ctx.align(sc["corner"], sc["surf"], synth.perturb_pose(sc["T_true"], rng), p)
+    assert sa["status"] == sb["status"] == 0 and sa["n_corr_last"] > 100000
+    assert max(pose_err(Ta, sc["T_true"])) < 2e-2 and max(pose_err(Ta, Tb)) < 2e-3
+    perm_c, perm_s = rng.permutation(len(sc["corner"])), rng.permutation(len(sc["surf"]))
+    p.fixed_iters = 5
+    T0 = synth.perturb_pose(sc["T_true"], rng)
+    T1, s1, _ = gpu_ctx.align(sc["corner"], sc["surf"], T0, p)
+    T2, s2, _ = gpu_ctx.align(sc["corner"][perm_c], sc["surf"][perm_s], T0, p)
+    assert s1["n_corr_last"] == s2["n_corr_last"] and max(pose_err(T1, T2)) < 1e-5
