@@ -153,6 +153,7 @@ DevParams make_dev_params(const lisreg_params& p)
     d.edge_min = p.edge_min; d.surf_min = p.surf_min; d.use_imu = p.use_imu_blend;
     d.imu_w = p.imu_rpy_weight; d.rot_tol = p.rotation_tol; d.z_tol = p.z_tol;
     for (int i = 0; i < 32; ++i) d.wtab[i] = (float)(2.0 - (double)p.label_score[i]);   // subMapOptmizationNode.cpp:1671
+    if (const char* e = getenv("LISREG_DBG")) d.dbg = atoi(e);
     return d;
 }
 

@@ -127,7 +127,7 @@ __device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float
     const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
     const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
     const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
-    const float inv_al = 1.f / (a012 * l12);     // one reciprocal for the three `/ a012 / l12` (:713-723)
+    const float inv_al = __builtin_amdgcn_rcpf(a012 * l12);     // one 1-ulp reciprocal for the three `/ a012 / l12` (:713-723)
     const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) * inv_al;
     const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) * inv_al;
     const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) * inv_al;
@@ -164,9 +164,9 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         float beta_, tau_, v_[5]; \
         if (tail_ <= 1.17549435e-38f) { tau_ = 0.f; beta_ = c0_; _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = 0.f; } \
         else { beta_ = sqrtf(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
-               const float invd_ = 1.f / (c0_ - beta_); \
+               const float invd_ = __builtin_amdgcn_rcpf(c0_ - beta_); \
                _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? a[i_][k] * invd_ : 0.f; \
-               tau_ = (beta_ - c0_) / beta_; } \
+               tau_ = (beta_ - c0_) * __builtin_amdgcn_rcpf(beta_); } \
         a[k][k] = beta_; \
         _Pragma("unroll") for (int j_ = k + 1; j_ < 3; ++j_) { \
             float dot_ = a[k][j_]; \
@@ -203,9 +203,9 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         else LISREG_HOUSEHOLDER(2);
     }
     if (rank == 3) {
-        y[2] = c[2] / a[2][2];
-        y[1] = (c[1] - a[1][2] * y[2]) / a[1][1];
-        y[0] = (c[0] - a[0][1] * y[1] - a[0][2] * y[2]) / a[0][0];
+        y[2] = c[2] * __builtin_amdgcn_rcpf(a[2][2]);
+        y[1] = (c[1] - a[1][2] * y[2]) * __builtin_amdgcn_rcpf(a[1][1]);
+        y[0] = (c[0] - a[0][1] * y[1] - a[0][2] * y[2]) * __builtin_amdgcn_rcpf(a[0][0]);
     } else if (rank == 2) {
         y[1] = c[1] / a[1][1];
         y[0] = (c[0] - a[0][1] * y[1]) / a[0][0];
@@ -229,7 +229,7 @@ __device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y
     lstsq5x3(nb, X);
     float pa = X[0], pb = X[1], pc = X[2], pd = 1.f;
     const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
-    const float ips = 1.f / ps;
+    const float ips = __builtin_amdgcn_rcpf(ps);          // 1-ulp reciprocal (the reference divides; <= 2 ulp apart)
     pa *= ips; pb *= ips; pc *= ips; pd = ips;
     bool valid = true;
 #pragma unroll
@@ -301,7 +301,9 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
         float w = 1.f;
         if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
         float cf[4];
-        const bool ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
+        bool ok;
+        if (P.dbg & 2) { cf[0] = nb[0].x - nb[4].x; cf[1] = nb[1].y - nb[3].y; cf[2] = nb[2].z; cf[3] = w; ok = true; }
+        else ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
         if (ok) { jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
     }
     // the 28 normal-equation terms of this row, produced on demand (float x float is exact in double):
@@ -318,6 +320,7 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
     // Each step exchanges HALF of the values with the partner lane (xor 32, 16, 8, 4, 2), so 32 values need
     // 16+8+4+2+1(+1) 64-bit shuffles instead of 32 x 6; after five steps lane l holds the 32-lane sum of value
     // index bits(l)[5:1] and one last xor-1 step completes it.  Deterministic: the pairing is fixed.
+    if (P.dbg & 4) { if (lane == 0 && wave == 0) out[0] = (double)(row[0] + rb + one); return; }
     double v16[16];
     {
         const bool up = (lane & 32) != 0;
@@ -508,24 +511,26 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 #define LISREG_TEST(c_, j_) do { \
         const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
         const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
-        if (d2_ < b4 && (j_) != i0 && (j_) != i1 && (j_) != i2 && (j_) != i3 && (j_) != i4) LISREG_INSERT(d2_, (j_)); } while (0)
+        if (d2_ < b4) { \
+            const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
+            if (!dup_) LISREG_INSERT(d2_, (j_)); } } while (0)
 
 #define LISREG_WALK(lim2_expr) do { \
-        const float rad_ = sqrtf(fminf(b4, (lim2_expr))) + kEps; \
+        const float lim_ = fminf(b4, (lim2_expr)); \
+        const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps;   /* 1-ulp sqrt is fine: only a bound */ \
         const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
         const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
+        const int cz0_ = max(grid_coord(qz - rad_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rad_, g.oz, g.inv_cell), g.nz - 1); \
+        if (cz0_ <= cz1_) \
         for (int ix_ = cx0_; ix_ <= cx1_; ++ix_) { \
             const float xl_ = g.ox + (float)ix_ * g.cell; \
             const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
-            if (dx_ * dx_ >= fminf(b4, (lim2_expr))) continue; \
+            const float dx2_ = dx_ * dx_; \
+            if (dx2_ >= fminf(b4, lim_)) continue; \
             for (int iy_ = cy0_; iy_ <= cy1_; ++iy_) { \
                 const float yl_ = g.oy + (float)iy_ * g.cell; \
                 const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
-                const float rem_ = fminf(b4, (lim2_expr)) - (dx_ * dx_ + dy_ * dy_); \
-                if (rem_ <= 0.f) continue; \
-                const float rz_ = sqrtf(rem_) + kEps; \
-                const int cz0_ = max(grid_coord(qz - rz_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rz_, g.oz, g.inv_cell), g.nz - 1); \
-                if (cz0_ > cz1_) continue; \
+                if (dx2_ + dy_ * dy_ >= fminf(b4, lim_)) continue; \
                 const int base_ = (ix_ * g.ny + iy_) * g.nz; \
                 const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
                 for (int j_ = js_; j_ < je_; j_ += 4) { \
@@ -590,11 +595,24 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
                 v4f sp[5];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) sp[k] = pts[sid[k]];
+                float sd[5];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const float ex = qx - sp[k].x, ey = qy - sp[k].y, ez = qz - sp[k].z;
-                    const float d2 = ex * ex + ey * ey + ez * ez;
-                    if (d2 < b4) LISREG_INSERT(d2, sid[k]);
+                    sd[k] = ex * ex + ey * ey + ez * ez;
+                }
+                // the seeds are nearly sorted already; a 9-comparator network orders (distance, index) pairs
+#define LISREG_CE(a, b) do { const bool sw_ = sd[b] < sd[a]; const float ta_ = sd[a]; const int ia_ = sid[a]; \
+                             sd[a] = sw_ ? sd[b] : ta_; sd[b] = sw_ ? ta_ : sd[b]; sid[a] = sw_ ? sid[b] : ia_; sid[b] = sw_ ? ia_ : sid[b]; } while (0)
+                LISREG_CE(0, 1); LISREG_CE(3, 4); LISREG_CE(2, 4); LISREG_CE(2, 3); LISREG_CE(0, 3);
+                LISREG_CE(0, 2); LISREG_CE(1, 4); LISREG_CE(1, 3); LISREG_CE(1, 2);
+#undef LISREG_CE
+                if (sd[4] < P.tau) {
+                    b0 = sd[0]; b1 = sd[1]; b2 = sd[2]; b3 = sd[3]; b4 = sd[4];
+                    i0 = sid[0]; i1 = sid[1]; i2 = sid[2]; i3 = sid[3]; i4 = sid[4];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) if (sd[k] < b4) LISREG_INSERT(sd[k], sid[k]);
                 }
                 seeded = true;
             }
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
         if (!seeded) {
             LISREG_WALK(first_pass_r2);                    // tight first pass establishes a bound cheaply
             if (!(b4 <= first_pass_r2)) LISREG_WALK(3.0e38f);
-        } else {
+        } else if (!(P.dbg & 1)) {
             LISREG_WALK(3.0e38f);
         }
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set")

@@ -330,3 +330,34 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_ubyte * 128)()
+    rc = lib().lisreg_comm_unique_id(buf)
+    if rc:
+        raise LisregError(rc, lib().lisreg_last_error(None).decode())
+    return bytes(buf)
+
+
+def _ctx_comm_init(self, rank: int, nranks: int, uid: bytes):
+    buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+    self._chk(self._L.lisreg_comm_init(self._h, rank, nranks, buf))
+
+
+def _ctx_gather_results(self, local_ptr: int, n_local: int, out_ptr: int):
+    self._chk(self._L.lisreg_gather_results(self._h, C.c_void_p(local_ptr), n_local, C.c_void_p(out_ptr)))
+
+
+Context.comm_init = _ctx_comm_init
+Context.gather_results = _ctx_gather_results
+
+
+def device_to_host(ptr: int, shape, dtype=np.float32) -> np.ndarray:
+    """Blocking D2H copy through the library's HIP runtime (tests only)."""
+    out = np.zeros(shape, dtype)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipDeviceSynchronize()
+    if hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) != 0:
+        raise RuntimeError("hipMemcpy D2H failed")
+    return out

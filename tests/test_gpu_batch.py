@@ -196,3 +196,25 @@ def test_full_size_properties(gpu_ctx):
     T1, s1, _ = gpu_ctx.align(sc["corner"], sc["surf"], T0, p)
     T2, s2, _ = gpu_ctx.align(sc["corner"][perm_c], sc["surf"][perm_s], T0, p)
     assert s1["n_corr_last"] == s2["n_corr_last"] and max(pose_err(T1, T2)) < 1e-5
+
+
+def test_native_rccl_gather_single_rank(gpu_ctx):
+    """lisreg_comm_* (dlopen'd librccl): a 1-rank communicator all-gathers the device result block onto itself —
+    exercises the bootstrap and the ncclAllGather call on the context's stream (N > 1 needs the 8-GPU node)."""
+    import lisreg
+    tc, ts, cases = _cases(3)
+    p = lisreg.default_params(1); p.fixed_iters = 4
+    D = lisreg.DeviceArray
+    recs = [(D(lisreg.pack_device_records(c["src_corner"])), D(lisreg.pack_device_records(c["src_surf"]))) for c in cases]
+    gpu_ctx.set_target(tc, ts)
+    items = [dict(corner_ptr=a.ptr, n_corner=a.shape[0], surf_ptr=b.ptr, n_surf=b.shape[0]) for a, b in recs]
+    gpu_ctx.batch_prepare_device(items, np.array([c["T_init"] for c in cases]), p)
+    gpu_ctx.batch_run()
+    out = D(np.zeros((3, 12), np.float32))
+    gpu_ctx.comm_init(0, 1, lisreg.comm_unique_id())
+    gpu_ctx.gather_results(gpu_ctx.result_device_ptr, 3, out.ptr)
+    T, st = gpu_ctx.batch_fetch()
+    got = lisreg.device_to_host(out.ptr, (3, 12))
+    assert np.array_equal(got[:, :6], T)
+    assert [int(v) for v in got[:, 6]] == [s["iters"] for s in st] == [4, 4, 4]
+    assert [int(v) for v in got[:, 11]] == [s["status"] for s in st]
