@@ -61,6 +61,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("rebuild_targets_each_run", 1)
+    if os.environ.get("LISREG_COUNT"):
+        ctx.set_option("count_searches", 1)
 
     # ---- synthetic inputs, generated straight into HBM ----------------------------------------------------------
     tc_dev, ts_dev, tc_host, ts_host = synth_torch.submap_device(M_SUBMAP, dev)
@@ -173,6 +175,9 @@ def main():
                           f"kd-tree leaf 15, two tree builds per registration), 1 thread of {os.cpu_count()} host cores",
                    seconds=round(tcpu, 2))
 
+    if os.environ.get("LISREG_COUNT"):
+        cnt = ctx.counters()
+        print("searched fraction per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in cnt[:ITERS]], file=sys.stderr)
     if rank == 0:
         out = {
             "metric": "scan-to-submap registrations/sec (64x1800 pts, 200k submap)",

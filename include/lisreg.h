@@ -175,8 +175,14 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
 
 /* Options outside the reference's parameter surface: "rebuild_targets_each_run" (0/1: re-run the target index
  * build inside every lisreg_batch_run, as the reference rebuilds both kd-trees per registration, :602-603),
- * "trace_cap" (per-item trace records kept on the device for batches; 0 = off). */
+ * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (0 LDS-staged workgroup box,
+ * 1 per-lane grid walk [default], 2 walk + motion certificate), "sort_sources" (0 caller order [default], 1 column sort),
+ * "cert_slack_mm", "first_pass_mm", "count_searches". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
+
+/* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):
+ * out[2*k] = queries re-searched at GN iteration k, out[2*k+1] = queries processed at iteration k (k < 32). */
+int  lisreg_get_counters(lisreg_ctx* ctx, unsigned long long* out, int n);
 
 /* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
 int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);

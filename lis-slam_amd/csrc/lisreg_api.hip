@@ -70,8 +70,10 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
     // batch
-    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn;
+    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters;
+    bool      count_searches = false;
     int       search_mode = 1;
+    float     cert_slack = 0.10f;
     int       sort_sources = 0;          // 0: keep the caller order (scan/voxel order is already coherent), 1: 2-D column sort
     float     first_pass_r = 0.45f;
     std::vector<BlockDesc> h_blocks;
@@ -288,6 +290,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
     if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
+    if (const char* m = getenv("LISREG_CERT_SLACK_MM")) c->cert_slack = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     *out = c;
     return LISREG_OK;
@@ -302,7 +305,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn };
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters };
     for (auto b : bufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -527,6 +530,9 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     HIPCHK(c, c->sorted_all.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->order_all.ensure(sizeof(int) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->nn.ensure(sizeof(int) * 5 * (size_t)std::max(flat, 1)));
+    HIPCHK(c, c->cert.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
+    HIPCHK(c, c->model0.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
+    HIPCHK(c, c->model1.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->partials.ensure(sizeof(double) * kNumAcc * (size_t)std::max(c->n_blocks, 1)));
     HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * (size_t)std::max(n_items, 1)));
     if (c->trace_cap > 0) HIPCHK(c, c->trace.ensure(sizeof(float) * kTraceStride * (size_t)c->trace_cap * (size_t)std::max(n_items, 1)));
@@ -560,7 +566,9 @@ int lisreg_batch_run(lisreg_ctx* c)
         prof_mark(c, 0);
         launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
                      c->items.as<ItemState>(), c->prm, c->sorted_all.as<float4>(), c->partials.as<double>(),
-                     c->search_mode, c->nn.as<int>(), c->n_elems, c->first_pass_r * c->first_pass_r, st);
+                     c->search_mode, c->nn.as<int>(), c->cert.as<float4>(), c->model0.as<float4>(), c->model1.as<float4>(),
+                     c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack,
+                     c->count_searches ? c->counters.as<unsigned long long>() : nullptr, st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, st);
@@ -600,6 +608,12 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "rebuild_targets_each_run")) { c->rebuild_targets_each_run = value != 0; return LISREG_OK; }
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
     if (!strcmp(name, "search_mode")) { c->search_mode = value; return LISREG_OK; }
+    if (!strcmp(name, "count_searches")) {
+        c->count_searches = value != 0;
+        if (c->count_searches) { HIPCHK(c, c->counters.ensure(64 * 8)); HIPCHK(c, hipMemset(c->counters.p, 0, 64 * 8)); }
+        return LISREG_OK;
+    }
+    if (!strcmp(name, "cert_slack_mm")) { c->cert_slack = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
@@ -687,6 +701,16 @@ int lisreg_get_trace(lisreg_ctx* c, float* buf, int max_iters)
     const int n = std::min(max_iters, c->last_trace_n);
     if (n > 0) memcpy(buf, c->last_trace.data(), sizeof(float) * kTraceStride * (size_t)n);
     return n;
+}
+
+int lisreg_get_counters(lisreg_ctx* c, unsigned long long* out, int n)
+{
+    if (!c || !out || n < 0) return LISREG_ERR_ARG;
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    if (!c->counters.p) return LISREG_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->counters.p, sizeof(unsigned long long) * (size_t)std::min(n, 64), hipMemcpyDeviceToHost));
+    return LISREG_OK;
 }
 
 int lisreg_set_profiling(lisreg_ctx* c, int enable)

@@ -97,9 +97,12 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
     v0[0] = x; v0[1] = y; v0[2] = z;
 }
 
-// cornerOptimization body for one point (odomEstimationNode.cpp:658-742)
-__device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float y0, float z0, float w,
-                                             const DevParams& P, float cf[4])
+// cornerOptimization body for one point (odomEstimationNode.cpp:658-742), split in two:
+//   corner_model : depends only on the five neighbours (centroid, principal direction, lambda0 > 3*lambda1 test) —
+//                  what k_assoc_cached keeps across iterations while the neighbour set is provably unchanged;
+//   corner_eval  : depends on the transformed query point (line residual, robust weight, accept test).
+// m0 = (cx, cy, cz, valid ? 1 : NaN), m1 = (vx, vy, vz, 0).
+__device__ __forceinline__ void corner_model(const float4 nb[5], const DevParams& P, float4& m0, float4& m1)
 {
     float cx = 0, cy = 0, cz = 0;
 #pragma unroll
@@ -114,14 +117,22 @@ __device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float
     a11 *= 0.2f; a12 *= 0.2f; a13 *= 0.2f; a22 *= 0.2f; a23 *= 0.2f; a33 *= 0.2f;
     float l0, l1, v[3];
     eigen_sym3(a11, a12, a13, a22, a23, a33, l0, l1, v);
-    if (!(l0 > P.line_ratio * l1)) return false;
+    const bool ok = l0 > P.line_ratio * l1;                               // :692
+    m0 = make_float4(cx, cy, cz, ok ? 1.f : __int_as_float(0x7fc00000));
+    m1 = make_float4(v[0], v[1], v[2], 0.f);
+}
+
+__device__ __forceinline__ bool corner_eval(const float4 m0, const float4 m1, float x0, float y0, float z0, float w,
+                                            const DevParams& P, float cf[4])
+{
+    const float cx = m0.x, cy = m0.y, cz = m0.z;
     // `cx + 0.1 * v` is double arithmetic in the reference (:697-702)
-    const float x1 = (float)((double)cx + 0.1 * (double)v[0]);
-    const float y1 = (float)((double)cy + 0.1 * (double)v[1]);
-    const float z1 = (float)((double)cz + 0.1 * (double)v[2]);
-    const float x2 = (float)((double)cx - 0.1 * (double)v[0]);
-    const float y2 = (float)((double)cy - 0.1 * (double)v[1]);
-    const float z2 = (float)((double)cz - 0.1 * (double)v[2]);
+    const float x1 = (float)((double)cx + 0.1 * (double)m1.x);
+    const float y1 = (float)((double)cy + 0.1 * (double)m1.y);
+    const float z1 = (float)((double)cz + 0.1 * (double)m1.z);
+    const float x2 = (float)((double)cx - 0.1 * (double)m1.x);
+    const float y2 = (float)((double)cy - 0.1 * (double)m1.y);
+    const float z2 = (float)((double)cz - 0.1 * (double)m1.z);
     const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
     const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
     const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
@@ -135,7 +146,15 @@ __device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float
     const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));
     const float ws = w * s;
     cf[0] = ws * la; cf[1] = ws * lb; cf[2] = ws * lc; cf[3] = ws * ld2;
-    return s > P.accept_s;
+    return (m0.w == 1.f) && (s > P.accept_s);                             // :734 (uses s, not w*s)
+}
+
+__device__ __forceinline__ bool corner_coeff(const float4 nb[5], float x0, float y0, float z0, float w,
+                                             const DevParams& P, float cf[4])
+{
+    float4 m0, m1;
+    corner_model(nb, P, m0, m1);
+    return corner_eval(m0, m1, x0, y0, z0, w, P, cf);
 }
 
 // Column-pivoted Householder QR least squares  [p_j] n = -1  (Eigen colPivHouseholderQr().solve, :783), all in
@@ -221,9 +240,10 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
 #undef LISREG_HOUSEHOLDER
 }
 
-// surfOptimization body for one point (odomEstimationNode.cpp:776-821)
-__device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y0, float z0, float w,
-                                           const DevParams& P, float cf[4])
+// surfOptimization body for one point (odomEstimationNode.cpp:776-821), split like the edge case:
+//   surf_model : plane (pa,pb,pc,pd) of the five neighbours + the |n.p+d| <= 0.2 validity test; pd = NaN if invalid;
+//   surf_eval  : point-to-plane residual, range-scaled robust weight, accept test for the transformed query.
+__device__ __forceinline__ float4 surf_model(const float4 nb[5], const DevParams& P)
 {
     float X[3];
     lstsq5x3(nb, X);
@@ -235,12 +255,25 @@ __device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y
 #pragma unroll
     for (int j = 0; j < 5; ++j)
         valid = valid && !(fabsf(pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd) > P.plane_tol);
+    return make_float4(pa, pb, pc, valid ? pd : __int_as_float(0x7fc00000));
+}
+
+__device__ __forceinline__ bool surf_eval(const float4 m, float x0, float y0, float z0, float w, const DevParams& P,
+                                          float cf[4])
+{
+    const float pa = m.x, pb = m.y, pc = m.z, pd = m.w;
     const float pd2 = pa * x0 + pb * y0 + pc * z0 + pd;
     const float rng = sqrtf(sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
     const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)rng);
     const float ws = w * s;
     cf[0] = ws * pa; cf[1] = ws * pb; cf[2] = ws * pc; cf[3] = ws * pd2;
-    return valid && (s > P.accept_s);
+    return (pd == pd) && (s > P.accept_s);
+}
+
+__device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y0, float z0, float w,
+                                           const DevParams& P, float cf[4])
+{
+    return surf_eval(surf_model(nb, P), x0, y0, z0, w, P, cf);
 }
 
 // LMOptimization row (odomEstimationNode.cpp:862-915); (ox,oy,oz) is the UNtransformed source point
@@ -281,15 +314,20 @@ __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
     return (int)floorf((v - origin) * inv_cell);
 }
 
-// Residual model + Jacobian row + fixed-order fp64 reduction shared by both search front-ends.
+// Jacobian row + fixed-order fp64 reduction of the 28 normal-equation terms: wave halving butterfly -> LDS ->
+// one partial row per workgroup.  `ok` = this lane contributes a correspondence with coefficients cf.
+__device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* sc,
+                                               const DevParams& P, double (*s_acc)[kNumAcc], double* __restrict__ out);
+
+// Residual model shared by the search front-ends that re-fit every iteration.
 // (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
                                                     const float* sc, const DevParams& P, int kind,
                                                     double (*s_acc)[kNumAcc], double* __restrict__ out)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
+    float cf[4] = { 0.f, 0.f, 0.f, 0.f };
+    bool ok = false;
     const bool found = valid && (i4 >= 0);          // five neighbours with sqDist < tau  (:657 / :776)
     if (found) {
         float4 nb[5];
@@ -300,12 +338,18 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
         nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
         float w = 1.f;
         if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
-        float cf[4];
-        bool ok;
         if (P.dbg & 2) { cf[0] = nb[0].x - nb[4].x; cf[1] = nb[1].y - nb[3].y; cf[2] = nb[2].z; cf[3] = w; ok = true; }
         else ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
-        if (ok) { jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
     }
+    row_and_reduce(ok, cf, q4, sc, P, s_acc, out);
+}
+
+__device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* sc,
+                                               const DevParams& P, double (*s_acc)[kNumAcc], double* __restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
+    if (ok) { jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
     // the 28 normal-equation terms of this row, produced on demand (float x float is exact in double):
     //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
     auto term = [&](int k) -> double {
@@ -631,18 +675,230 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
     residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
 }
 
+// walk with a FIXED coverage radius: every cell that can hold a point with d^2 < cov2 is visited, so after the
+// walk any point that was not seen is at least sqrt(cov2) away.  Tracks b5 = smallest squared distance among the
+// visited points that did not end up in the top-5 (needed for the motion certificate of k_assoc_cached).
+#define LISREG_TEST6(c_, j_) do { \
+        const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
+        const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
+        if (d2_ < b4) { \
+            const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
+            if (!dup_) { b5 = fminf(b5, b4); LISREG_INSERT(d2_, (j_)); } \
+        } else if ((j_) != i4) b5 = fminf(b5, d2_); } while (0)
+
+#define LISREG_WALK_COV(cov2_expr) do { \
+        const float lim_ = (cov2_expr); \
+        const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps; \
+        const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
+        const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
+        const int cz0_ = max(grid_coord(qz - rad_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rad_, g.oz, g.inv_cell), g.nz - 1); \
+        if (cz0_ <= cz1_) \
+        for (int ix_ = cx0_; ix_ <= cx1_; ++ix_) { \
+            const float xl_ = g.ox + (float)ix_ * g.cell; \
+            const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
+            const float dx2_ = dx_ * dx_; \
+            if (dx2_ >= lim_) continue; \
+            for (int iy_ = cy0_; iy_ <= cy1_; ++iy_) { \
+                const float yl_ = g.oy + (float)iy_ * g.cell; \
+                const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
+                if (dx2_ + dy_ * dy_ >= lim_) continue; \
+                const int base_ = (ix_ * g.ny + iy_) * g.nz; \
+                const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
+                for (int j_ = js_; j_ < je_; j_ += 4) { \
+                    const int l_ = je_ - 1; \
+                    const v4f c0_ = pts[j_], c1_ = pts[min(j_ + 1, l_)], c2_ = pts[min(j_ + 2, l_)], c3_ = pts[min(j_ + 3, l_)]; \
+                    LISREG_TEST6(c0_, j_); \
+                    if (j_ + 1 <= l_) LISREG_TEST6(c1_, j_ + 1); \
+                    if (j_ + 2 <= l_) LISREG_TEST6(c2_, j_ + 2); \
+                    if (j_ + 3 <= l_) LISREG_TEST6(c3_, j_ + 3); \
+                } \
+            } \
+        } } while (0)
+
+// k_assoc_cached — the default front-end.  Same exact neighbour sets and the same residual arithmetic as
+// k_assoc_walk, but the search and the line/plane fit are only redone for queries whose neighbour set might have
+// changed since it was last computed:
+//
+//   motion certificate.  When a query is searched at position q_ref we record d5 (5th-nearest distance) and a lower
+//   bound d6 on the distance of every OTHER target point (smallest rejected distance seen, capped by the walk's
+//   coverage radius d5 + slack).  Later, at position q with delta = |q - q_ref|, every top-5 point is within
+//   d5 + delta and every other point is at least d6 - delta away (triangle inequality), so if
+//   delta < min((d6 - d5)/2, sqrt(tau) - d5) the five nearest neighbours inside radius sqrt(tau) are the same SET and
+//   the cached line / plane model (a function of the set only, kept in the order it was fitted) is reused.  Gauss-Newton
+//   steps shrink geometrically, so from the third iteration on most queries pass.
+//
+//   compaction.  Queries that fail the certificate are compacted through LDS into the first lanes of the workgroup
+//   ("jobs"), so the expensive search + fit runs on densely populated waves instead of on every wave that happens
+//   to contain one failing lane; results go back to the owning lanes through LDS.
+//
+// Per passing query the kernel touches 48 B (point, certificate, model), all coalesced.
+__global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __restrict__ blocks,
+                                                          const Segment* __restrict__ segs,
+                                                          const GridIndex* __restrict__ grids,
+                                                          const ItemState* __restrict__ items, const DevParams P,
+                                                          const float4* __restrict__ sorted_all,
+                                                          int* __restrict__ nn_, float4* __restrict__ cert,
+                                                          float4* __restrict__ model0, float4* __restrict__ model1,
+                                                          int n_elems, float first_pass_r2, float slack,
+                                                          unsigned long long* __restrict__ counters,
+                                                          double* __restrict__ partials)
+{
+    __shared__ double s_acc[4][kNumAcc];
+    __shared__ int    s_cnt[4];
+    __shared__ float4 s_job_in[kBlockQ];          // qx, qy, qz, owner tid
+    __shared__ float4 s_job_m0[kBlockQ], s_job_m1[kBlockQ];
+    constexpr float kEps = 1e-3f;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ItemState* it = &items[bd.item];
+    if (it->done) return;
+    const Segment sg = segs[bd.seg];
+    const GridIndex g = grids[sg.target];
+    double* out = partials + (size_t)blockIdx.x * kNumAcc;
+    if (g.n < 5) {
+        if (tid < kNumAcc) out[tid] = 0.0;
+        return;
+    }
+    const gptr_f4 pts = (gptr_f4)g.pts;
+    const gptr_i32 cells = (gptr_i32)g.cell_start;
+    const gptr_i32w nn = (gptr_i32w)nn_;
+    const float* M = it->M;
+    const int iter = it->iter;
+    const int kind = sg.kind;
+
+    const bool valid = tid < bd.count;
+    const int qbase = sg.flat_base + bd.start;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) q4 = sorted_all[qbase + tid];
+    const float px = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
+    const float py = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
+    const float pz = M[8] * q4.x + M[9] * q4.y + M[10] * q4.z + M[11];
+
+    // ---- motion certificate ---------------------------------------------------------------------------------------
+    float4 m0 = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000)), m1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool pass = false;
+    if (valid && iter > 0) {
+        const float4 c = cert[qbase + tid];
+        const float ex = px - c.x, ey = py - c.y, ez = pz - c.z;
+        pass = (c.w > 0.f) && (ex * ex + ey * ey + ez * ez < c.w * c.w);
+        if (pass) {
+            m0 = model0[qbase + tid];
+            if (kind == 0) m1 = model1[qbase + tid];
+        }
+    }
+    const bool need = valid && !pass;
+
+    // ---- compact the failing queries into jobs -----------------------------------------------------------------------
+    const unsigned long long ballot = __ballot(need);
+    if (lane == 0) s_cnt[wave] = __popcll(ballot);
+    __syncthreads();
+    int jbase = 0, njobs = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = s_cnt[w]; if (w < wave) jbase += c; njobs += c; }
+    const int slot = jbase + __popcll(ballot & ((1ull << lane) - 1ull));
+    if (counters && tid == 0 && iter < 32) {            // diagnostics: searched vs total queries per GN iteration
+        atomicAdd(&counters[2 * iter], (unsigned long long)njobs);
+        atomicAdd(&counters[2 * iter + 1], (unsigned long long)bd.count);
+    }
+    if (need) s_job_in[slot] = make_float4(px, py, pz, __int_as_float(tid));
+    __syncthreads();
+
+    if (tid < njobs) {
+        const float4 jin = s_job_in[tid];
+        const float qx = jin.x, qy = jin.y, qz = jin.z;
+        const int qflat = qbase + __float_as_int(jin.w);
+        float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau, b5 = 3.0e38f;
+        int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
+        bool seeded = false;
+        if (iter > 0) {
+            const int s4 = nn[4 * (size_t)n_elems + qflat];
+            if (s4 >= 0) {
+                int sid[5];
+                sid[4] = s4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sid[k] = nn[(size_t)k * n_elems + qflat];
+                v4f sp[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sp[k] = pts[sid[k]];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float ex = qx - sp[k].x, ey = qy - sp[k].y, ez = qz - sp[k].z;
+                    const float d2 = ex * ex + ey * ey + ez * ez;
+                    if (d2 < b4) LISREG_INSERT(d2, sid[k]);       // seeds beyond tau are simply dropped
+                }
+                seeded = true;
+            }
+        }
+        float cov2;
+        if (!seeded || i4 < 0) {
+            cov2 = first_pass_r2;                          // tight first pass establishes a bound cheaply
+            LISREG_WALK_COV(cov2);
+            if (!(b4 <= first_pass_r2)) {
+                const float r = __builtin_amdgcn_sqrtf(b4) + slack;
+                cov2 = (i4 >= 0) ? r * r : P.tau;         // nothing beyond tau matters while five are not found
+                cov2 = fmaxf(cov2, first_pass_r2);
+                LISREG_WALK_COV(cov2);
+            }
+        } else {
+            const float r = __builtin_amdgcn_sqrtf(b4) + slack;
+            cov2 = r * r;
+            LISREG_WALK_COV(cov2);
+        }
+        nn[0 * (size_t)n_elems + qflat] = i0; nn[1 * (size_t)n_elems + qflat] = i1;
+        nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
+        nn[4 * (size_t)n_elems + qflat] = i4;
+
+        float4 jm0 = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000)), jm1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float r_safe = -1.f;
+        if (i4 >= 0) {
+            float4 nb[5];
+            const v4f n0 = pts[i0], n1 = pts[i1], n2 = pts[i2], n3 = pts[i3], n4 = pts[i4];
+            nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
+            nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
+            nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
+            if (kind == 0) corner_model(nb, P, jm0, jm1); else jm0 = surf_model(nb, P);
+            // certificate radius: all of the top five stay inside tau and ahead of every other point while the query
+            // moves less than r_safe (2e-4 m covers fp32 rounding of the distances involved)
+            const float d5 = sqrtf(b4), d6 = sqrtf(fminf(b5, cov2));
+            r_safe = fminf(0.5f * (d6 - d5), sqrtf(P.tau) - d5) - 2e-4f;
+        }
+        cert[qflat] = make_float4(qx, qy, qz, r_safe);
+        model0[qflat] = jm0;
+        if (kind == 0) model1[qflat] = jm1;
+        s_job_m0[tid] = jm0; s_job_m1[tid] = jm1;
+    }
+    __syncthreads();
+    if (need) { m0 = s_job_m0[slot]; m1 = s_job_m1[slot]; }
+
+    // ---- residual from the (cached or fresh) model ---------------------------------------------------------------------
+    float cf[4] = { 0.f, 0.f, 0.f, 0.f };
+    bool ok = false;
+    if (valid) {
+        float w = 1.f;
+        if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
+        if (kind == 0) { if (m0.w == 1.f) ok = corner_eval(m0, m1, px, py, pz, w, P, cf); }
+        else           { if (m0.w == m0.w) ok = surf_eval(m0, px, py, pz, w, P, cf); }
+    }
+    row_and_reduce(ok, cf, q4, it->sc, P, s_acc, out);
+}
+
 }  // namespace
 
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                  int mode, int* nn, int n_elems, float first_pass_r2, hipStream_t st)
+                  int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
+                  float slack, unsigned long long* counters, hipStream_t st)
 {
     if (n_blocks <= 0) return;
     if (mode == 0)
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
-    else
+    else if (mode == 1)
         k_assoc_walk<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                    first_pass_r2, partials);
+    else
+        k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
+                                                     model1, n_elems, first_pass_r2, slack, counters, partials);
 }
 
 }  // namespace lisreg

@@ -101,8 +101,9 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
 void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_t st);
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                  int mode /* 0 = LDS-staged workgroup box, 1 = per-lane grid walk */, int* nn, int n_elems,
-                  float first_pass_r2, hipStream_t st);
+                  int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion certificate */,
+                  int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
+                  float slack, unsigned long long* counters /* may be null */, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);

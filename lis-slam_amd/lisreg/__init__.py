@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_counters", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
 ]
@@ -105,6 +105,7 @@ def lib():
         L.lisreg_batch_result_device.argtypes = [vp]
         L.lisreg_batch_result_device.restype = vp
         L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.lisreg_get_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
         L.lisreg_set_profiling.argtypes = [vp, C.c_int]
         L.lisreg_get_timing.argtypes = [vp, C.POINTER(C.c_double)]
@@ -281,6 +282,11 @@ class Context:
     @property
     def result_device_ptr(self) -> int:
         return self._L.lisreg_batch_result_device(self._h) or 0
+
+    def counters(self) -> np.ndarray:
+        out = (C.c_ulonglong * 64)()
+        self._chk(self._L.lisreg_get_counters(self._h, out, 64))
+        return np.array(out[:], np.int64).reshape(32, 2)
 
     def set_profiling(self, on: bool):
         self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))
