@@ -42,8 +42,18 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-regs", type=int, default=3, help="registrations in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
+                    help="cfg2 (default, the metric's config): 64 scans 64x1800 vs one shared 200k submap, 10 iters; "
+                         "cfg4: loop-closure style, every item has its OWN 200k target (index built per item per step); "
+                         "cfg5: stress, 8 scans 128x2048 vs one shared 1M submap, 30 iters")
     args = ap.parse_args()
 
+    global H, W, M_SUBMAP, ITERS
+    if args.workload == "cfg5":
+        H, W, M_SUBMAP, ITERS = 128, 2048, 1_000_000, 30
+        if args.batch == BATCH:
+            args.batch = 8
+    own_targets = args.workload == "cfg4"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,6 +90,14 @@ def main():
     params.fixed_iters = ITERS
     ctx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
     items = [dict(corner_ptr=c.data_ptr(), n_corner=c.shape[0], surf_ptr=s.data_ptr(), n_surf=s.shape[0]) for c, s in scans]
+    own = []
+    if own_targets:                      # every candidate pair gets its own copy of the submap in its own slot
+        for i in range(args.batch):
+            a, b = tc_dev.clone(), ts_dev.clone()
+            own.append((a, b))
+            ctx.set_target_device(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], slot=i)
+            items[i]["target"] = i
+        torch.cuda.synchronize()
     ctx.batch_prepare_device(items, T_init, params)
 
     gathered = torch.empty((world, args.batch, lisreg.RESULT_SIZE), dtype=torch.float32, device=dev)
@@ -171,7 +189,7 @@ def main():
         d = np.abs(T_gpu[:k].astype(np.float64) - T_cpu.astype(np.float64))
         parity = dict(items=k, max_rot_err_rad=float(d[:, :3].max()), max_trans_err_m=float(d[:, 3:].max()))
         cpu = dict(value=round(k / tcpu, 4), unit="registrations/s", cores=1, kind="port",
-                   sample=f"{k} of the {args.batch} scans of this batch (64x1800 vs 200k submap, {ITERS} GN iters, "
+                   sample=f"{k} of the {args.batch} scans of this batch ({H}x{W} vs {M_SUBMAP // 1000}k submap, {ITERS} GN iters, "
                           f"kd-tree leaf 15, two tree builds per registration), 1 thread of {os.cpu_count()} host cores",
                    seconds=round(tcpu, 2))
 
@@ -184,8 +202,11 @@ def main():
             "value": round(value, 2), "unit": "registrations/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=64 synthetic 64x1800 scans vs one shared 200k-pt submap per GPU, "
-                                   "semantic mask off, 10 fixed GN iterations, target index build inside the step",
+            "config": {"workload": {"cfg2": "configs[1]: batch=64 synthetic 64x1800 scans vs one shared 200k-pt submap per GPU, "
+                                            "semantic mask off, 10 fixed GN iterations, target index build inside the step",
+                                    "cfg4": "configs[3]-style: independent registrations, each against its OWN 200k-pt target "
+                                            "(index built per item inside the step), 10 fixed GN iterations",
+                                    "cfg5": "configs[4]: 128x2048 scans vs one shared 1M-pt submap, 30 fixed GN iterations"}[args.workload],
                        "batch_per_gpu": args.batch, "scan": [H, W], "submap_points": M_SUBMAP, "gn_iters": ITERS,
                        "source_points_per_batch": int(n_src), "parallelism": f"independent batches x{n_gpus} + RCCL all-gather of results"},
             "roofline": roof, "cpu_baseline": cpu,

@@ -70,7 +70,10 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
     // batch
-    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters;
+    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev;
+    std::vector<TargetSeg> h_tsegs;
+    std::vector<BlockDesc> h_tblocks;
+    int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
     int       search_mode = 1;
     float     cert_slack = 0.10f;
@@ -305,7 +308,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters };
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev };
     for (auto b : bufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -540,6 +543,31 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     if (c->n_segs) HIPCHK(c, hipMemcpyAsync(c->segs.p, c->h_segs.data(), sizeof(Segment) * (size_t)c->n_segs, hipMemcpyHostToDevice, c->stream));
     if (n_items) HIPCHK(c, hipMemcpyAsync(c->items.p, c->h_items.data(), sizeof(ItemState) * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
     if (c->grids_dirty) { rc = upload_grids(c); if (rc) return rc; }
+    // table for rebuilding every target index of this batch in ONE launch sequence (rebuild_targets_each_run)
+    c->h_tsegs.clear(); c->h_tblocks.clear();
+    int tflat = 0, tbucket = 0;
+    for (int slot : c->batch_slots)
+        for (int k = 0; k < 2; ++k) {
+            Target& t = c->targets[(size_t)slot];
+            TargetSeg ts;
+            memset(&ts, 0, sizeof ts);
+            ts.raw = t.raw_ptr[k]; ts.sorted_out = t.sorted[k].as<float4>(); ts.cell_start_out = t.cell_start[k].as<int>();
+            ts.n = t.n[k]; ts.n_cells = t.n[k] > 0 ? t.n_cells[k] : 0;
+            ts.flat_base = tflat; ts.bucket_base = tbucket;
+            ts.ox = t.g[k].ox; ts.oy = t.g[k].oy; ts.oz = t.g[k].oz; ts.inv_cell = t.g[k].inv_cell;
+            ts.nx = t.g[k].nx; ts.ny = t.g[k].ny; ts.nz = t.g[k].nz;
+            const int id = (int)c->h_tsegs.size();
+            c->h_tsegs.push_back(ts);
+            for (int s = 0; s < ts.n; s += kBlockQ) c->h_tblocks.push_back(BlockDesc{ id, s, std::min(kBlockQ, ts.n - s), 0 });
+            tflat += ts.n; tbucket += ts.n_cells;
+        }
+    c->t_elems = tflat; c->t_buckets = std::max(tbucket, 1);
+    rc = ensure_sort_scratch(c, (size_t)std::max(std::max(flat, tflat), 1), (size_t)std::max(c->n_buckets, c->t_buckets));
+    if (rc) return rc;
+    HIPCHK(c, c->tseg_dev.ensure(sizeof(TargetSeg) * std::max<size_t>(c->h_tsegs.size(), 1)));
+    HIPCHK(c, c->tblk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tblocks.size(), 1)));
+    if (!c->h_tsegs.empty()) HIPCHK(c, hipMemcpyAsync(c->tseg_dev.p, c->h_tsegs.data(), sizeof(TargetSeg) * c->h_tsegs.size(), hipMemcpyHostToDevice, c->stream));
+    if (!c->h_tblocks.empty()) HIPCHK(c, hipMemcpyAsync(c->tblk_dev.p, c->h_tblocks.data(), sizeof(BlockDesc) * c->h_tblocks.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->prepared = true;
     return LISREG_OK;
@@ -553,8 +581,8 @@ int lisreg_batch_run(lisreg_ctx* c)
     hipStream_t st = c->stream;
     if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
         prof_mark(c, 2);
-        for (int slot : c->batch_slots)
-            for (int k = 0; k < 2; ++k) { int rc = build_target_kind(c, c->targets[(size_t)slot], k); if (rc) return rc; }
+        launch_build_targets_batched(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
+                                     (int)c->h_tsegs.size(), c->t_elems, c->t_buckets, sort_buffers(c), st);
         prof_mark(c, -1);
     }
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, st);

@@ -259,6 +259,59 @@ __global__ __launch_bounds__(256) void k_rank_source(const Segment* __restrict__
     order_all[dst] = e;
 }
 
+// ---- batched target builds: many grids, one bucket sort ------------------------------------------------------------
+__global__ __launch_bounds__(kBlockQ) void k_tseg_keys(const BlockDesc* __restrict__ blocks,
+                                                       const TargetSeg* __restrict__ tsegs,
+                                                       uint32_t* __restrict__ elem_bucket,
+                                                       uint32_t* __restrict__ elem_sub, int* __restrict__ hist)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    if ((int)threadIdx.x >= bd.count) return;
+    const TargetSeg t = tsegs[bd.seg];
+    const int e = bd.start + threadIdx.x;
+    const float4 p = t.raw[e];
+    const int ix = cell_coord(p.x, t.ox, t.inv_cell, t.nx);
+    const int iy = cell_coord(p.y, t.oy, t.inv_cell, t.ny);
+    const int iz = cell_coord(p.z, t.oz, t.inv_cell, t.nz);
+    const uint32_t b = (uint32_t)(t.bucket_base + (ix * t.ny + iy) * t.nz + iz);
+    elem_bucket[t.flat_base + e] = b;
+    elem_sub[t.flat_base + e] = 0u;
+    atomicAdd(&hist[b], 1);
+}
+
+__device__ __forceinline__ int find_tseg_by_flat(const TargetSeg* __restrict__ tsegs, int n, int flat)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tsegs[mid].flat_base <= flat) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_rank_tsegs(const TargetSeg* __restrict__ tsegs, int n_tsegs, int n,
+                                                    const uint32_t* __restrict__ tmp_bucket,
+                                                    const uint32_t* __restrict__ tmp_sub,
+                                                    const int* __restrict__ tmp_idx,
+                                                    const int* __restrict__ bucket_start)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int flat;
+    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &flat);
+    const TargetSeg t = tsegs[find_tseg_by_flat(tsegs, n_tsegs, flat)];
+    const int e = flat - t.flat_base;
+    float4 v = t.raw[e];
+    v.w = __int_as_float(e);
+    t.sorted_out[dst - t.flat_base] = v;
+}
+
+// per-target cell_start = slice of the global bucket scan, rebased to the target's own sorted array
+__global__ __launch_bounds__(256) void k_tseg_cell_starts(const TargetSeg* __restrict__ tsegs, int n_tsegs,
+                                                          const int* __restrict__ bucket_start)
+{
+    const TargetSeg t = tsegs[blockIdx.y];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c <= t.n_cells; c += gridDim.x * 256)
+        t.cell_start_out[c] = (c < t.n_cells ? bucket_start[t.bucket_base + c] : t.flat_base + t.n) - t.flat_base;
+}
+
 // identity "sort": keep the caller's order (already spatially coherent scan order) — just flatten the segments
 __global__ __launch_bounds__(kBlockQ) void k_copy_sources(const BlockDesc* __restrict__ blocks,
                                                           const Segment* __restrict__ segs,
@@ -296,6 +349,22 @@ void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_o
         k_rank_target<<<(n + 255) / 256, 256, 0, st>>>(pts, n, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx,
                                                        cell_start_out, sorted_out);
     }
+}
+
+void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, int n_tsegs,
+                                  int n_elems, int n_buckets, SortBuffers sb, hipStream_t st)
+{
+    if (n_tsegs <= 0) return;
+    (void)hipMemsetAsync(sb.hist, 0, sizeof(int) * (size_t)n_buckets, st);
+    if (n_blocks > 0) k_tseg_keys<<<n_blocks, kBlockQ, 0, st>>>(blocks, tsegs, sb.elem_bucket, sb.elem_sub, sb.hist);
+    exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
+    if (n_elems > 0) {
+        k_scatter<<<(n_elems + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n_elems, sb.bucket_start, sb.hist,
+                                                         sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
+        k_rank_tsegs<<<(n_elems + 255) / 256, 256, 0, st>>>(tsegs, n_tsegs, n_elems, sb.tmp_bucket, sb.tmp_sub,
+                                                            sb.tmp_idx, sb.bucket_start);
+    }
+    k_tseg_cell_starts<<<dim3(64, n_tsegs), 256, 0, st>>>(tsegs, n_tsegs, sb.bucket_start);
 }
 
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,

@@ -39,6 +39,18 @@ struct Segment {
     float inv_tile;
 };
 
+// One target cloud of a batched index build (many submaps at once: loop-closure candidate batches).
+struct TargetSeg {
+    const float4* raw;         // caller's records
+    float4*       sorted_out;  // [n]
+    int*          cell_start_out;  // [n_cells + 1]
+    int   n, n_cells;
+    int   flat_base;           // first element in the batch-wide numbering
+    int   bucket_base;         // first bucket
+    float ox, oy, oz, inv_cell;
+    int   nx, ny, nz;
+};
+
 // One workgroup of the correspondence kernel (also the unit of the source-key kernel).
 struct BlockDesc {
     int seg;                   // segment id
@@ -94,6 +106,9 @@ void launch_bbox(const float4* pts, int n, float* bbox6, float* scratch /* >= 6*
 // target index: sorted_out / cell_start_out for the grid described by `g` (g.pts / g.cell_start ignored)
 void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_out, int* cell_start_out,
                          int n_cells, SortBuffers sb, hipStream_t st);
+// several target indexes in one launch sequence (blocks: seg = TargetSeg id, start/count = point chunk)
+void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, int n_tsegs,
+                                  int n_elems, int n_buckets, SortBuffers sb, hipStream_t st);
 // sources of a whole batch: tile-sort every segment under its item's initial pose
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
