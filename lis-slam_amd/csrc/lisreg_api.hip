@@ -70,7 +70,9 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
     // batch
-    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev;
+    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev;
+    int*      done_host = nullptr;          // pinned
+    int       early_stop_chunk = 3;
     std::vector<TargetSeg> h_tsegs;
     std::vector<BlockDesc> h_tblocks;
     int       t_elems = 0, t_buckets = 0;
@@ -290,6 +292,8 @@ int lisreg_create(int device, lisreg_ctx** out)
     }
     c->stream = c->own_stream;
     c->targets.resize(1);
+    if (hipHostMalloc((void**)&c->done_host, sizeof(int), hipHostMallocDefault) != hipSuccess) c->done_host = nullptr;
+    if (c->done_dev.ensure(sizeof(int)) != hipSuccess) { lisreg_destroy(c); return fail(nullptr, LISREG_ERR_HIP, "lisreg_create: hipMalloc failed"); }
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
     if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
@@ -308,9 +312,10 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev };
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev };
     for (auto b : bufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
+    if (c->done_host) (void)hipHostFree(c->done_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -573,9 +578,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     return LISREG_OK;
 }
 
-int lisreg_batch_run(lisreg_ctx* c)
+// Enqueue one full pass.  early_stop (synchronous entry points only): after every few iterations the host reads a
+// 4-byte "registrations finished" counter and stops launching once every item has converged — the reference's
+// `break` at :617 — instead of launching no-op kernels up to max_iters.  Results are identical either way.
+static int run_impl(lisreg_ctx* c, bool early_stop)
 {
-    if (!c) return LISREG_ERR_ARG;
     if (!c->prepared) return fail(c, LISREG_ERR_ARG, "batch_run: no prepared batch");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -585,11 +592,12 @@ int lisreg_batch_run(lisreg_ctx* c)
                                      (int)c->h_tsegs.size(), c->t_elems, c->t_buckets, sort_buffers(c), st);
         prof_mark(c, -1);
     }
-    launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, st);
+    launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_sources ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
+    const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk > 0;
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
         launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
@@ -599,12 +607,23 @@ int lisreg_batch_run(lisreg_ctx* c)
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr, st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
-                     c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, st);
+                     c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
         prof_mark(c, -1);
+        if (can_stop && (it + 1) % c->early_stop_chunk == 0 && it + 1 < c->prm.bound) {
+            HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (*c->done_host >= c->n_items) break;
+        }
     }
     launch_finalize(c->items.as<ItemState>(), c->n_items, c->prm, c->results.as<float>(), st);
     HIPCHK(c, hipGetLastError());
     return LISREG_OK;
+}
+
+int lisreg_batch_run(lisreg_ctx* c)
+{
+    if (!c) return LISREG_ERR_ARG;
+    return run_impl(c, false);
 }
 
 int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
@@ -636,6 +655,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "rebuild_targets_each_run")) { c->rebuild_targets_each_run = value != 0; return LISREG_OK; }
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
     if (!strcmp(name, "search_mode")) { c->search_mode = value; return LISREG_OK; }
+    if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
     if (!strcmp(name, "count_searches")) {
         c->count_searches = value != 0;
         if (c->count_searches) { HIPCHK(c, c->counters.ensure(64 * 8)); HIPCHK(c, hipMemset(c->counters.p, 0, 64 * 8)); }
@@ -682,7 +702,7 @@ int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, con
     if (total) HIPCHK(c, hipMemcpy(c->src_upload.p, h.data(), sizeof(lisreg_dpoint) * total, hipMemcpyHostToDevice));
     int rc = lisreg_batch_prepare(c, n_items, dev_items.data(), params, T);
     if (rc) return rc;
-    rc = lisreg_batch_run(c);
+    rc = run_impl(c, true);
     if (rc) return rc;
     return lisreg_batch_fetch(c, T, stats);
 }

@@ -559,6 +559,11 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
             const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
             if (!dup_) LISREG_INSERT(d2_, (j_)); } } while (0)
 
+#define LISREG_TRY(d2_, j_) do { \
+        if ((d2_) < b4) { \
+            const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
+            if (!dup_) LISREG_INSERT((d2_), (j_)); } } while (0)
+
 #define LISREG_WALK(lim2_expr) do { \
         const float lim_ = fminf(b4, (lim2_expr)); \
         const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps;   /* 1-ulp sqrt is fine: only a bound */ \
@@ -579,11 +584,19 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
                 const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
                 for (int j_ = js_; j_ < je_; j_ += 4) { \
                     const int l_ = je_ - 1; \
-                    const v4f c0_ = pts[j_], c1_ = pts[min(j_ + 1, l_)], c2_ = pts[min(j_ + 2, l_)], c3_ = pts[min(j_ + 3, l_)]; \
-                    LISREG_TEST(c0_, j_); \
-                    if (j_ + 1 <= l_) LISREG_TEST(c1_, j_ + 1); \
-                    if (j_ + 2 <= l_) LISREG_TEST(c2_, j_ + 2); \
-                    if (j_ + 3 <= l_) LISREG_TEST(c3_, j_ + 3); \
+                    const int j1_ = min(j_ + 1, l_), j2_ = min(j_ + 2, l_), j3_ = min(j_ + 3, l_); \
+                    const v4f c0_ = pts[j_], c1_ = pts[j1_], c2_ = pts[j2_], c3_ = pts[j3_]; \
+                    /* four squared distances at once (clamped tail entries repeat the last point: the index check in \
+                       the insert path drops them), one branch for the common "nothing closer" case */ \
+                    const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
+                    const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
+                    const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
+                    const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
+                    const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
+                    const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
+                    if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
+                        LISREG_TRY(e0_, j_); LISREG_TRY(e1_, j1_); LISREG_TRY(e2_, j2_); LISREG_TRY(e3_, j3_); \
+                    } \
                 } \
             } \
         } } while (0)
@@ -667,7 +680,8 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
         } else if (!(P.dbg & 1)) {
             LISREG_WALK(3.0e38f);
         }
-        // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set")
+        // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
+        // when the set is unchanged was measured and lost: the extra live registers cost an occupancy step (8 -> 7).
         nn[0 * (size_t)n_elems + qflat] = i0; nn[1 * (size_t)n_elems + qflat] = i1;
         nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
         nn[4 * (size_t)n_elems + qflat] = i4;

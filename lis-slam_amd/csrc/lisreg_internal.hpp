@@ -113,14 +113,14 @@ void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const T
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
                          hipStream_t st);
-void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_t st);
+void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st);
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion certificate */,
                   int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
                   float slack, unsigned long long* counters /* may be null */, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
-                  int trace_cap, hipStream_t st);
+                  int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);
 
 }  // namespace lisreg

@@ -86,45 +86,71 @@ __device__ void eigen_sym6(float* A, float* W, float* V, int* indR, int* indC)
     }
 }
 
-// cv::solve(AtA, AtB, X, DECOMP_QR): Householder QR.  A (6x6) and c (6) are destroyed.  false if singular.
-__device__ bool solve6_qr(float* A, float* c, float* x, float* v)
+// cv::solve(AtA, AtB, X, DECOMP_QR): Householder QR in float; x zeroed and false returned if singular.
+// Same algorithm with everything in registers (all loops fully unrolled, compile-time indices): the per-iteration
+// critical path of a single registration is this solve, and LDS round trips tripled its latency.
+__device__ __forceinline__ bool solve6_qr_reg(const float* __restrict__ Ain, const float* __restrict__ bin, float* x)
 {
-    const int N = 6;
-    for (int k = 0; k < N; ++k) {
-        const float c0 = A[k * N + k];
+    float A[6][6], c[6], v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        c[i] = bin[i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[i][j] = Ain[i * 6 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float c0 = A[k][k];
         float tail = 0.f;
-        for (int i = k + 1; i < N; ++i) tail += A[i * N + k] * A[i * N + k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) tail += A[i][k] * A[i][k];
         float beta, tau;
-        if (tail <= 1.17549435e-38f) { tau = 0.f; beta = c0; for (int i = k + 1; i < N; ++i) v[i] = 0.f; }
-        else {
+        if (tail <= 1.17549435e-38f) {
+            tau = 0.f; beta = c0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = 0.f;
+        } else {
             beta = sqrtf(c0 * c0 + tail);
             if (c0 >= 0.f) beta = -beta;
-            for (int i = k + 1; i < N; ++i) v[i] = A[i * N + k] / (c0 - beta);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = (i > k) ? A[i][k] / (c0 - beta) : 0.f;
             tau = (beta - c0) / beta;
         }
-        A[k * N + k] = beta;
+        A[k][k] = beta;
         if (tau != 0.f) {
-            for (int j = k + 1; j < N; ++j) {
-                float dot = A[k * N + j];
-                for (int i = k + 1; i < N; ++i) dot += v[i] * A[i * N + j];
+#pragma unroll
+            for (int j = k + 1; j < 6; ++j) {
+                float dot = A[k][j];
+#pragma unroll
+                for (int i = k + 1; i < 6; ++i) dot += v[i] * A[i][j];
                 dot *= tau;
-                A[k * N + j] -= dot;
-                for (int i = k + 1; i < N; ++i) A[i * N + j] -= dot * v[i];
+                A[k][j] -= dot;
+#pragma unroll
+                for (int i = k + 1; i < 6; ++i) A[i][j] -= dot * v[i];
             }
             float dot = c[k];
-            for (int i = k + 1; i < N; ++i) dot += v[i] * c[i];
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) dot += v[i] * c[i];
             dot *= tau;
             c[k] -= dot;
-            for (int i = k + 1; i < N; ++i) c[i] -= dot * v[i];
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) c[i] -= dot * v[i];
         }
     }
-    for (int i = 0; i < N; ++i) if (fabsf(A[i * N + i]) <= 1.17549435e-38f) { for (int j = 0; j < N; ++j) x[j] = 0.f; return false; }
-    for (int i = N - 1; i >= 0; --i) {
+    bool singular = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) singular = singular || (fabsf(A[i][i]) <= 1.17549435e-38f);
+    float y[6];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
         float s = c[i];
-        for (int j = i + 1; j < N; ++j) s -= A[i * N + j] * x[j];
-        x[i] = s / A[i * N + i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= A[i][j] * y[j];
+        y[i] = s / A[i][i];
     }
-    return true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = singular ? 0.f : y[i];
+    return !singular;
 }
 
 // cv::Mat::inv() (DECOMP_LU): LU with partial pivoting.  A destroyed, B receives the inverse (zeros if singular).
@@ -171,7 +197,8 @@ __device__ void write_pose_cache(ItemState* it)
     it->sc[4] = F; it->sc[5] = E;      // srz = sin(roll),  crz = cos(roll)
 }
 
-__global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P)
+__global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P,
+                                                    int* __restrict__ done_counter)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_items) return;
@@ -182,6 +209,7 @@ __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ item
     it->iter = 0;
     it->guard_failed = guard_ok ? 0 : 1;
     it->done = guard_ok ? 0 : 1;
+    if (!guard_ok) atomicAdd(done_counter, 1);
     it->iters_out = 0;
     it->deltaR = 100.f; it->deltaT = 100.f;                                      // member initialisers :70-71
     it->degenerate = it->degenerate_in;
@@ -194,9 +222,10 @@ constexpr int kSolveThreads = 256;
 
 __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__ items, const DevParams P,
                                                          const double* __restrict__ partials,
-                                                         float* __restrict__ trace, int trace_cap)
+                                                         float* __restrict__ trace, int trace_cap,
+                                                         int* __restrict__ done_counter)
 {
-    __shared__ float s_AtA[36], s_AtB[6], s_X[6], s_A[36], s_c[6], s_v[6];
+    __shared__ float s_AtA[36], s_AtB[6], s_X[6], s_A[36];
     __shared__ float s_E[6], s_V[36], s_V2[36], s_Vi[36];
     __shared__ int   s_ind[12];
     __shared__ double s_part[kSolveThreads / 32][32];
@@ -242,9 +271,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
         for (int r = 0; r < 6; ++r)
             for (int c = r; c < 6; ++c) { const float v = (float)s_sum[k++]; s_AtA[r * 6 + c] = v; s_AtA[c * 6 + r] = v; }
         for (int r = 0; r < 6; ++r) s_AtB[r] = (float)s_sum[21 + r];
-        for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
-        for (int i = 0; i < 6; ++i) s_c[i] = s_AtB[i];
-        solve6_qr(s_A, s_c, s_X, s_v);                           // :921
+        solve6_qr_reg(s_AtA, s_AtB, s_X);                        // :921
         int isDeg = it->degenerate;
         if (iter == 0) {                                         // :923-946
             for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
     }
     it->iter = iter + 1;
     if (!finished && iter + 1 >= P.bound) { it->iters_out = P.bound; finished = true; }
-    if (finished) it->done = 1;
+    if (finished) { it->done = 1; atomicAdd(done_counter, 1); }     // host-side early stop of the launch loop
 }
 
 // tf::Quaternion / tf::Matrix3x3 pieces of transformUpdate (odomEstimationNode.cpp:976-1006), double like tf
@@ -371,15 +398,16 @@ __global__ __launch_bounds__(64) void k_finalize(ItemState* __restrict__ items, 
 
 }  // namespace
 
-void launch_reset_items(ItemState* items, int n_items, DevParams prm, hipStream_t st)
+void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st)
 {
-    if (n_items > 0) k_reset_items<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm);
+    (void)hipMemsetAsync(done_counter, 0, sizeof(int), st);
+    if (n_items > 0) k_reset_items<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, done_counter);
 }
 
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
-                  int trace_cap, hipStream_t st)
+                  int trace_cap, int* done_counter, hipStream_t st)
 {
-    if (n_items > 0) k_solve<<<n_items, kSolveThreads, 0, st>>>(items, prm, partials, trace, trace_cap);
+    if (n_items > 0) k_solve<<<n_items, kSolveThreads, 0, st>>>(items, prm, partials, trace, trace_cap, done_counter);
 }
 
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st)
