@@ -218,3 +218,42 @@ def test_native_rccl_gather_single_rank(gpu_ctx):
     assert np.array_equal(got[:, :6], T)
     assert [int(v) for v in got[:, 6]] == [s["iters"] for s in st] == [4, 4, 4]
     assert [int(v) for v in got[:, 11]] == [s["status"] for s in st]
+
+
+def test_two_contexts_on_two_threads_match_sequential():
+    """Callers #2 and #3 of the reference run concurrently in one process (subMapOptmizationNode.cpp:5188-5195):
+    two contexts (own HIP streams, no shared mutable state) driven from two host threads give bit-identical
+    results to running the same work sequentially."""
+    import threading
+    import lisreg
+    from lisreg import synth
+    jobs = []
+    for k, (variant, labelled) in enumerate(((2, True), (3, True))):
+        case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=1400 + k, labelled=labelled)
+        jobs.append((variant, case))
+
+    def run(variant, case, out, reps):
+        ctx = lisreg.Context(0)
+        p = lisreg.default_params(variant)
+        res = []
+        for _ in range(reps):
+            ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+            T, st, tr = ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+            res.append((T.copy(), st, tr.copy()))
+        ctx.close()
+        out.append(res)
+
+    seq = []
+    for variant, case in jobs:
+        run(variant, case, seq, 1)
+    par = [[], []]
+    th = [threading.Thread(target=run, args=(jobs[k][0], jobs[k][1], par[k], 8)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        T0, st0, tr0 = seq[k][0]
+        assert len(par[k][0]) == 8
+        for T, st, tr in par[k][0]:
+            assert np.array_equal(T, T0) and st == st0 and np.array_equal(tr, tr0)
