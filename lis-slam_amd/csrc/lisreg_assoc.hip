@@ -681,7 +681,8 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
             LISREG_WALK(3.0e38f);
         }
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
-        // when the set is unchanged was measured and lost: the extra live registers cost an occupancy step (8 -> 7).
+        // while the set is unchanged was measured twice: keeping the five ids live costs an occupancy step (8 -> 7,
+        // 4 % slower); a one-register XOR signature keeps 8 waves but gains nothing — the kernel is not HBM-bound.
         nn[0 * (size_t)n_elems + qflat] = i0; nn[1 * (size_t)n_elems + qflat] = i1;
         nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
         nn[4 * (size_t)n_elems + qflat] = i4;
