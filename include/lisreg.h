@@ -36,6 +36,7 @@ extern "C" {
 #define LISREG_OK                        0
 #define LISREG_NOT_ENOUGH_FEATURES       1   /* guard at odomEstimationNode.cpp:598,623-625 failed: T untouched */
 #define LISREG_TOO_FEW_CORRESPONDENCES   2   /* every iteration hit the `< 50` early return (:870-872): T untouched */
+#define LISREG_LEAF_TOO_SMALL            3   /* VoxelGrid: dx*dy*dz overflows int32 — PCL warns and copies the input  */
 #define LISREG_ERR_ARG                  -1
 #define LISREG_ERR_HIP                  -2
 #define LISREG_ERR_NO_TARGET            -3
@@ -192,6 +193,22 @@ int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);
  * out[2] = total ms in the solve/update kernel, out[3] = its launch count, out[4] = index build ms. */
 int  lisreg_set_profiling(lisreg_ctx* ctx, int enable);
 int  lisreg_get_timing(lisreg_ctx* ctx, double out[5]);
+
+/* ---- the step before the registration --------------------------------------------------- */
+/* Replaces pcl::VoxelGrid<PointT>::filter with the reference's default settings — downSizeFilterCorner/Surf on the
+ * incoming feature clouds (odomEstimationNode.cpp:272-277) and on the assembled local map (:196-201), and
+ * voxel_downsample_pcl on submap class clouds (src/include/subMap.h:1207-1249): one centroid per occupied voxel of
+ * edge `leaf` (xyz and intensity averaged, label = most frequent), output in ascending PCL voxel index.
+ * in/out: LISREG_FMT_XYZI / _XYZIL host clouds (out has the input's stride), or LISREG_FMT_DEVICE (in and out are device
+ * lisreg_dpoint arrays; payload label majority-voted) so the result can feed lisreg_align / lisreg_set_target directly.
+ * *n_out receives the voxel count; if it exceeds out_capacity nothing is written and LISREG_ERR_ARG is returned.
+ * Returns LISREG_LEAF_TOO_SMALL (and copies the input, as PCL does) when the voxel index would overflow int32. */
+int  lisreg_voxel_downsample(lisreg_ctx* ctx, const void* in, int n, int stride_bytes, int fmt, float leaf,
+                             void* out, int out_capacity, int* n_out);
+/* Replaces transformPointCloud(cloud, &pose6D) (src/core/common.cpp:112-173 and the PointXYZIL overload; callers
+ * odomEstimationNode.cpp:457-458, 574-575): p' = R(T) p + t with T = {roll,pitch,yaw,x,y,z}; other fields copied.
+ * Same formats as above; in == out is allowed. */
+int  lisreg_transform_cloud(lisreg_ctx* ctx, const void* in, int n, int stride_bytes, int fmt, const float T[6], void* out);
 
 /* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
 /* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */

@@ -70,7 +70,8 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
     // batch
-    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev;
+    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
+           vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M;
     int*      done_host = nullptr;          // pinned
     int       early_stop_chunk = 3;
     std::vector<TargetSeg> h_tsegs;
@@ -312,7 +313,8 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev };
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M };
     for (auto b : bufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);
@@ -772,6 +774,150 @@ int lisreg_get_timing(lisreg_ctx* c, double out[5])
 {
     if (!c || !out) return LISREG_ERR_ARG;
     for (int i = 0; i < 5; ++i) out[i] = c->timing[i];
+    return LISREG_OK;
+}
+
+// ---- §8 f-1: voxel-grid down-sampling and cloud transform --------------------------------------------------------------
+int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, int fmt, float leaf, void* out,
+                            int out_capacity, int* n_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!n_out || n < 0 || !(leaf > 0.f) || (n > 0 && (!in || !out))) return fail(c, LISREG_ERR_ARG, "voxel_downsample: bad arguments");
+    if (fmt != LISREG_FMT_DEVICE && (stride < 12 || (fmt == LISREG_FMT_XYZIL && stride < 22)))
+        return fail(c, LISREG_ERR_ARG, "voxel_downsample: bad stride");
+    *n_out = 0;
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool dev = fmt == LISREG_FMT_DEVICE;
+    const bool has_intensity = !dev && stride >= 20;
+    // ---- stage the input as float4 (x,y,z, intensity | payload) [+ labels] ---------------------------------------
+    const float4* pts = nullptr;
+    const uint32_t* labels = nullptr;
+    std::vector<float4> h_pts;
+    std::vector<uint32_t> h_lab;
+    if (dev) pts = static_cast<const float4*>(in);
+    else {
+        h_pts.resize((size_t)n);
+        if (fmt == LISREG_FMT_XYZIL) h_lab.resize((size_t)n);
+        const unsigned char* b = static_cast<const unsigned char*>(in);
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* r = b + (size_t)i * (size_t)stride;
+            float v[3], it = 0.f;
+            memcpy(v, r, 12);
+            if (has_intensity) memcpy(&it, r + 16, 4);
+            h_pts[(size_t)i] = make_float4(v[0], v[1], v[2], it);
+            if (fmt == LISREG_FMT_XYZIL) { uint16_t l; memcpy(&l, r + 20, 2); h_lab[(size_t)i] = l; }
+        }
+        HIPCHK(c, c->vox_in.ensure(sizeof(float4) * (size_t)n));
+        HIPCHK(c, hipMemcpyAsync(c->vox_in.p, h_pts.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
+        pts = c->vox_in.as<float4>();
+        if (fmt == LISREG_FMT_XYZIL) {
+            HIPCHK(c, c->vox_lab.ensure(sizeof(uint32_t) * (size_t)n));
+            HIPCHK(c, hipMemcpyAsync(c->vox_lab.p, h_lab.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+            labels = c->vox_lab.as<uint32_t>();
+        }
+    }
+    // ---- getMinMax3D + grid geometry (voxel_grid.hpp) -------------------------------------------------------------
+    float bb[6];
+    HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 8));
+    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
+    launch_bbox(pts, n, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), st);
+    HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const float inv = 1.0f / leaf;
+    const long long dx = (long long)((bb[3] - bb[0]) * inv) + 1, dy = (long long)((bb[4] - bb[1]) * inv) + 1,
+                    dz = (long long)((bb[5] - bb[2]) * inv) + 1;
+    if (dx * dy * dz > 2147483647LL) {           // "Leaf size is too small for the input dataset": output = input
+        if (n > out_capacity) { *n_out = n; return fail(c, LISREG_ERR_ARG, "voxel_downsample: out_capacity too small"); }
+        if (dev) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        else memcpy(out, in, (size_t)n * (size_t)stride);
+        HIPCHK(c, hipStreamSynchronize(st));
+        *n_out = n;
+        return LISREG_LEAF_TOO_SMALL;
+    }
+    VoxelDesc d;
+    int div_b[3];
+    const int min_b[3] = { (int)floorf(bb[0] * inv), (int)floorf(bb[1] * inv), (int)floorf(bb[2] * inv) };
+    const int max_b[3] = { (int)floorf(bb[3] * inv), (int)floorf(bb[4] * inv), (int)floorf(bb[5] * inv) };
+    for (int k = 0; k < 3; ++k) div_b[k] = max_b[k] - min_b[k] + 1;
+    d.inv_leaf = inv; d.min_b0 = min_b[0]; d.min_b1 = min_b[1]; d.min_b2 = min_b[2];
+    d.mul1 = div_b[0]; d.mul2 = div_b[0] * div_b[1];
+    const long long total = (long long)div_b[0] * div_b[1] * div_b[2];
+    const long long max_buckets = 1LL << 22;
+    d.span = (uint32_t)std::max(1LL, (total + max_buckets - 1) / max_buckets);
+    const int n_buckets = (int)((total + d.span - 1) / d.span);
+    // ---- sort by voxel index, count voxels ------------------------------------------------------------------------
+    int rc = ensure_sort_scratch(c, (size_t)n, (size_t)std::max(n_buckets, n) + 1);
+    if (rc) return rc;
+    HIPCHK(c, c->vox_order.ensure(sizeof(int) * (size_t)n));
+    HIPCHK(c, c->vox_sidx.ensure(sizeof(uint32_t) * (size_t)n));
+    HIPCHK(c, c->vox_head.ensure(sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(c, c->vox_slot.ensure(sizeof(int) * ((size_t)n + 2)));
+    launch_voxel_sort(pts, n, d, n_buckets, sort_buffers(c), c->vox_order.as<int>(), c->vox_sidx.as<uint32_t>(),
+                      c->vox_head.as<int>(), c->vox_slot.as<int>(), st);
+    int n_vox = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_vox, c->vox_slot.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *n_out = n_vox;
+    if (n_vox > out_capacity) return fail(c, LISREG_ERR_ARG, "voxel_downsample: out_capacity too small (see *n_out)");
+    // ---- centroids ---------------------------------------------------------------------------------------------------
+    HIPCHK(c, c->vox_start.ensure(sizeof(int) * ((size_t)n_vox + 2)));
+    float4* out_pts = dev ? static_cast<float4*>(out) : nullptr;
+    if (!dev) { HIPCHK(c, c->vox_out.ensure(sizeof(float4) * (size_t)n_vox)); out_pts = c->vox_out.as<float4>(); }
+    uint32_t* out_lab = nullptr;
+    if (fmt == LISREG_FMT_XYZIL) { HIPCHK(c, c->vox_outlab.ensure(sizeof(uint32_t) * (size_t)n_vox)); out_lab = c->vox_outlab.as<uint32_t>(); }
+    launch_voxel_centroids(n, n_vox, pts, labels, dev ? 1 : 0, c->vox_order.as<int>(), c->vox_head.as<int>(),
+                           c->vox_slot.as<int>(), c->vox_start.as<int>(), out_pts, out_lab, st);
+    HIPCHK(c, hipGetLastError());
+    if (!dev) {
+        std::vector<float4> r((size_t)n_vox);
+        std::vector<uint32_t> rl(fmt == LISREG_FMT_XYZIL ? (size_t)n_vox : 0);
+        HIPCHK(c, hipMemcpyAsync(r.data(), out_pts, sizeof(float4) * (size_t)n_vox, hipMemcpyDeviceToHost, st));
+        if (out_lab) HIPCHK(c, hipMemcpyAsync(rl.data(), out_lab, sizeof(uint32_t) * (size_t)n_vox, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        unsigned char* o = static_cast<unsigned char*>(out);
+        for (int i = 0; i < n_vox; ++i) {
+            unsigned char* q = o + (size_t)i * (size_t)stride;
+            memset(q, 0, (size_t)stride);
+            memcpy(q, &r[(size_t)i], 12);
+            if (has_intensity) memcpy(q + 16, &r[(size_t)i].w, 4);
+            if (out_lab) { const uint16_t l = (uint16_t)rl[(size_t)i]; memcpy(q + 20, &l, 2); }
+        }
+    } else HIPCHK(c, hipStreamSynchronize(st));
+    return LISREG_OK;
+}
+
+int lisreg_transform_cloud(lisreg_ctx* c, const void* in, int n, int stride, int fmt, const float T[6], void* out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n < 0 || !T || (n > 0 && (!in || !out))) return fail(c, LISREG_ERR_ARG, "transform_cloud: bad arguments");
+    if (fmt != LISREG_FMT_DEVICE && stride < 12) return fail(c, LISREG_ERR_ARG, "transform_cloud: bad stride");
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    float M[12];
+    pose_to_matrix_host(T, M);                       // pcl::getTransformation (common.cpp:140-142)
+    HIPCHK(c, c->vox_M.ensure(sizeof M));
+    HIPCHK(c, hipMemcpyAsync(c->vox_M.p, M, sizeof M, hipMemcpyHostToDevice, st));
+    if (fmt == LISREG_FMT_DEVICE) {
+        launch_transform_cloud(static_cast<const float4*>(in), n, c->vox_M.as<float>(), static_cast<float4*>(out), st);
+        HIPCHK(c, hipStreamSynchronize(st));         // M is a local
+        return LISREG_OK;
+    }
+    std::vector<float4> h((size_t)n);
+    const unsigned char* b = static_cast<const unsigned char*>(in);
+    for (int i = 0; i < n; ++i) { float v[3]; memcpy(v, b + (size_t)i * (size_t)stride, 12); h[(size_t)i] = make_float4(v[0], v[1], v[2], 0.f); }
+    HIPCHK(c, c->vox_in.ensure(sizeof(float4) * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(c->vox_in.p, h.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
+    launch_transform_cloud(c->vox_in.as<float4>(), n, c->vox_M.as<float>(), c->vox_in.as<float4>(), st);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->vox_in.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    unsigned char* o = static_cast<unsigned char*>(out);
+    for (int i = 0; i < n; ++i) {
+        if (o != b) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)i * (size_t)stride, (size_t)stride);   // other fields copied
+        memcpy(o + (size_t)i * (size_t)stride, &h[(size_t)i], 12);
+    }
     return LISREG_OK;
 }
 

@@ -325,6 +325,108 @@ __global__ __launch_bounds__(kBlockQ) void k_copy_sources(const BlockDesc* __res
     order_all[sg.flat_base + e] = e;
 }
 
+// ---- §8 f-1: pcl::VoxelGrid (default settings) -----------------------------------------------------------------------
+// Same deterministic bucket sort, keyed by PCL's voxel index idx = ijk0 + ijk1*div0 + ijk2*div0*div1
+// (filters/impl/voxel_grid.hpp; call sites /root/reference/src/node/odomEstimationNode.cpp:196-201, 272-277 and
+// src/include/subMap.h:1207-1249).  The index space can be as large as 2^31, so a bucket is a RANGE of `span`
+// consecutive indices and the rank pass orders each bucket by (idx, input order): the sorted sequence is exactly
+// "ascending idx, ties by input index" — PCL's output order with the summation order fixed.
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ pts, int n, VoxelDesc d,
+                                                    uint32_t* __restrict__ elem_bucket, uint32_t* __restrict__ elem_sub,
+                                                    int* __restrict__ hist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    // ijk = static_cast<int>(floor(p * inverse_leaf) - static_cast<float>(min_b))
+    const int i0 = (int)(floorf(p.x * d.inv_leaf) - (float)d.min_b0);
+    const int i1 = (int)(floorf(p.y * d.inv_leaf) - (float)d.min_b1);
+    const int i2 = (int)(floorf(p.z * d.inv_leaf) - (float)d.min_b2);
+    const uint32_t idx = (uint32_t)(i0 + i1 * d.mul1 + i2 * d.mul2);
+    const uint32_t b = idx / d.span;
+    elem_bucket[i] = b;
+    elem_sub[i] = idx - b * d.span;
+    atomicAdd(&hist[b], 1);
+}
+
+__global__ __launch_bounds__(256) void k_voxel_rank(int n, uint32_t span, const uint32_t* __restrict__ tmp_bucket,
+                                                    const uint32_t* __restrict__ tmp_sub, const int* __restrict__ tmp_idx,
+                                                    const int* __restrict__ bucket_start, int* __restrict__ order,
+                                                    uint32_t* __restrict__ sidx)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int e;
+    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
+    order[dst] = e;
+    sidx[dst] = tmp_bucket[p] * span + tmp_sub[p];
+}
+
+__global__ __launch_bounds__(256) void k_voxel_heads(int n, const uint32_t* __restrict__ sidx, int* __restrict__ head)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    head[p] = (p == 0 || sidx[p] != sidx[p - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_starts(int n, const int* __restrict__ head, const int* __restrict__ slot,
+                                                      int* __restrict__ vstart)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    if (head[p]) vstart[slot[p]] = p;
+    if (p == n - 1) vstart[slot[p] + head[p]] = n;
+}
+
+// CentroidPoint (common/impl/accumulators.hpp): xyz and intensity = sequential float sums / n, label = most frequent
+// (smallest on ties).  One thread per output voxel; voxels hold a handful of points.
+// w_mode 0: .w is an intensity (averaged), labels (if any) in `labels`; w_mode 1: .w is a lisreg_dpoint payload whose
+// low 16 bits are the label (majority-voted into the output payload).
+__global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4* __restrict__ pts,
+                                                         const uint32_t* __restrict__ labels, int w_mode,
+                                                         const int* __restrict__ order, const int* __restrict__ vstart,
+                                                         float4* __restrict__ out_pts, uint32_t* __restrict__ out_labels)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_vox) return;
+    const int a = vstart[v], b = vstart[v + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+    for (int p = a; p < b; ++p) {
+        const float4 q = pts[order[p]];
+        sx += q.x; sy += q.y; sz += q.z;
+        if (w_mode == 0) sw += q.w;
+    }
+    const float cnt = (float)(b - a);
+    uint32_t best = 0u;
+    if (w_mode == 1 || labels) {
+        int bestc = 0;
+        for (int p = a; p < b; ++p) {
+            const int e = order[p];
+            const uint32_t lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
+            int c = 0;
+            for (int m = a; m < b; ++m) {
+                const int em = order[m];
+                c += (((w_mode == 1 ? __float_as_uint(pts[em].w) : labels[em]) & 0xffffu) == lp) ? 1 : 0;
+            }
+            if (c > bestc || (c == bestc && lp < best)) { bestc = c; best = lp; }
+        }
+    }
+    out_pts[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, w_mode == 1 ? __uint_as_float(best) : sw / cnt);
+    if (out_labels) out_labels[v] = best;
+}
+
+// transformPointCloud (src/core/common.cpp:112-173): p' = R p + t, the fourth channel is copied
+__global__ __launch_bounds__(256) void k_transform_cloud(const float4* __restrict__ in, int n, const float* __restrict__ M12,
+                                                         float4* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    out[i] = make_float4(M12[0] * p.x + M12[1] * p.y + M12[2] * p.z + M12[3],
+                         M12[4] * p.x + M12[5] * p.y + M12[6] * p.z + M12[7],
+                         M12[8] * p.x + M12[9] * p.y + M12[10] * p.z + M12[11], p.w);
+}
+
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------------------------------------
@@ -385,6 +487,33 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
         k_rank_source<<<(n_elems + 255) / 256, 256, 0, st>>>(segs, n_segs, n_elems, sb.tmp_bucket, sb.tmp_sub,
                                                              sb.tmp_idx, sb.bucket_start, sorted_all, order_all);
     }
+}
+
+// sort the cloud by voxel index; head flags + their exclusive scan (slot[n] = number of voxels) are left on the device
+void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
+                       int* head, int* slot, hipStream_t st)
+{
+    (void)hipMemsetAsync(sb.hist, 0, sizeof(int) * (size_t)n_buckets, st);
+    k_voxel_keys<<<(n + 255) / 256, 256, 0, st>>>(pts, n, d, sb.elem_bucket, sb.elem_sub, sb.hist);
+    exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
+    k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, sb.bucket_start, sb.hist, sb.tmp_bucket,
+                                               sb.tmp_sub, sb.tmp_idx);
+    k_voxel_rank<<<(n + 255) / 256, 256, 0, st>>>(n, d.span, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, sb.bucket_start, order, sidx);
+    k_voxel_heads<<<(n + 255) / 256, 256, 0, st>>>(n, sidx, head);
+    exclusive_scan(head, slot, sb.scan_tmp, n, st);
+}
+
+void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t* labels, int w_mode, const int* order,
+                            const int* head, const int* slot, int* vstart, float4* out_pts, uint32_t* out_labels,
+                            hipStream_t st)
+{
+    k_voxel_starts<<<(n + 255) / 256, 256, 0, st>>>(n, head, slot, vstart);
+    k_voxel_centroids<<<(n_vox + 255) / 256, 256, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
+}
+
+void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st)
+{
+    if (n > 0) k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(in, n, M12_dev, out);
 }
 
 }  // namespace lisreg

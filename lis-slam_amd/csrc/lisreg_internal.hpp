@@ -89,6 +89,14 @@ struct ItemState {
     lisreg_imu imu;
 };
 
+// pcl::VoxelGrid geometry (filters/impl/voxel_grid.hpp): computed on the host from the bounding box
+struct VoxelDesc {
+    float    inv_leaf;             // inverse_leaf_size_ = 1 / leaf (float)
+    int      min_b0, min_b1, min_b2;
+    int      mul1, mul2;           // divb_mul_ = (1, div0, div0*div1)
+    uint32_t span;                 // consecutive voxel indices per sort bucket
+};
+
 // ---- launchers (lisreg_kernels.hip); all enqueue on `st`, none synchronise --------------------------------
 struct SortBuffers {           // scratch for one deterministic bucket sort
     int*      hist;            // [n_buckets] counts (consumed by the scatter)
@@ -122,5 +130,13 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);
+
+// §8 f-1 (lisreg_index.hip)
+void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
+                       int* head, int* slot /* [n+1], slot[n] = number of voxels */, hipStream_t st);
+void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t* labels, int w_mode, const int* order,
+                            const int* head, const int* slot, int* vstart /* [n_vox+1] */, float4* out_pts,
+                            uint32_t* out_labels /* may be null */, hipStream_t st);
+void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st);
 
 }  // namespace lisreg

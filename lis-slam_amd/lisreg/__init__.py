@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "liblisreg.so")
 CSRC = os.path.join(_PKG, "csrc")
 
-OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES = 0, 1, 2
+OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES, LEAF_TOO_SMALL = 0, 1, 2, 3
 ERR_ARG, ERR_HIP, ERR_NO_TARGET, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5
 FMT_XYZI, FMT_XYZIL, FMT_DEVICE = 0, 1, 2
 VARIANT_ODOM, VARIANT_KEYFRAME, VARIANT_SUBMAP = 1, 2, 3
@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_counters", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
+    "lisreg_voxel_downsample", "lisreg_transform_cloud",
 ]
 
 
@@ -118,6 +119,8 @@ def lib():
         L.lisreg_gather_results.argtypes = [vp, vp, C.c_int, vp]
         L.lisreg_comm_destroy.argtypes = [vp]
         L.lisreg_comm_destroy.restype = None
+        L.lisreg_voxel_downsample.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, ip]
+        L.lisreg_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, vp]
         _lib = L
     return _lib
 
@@ -287,6 +290,37 @@ class Context:
         out = (C.c_ulonglong * 64)()
         self._chk(self._L.lisreg_get_counters(self._h, out, 64))
         return np.array(out[:], np.int64).reshape(32, 2)
+
+    # -- §8 f-1 -------------------------------------------------------------------------------------------
+    def voxel_downsample(self, cloud: np.ndarray, leaf: float):
+        """pcl::VoxelGrid replacement on a PCL struct array.  Returns (status, downsampled array)."""
+        cloud = np.ascontiguousarray(cloud)
+        out = np.zeros_like(cloud)
+        n_out = C.c_int(0)
+        rc = self._L.lisreg_voxel_downsample(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud), leaf,
+                                             out.ctypes.data_as(C.c_void_p), len(out), C.byref(n_out))
+        self._chk(rc, allow=(OK, LEAF_TOO_SMALL))
+        return rc, out[: n_out.value]
+
+    def voxel_downsample_device(self, in_ptr: int, n: int, leaf: float, out_ptr: int, capacity: int):
+        n_out = C.c_int(0)
+        rc = self._L.lisreg_voxel_downsample(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, leaf, C.c_void_p(out_ptr),
+                                             capacity, C.byref(n_out))
+        self._chk(rc, allow=(OK, LEAF_TOO_SMALL))
+        return rc, n_out.value
+
+    def transform_cloud(self, cloud: np.ndarray, T):
+        cloud = np.ascontiguousarray(cloud)
+        out = np.zeros_like(cloud)
+        Tf = np.ascontiguousarray(T, np.float32)
+        self._chk(self._L.lisreg_transform_cloud(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud),
+                                                 Tf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def transform_cloud_device(self, in_ptr: int, n: int, T, out_ptr: int):
+        Tf = np.ascontiguousarray(T, np.float32)
+        self._chk(self._L.lisreg_transform_cloud(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE,
+                                                 Tf.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(out_ptr)))
 
     def set_profiling(self, on: bool):
         self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))

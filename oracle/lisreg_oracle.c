@@ -778,3 +778,103 @@ int orc_align(const void* tgt_corner, int n_tc, const void* tgt_surf, int n_ts,
     cloud_free(&tc); cloud_free(&ts); cloud_free(&sc); cloud_free(&ss);
     return st.status;
 }
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* §8 f-1: pcl::VoxelGrid (default settings) and transformPointCloud                                         */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct { unsigned int idx; int pt; } vox_pair;
+
+static int vox_cmp(const void* a, const void* b)
+{
+    const vox_pair* x = (const vox_pair*)a; const vox_pair* y = (const vox_pair*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0);       /* fixed choice inside PCL's unstable order */
+}
+
+int orc_voxel_grid(const void* in, int n, int stride, int fmt, float leaf, void* out, int* n_out)
+{
+    const unsigned char* src = (const unsigned char*)in;
+    unsigned char* dst = (unsigned char*)out;
+    *n_out = 0;
+    if (n <= 0) return 0;
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = 0; i < n; ++i) {                             /* getMinMax3D */
+        float p[3]; memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        for (int d = 0; d < 3; ++d) { if (p[d] < mn[d]) mn[d] = p[d]; if (p[d] > mx[d]) mx[d] = p[d]; }
+    }
+    const float inv = 1.0f / leaf;                            /* inverse_leaf_size_ = Ones() / leaf_size_ */
+    long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+              dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > 2147483647LL) {                        /* "Leaf size is too small for the input dataset" */
+        memcpy(dst, src, (size_t)n * (size_t)stride);
+        *n_out = n;
+        return 3;
+    }
+    int min_b[3], max_b[3], div_b[3];
+    for (int d = 0; d < 3; ++d) {
+        min_b[d] = (int)floorf(mn[d] * inv);
+        max_b[d] = (int)floorf(mx[d] * inv);
+        div_b[d] = max_b[d] - min_b[d] + 1;
+    }
+    const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+    vox_pair* iv = (vox_pair*)malloc(sizeof(vox_pair) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        int ijk0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+        int ijk1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+        int ijk2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+        iv[i].idx = (unsigned int)(ijk0 + ijk1 * mul1 + ijk2 * mul2);
+        iv[i].pt = i;
+    }
+    qsort(iv, (size_t)n, sizeof(vox_pair), vox_cmp);
+    int no = 0;
+    for (int a = 0; a < n;) {
+        int b = a + 1;
+        while (b < n && iv[b].idx == iv[a].idx) ++b;
+        /* CentroidPoint: AccumulatorXYZ (Vector3f sum), AccumulatorIntensity (float sum), AccumulatorLabel (map) */
+        float sx = 0, sy = 0, sz = 0, si = 0;
+        for (int k = a; k < b; ++k) {
+            const unsigned char* r = src + (size_t)iv[k].pt * (size_t)stride;
+            float p[3], it = 0; memcpy(p, r, 12);
+            if (stride >= 20) memcpy(&it, r + 16, 4);
+            sx += p[0]; sy += p[1]; sz += p[2]; si += it;
+        }
+        const float cnt = (float)(size_t)(b - a);
+        unsigned char* o = dst + (size_t)no * (size_t)stride;
+        memset(o, 0, (size_t)stride);
+        float c[3] = { sx / cnt, sy / cnt, sz / cnt }, ci = si / cnt;
+        memcpy(o, c, 12);
+        if (stride >= 20) memcpy(o + 16, &ci, 4);
+        if (fmt == LISREG_FMT_XYZIL) {
+            unsigned short best = 0; int bestc = 0;
+            for (int k = a; k < b; ++k) {
+                unsigned short lk; memcpy(&lk, src + (size_t)iv[k].pt * (size_t)stride + 20, 2);
+                int cc = 0;
+                for (int m = a; m < b; ++m) { unsigned short lm; memcpy(&lm, src + (size_t)iv[m].pt * (size_t)stride + 20, 2); cc += lm == lk; }
+                if (cc > bestc || (cc == bestc && lk < best)) { bestc = cc; best = lk; }   /* smallest label on ties */
+            }
+            memcpy(o + 20, &best, 2);
+        }
+        ++no;
+        a = b;
+    }
+    free(iv);
+    *n_out = no;
+    return 0;
+}
+
+void orc_transform_cloud(const void* in, int n, int stride, int fmt, const float T[6], void* out)
+{
+    (void)fmt;
+    float M[12];
+    orc_pose_to_matrix(T, M);                                 /* pcl::getTransformation (common.cpp:140-142) */
+    const unsigned char* src = (const unsigned char*)in;
+    unsigned char* dst = (unsigned char*)out;
+    for (int i = 0; i < n; ++i) {
+        float p[3], q[3];
+        if (dst != src) memcpy(dst + (size_t)i * (size_t)stride, src + (size_t)i * (size_t)stride, (size_t)stride);
+        memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        transform_point(M, p, q);
+        memcpy(dst + (size_t)i * (size_t)stride, q, 12);
+    }
+}

@@ -80,6 +80,19 @@ int  orc_align(const void* tgt_corner, int n_tc, const void* tgt_surf, int n_ts,
 void orc_stage_coeffs(int kind, const void* tgt, int n_t, const void* src, int n_s, int stride_bytes, int fmt,
                       const lisreg_params* params, const float T[6], unsigned char* flags, float* coeffs);
 
+/* ---- §8 f-1: the step immediately before the registration on both inputs ----------------------------------- */
+/* pcl::VoxelGrid<PointT>::filter with default settings (call sites odomEstimationNode.cpp:196-201, 272-277;
+ * subMap.h:1207-1249), restated from PCL 1.8.1 filters/impl/voxel_grid.hpp + common/impl/accumulators.hpp:
+ * getMinMax3D -> min_b/div_b from floor(min * inverse_leaf) -> per point idx = ijk0 + ijk1*div0 + ijk2*div0*div1 with
+ * ijk = (int)(floor(p * inverse_leaf) - (float)min_b) -> sort by idx -> per voxel CentroidPoint: xyz and intensity are
+ * float sums / n, label = most frequent (smallest label on ties) -> output in ascending idx.  PCL's std::sort is
+ * unstable, so the summation order inside a voxel is implementation-defined there; the restatement fixes it to
+ * ascending input index.  Returns 0, or 3 when dx*dy*dz would overflow int32 (PCL warns and copies the input).
+ * `out` has room for n points of the input layout; label written only for LISREG_FMT_XYZIL. */
+int  orc_voxel_grid(const void* in, int n, int stride_bytes, int fmt, float leaf, void* out, int* n_out);
+/* transformPointCloud (src/core/common.cpp:112-173 and the PointXYZIL overload): p' = R(T) p + t, other fields copied. */
+void orc_transform_cloud(const void* in, int n, int stride_bytes, int fmt, const float T[6], void* out);
+
 #ifdef __cplusplus
 }
 #endif

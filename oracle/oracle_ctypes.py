@@ -87,6 +87,9 @@ def lib():
                                 C.c_int, C.c_int]
         L.orc_stage_coeffs.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Params), fp,
                                        C.POINTER(C.c_ubyte), fp]
+        L.orc_voxel_grid.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, ip]
+        L.orc_transform_cloud.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, vp]
+        L.orc_transform_cloud.restype = None
         _lib = L
     return _lib
 
@@ -128,3 +131,22 @@ def stage_coeffs(kind, tgt, src, T, params: Params, fmt: int = 1):
     L.orc_stage_coeffs(kind, _vp(tgt), len(tgt), _vp(src), len(src), tgt.dtype.itemsize, fmt, C.byref(params),
                        _fp(Tf), flags.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(coeffs))
     return flags.astype(bool), coeffs
+
+
+def voxel_grid(cloud, leaf: float, fmt: int = 1):
+    """orc_voxel_grid on a PCL-struct array.  Returns (status, downsampled array)."""
+    L = lib()
+    cloud = np.ascontiguousarray(cloud)
+    out = np.zeros_like(cloud)
+    n_out = C.c_int(0)
+    rc = L.orc_voxel_grid(_vp(cloud), len(cloud), cloud.dtype.itemsize, fmt, leaf, out.ctypes.data_as(C.c_void_p), C.byref(n_out))
+    return rc, out[: n_out.value]
+
+
+def transform_cloud(cloud, T, fmt: int = 1):
+    L = lib()
+    cloud = np.ascontiguousarray(cloud)
+    out = np.zeros_like(cloud)
+    Tf = np.array(T, np.float32)
+    L.orc_transform_cloud(_vp(cloud), len(cloud), cloud.dtype.itemsize, fmt, _fp(Tf), out.ctypes.data_as(C.c_void_p))
+    return out
