@@ -399,16 +399,42 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4
     const float cnt = (float)(b - a);
     uint32_t best = 0u;
     if (w_mode == 1 || labels) {
-        int bestc = 0;
+        // AccumulatorLabel: most frequent label, smallest on ties.  Voxels next to the sensor can hold thousands of
+        // points, so count through up to 8 distinct (label, count) slots held in registers (compile-time indices);
+        // only a voxel with more distinct labels than that falls back to the quadratic count.
+        uint32_t sl[8]; int sc[8]; int ns = 0; bool overflow = false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { sl[s] = 0xffffffffu; sc[s] = 0; }
         for (int p = a; p < b; ++p) {
             const int e = order[p];
             const uint32_t lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
-            int c = 0;
-            for (int m = a; m < b; ++m) {
-                const int em = order[m];
-                c += (((w_mode == 1 ? __float_as_uint(pts[em].w) : labels[em]) & 0xffffu) == lp) ? 1 : 0;
+            bool hit = false;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) if (sl[s] == lp) { ++sc[s]; hit = true; }
+            if (!hit) {
+                if (ns < 8) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) if (s == ns) { sl[s] = lp; sc[s] = 1; }
+                    ++ns;
+                } else { overflow = true; break; }
             }
-            if (c > bestc || (c == bestc && lp < best)) { bestc = c; best = lp; }
+        }
+        int bestc = 0;
+        if (!overflow) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (sc[s] > bestc || (sc[s] == bestc && sc[s] > 0 && sl[s] < best)) { bestc = sc[s]; best = sl[s]; }
+        } else {
+            for (int p = a; p < b; ++p) {
+                const int e = order[p];
+                const uint32_t lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
+                int c = 0;
+                for (int m = a; m < b; ++m) {
+                    const int em = order[m];
+                    c += (((w_mode == 1 ? __float_as_uint(pts[em].w) : labels[em]) & 0xffffu) == lp) ? 1 : 0;
+                }
+                if (c > bestc || (c == bestc && lp < best)) { bestc = c; best = lp; }
+            }
         }
     }
     out_pts[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, w_mode == 1 ? __uint_as_float(best) : sw / cnt);

@@ -38,6 +38,19 @@ int main()
     for (size_t i = 0; i < mapCorner.size(); i += 5) corner.push_back(inv(mapCorner.points[i]));
 
     Scan2SubMapRegistration<> reg(Variant::Odom);
+    // the reference's per-frame order: voxel-grid the local map and the incoming features, then register
+    // (odomEstimationNode.cpp:196-201, 272-277, 596)
+    VoxelGrid<> downSizeFilterCorner(reg.handle()), downSizeFilterSurf(reg.handle());
+    downSizeFilterCorner.setLeafSize(0.2f, 0.2f, 0.2f);
+    downSizeFilterSurf.setLeafSize(0.4f, 0.4f, 0.4f);
+    PointCloud<PointType> mapCornerDS, mapSurfDS, cornerDS, surfDS;
+    downSizeFilterCorner.setInputCloud(&mapCorner); downSizeFilterCorner.filter(mapCornerDS);
+    downSizeFilterSurf.setInputCloud(&mapSurf);     downSizeFilterSurf.filter(mapSurfDS);
+    downSizeFilterCorner.setInputCloud(&corner);    downSizeFilterCorner.filter(cornerDS);
+    downSizeFilterSurf.setInputCloud(&surf);        downSizeFilterSurf.filter(surfDS);
+    std::printf("VoxelGrid: map %zu/%zu -> %zu/%zu, scan %zu/%zu -> %zu/%zu\n", mapCorner.size(), mapSurf.size(), mapCornerDS.size(),
+                mapSurfDS.size(), corner.size(), surf.size(), cornerDS.size(), surfDS.size());
+    mapCorner = mapCornerDS; mapSurf = mapSurfDS; corner = cornerDS; surf = surfDS;
     reg.setInputTarget(mapCorner, mapSurf);
     cloud_info info;
     int rc = reg.scan2SubMapOptimization(corner, surf, info);

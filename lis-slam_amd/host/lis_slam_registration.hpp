@@ -13,6 +13,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/lisreg.h"
@@ -129,5 +130,48 @@ private:
     void check(int rc) { if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_)); }
     lisreg_ctx* ctx_ = nullptr;
 };
+
+// ---- the pcl::VoxelGrid surface the nodes use ------------------------------------------------------
+// downSizeFilterCorner / downSizeFilterSurf (odomEstimationNode.cpp:34-35, 110-111, 196-201, 272-277) and
+// voxel_downsample_pcl (src/include/subMap.h:1207-1249) call exactly setLeafSize / setInputCloud / filter.
+// Shares the registration object's context (and stream), so down-sampling and registration stay ordered.
+template <class PointT = PointType>
+class VoxelGrid {
+public:
+    explicit VoxelGrid(lisreg_ctx* ctx) : ctx_(ctx) {}
+    void setLeafSize(float lx, float ly, float lz) {
+        if (lx != ly || ly != lz) throw RegistrationError(LISREG_ERR_ARG, "VoxelGrid: the reference only uses cubic leaves");
+        leaf_ = lx;
+    }
+    void setInputCloud(const PointCloud<PointT>* cloud) { input_ = cloud; }
+    // returns LISREG_OK or LISREG_LEAF_TOO_SMALL (PCL's warning case: output = input)
+    int filter(PointCloud<PointT>& output) {
+        if (!input_) throw RegistrationError(LISREG_ERR_ARG, "VoxelGrid: no input cloud");
+        std::vector<PointT> tmp(input_->size());
+        int n_out = 0;
+        const int fmt = std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI;
+        int rc = lisreg_voxel_downsample(ctx_, input_->points.data(), (int)input_->size(), (int)sizeof(PointT), fmt, leaf_,
+                                         tmp.data(), (int)tmp.size(), &n_out);
+        if (rc < 0) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        tmp.resize((size_t)n_out);
+        output.points.swap(tmp);
+        return rc;
+    }
+private:
+    lisreg_ctx* ctx_;
+    const PointCloud<PointT>* input_ = nullptr;
+    float leaf_ = 0.4f;
+};
+
+// transformPointCloud(cloudIn, &pose6D) (src/core/common.cpp:130-173); pose = {roll, pitch, yaw, x, y, z}
+template <class PointT>
+inline PointCloud<PointT> transformPointCloud(lisreg_ctx* ctx, const PointCloud<PointT>& cloudIn, const float pose[6]) {
+    PointCloud<PointT> out;
+    out.points.resize(cloudIn.size());
+    const int fmt = std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI;
+    int rc = lisreg_transform_cloud(ctx, cloudIn.points.data(), (int)cloudIn.size(), (int)sizeof(PointT), fmt, pose, out.points.data());
+    if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx));
+    return out;
+}
 
 }  // namespace lis_slam
