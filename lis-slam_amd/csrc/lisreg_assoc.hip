@@ -6,18 +6,25 @@
 //   :829-850 (compaction — fused away: accepted rows go straight into the reduction), :862-920 (J rows, AtA, AtB)
 // and the label-weighted copies src/node/subMapOptmizationNode.cpp:1557-1917, 4556-4916.
 //
-// gfx950 mapping
-//   * a workgroup = 256 spatially compact queries (tile-sorted by lisreg_index.hip) of one (item, stage);
-//   * pcl::KdTreeFLANN::nearestKSearch(k=5) + `sqDist[4] < tau` is replaced by an exact fixed-radius 5-NN:
-//     the workgroup takes the bounding box of its transformed queries, grows it by r = sqrt(tau), stages every
-//     target point of the covered grid cells through LDS (coalesced 16-B loads of contiguous cell runs), and all
-//     lanes scan the staged points (LDS broadcast reads) keeping a sorted top-5 in registers initialised at tau.
-//     Any target point closer than r to a query lies in a staged cell, so the 5 nearest within r are exact;
-//   * the 5 neighbours are gathered once (5 x 16 B), the 3x3 eigen / 5x3 QR fit, weights and the Jacobian row
-//     stay in registers, and 28 normal-equation scalars are reduced in fp64 by wave shuffles -> LDS -> one
-//     partial row per workgroup (fixed order, no float atomics: reproducible).
-// No dense contraction exists here (K = n_corr, M = N = 6), so MFMA is not used; the kernel is bound by VALU
-// issue and LDS broadcast bandwidth, with the submap resident in L2 / Infinity Cache.
+// gfx950 mapping (three search front-ends share one residual / reduction tail; `search_mode` selects)
+//   * a workgroup = 256 consecutive queries of one (item, stage), kept in caller order (scan / voxel order is
+//     spatially coherent, which is what the cell walk's L1 hit rate needs);
+//   * pcl::KdTreeFLANN::nearestKSearch(k=5) + `sqDist[4] < tau` is replaced by an exact fixed-radius 5-NN over the
+//     uniform grid of lisreg_index.hip, with a sorted top-5 in registers initialised at tau:
+//       k_assoc_walk   (default) every lane walks only the cells that can hold a point closer than its current
+//                      5th-best distance, seeded with last iteration's neighbours (any five points bound the radius);
+//                      candidates are 16-B records read through L1/L2, four loads in flight per lane;
+//       k_assoc_cached (experimental) the same walk, run only for queries that fail a triangle-inequality motion
+//                      certificate, compacted through LDS; line/plane model cached per neighbour set;
+//       k_assoc_staged (first version, kept for cross-checks) workgroup bounding box + sqrt(tau), covered cell runs
+//                      staged through LDS, all lanes scan via LDS broadcast;
+//     all three return the same neighbour SETS (tests require identical correspondence counts);
+//   * the 5 neighbours are gathered once (5 x 16 B), the 3x3 eigen / 5x3 QR fit, weights and the Jacobian row stay in
+//     registers, and the 28 normal-equation scalars (exact fp64 products of floats) are reduced by a wave-level
+//     halving butterfly -> LDS -> one partial row per workgroup (fixed order, no float atomics: reproducible).
+// No dense contraction exists here (K = n_corr, M = N = 6), so MFMA is not used.  Measured: the
+// submap is L2 / Infinity-Cache resident, HBM traffic is below the algorithmic bytes, and the kernel is bound by VALU
+// issue, per-lane gather address processing and dependent-load latency at 8 waves/SIMD (63 VGPRs).
 #include "lisreg_internal.hpp"
 
 namespace lisreg {

@@ -2,12 +2,13 @@
 //
 // Replaces the two pcl::KdTreeFLANN::setInputCloud calls of every registration
 // (/root/reference/src/node/odomEstimationNode.cpp:602-603; subMapOptmizationNode.cpp:1516-1517, 4496-4497) with a
-// uniform-grid bucket sort of the target cloud, and tile-sorts the source features of a whole batch so that a
-// workgroup's 256 queries are spatially compact (small LDS staging footprint in lisreg_assoc.hip).
+// uniform-grid bucket sort of the target cloud (one or many targets per launch sequence), offers an optional 2-D
+// column sort of the source features for callers whose clouds are not spatially coherent, and implements the row
+// before the registration: pcl::VoxelGrid and transformPointCloud.
 //
-// One deterministic bucket sort serves both: histogram (integer atomics, order-independent counts) ->
+// One deterministic bucket sort serves all of them: histogram (integer atomics, order-independent counts) ->
 // exclusive scan -> scatter (atomic cursor, arbitrary order inside a bucket) -> rank pass that orders every
-// bucket by (sub-key, original index).  The result is bit-reproducible run to run.  All passes are HBM-bound
+// bucket by (sub-key, original index).  The result is bit-reproducible run to run.  All passes are HBM
 // streaming/gather passes with coalesced 16-byte records; nothing here is GEMM-shaped.
 #include "lisreg_internal.hpp"
 
