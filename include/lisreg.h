@@ -210,6 +210,36 @@ int  lisreg_voxel_downsample(lisreg_ctx* ctx, const void* in, int n, int stride_
  * Same formats as above; in == out is allowed. */
 int  lisreg_transform_cloud(lisreg_ctx* ctx, const void* in, int n, int stride_bytes, int fmt, const float T[6], void* out);
 
+/* ---- producer of cloud_info: range-image projection + LOAM feature extraction ----------------- */
+/* Host point layout of the raw scan: PointXYZIRT (src/include/common.h:12-23): x@0 y@4 z@8 intensity@16 uint16 ring@20
+ * float time@24, 32-byte stride.  Device layout: lisreg_dpoint with the ring in the low 16 bits of the payload. */
+#define LISREG_FMT_XYZIRT  3
+typedef struct lisreg_feature_params {
+    int   n_scan;             /* N_SCAN        (config/params.yaml:68 = 64)   */
+    int   horizon_scan;       /* Horizon_SCAN  (config/params.yaml:69 = 1800) */
+    int   downsample_rate;    /* downsampleRate(config/params.yaml:72 = 2): rows with ring % rate != 0 are dropped */
+    float min_range;          /* lidarMinRange (config/params.yaml:73 = 0.0)  */
+    float max_range;          /* lidarMaxRange (config/params.yaml:74 = 70.0) */
+    float edge_threshold;     /* edgeThreshold (config/params.yaml:117 = 1.0) */
+    float surf_threshold;     /* surfThreshold (config/params.yaml:118 = 0.1) */
+} lisreg_feature_params;
+/* The five clouds of cloud_info (msg/cloud_info.msg:20-25).  Buffers are caller-allocated in the INPUT's layout with the
+ * stated capacities (points); counts are written back.  n_scan*horizon_scan is always enough for each. */
+typedef struct lisreg_feature_out {
+    void* deskewed;      int cap_deskewed,      n_deskewed;       /* extractedCloud    -> cloud_deskewed        */
+    void* corner;        int cap_corner,        n_corner;         /* cornerCloud       -> cloud_corner          */
+    void* surface;       int cap_surface,       n_surface;        /* surfaceCloud      -> cloud_surface         */
+    void* corner_sharp;  int cap_corner_sharp,  n_corner_sharp;   /* sharpCornerCloud  -> cloud_corner_sharp    */
+    void* surface_sharp; int cap_surface_sharp, n_surface_sharp;  /* SharpSurfaceCloud -> cloud_surface_sharp   */
+} lisreg_feature_out;
+/* Replaces LaserProcessing::projectPointCloud, cloudExtraction, calculateSmoothness, markOccludedPoints and
+ * extractFeatures (src/core/laserProcessing.cpp:467-510, 515-539, 544-563, 568-605, 610-713) for one scan, without the
+ * IMU de-skew (deskewPoint returns the point unchanged when no IMU data is available, :404-406).  Output order is the
+ * reference's: rings ascending, six sectors per ring, corners in pick order (largest curvature first). */
+int  lisreg_extract_features(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
+                             const lisreg_feature_params* params, lisreg_feature_out* out);
+int  lisreg_default_feature_params(lisreg_feature_params* p);
+
 /* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
 /* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */
 void lisreg_pose_to_matrix(const float T[6], float M[12]);

@@ -71,7 +71,9 @@ struct lisreg_ctx {
     DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
     // batch
     DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
-           vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M;
+           vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
+           ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
+           ft_lists, ft_counts, ft_rings, ft_gather;
     int*      done_host = nullptr;          // pinned
     int       early_stop_chunk = 3;
     std::vector<TargetSeg> h_tsegs;
@@ -314,7 +316,10 @@ void lisreg_destroy(lisreg_ctx* c)
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
                        &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
-                       &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M };
+                       &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
+                       &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
+                       &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
+                       &c->ft_gather };
     for (auto b : bufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);
@@ -918,6 +923,96 @@ int lisreg_transform_cloud(lisreg_ctx* c, const void* in, int n, int stride, int
         if (o != b) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)i * (size_t)stride, (size_t)stride);   // other fields copied
         memcpy(o + (size_t)i * (size_t)stride, &h[(size_t)i], 12);
     }
+    return LISREG_OK;
+}
+
+// ---- §8 f-2: range-image projection + feature extraction ----------------------------------------------------------------
+int lisreg_default_feature_params(lisreg_feature_params* p)
+{
+    if (!p) return LISREG_ERR_ARG;
+    p->n_scan = 64; p->horizon_scan = 1800; p->downsample_rate = 2;        // config/params.yaml:68-72
+    p->min_range = 0.0f; p->max_range = 70.0f;                            // :73-74
+    p->edge_threshold = 1.0f; p->surf_threshold = 0.1f;                   // :117-118
+    return LISREG_OK;
+}
+
+int lisreg_extract_features(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const lisreg_feature_params* P,
+                            lisreg_feature_out* out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!P || !out || n < 0 || (n > 0 && !cloud)) return fail(c, LISREG_ERR_ARG, "extract_features: bad arguments");
+    if (fmt != LISREG_FMT_XYZIRT && fmt != LISREG_FMT_DEVICE) return fail(c, LISREG_ERR_ARG, "extract_features: fmt must be XYZIRT or DEVICE");
+    if (fmt == LISREG_FMT_XYZIRT && stride < 22) return fail(c, LISREG_ERR_ARG, "extract_features: XYZIRT needs stride >= 22");
+    if (P->n_scan < 1 || P->n_scan > 1024 || P->horizon_scan < 16 || P->horizon_scan > 4096 || P->downsample_rate < 1)
+        return fail(c, LISREG_ERR_ARG, "extract_features: n_scan in [1,1024], horizon_scan in [16,4096], downsample_rate >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool dev = fmt == LISREG_FMT_DEVICE;
+    const int H = P->n_scan, W = P->horizon_scan, hw = H * W;
+    const size_t L = (size_t)hw + 16;
+    HIPCHK(c, c->ft_owner.ensure(sizeof(int) * (size_t)hw));      HIPCHK(c, c->ft_flag.ensure(sizeof(int) * L));
+    HIPCHK(c, c->ft_pos.ensure(sizeof(int) * 2 * (L + 1)));       HIPCHK(c, c->ft_scan.ensure(sizeof(int) * (L / 2048 + 8)));
+    HIPCHK(c, c->ft_col.ensure(sizeof(int) * L));                 HIPCHK(c, c->ft_range.ensure(sizeof(float) * L));
+    HIPCHK(c, c->ft_src.ensure(sizeof(int) * L));                 HIPCHK(c, c->ft_curv.ensure(sizeof(float) * L));
+    HIPCHK(c, c->ft_picked.ensure(sizeof(int) * L));              HIPCHK(c, c->ft_label.ensure(sizeof(int) * L));
+    HIPCHK(c, c->ft_rlists.ensure(sizeof(int) * (size_t)H * 3 * 128));
+    HIPCHK(c, c->ft_rcounts.ensure(sizeof(int) * (size_t)H * 4)); HIPCHK(c, c->ft_lists.ensure(sizeof(int) * 4 * L));
+    HIPCHK(c, c->ft_counts.ensure(sizeof(int) * 8));
+    FeatureBuffers fb;
+    fb.owner = c->ft_owner.as<int>(); fb.flag = c->ft_flag.as<int>(); fb.pos = c->ft_pos.as<int>(); fb.scan_tmp = c->ft_scan.as<int>();
+    fb.col = c->ft_col.as<int>(); fb.range = c->ft_range.as<float>(); fb.src = c->ft_src.as<int>(); fb.curv = c->ft_curv.as<float>();
+    fb.picked = c->ft_picked.as<int>(); fb.label = c->ft_label.as<int>(); fb.ring_lists = c->ft_rlists.as<int>();
+    fb.ring_counts = c->ft_rcounts.as<int>(); fb.lists = c->ft_lists.as<int>(); fb.counts = c->ft_counts.as<int>();
+    // ---- stage the sweep -----------------------------------------------------------------------------------------
+    const float4* pts = nullptr;
+    const uint32_t* rings = nullptr;
+    std::vector<float4> h_pts;
+    std::vector<uint32_t> h_rings;
+    if (dev) pts = static_cast<const float4*>(cloud);
+    else if (n > 0) {
+        h_pts.resize((size_t)n); h_rings.resize((size_t)n);
+        const unsigned char* b = static_cast<const unsigned char*>(cloud);
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* r = b + (size_t)i * (size_t)stride;
+            float v[3], it = 0.f; uint16_t ring;
+            memcpy(v, r, 12); memcpy(&it, r + 16, 4); memcpy(&ring, r + 20, 2);
+            h_pts[(size_t)i] = make_float4(v[0], v[1], v[2], it); h_rings[(size_t)i] = ring;
+        }
+        HIPCHK(c, c->vox_in.ensure(sizeof(float4) * (size_t)n));
+        HIPCHK(c, c->ft_rings.ensure(sizeof(uint32_t) * (size_t)n));
+        HIPCHK(c, hipMemcpyAsync(c->vox_in.p, h_pts.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ft_rings.p, h_rings.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        pts = c->vox_in.as<float4>(); rings = c->ft_rings.as<uint32_t>();
+    }
+    launch_extract_features(pts, rings, n, *P, fb, st);
+    HIPCHK(c, hipGetLastError());
+    int counts[8];
+    HIPCHK(c, hipMemcpyAsync(counts, fb.counts, sizeof counts, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // ---- hand the five clouds back in the caller's layout ------------------------------------------------------------
+    struct Slot { void* buf; int cap; int* n; const int* idx; int cnt; };
+    Slot slots[5] = { { out->deskewed, out->cap_deskewed, &out->n_deskewed, fb.src, counts[0] },
+                      { out->corner, out->cap_corner, &out->n_corner, fb.lists + 0 * L, counts[1] },
+                      { out->surface, out->cap_surface, &out->n_surface, fb.lists + 1 * L, counts[2] },
+                      { out->corner_sharp, out->cap_corner_sharp, &out->n_corner_sharp, fb.lists + 2 * L, counts[3] },
+                      { out->surface_sharp, out->cap_surface_sharp, &out->n_surface_sharp, fb.lists + 3 * L, counts[4] } };
+    for (auto& sl : slots) *sl.n = sl.cnt;
+    for (auto& sl : slots)
+        if (sl.buf && sl.cnt > sl.cap) return fail(c, LISREG_ERR_ARG, "extract_features: an output buffer is too small (counts written back)");
+    std::vector<int> h_idx;
+    for (auto& sl : slots) {
+        if (!sl.buf || sl.cnt == 0) continue;
+        if (dev) launch_gather_points(pts, sl.idx, sl.cnt, static_cast<float4*>(sl.buf), st);
+        else {
+            h_idx.resize((size_t)sl.cnt);
+            HIPCHK(c, hipMemcpyAsync(h_idx.data(), sl.idx, sizeof(int) * (size_t)sl.cnt, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            const unsigned char* b = static_cast<const unsigned char*>(cloud);
+            unsigned char* o = static_cast<unsigned char*>(sl.buf);
+            for (int i = 0; i < sl.cnt; ++i) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)h_idx[(size_t)i] * (size_t)stride, (size_t)stride);
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
     return LISREG_OK;
 }
 

@@ -1,0 +1,281 @@
+// lisreg_features.hip — SURVEY.md §8 f-2: the producer of cloud_info.
+//
+// Replaces LaserProcessing::projectPointCloud / cloudExtraction / calculateSmoothness / markOccludedPoints /
+// extractFeatures (/root/reference/src/core/laserProcessing.cpp:467-510, 515-539, 544-563, 568-605, 610-713) for one
+// LiDAR sweep, without the IMU de-skew (deskewPoint is the identity when no IMU data is available, :404-406).
+//
+// gfx950 mapping
+//   * projection: one thread per input point, coalesced 16-B reads; "the first point to land in a pixel wins"
+//     (:499 `if (rangeMat != FLT_MAX) continue`) becomes atomicMin on the INPUT INDEX per pixel — deterministic;
+//   * extraction: the row-major `count++` loop is a flag + exclusive scan over the H x W image;
+//   * smoothness (10-tap range stencil) and occlusion marks are flat streaming kernels (the marks only ever store 1,
+//     so they are order-independent);
+//   * selection: the greedy pick with +-5 suppression is sequential inside a ring (suppression spills into the next
+//     sector) but rings are independent: one wave per ring; the ring's picked / curvature / column arrays live in LDS,
+//     every sector is bitonic-sorted by (curvature, index) in LDS (std::sort is unstable: ties fixed by index), lane 0
+//     walks the sorted sector against LDS; picks go to per-ring lists that a last kernel concatenates in ring order.
+// Everything is integer/byte work plus one float stencil: HBM-streaming passes, nothing GEMM-shaped.
+// Defined behaviour where the reference has none (oracle/lisreg_oracle.h): per-frame arrays start at zero, the +-5
+// neighbour accesses are bounds-checked against the extracted cloud.
+#include "lisreg_internal.hpp"
+
+namespace lisreg {
+
+namespace {
+
+constexpr int kMaxSector = 1024;      // points per sector that the in-LDS sort handles (W/6 + 1 <= 1024 <=> W <= 6138)
+constexpr int kMaxRingPts = 4096 + 16;
+constexpr int kListCap = 128;         // per ring: <= 6*20 corners, <= 6*4 sharp corners, <= 6*10 sharp surfaces
+constexpr int kEmpty = 0x7f7f7f7f;   // pixel owner after a byte-wise 0x7f fill: larger than any input index
+
+__global__ __launch_bounds__(256) void k_feat_project(const float4* __restrict__ pts, const uint32_t* __restrict__ rings,
+                                                      int n, lisreg_feature_params P, int* __restrict__ owner)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const float range = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);                    // pointDistance (common.h:110-113)
+    if (range < P.min_range || range > P.max_range) return;
+    const int row = (int)((rings ? rings[i] : __float_as_uint(p.w)) & 0xffffu);
+    if (row >= P.n_scan) return;
+    if (row % P.downsample_rate != 0) return;
+    // :489-494 — float atan2, then double arithmetic, round(), int conversion
+    // float atan2 defined as the correctly rounded value (double atan2 rounded to float): libm float atan2 differs
+    // between implementations in the last ulp, enough to move a point across a column boundary (see the oracle)
+    const float at = (float)atan2((double)p.x, (double)p.y);
+    const float horizonAngle = (float)((double)(at * 180) / 3.14159265358979323846);
+    const float ang_res_x = (float)(360.0 / (double)(float)P.horizon_scan);
+    int col = (int)(-round(((double)horizonAngle - 90.0) / (double)ang_res_x) + (double)(P.horizon_scan / 2));
+    if (col >= P.horizon_scan) col -= P.horizon_scan;
+    if (col < 0 || col >= P.horizon_scan) return;
+    atomicMin(&owner[row * P.horizon_scan + col], i);                                // first point in input order wins
+}
+
+__global__ __launch_bounds__(256) void k_feat_valid(const int* __restrict__ owner, int hw, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < hw) flag[i] = owner[i] != kEmpty ? 1 : 0;
+}
+
+// cloudExtraction (:515-539) + array initialisation
+__global__ __launch_bounds__(256) void k_feat_extract(const float4* __restrict__ pts, const int* __restrict__ owner,
+                                                      const int* __restrict__ pos, int H, int W, FeatureBuffers fb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int hw = H * W;
+    if (i < hw + 16) { fb.curv[i] = 0.f; fb.picked[i] = 0; fb.label[i] = 0; }
+    if (i == 0) fb.counts[0] = pos[hw];
+    if (i >= hw) return;
+    const int o = owner[i];
+    if (o == kEmpty) return;
+    const int e = pos[i];
+    const float4 p = pts[o];
+    fb.col[e] = i % W;
+    fb.range[e] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    fb.src[e] = o;
+}
+
+// calculateSmoothness (:544-563)
+__global__ __launch_bounds__(256) void k_feat_smooth(const int* __restrict__ counts, const float* __restrict__ r,
+                                                     float* __restrict__ curv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int size = counts[0];
+    if (i < 5 || i >= size - 5) return;
+    const float d = r[i - 5] + r[i - 4] + r[i - 3] + r[i - 2] + r[i - 1] - r[i] * 10 + r[i + 1] + r[i + 2] + r[i + 3] +
+                    r[i + 4] + r[i + 5];
+    curv[i] = d * d;
+}
+
+// markOccludedPoints (:568-605): only ever stores 1 -> order-independent
+__global__ __launch_bounds__(256) void k_feat_occlude(const int* __restrict__ counts, const float* __restrict__ r,
+                                                      const int* __restrict__ col, int* __restrict__ picked)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int size = counts[0];
+    if (i < 5 || i >= size - 6) return;
+    const float depth1 = r[i], depth2 = r[i + 1];
+    const int columnDiff = abs(col[i + 1] - col[i]);
+    if (columnDiff < 10) {
+        if ((double)(depth1 - depth2) > 0.3) { for (int l = -5; l <= 0; ++l) picked[i + l] = 1; }
+        else if ((double)(depth2 - depth1) > 0.3) { for (int l = 1; l <= 6; ++l) picked[i + l] = 1; }
+    }
+    const float diff1 = fabsf(r[i - 1] - r[i]), diff2 = fabsf(r[i + 1] - r[i]);
+    if ((double)diff1 > 0.02 * (double)r[i] && (double)diff2 > 0.02 * (double)r[i]) picked[i] = 1;
+}
+
+// extractFeatures (:610-713): one wave per ring
+__global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos, int H, int W, lisreg_feature_params P,
+                                                    FeatureBuffers fb)
+{
+    __shared__ int   s_picked[kMaxRingPts];
+    __shared__ float s_curv[kMaxRingPts];
+    __shared__ int   s_col[kMaxRingPts];
+    __shared__ float s_val[kMaxSector];
+    __shared__ int   s_ind[kMaxSector];
+
+    const int ring = blockIdx.x, lane = threadIdx.x;
+    const int size = fb.counts[0];
+    const int r0 = pos[ring * W], r1 = pos[(ring + 1) * W];           // this ring's extracted range [r0, r1)
+    const int startRing = r0 - 1 + 5, endRing = r1 - 1 - 5;           // startRingIndex / endRingIndex (:521, :537)
+    int* lists = fb.ring_lists + (size_t)ring * 3 * kListCap;
+    int n_corner = 0, n_csharp = 0, n_ssharp = 0;
+    // window [lo, hi) of the extracted arrays mirrored in LDS: the ring +-6 (suppression reaches 5 beyond a pick)
+    const int lo = max(r0 - 6, 0), hi = min(r1 + 6, size);
+    for (int k = lo + lane; k < hi; k += 64) { s_picked[k - lo] = fb.picked[k]; s_curv[k - lo] = fb.curv[k]; s_col[k - lo] = fb.col[k]; }
+    __syncthreads();
+
+    for (int j = 0; j < 6; ++j) {
+        const int sp = (startRing * (6 - j) + endRing * j) / 6;
+        const int ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
+        if (sp >= ep) continue;                                        // wave-uniform
+        const int m = ep - sp;                                         // std::sort range [sp, ep)
+        int np2 = 1; while (np2 < m) np2 <<= 1;
+        for (int t = lane; t < np2; t += 64) {
+            s_val[t] = t < m ? s_curv[sp + t - lo] : 3.0e38f;
+            s_ind[t] = t < m ? sp + t : 0x7fffffff;
+        }
+        __syncthreads();
+        // bitonic sort ascending by (value, index)
+        for (int ksz = 2; ksz <= np2; ksz <<= 1)
+            for (int jj = ksz >> 1; jj > 0; jj >>= 1) {
+                for (int t = lane; t < np2; t += 64) {
+                    const int u = t ^ jj;
+                    if (u > t) {
+                        const float va = s_val[t], vb = s_val[u];
+                        const int ia = s_ind[t], ib = s_ind[u];
+                        const bool a_gt_b = va > vb || (va == vb && ia > ib);
+                        const bool up = (t & ksz) == 0;
+                        if (a_gt_b == up) { s_val[t] = vb; s_val[u] = va; s_ind[t] = ib; s_ind[u] = ia; }
+                    }
+                }
+                __syncthreads();
+            }
+        if (lane == 0) {
+#define LISREG_SUPPRESS(ind_) do { \
+                for (int l = 1; l <= 5; l++) { if ((ind_) + l >= size || (ind_) + l - 1 < 0) break; \
+                    if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l - 1 - lo]) > 10) break; \
+                    s_picked[(ind_) + l - lo] = 1; } \
+                for (int l = -1; l >= -5; l--) { if ((ind_) + l < 0 || (ind_) + l + 1 >= size) break; \
+                    if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l + 1 - lo]) > 10) break; \
+                    s_picked[(ind_) + l - lo] = 1; } } while (0)
+            int largest = 0;
+            for (int k = ep; k >= sp; k--) {                           // :626-661
+                const int ind = (k == ep) ? ep : s_ind[k - sp];        // element ep lies outside the sorted range
+                if (s_picked[ind - lo] == 0 && s_curv[ind - lo] > P.edge_threshold) {
+                    largest++;
+                    if (largest <= 20) {
+                        fb.label[ind] = 1;
+                        lists[0 * kListCap + n_corner++] = ind;
+                        if (largest <= 4) lists[1 * kListCap + n_csharp++] = ind;
+                    } else break;
+                    s_picked[ind - lo] = 1;
+                    LISREG_SUPPRESS(ind);
+                }
+            }
+            largest = 0;
+            for (int k = sp; k <= ep; k++) {                           // :663-695
+                const int ind = (k == ep) ? ep : s_ind[k - sp];
+                if (s_picked[ind - lo] == 0 && s_curv[ind - lo] < P.surf_threshold) {
+                    largest++;
+                    fb.label[ind] = -1;
+                    s_picked[ind - lo] = 1;
+                    if (largest <= 10) lists[2 * kListCap + n_ssharp++] = ind;
+                    LISREG_SUPPRESS(ind);
+                }
+            }
+#undef LISREG_SUPPRESS
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        int* c = fb.ring_counts + ring * 4;
+        c[0] = n_corner; c[1] = n_csharp; c[2] = n_ssharp;
+    }
+}
+
+// surfaceCloud (:697-704): every k inside a processed sector with cloudLabel <= 0, in ascending k
+__global__ __launch_bounds__(256) void k_feat_surface_flags(const int* __restrict__ pos, int H, int W, FeatureBuffers fb)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int hw = H * W;
+    if (k >= hw + 16) return;
+    int f = 0;
+    if (k < fb.counts[0]) {
+        int lo = 0, hi = H - 1;                                        // ring of k: last ring with pos[ring*W] <= k
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pos[mid * W] <= k) lo = mid; else hi = mid - 1; }
+        const int r0 = pos[lo * W], r1 = pos[(lo + 1) * W];
+        const int startRing = r0 - 1 + 5, endRing = r1 - 1 - 5;
+        for (int j = 0; j < 6; ++j) {
+            const int sp = (startRing * (6 - j) + endRing * j) / 6;
+            const int ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
+            if (sp < ep && k >= sp && k <= ep) f = 1;
+        }
+        if (fb.label[k] > 0) f = 0;
+    }
+    fb.flag[k] = f;
+}
+
+__global__ __launch_bounds__(256) void k_feat_surface_write(int hw, const int* __restrict__ spos, FeatureBuffers fb)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) fb.counts[2] = spos[hw + 16];
+    if (k >= hw + 16 || !fb.flag[k]) return;
+    fb.lists[(size_t)1 * (hw + 16) + spos[k]] = fb.src[k];
+}
+
+// concatenate the per-ring pick lists in ring order (H <= a few hundred: one wave)
+__global__ __launch_bounds__(64) void k_feat_concat(int H, int hw, FeatureBuffers fb)
+{
+    __shared__ int s_off[3];
+    if (threadIdx.x == 0) { s_off[0] = s_off[1] = s_off[2] = 0; }
+    __syncthreads();
+    const int list_of[3] = { 0, 2, 3 };                                // corner, corner_sharp, surface_sharp
+    for (int ring = 0; ring < H; ++ring) {
+        const int* c = fb.ring_counts + ring * 4;
+        for (int w = 0; w < 3; ++w) {
+            const int cnt = c[w], off = s_off[w];
+            for (int t = threadIdx.x; t < cnt; t += 64)
+                fb.lists[(size_t)list_of[w] * (hw + 16) + off + t] = fb.src[fb.ring_lists[((size_t)ring * 3 + w) * kListCap + t]];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_off[0] += c[0]; s_off[1] += c[1]; s_off[2] += c[2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { fb.counts[1] = s_off[0]; fb.counts[3] = s_off[1]; fb.counts[4] = s_off[2]; }
+}
+
+__global__ __launch_bounds__(256) void k_gather_points(const float4* __restrict__ pts, const int* __restrict__ idx, int n,
+                                                       float4* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = pts[idx[i]];
+}
+
+}  // namespace
+
+void launch_extract_features(const float4* pts, const uint32_t* rings, int n, lisreg_feature_params P, FeatureBuffers fb,
+                             hipStream_t st)
+{
+    const int H = P.n_scan, W = P.horizon_scan, hw = H * W;
+    (void)hipMemsetAsync(fb.owner, 0x7f, sizeof(int) * (size_t)hw, st);             // every pixel = kEmpty
+    if (n > 0) k_feat_project<<<(n + 255) / 256, 256, 0, st>>>(pts, rings, n, P, fb.owner);
+    k_feat_valid<<<(hw + 255) / 256, 256, 0, st>>>(fb.owner, hw, fb.flag);
+    launch_exclusive_scan(fb.flag, fb.pos, fb.scan_tmp, hw, st);
+    k_feat_extract<<<(hw + 16 + 255) / 256, 256, 0, st>>>(pts, fb.owner, fb.pos, H, W, fb);
+    k_feat_smooth<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.curv);
+    k_feat_occlude<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.col, fb.picked);
+    k_feat_select<<<H, 64, 0, st>>>(fb.pos, H, W, P, fb);
+    k_feat_surface_flags<<<(hw + 16 + 255) / 256, 256, 0, st>>>(fb.pos, H, W, fb);
+    // the second scan goes to the upper half of `pos`; the lower half (ring boundaries) stays valid
+    launch_exclusive_scan(fb.flag, fb.pos + (hw + 17), fb.scan_tmp, hw + 16, st);
+    k_feat_surface_write<<<(hw + 16 + 255) / 256, 256, 0, st>>>(hw, fb.pos + (hw + 17), fb);
+    k_feat_concat<<<1, 64, 0, st>>>(H, hw, fb);
+}
+
+void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st)
+{
+    if (n > 0) k_gather_points<<<(n + 255) / 256, 256, 0, st>>>(pts, idx, n, out);
+}
+
+}  // namespace lisreg

@@ -538,6 +538,8 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
     k_voxel_centroids<<<(n_vox + 255) / 256, 256, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
 }
 
+void launch_exclusive_scan(const int* in, int* out, int* tmp, int n, hipStream_t st) { exclusive_scan(in, out, tmp, n, st); }
+
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st)
 {
     if (n > 0) k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(in, n, M12_dev, out);

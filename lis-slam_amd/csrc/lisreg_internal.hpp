@@ -138,5 +138,28 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
                             const int* head, const int* slot, int* vstart /* [n_vox+1] */, float4* out_pts,
                             uint32_t* out_labels /* may be null */, hipStream_t st);
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st);
+// out[n+1] = exclusive scan of in[n] (out[n] = total); tmp: n/2048 + 4 ints
+void launch_exclusive_scan(const int* in, int* out, int* tmp, int n, hipStream_t st);
+
+// §8 f-2 (lisreg_features.hip): range-image projection + LOAM feature extraction for one scan
+struct FeatureBuffers {
+    int*   owner;      // [HW]      input index owning each range-image pixel (INT_MAX = empty)
+    int*   flag;       // [HW+16]   scratch flags for the scans
+    int*   pos;        // [2*(HW+17)] exclusive scans: [0, HW] pixel -> extracted position; upper half: surface scan
+    int*   scan_tmp;   // [HW/2048 + 4]
+    int*   col;        // [HW+16]   pointColInd
+    float* range;      // [HW+16]   pointRange
+    int*   src;        // [HW+16]   extracted position -> input index   (list 0: deskewed)
+    float* curv;       // [HW+16]   cloudCurvature
+    int*   picked;     // [HW+16]   cloudNeighborPicked
+    int*   label;      // [HW+16]   cloudLabel
+    int*   ring_lists; // [H][3][128] per-ring corner / sharp-corner / sharp-surface picks (extracted positions)
+    int*   ring_counts;// [H][4]
+    int*   lists;      // [4][HW+16] corner, surface, corner_sharp, surface_sharp as INPUT indices
+    int*   counts;     // [8]       deskewed, corner, surface, corner_sharp, surface_sharp
+};
+void launch_extract_features(const float4* pts, const uint32_t* rings /* null: ring = payload & 0xffff */, int n,
+                             lisreg_feature_params P, FeatureBuffers fb, hipStream_t st);
+void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st);
 
 }  // namespace lisreg

@@ -19,7 +19,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES, LEAF_TOO_SMALL = 0, 1, 2, 3
 ERR_ARG, ERR_HIP, ERR_NO_TARGET, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5
-FMT_XYZI, FMT_XYZIL, FMT_DEVICE = 0, 1, 2
+FMT_XYZI, FMT_XYZIL, FMT_DEVICE, FMT_XYZIRT = 0, 1, 2, 3
 VARIANT_ODOM, VARIANT_KEYFRAME, VARIANT_SUBMAP = 1, 2, 3
 TRACE_STRIDE = 56
 RESULT_SIZE = 12
@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
+    "lisreg_extract_features", "lisreg_default_feature_params",
 ]
 
 
@@ -59,6 +60,16 @@ class Item(C.Structure):
     _fields_ = [("src_corner", C.c_void_p), ("n_corner", C.c_int), ("src_surf", C.c_void_p), ("n_surf", C.c_int),
                 ("stride_bytes", C.c_int), ("fmt", C.c_int), ("target", C.c_int), ("degenerate_in", C.c_int),
                 ("imu", Imu)]
+
+
+class FeatureParams(C.Structure):
+    _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int), ("min_range", C.c_float),
+                ("max_range", C.c_float), ("edge_threshold", C.c_float), ("surf_threshold", C.c_float)]
+
+
+class FeatureOut(C.Structure):
+    _fields_ = [(f, t) for name in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
+                for f, t in ((name, C.c_void_p), ("cap_" + name, C.c_int), ("n_" + name, C.c_int))]
 
 
 class LisregError(RuntimeError):
@@ -121,6 +132,8 @@ def lib():
         L.lisreg_comm_destroy.restype = None
         L.lisreg_voxel_downsample.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, ip]
         L.lisreg_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, vp]
+        L.lisreg_extract_features.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(FeatureOut)]
+        L.lisreg_default_feature_params.argtypes = [C.POINTER(FeatureParams)]
         _lib = L
     return _lib
 
@@ -322,6 +335,27 @@ class Context:
         self._chk(self._L.lisreg_transform_cloud(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE,
                                                  Tf.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(out_ptr)))
 
+    # -- §8 f-2 -------------------------------------------------------------------------------------------
+    def extract_features(self, cloud: np.ndarray, params: "FeatureParams") -> dict:
+        """LaserProcessing replacement on a PointXYZIRT struct array: the five clouds of cloud_info."""
+        cloud = np.ascontiguousarray(cloud)
+        cap = params.n_scan * params.horizon_scan
+        names = ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
+        bufs = {k: np.zeros(cap, cloud.dtype) for k in names}
+        fo = FeatureOut()
+        for k in names:
+            setattr(fo, k, bufs[k].ctypes.data_as(C.c_void_p)); setattr(fo, "cap_" + k, cap)
+        self._chk(self._L.lisreg_extract_features(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIRT,
+                                                  C.byref(params), C.byref(fo)))
+        return {k: bufs[k][: getattr(fo, "n_" + k)] for k in names}
+
+    def extract_features_device(self, in_ptr: int, n: int, params: "FeatureParams", out_ptrs: dict, cap: int) -> dict:
+        fo = FeatureOut()
+        for k, ptr in out_ptrs.items():
+            setattr(fo, k, C.c_void_p(ptr)); setattr(fo, "cap_" + k, cap)
+        self._chk(self._L.lisreg_extract_features(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, C.byref(params), C.byref(fo)))
+        return {k: getattr(fo, "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")}
+
     def set_profiling(self, on: bool):
         self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))
 
@@ -401,3 +435,11 @@ def device_to_host(ptr: int, shape, dtype=np.float32) -> np.ndarray:
     if hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) != 0:
         raise RuntimeError("hipMemcpy D2H failed")
     return out
+
+
+def default_feature_params() -> FeatureParams:
+    p = FeatureParams()
+    rc = lib().lisreg_default_feature_params(C.byref(p))
+    if rc:
+        raise LisregError(rc, "lisreg_default_feature_params")
+    return p

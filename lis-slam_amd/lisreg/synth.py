@@ -196,3 +196,34 @@ def make_plane_case(n_tgt=6000, n_src=1500, seed=5, half=8.0, trans=0.2, rot_deg
     return dict(tgt_corner=empty, tgt_surf=to_pcl(tgt.astype(np.float32), np.zeros(n_tgt, np.uint16)),
                 src_corner=empty, src_surf=to_pcl(src.astype(np.float32), np.zeros(n_src, np.uint16)),
                 T_init=T0, T_true=T_true.astype(np.float32))
+
+
+# PointXYZIRT (src/include/common.h:12-23): x y z pad intensity, uint16 ring @20, float time @24; 32 bytes
+XYZIRT_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity", "ring", "time"],
+                         "formats": ["<f4", "<f4", "<f4", "<f4", "<u2", "<f4"],
+                         "offsets": [0, 4, 8, 16, 20, 24], "itemsize": 32})
+
+
+def make_raw_scan(h: int, w: int, seed: int, scene_seed: int = 1234, dup_fraction: float = 0.05, shuffle: bool = False):
+    """A raw LiDAR sweep as laserPretreatment hands it to LaserProcessing (ring + time channels, valid returns only),
+    plus a few jittered duplicates so that several points compete for one range-image pixel (first one must win)."""
+    rng = np.random.default_rng(seed + 31)
+    sc = make_scan(h, w, seed, scene_seed)
+    both = np.concatenate([sc["corner"], sc["surf"]])
+    xyz = pcl_xyz(both)
+    el = np.degrees(np.arctan2(xyz[:, 2], np.hypot(xyz[:, 0], xyz[:, 1])))
+    ring = np.clip(np.rint((el + 24.8) / (26.8 / (h - 1))), 0, h - 1).astype(np.uint16)
+    order = np.lexsort((np.arctan2(xyz[:, 1], xyz[:, 0]), ring))          # a sweep: ring-major, azimuth ascending
+    xyz, ring = xyz[order], ring[order]
+    k = int(dup_fraction * len(xyz))
+    pick = rng.integers(0, len(xyz), k)
+    xyz = np.concatenate([xyz, xyz[pick] * (1 + rng.normal(0, 1e-3, (k, 1))).astype(np.float32)])
+    ring = np.concatenate([ring, ring[pick]])
+    if shuffle:
+        perm = rng.permutation(len(xyz)); xyz, ring = xyz[perm], ring[perm]
+    out = np.zeros(len(xyz), XYZIRT_DTYPE)
+    out["x"], out["y"], out["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    out["intensity"] = rng.uniform(0, 255, len(xyz)).astype(np.float32)
+    out["ring"] = ring
+    out["time"] = np.linspace(0, 0.1, len(xyz), dtype=np.float32)
+    return out

@@ -191,3 +191,102 @@ def align(tgt_c, tgt_s, src_c, src_s, lab_c, lab_s, T_init, p, degenerate_in=0):
     stats["degenerate"] = int(is_deg)
     stats["status"] = 0 if solved else 2
     return T, stats, trace
+
+
+def extract_features(x, y, z, ring, p):
+    """Independent Python mirror of LaserProcessing's projection + feature extraction
+    (/root/reference/src/core/laserProcessing.cpp:467-713, no IMU de-skew) for SMALL scans — plain loops, written
+    from the reference text separately from oracle/lisreg_oracle.c.  p: dict(n_scan, horizon_scan, downsample_rate,
+    min_range, max_range, edge_threshold, surf_threshold).  Returns index lists into the input arrays, with the same
+    defined behaviour as the oracle where the reference has none (zero-initialised per-frame arrays, bounds-checked
+    +-5 accesses, (value, index) order for equal curvatures)."""
+    H, W = p["n_scan"], p["horizon_scan"]
+    owner = -np.ones((H, W), np.int64)
+    rmat = np.full((H, W), np.inf, np.float32)
+    ang_res = f32(360.0 / float(f32(W)))
+    for i in range(len(x)):
+        rng_ = f32(np.sqrt(f32(f32(x[i] * x[i] + y[i] * y[i]) + z[i] * z[i])))
+        if rng_ < p["min_range"] or rng_ > p["max_range"]:
+            continue
+        row = int(ring[i])
+        if row < 0 or row >= H or row % p["downsample_rate"] != 0:
+            continue
+        ha = f32(float(f32(f32(np.arctan2(float(x[i]), float(y[i]))) * f32(180))) / np.pi)   # double atan2 rounded to float
+        col = int(-np.round((float(ha) - 90.0) / float(ang_res)) + W // 2)
+        if col >= W:
+            col -= W
+        if col < 0 or col >= W or owner[row, col] >= 0:
+            continue
+        owner[row, col] = i
+        rmat[row, col] = rng_
+    src, col_ind, pr, start, end = [], [], [], [], []
+    for i in range(H):
+        start.append(len(src) - 1 + 5)
+        for j in range(W):
+            if owner[i, j] >= 0:
+                src.append(int(owner[i, j])); col_ind.append(j); pr.append(rmat[i, j])
+        end.append(len(src) - 1 - 5)
+    n = len(src)
+    pr = np.array(pr + [0.0] * 16, f32)
+    curv = np.zeros(n + 16, f32); picked = np.zeros(n + 16, np.int64); label = np.zeros(n + 16, np.int64)
+    for i in range(5, n - 5):
+        d = f32(0)
+        for t in (pr[i - 5], pr[i - 4], pr[i - 3], pr[i - 2], pr[i - 1]):
+            d = f32(d + t)
+        d = f32(d - f32(pr[i] * f32(10)))
+        for t in (pr[i + 1], pr[i + 2], pr[i + 3], pr[i + 4], pr[i + 5]):
+            d = f32(d + t)
+        curv[i] = f32(d * d)
+    for i in range(5, n - 6):
+        if abs(col_ind[i + 1] - col_ind[i]) < 10:
+            if float(f32(pr[i] - pr[i + 1])) > 0.3:
+                picked[i - 5:i + 1] = 1
+            elif float(f32(pr[i + 1] - pr[i])) > 0.3:
+                picked[i + 1:i + 7] = 1
+        if float(abs(f32(pr[i - 1] - pr[i]))) > 0.02 * float(pr[i]) and float(abs(f32(pr[i + 1] - pr[i]))) > 0.02 * float(pr[i]):
+            picked[i] = 1
+
+    def suppress(ind):
+        for l in range(1, 6):
+            if ind + l >= n or ind + l - 1 < 0 or abs(col_ind[ind + l] - col_ind[ind + l - 1]) > 10:
+                break
+            picked[ind + l] = 1
+        for l in range(-1, -6, -1):
+            if ind + l < 0 or ind + l + 1 >= n or abs(col_ind[ind + l] - col_ind[ind + l + 1]) > 10:
+                break
+            picked[ind + l] = 1
+
+    corner, surface, csharp, ssharp = [], [], [], []
+    for i in range(H):
+        for j in range(6):
+            sp = (start[i] * (6 - j) + end[i] * j) // 6 if (start[i] * (6 - j) + end[i] * j) >= 0 else -((-(start[i] * (6 - j) + end[i] * j)) // 6)
+            e_ = start[i] * (5 - j) + end[i] * (j + 1)
+            ep = (e_ // 6 if e_ >= 0 else -((-e_) // 6)) - 1          # C integer division truncates toward zero
+            if sp >= ep:
+                continue
+            order = sorted(range(sp, ep), key=lambda k: (float(curv[k]), k)) + [ep]
+            cnt = 0
+            for k in range(ep, sp - 1, -1):
+                ind = order[k - sp]
+                if picked[ind] == 0 and curv[ind] > p["edge_threshold"]:
+                    cnt += 1
+                    if cnt <= 20:
+                        label[ind] = 1; corner.append(src[ind])
+                        if cnt <= 4:
+                            csharp.append(src[ind])
+                    else:
+                        break
+                    picked[ind] = 1; suppress(ind)
+            cnt = 0
+            for k in range(sp, ep + 1):
+                ind = order[k - sp]
+                if picked[ind] == 0 and curv[ind] < p["surf_threshold"]:
+                    cnt += 1; label[ind] = -1; picked[ind] = 1
+                    if cnt <= 10:
+                        ssharp.append(src[ind])
+                    suppress(ind)
+            for k in range(sp, ep + 1):
+                if label[k] <= 0:
+                    surface.append(src[k])
+    return dict(deskewed=np.array(src, np.int32), corner=np.array(corner, np.int32), surface=np.array(surface, np.int32),
+                corner_sharp=np.array(csharp, np.int32), surface_sharp=np.array(ssharp, np.int32))

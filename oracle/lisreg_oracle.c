@@ -878,3 +878,139 @@ void orc_transform_cloud(const void* in, int n, int stride, int fmt, const float
         memcpy(dst + (size_t)i * (size_t)stride, q, 12);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* §8 f-2: LaserProcessing range-image projection + feature extraction (src/core/laserProcessing.cpp)        */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct { float value; int ind; } smooth_t;
+
+static int smooth_cmp(const void* a, const void* b)
+{
+    const smooth_t* x = (const smooth_t*)a; const smooth_t* y = (const smooth_t*)b;
+    if (x->value != y->value) return x->value < y->value ? -1 : 1;      /* by_value (laserProcessing.h:25-31) */
+    return x->ind < y->ind ? -1 : (x->ind > y->ind ? 1 : 0);            /* std::sort is unstable: fix ties by index */
+}
+
+/* the two +-5 suppression loops of extractFeatures (:648-660, :681-694); index accesses bounds-checked */
+static void suppress_neighbours(int ind, int cloudSize, const int* colInd, int* picked)
+{
+    for (int l = 1; l <= 5; l++) {
+        if (ind + l >= cloudSize || ind + l - 1 < 0) break;
+        if (abs(colInd[ind + l] - colInd[ind + l - 1]) > 10) break;
+        picked[ind + l] = 1;
+    }
+    for (int l = -1; l >= -5; l--) {
+        if (ind + l < 0 || ind + l + 1 >= cloudSize) break;
+        if (abs(colInd[ind + l] - colInd[ind + l + 1]) > 10) break;
+        picked[ind + l] = 1;
+    }
+}
+
+void orc_extract_features(const void* cloud, int n, int stride, const lisreg_feature_params* P,
+                          int* deskewed, int* corner, int* surface, int* corner_sharp, int* surface_sharp, int counts[5])
+{
+    const unsigned char* src = (const unsigned char*)cloud;
+    const int H = P->n_scan, W = P->horizon_scan, HW = H * W;
+    float* rangeMat = (float*)malloc(sizeof(float) * (size_t)HW);
+    int* owner = (int*)malloc(sizeof(int) * (size_t)HW);
+    for (int i = 0; i < HW; ++i) { rangeMat[i] = FLT_MAX; owner[i] = -1; }          /* resetParameters :53 */
+    /* projectPointCloud :467-510 */
+    for (int i = 0; i < n; ++i) {
+        const unsigned char* r = src + (size_t)i * (size_t)stride;
+        float p[3]; unsigned short ring;
+        memcpy(p, r, 12); memcpy(&ring, r + 20, 2);
+        float range = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);                /* pointDistance, common.h:110-113 */
+        if (range < P->min_range || range > P->max_range) continue;
+        int rowIdn = ring;
+        if (rowIdn < 0 || rowIdn >= H) continue;
+        if (rowIdn % P->downsample_rate != 0) continue;
+        /* :489 `atan2(x, y) * 180 / M_PI` — float atan2 there; libm float atan2 is not correctly rounded and differs
+         * between implementations in the last ulp, which can move a point across a column boundary.  The restatement
+         * defines it as the correctly rounded value: double atan2 rounded to float. */
+        float at = (float)atan2((double)p[0], (double)p[1]);
+        float horizonAngle = (float)((double)(at * 180) / M_PI);
+        float ang_res_x = (float)(360.0 / (double)(float)W);
+        int columnIdn = (int)(-round(((double)horizonAngle - 90.0) / (double)ang_res_x) + (double)(W / 2));
+        if (columnIdn >= W) columnIdn -= W;
+        if (columnIdn < 0 || columnIdn >= W) continue;
+        if (rangeMat[rowIdn * W + columnIdn] != FLT_MAX) continue;                   /* first point wins */
+        rangeMat[rowIdn * W + columnIdn] = range;
+        owner[rowIdn * W + columnIdn] = i;
+    }
+    /* cloudExtraction :515-539 */
+    int* startRing = (int*)malloc(sizeof(int) * (size_t)H); int* endRing = (int*)malloc(sizeof(int) * (size_t)H);
+    int* colInd = (int*)calloc((size_t)HW + 16, sizeof(int));
+    float* prange = (float*)calloc((size_t)HW + 16, sizeof(float));
+    int count = 0;
+    for (int i = 0; i < H; ++i) {
+        startRing[i] = count - 1 + 5;
+        for (int j = 0; j < W; ++j)
+            if (rangeMat[i * W + j] != FLT_MAX) { colInd[count] = j; prange[count] = rangeMat[i * W + j]; deskewed[count] = owner[i * W + j]; ++count; }
+        endRing[i] = count - 1 - 5;
+    }
+    const int cloudSize = count;
+    /* per-frame arrays: zero-initialised here (the reference leaves [0,5) and [size-5,size) untouched) */
+    float* curv = (float*)calloc((size_t)HW + 16, sizeof(float));
+    int* picked = (int*)calloc((size_t)HW + 16, sizeof(int));
+    int* label = (int*)calloc((size_t)HW + 16, sizeof(int));
+    smooth_t* sm = (smooth_t*)malloc(sizeof(smooth_t) * ((size_t)HW + 16));
+    for (int i = 0; i < HW + 16; ++i) { sm[i].value = 0.f; sm[i].ind = i; }
+    /* calculateSmoothness :544-563 */
+    for (int i = 5; i < cloudSize - 5; i++) {
+        float diffRange = prange[i - 5] + prange[i - 4] + prange[i - 3] + prange[i - 2] + prange[i - 1] - prange[i] * 10 +
+                          prange[i + 1] + prange[i + 2] + prange[i + 3] + prange[i + 4] + prange[i + 5];
+        curv[i] = diffRange * diffRange;
+        picked[i] = 0; label[i] = 0;
+        sm[i].value = curv[i]; sm[i].ind = i;
+    }
+    /* markOccludedPoints :568-605 */
+    for (int i = 5; i < cloudSize - 6; ++i) {
+        float depth1 = prange[i], depth2 = prange[i + 1];
+        int columnDiff = abs(colInd[i + 1] - colInd[i]);
+        if (columnDiff < 10) {
+            if (depth1 - depth2 > 0.3) { for (int l = -5; l <= 0; ++l) picked[i + l] = 1; }
+            else if (depth2 - depth1 > 0.3) { for (int l = 1; l <= 6; ++l) picked[i + l] = 1; }
+        }
+        float diff1 = fabsf(prange[i - 1] - prange[i]), diff2 = fabsf(prange[i + 1] - prange[i]);
+        if (diff1 > 0.02 * prange[i] && diff2 > 0.02 * prange[i]) picked[i] = 1;
+    }
+    /* extractFeatures :610-713 */
+    int nc = 0, ns = 0, ncs = 0, nss = 0;
+    for (int i = 0; i < H; i++) {
+        for (int j = 0; j < 6; j++) {
+            int sp = (startRing[i] * (6 - j) + endRing[i] * j) / 6;
+            int ep = (startRing[i] * (5 - j) + endRing[i] * (j + 1)) / 6 - 1;
+            if (sp >= ep) continue;
+            qsort(sm + sp, (size_t)(ep - sp), sizeof(smooth_t), smooth_cmp);        /* [sp, ep): ep itself stays put */
+            int largestPickedNum = 0;
+            for (int k = ep; k >= sp; k--) {
+                int ind = sm[k].ind;
+                if (picked[ind] == 0 && curv[ind] > P->edge_threshold) {
+                    largestPickedNum++;
+                    if (largestPickedNum <= 20) {
+                        label[ind] = 1;
+                        corner[nc++] = deskewed[ind];
+                        if (largestPickedNum <= 4) corner_sharp[ncs++] = deskewed[ind];
+                    } else break;
+                    picked[ind] = 1;
+                    suppress_neighbours(ind, cloudSize, colInd, picked);
+                }
+            }
+            largestPickedNum = 0;
+            for (int k = sp; k <= ep; k++) {
+                int ind = sm[k].ind;
+                if (picked[ind] == 0 && curv[ind] < P->surf_threshold) {
+                    largestPickedNum++;
+                    label[ind] = -1;
+                    picked[ind] = 1;
+                    if (largestPickedNum <= 10) surface_sharp[nss++] = deskewed[ind];
+                    suppress_neighbours(ind, cloudSize, colInd, picked);
+                }
+            }
+            for (int k = sp; k <= ep; k++) if (label[k] <= 0) surface[ns++] = deskewed[k];
+        }
+    }
+    counts[0] = cloudSize; counts[1] = nc; counts[2] = ns; counts[3] = ncs; counts[4] = nss;
+    free(rangeMat); free(owner); free(startRing); free(endRing); free(colInd); free(prange); free(curv); free(picked);
+    free(label); free(sm);
+}

@@ -93,6 +93,15 @@ int  orc_voxel_grid(const void* in, int n, int stride_bytes, int fmt, float leaf
 /* transformPointCloud (src/core/common.cpp:112-173 and the PointXYZIL overload): p' = R(T) p + t, other fields copied. */
 void orc_transform_cloud(const void* in, int n, int stride_bytes, int fmt, const float T[6], void* out);
 
+/* ---- §8 f-2: range-image projection + feature extraction (src/core/laserProcessing.cpp:467-713) ---------------- */
+/* cloud: PointXYZIRT host structs.  Outputs are index lists into the INPUT cloud (the points themselves are copies):
+ * deskewed[n_deskewed] = extractedCloud in row-major pixel order, and the four feature lists in the reference's push
+ * order.  All output arrays need n_scan*horizon_scan ints.  counts[5] = {deskewed, corner, surface, corner_sharp,
+ * surface_sharp}.  Defined behaviour where the reference has none: the per-frame arrays are zero-initialised every call
+ * (cloudSmoothness[i].ind = i), the +-5 neighbour accesses are bounds-checked, equal curvatures sort by index. */
+void orc_extract_features(const void* cloud, int n, int stride_bytes, const lisreg_feature_params* p,
+                          int* deskewed, int* corner, int* surface, int* corner_sharp, int* surface_sharp, int counts[5]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,16 @@ class Imu(C.Structure):
     _fields_ = [("imu_available", C.c_int), ("imu_roll_init", C.c_float), ("imu_pitch_init", C.c_float)]
 
 
+class FeatureParams(C.Structure):
+    _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int), ("min_range", C.c_float),
+                ("max_range", C.c_float), ("edge_threshold", C.c_float), ("surf_threshold", C.c_float)]
+
+
+def default_feature_params() -> "FeatureParams":
+    """config/params.yaml:68-74, 117-118 (KITTI HDL-64 settings)."""
+    return FeatureParams(64, 1800, 2, 0.0, 70.0, 1.0, 0.1)
+
+
 class Stats(C.Structure):
     _fields_ = [("iters", C.c_int), ("deltaR", C.c_float), ("deltaT", C.c_float), ("degenerate", C.c_int),
                 ("n_corr_last", C.c_int), ("status", C.c_int)]
@@ -90,6 +100,8 @@ def lib():
         L.orc_voxel_grid.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, ip]
         L.orc_transform_cloud.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, vp]
         L.orc_transform_cloud.restype = None
+        L.orc_extract_features.argtypes = [vp, C.c_int, C.c_int, C.POINTER(FeatureParams), ip, ip, ip, ip, ip, ip]
+        L.orc_extract_features.restype = None
         _lib = L
     return _lib
 
@@ -150,3 +162,16 @@ def transform_cloud(cloud, T, fmt: int = 1):
     Tf = np.array(T, np.float32)
     L.orc_transform_cloud(_vp(cloud), len(cloud), cloud.dtype.itemsize, fmt, _fp(Tf), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def extract_features(cloud, params: "FeatureParams"):
+    """orc_extract_features on a PointXYZIRT struct array.  Returns dict of index arrays into `cloud`."""
+    L = lib()
+    cloud = np.ascontiguousarray(cloud)
+    hw = params.n_scan * params.horizon_scan
+    bufs = [np.zeros(hw + 16, np.int32) for _ in range(5)]
+    counts = np.zeros(5, np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    L.orc_extract_features(_vp(cloud), len(cloud), cloud.dtype.itemsize, C.byref(params), *[ip(b) for b in bufs], ip(counts))
+    names = ["deskewed", "corner", "surface", "corner_sharp", "surface_sharp"]
+    return {k: bufs[i][: counts[i]].copy() for i, k in enumerate(names)}

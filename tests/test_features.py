@@ -1,0 +1,102 @@
+"""range-image projection + LOAM feature extraction (the producer of cloud_info).
+
+CPU: the C oracle against an independent pure-Python mirror written separately from the reference text.
+GPU: liblisreg against the oracle — all five index lists (deskewed, corner, surface, corner_sharp, surface_sharp)
+identical, element for element and in the reference's order: this is integer / index work, so the bar is exact."""
+import numpy as np
+import pytest
+
+NAMES = ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
+
+
+def same_points(got, want):
+    """Field-by-field equality of two PointXYZIRT arrays (numpy fancy indexing does not preserve struct padding)."""
+    return len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in want.dtype.names)
+
+
+def _pd(p):
+    return {f: getattr(p, f) for f, _ in p._fields_}
+
+
+@pytest.mark.parametrize("h,w,rate,seed,shuffle", [(8, 240, 1, 1, False), (16, 450, 2, 2, False), (16, 450, 1, 3, True)])
+def test_oracle_matches_python_mirror(oracle, h, w, rate, seed, shuffle):
+    import lisreg_numpy as ln
+    from lisreg import synth
+    c = synth.make_raw_scan(h, w, 7000 + seed, shuffle=shuffle)
+    p = oracle.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    a = oracle.extract_features(c, p)
+    b = ln.extract_features(c["x"], c["y"], c["z"], c["ring"], _pd(p))
+    for k in NAMES:
+        assert np.array_equal(a[k], b[k]), k
+    assert len(a["corner"]) > 0 and len(a["surface_sharp"]) > 0 and len(a["deskewed"]) <= h * w
+
+
+def test_oracle_feature_invariants(oracle):
+    from lisreg import synth
+    c = synth.make_raw_scan(64, 1800, 7100)
+    p = oracle.default_feature_params()
+    r = oracle.extract_features(c, p)
+    assert len(np.unique(r["deskewed"])) == len(r["deskewed"])                   # one point per pixel
+    assert np.all(c["ring"][r["deskewed"]] % p.downsample_rate == 0)             # dropped rows stay empty
+    assert np.all(np.diff(c["ring"][r["deskewed"]].astype(int)) >= 0)            # row-major order
+    assert set(r["corner_sharp"]) <= set(r["corner"]) and set(r["surface_sharp"]) <= set(r["surface"])
+    assert not (set(r["corner"]) & set(r["surface"]))                           # label 1 never enters the surface cloud
+    # per ring at most 6*20 corners, 6*4 sharp corners, 6*10 sharp surfaces
+    for name, cap in (("corner", 120), ("corner_sharp", 24), ("surface_sharp", 60)):
+        assert np.bincount(c["ring"][r[name]], minlength=64).max() <= cap
+    # first point in input order wins a pixel: shuffling the input changes owners, not the pixel count
+    c2 = synth.make_raw_scan(64, 1800, 7100, shuffle=True)
+    assert len(oracle.extract_features(c2, p)["deskewed"]) == len(r["deskewed"])
+    # range limits
+    p.max_range = 20.0
+    r2 = oracle.extract_features(c, p)
+    rng = np.sqrt(c["x"] ** 2 + c["y"] ** 2 + c["z"] ** 2)
+    assert len(r2["deskewed"]) < len(r["deskewed"]) and rng[r2["deskewed"]].max() <= 20.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,rate,seed,shuffle", [(16, 450, 1, 11, False), (64, 1800, 2, 12, False), (64, 1800, 1, 13, True),
+                                                   (128, 2048, 1, 14, False), (32, 1024, 4, 15, True)])
+def test_hip_features_match_oracle(oracle, gpu_ctx, h, w, rate, seed, shuffle):
+    import lisreg
+    from lisreg import synth
+    c = synth.make_raw_scan(h, w, 7200 + seed, shuffle=shuffle)
+    po = oracle.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    pg = lisreg.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    ro = oracle.extract_features(c, po)
+    rg = gpu_ctx.extract_features(c, pg)
+    for k in NAMES:
+        assert len(rg[k]) == len(ro[k]), k
+        assert same_points(rg[k], c[ro[k]]), k                                # the same points, in the same order, all fields
+
+
+@pytest.mark.gpu
+def test_hip_features_edges_and_device_format(oracle, gpu_ctx):
+    import lisreg
+    from lisreg import synth
+    c = synth.make_raw_scan(16, 450, 7300)
+    pg = lisreg.FeatureParams(16, 450, 1, 0.0, 70.0, 1.0, 0.1)
+    po = oracle.FeatureParams(16, 450, 1, 0.0, 70.0, 1.0, 0.1)
+    r = gpu_ctx.extract_features(c[:0], pg)
+    assert all(len(r[k]) == 0 for k in NAMES)
+    few = c[:40]                                                              # fewer points than the 11-tap stencil needs per ring
+    ro, rg = oracle.extract_features(few, po), gpu_ctx.extract_features(few, pg)
+    for k in NAMES:
+        assert same_points(rg[k], few[ro[k]]), k
+    far = c.copy(); far["x"] += 500.0                                         # everything beyond lidarMaxRange
+    assert all(len(v) == 0 for v in gpu_ctx.extract_features(far, pg).values())
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.extract_features(c, lisreg.FeatureParams(16, 8000, 1, 0.0, 70.0, 1.0, 0.1))
+    # device records in (ring in the payload), device records out
+    rec = np.zeros((len(c), 4), np.float32)
+    rec[:, 0], rec[:, 1], rec[:, 2] = c["x"], c["y"], c["z"]
+    rec[:, 3] = c["ring"].astype(np.uint32).view(np.float32)
+    din = lisreg.DeviceArray(rec)
+    cap = 16 * 450
+    outs = {k: lisreg.DeviceArray(np.zeros((cap, 4), np.float32)) for k in NAMES}
+    counts = gpu_ctx.extract_features_device(din.ptr, len(c), pg, {k: v.ptr for k, v in outs.items()}, cap)
+    ro = oracle.extract_features(c, po)
+    for k in NAMES:
+        assert counts[k] == len(ro[k]), k
+        got = lisreg.device_to_host(outs[k].ptr, (cap, 4))[: counts[k]]
+        assert got.tobytes() == rec[ro[k]].tobytes(), k
