@@ -174,4 +174,41 @@ inline PointCloud<PointT> transformPointCloud(lisreg_ctx* ctx, const PointCloud<
     return out;
 }
 
+// ---- the producer of cloud_info ------------------------------------------------------------------------
+// PointXYZIRT (src/include/common.h:12-23) and the part of LaserProcessing that turns one sweep into the five clouds of
+// cloud_info (src/core/laserProcessing.cpp:467-713: projectPointCloud, cloudExtraction, calculateSmoothness,
+// markOccludedPoints, extractFeatures), without the IMU de-skew.
+struct alignas(16) PointXYZIRT { float x, y, z, _pad0; float intensity; uint16_t ring; uint16_t _pad1; float time; float _pad2; };
+static_assert(sizeof(PointXYZIRT) == 32, "PCL point layout");
+
+struct ExtractedFeatures {             // what assignCouldInfo/publishClouds put into cloud_info (:718-760)
+    PointCloud<PointXYZIRT> extractedCloud, cornerCloud, surfaceCloud, sharpCornerCloud, SharpSurfaceCloud;
+};
+
+class LaserProcessing {
+public:
+    lisreg_feature_params params;
+    explicit LaserProcessing(lisreg_ctx* ctx) : ctx_(ctx) { lisreg_default_feature_params(&params); }
+    ExtractedFeatures process(const PointCloud<PointXYZIRT>& laserCloudIn) {
+        ExtractedFeatures f;
+        const size_t cap = (size_t)params.n_scan * (size_t)params.horizon_scan;
+        PointCloud<PointXYZIRT>* clouds[5] = { &f.extractedCloud, &f.cornerCloud, &f.surfaceCloud, &f.sharpCornerCloud, &f.SharpSurfaceCloud };
+        for (auto* c : clouds) c->points.resize(cap);
+        lisreg_feature_out o{};
+        o.deskewed = f.extractedCloud.points.data();       o.cap_deskewed = (int)cap;
+        o.corner = f.cornerCloud.points.data();            o.cap_corner = (int)cap;
+        o.surface = f.surfaceCloud.points.data();          o.cap_surface = (int)cap;
+        o.corner_sharp = f.sharpCornerCloud.points.data(); o.cap_corner_sharp = (int)cap;
+        o.surface_sharp = f.SharpSurfaceCloud.points.data(); o.cap_surface_sharp = (int)cap;
+        int rc = lisreg_extract_features(ctx_, laserCloudIn.points.data(), (int)laserCloudIn.size(), (int)sizeof(PointXYZIRT),
+                                         LISREG_FMT_XYZIRT, &params, &o);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        const int n[5] = { o.n_deskewed, o.n_corner, o.n_surface, o.n_corner_sharp, o.n_surface_sharp };
+        for (int k = 0; k < 5; ++k) clouds[k]->points.resize((size_t)n[k]);
+        return f;
+    }
+private:
+    lisreg_ctx* ctx_;
+};
+
 }  // namespace lis_slam
