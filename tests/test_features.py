@@ -100,3 +100,38 @@ def test_hip_features_edges_and_device_format(oracle, gpu_ctx):
         assert counts[k] == len(ro[k]), k
         got = lisreg.device_to_host(outs[k].ptr, (cap, 4))[: counts[k]]
         assert got.tobytes() == rec[ro[k]].tobytes(), k
+
+
+@pytest.mark.gpu
+def test_full_front_end_pipeline_matches_oracle(oracle, gpu_ctx):
+    """The reference's per-frame chain: laserProcessing (project + extract features) -> odomEstimation (voxel-grid the
+    features, register against the local map).  HIP chain vs oracle chain: identical features, identical down-sampled
+    clouds, pose within the 1e-3 bar."""
+    import lisreg
+    from helpers import pose_err
+    from lisreg import synth
+    h, w = 64, 1800
+    sweep = synth.make_raw_scan(h, w, 1000)
+    sc_truth = synth.make_scan(h, w, 1000)["T_true"]
+    po = oracle.FeatureParams(h, w, 1, 0.0, 70.0, 1.0, 0.1); pg = lisreg.FeatureParams(h, w, 1, 0.0, 70.0, 1.0, 0.1)
+    fo, fg = oracle.extract_features(sweep, po), gpu_ctx.extract_features(sweep, pg)
+
+    def as_xyzi(c):                                   # PointXYZIRT -> PointXYZI (what pcl::fromROSMsg hands the odometry node)
+        return synth.to_pcl(np.stack([c["x"], c["y"], c["z"]], 1), None, c["intensity"])
+    clouds_o = {k: as_xyzi(sweep[fo[k]]) for k in ("corner", "surface")}
+    clouds_g = {k: as_xyzi(fg[k]) for k in ("corner", "surface")}
+    for k in clouds_o:
+        assert same_points(clouds_g[k], clouds_o[k]), k
+    tc, ts = synth.make_submap(200000, 42)
+    ds_o, ds_g = {}, {}
+    for name, cloud_o, cloud_g, leaf in (("tc", tc, tc, 0.2), ("ts", ts, ts, 0.4), ("sc", clouds_o["corner"], clouds_g["corner"], 0.2),
+                                         ("ss", clouds_o["surface"], clouds_g["surface"], 0.4)):
+        ro, ds_o[name] = oracle.voxel_grid(cloud_o, leaf, fmt=0)
+        rg, ds_g[name] = gpu_ctx.voxel_downsample(cloud_g, leaf)
+        assert ro == rg == 0 and same_points(ds_g[name], ds_o[name]), name
+    T0 = synth.perturb_pose(sc_truth, np.random.default_rng(3))
+    To, so, _ = oracle.align(ds_o["tc"], ds_o["ts"], ds_o["sc"], ds_o["ss"], T0, oracle.default_params(1), fmt=0)
+    gpu_ctx.set_target(ds_g["tc"], ds_g["ts"])
+    Tg, sg, _ = gpu_ctx.align(ds_g["sc"], ds_g["ss"], T0, lisreg.default_params(1))
+    assert so["status"] == sg["status"] == 0 and len(ds_g["ss"]) > 2000
+    assert max(pose_err(Tg, To)) <= 1e-3 and max(pose_err(Tg, sc_truth)) < 3e-2
