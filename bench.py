@@ -80,6 +80,8 @@ def main():
     for i in range(args.batch):
         seed = 1000 + rank * args.batch + i
         c, s, tt = synth_torch.make_scan_device(H, W, seed, dev)
+        if os.environ.get("LISREG_BENCH_SHUFFLE"):      # robustness probe: destroy the scan order of the sources
+            c = c[torch.randperm(c.shape[0], device=dev)].contiguous(); s = s[torch.randperm(s.shape[0], device=dev)].contiguous()
         scans.append((c, s)); T_true.append(tt)
         T_init.append(synth.perturb_pose(tt, np.random.default_rng(seed + 7919)))
     torch.cuda.synchronize()

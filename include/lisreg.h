@@ -177,7 +177,7 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
 /* Options outside the reference's parameter surface: "rebuild_targets_each_run" (0/1: re-run the target index
  * build inside every lisreg_batch_run, as the reference rebuilds both kd-trees per registration, :602-603),
  * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (0 LDS-staged workgroup box,
- * 1 per-lane grid walk [default], 2 walk + motion certificate), "sort_sources" (0 caller order [default], 1 column sort),
+ * 1 per-lane grid walk [default], 2 walk + motion certificate), "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
  * "cert_slack_mm", "first_pass_mm", "count_searches". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 

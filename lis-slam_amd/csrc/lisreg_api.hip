@@ -82,7 +82,8 @@ struct lisreg_ctx {
     bool      count_searches = false;
     int       search_mode = 1;
     float     cert_slack = 0.10f;
-    int       sort_sources = 0;          // 0: keep the caller order (scan/voxel order is already coherent), 1: 2-D column sort
+    int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
+    bool      sort_now = false;          // decision for the prepared batch
     float     first_pass_r = 0.45f;
     std::vector<BlockDesc> h_blocks;
     std::vector<Segment>   h_segs;
@@ -580,6 +581,16 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     HIPCHK(c, c->tblk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tblocks.size(), 1)));
     if (!c->h_tsegs.empty()) HIPCHK(c, hipMemcpyAsync(c->tseg_dev.p, c->h_tsegs.data(), sizeof(TargetSeg) * c->h_tsegs.size(), hipMemcpyHostToDevice, c->stream));
     if (!c->h_tblocks.empty()) HIPCHK(c, hipMemcpyAsync(c->tblk_dev.p, c->h_tblocks.data(), sizeof(BlockDesc) * c->h_tblocks.size(), hipMemcpyHostToDevice, c->stream));
+    // sort_sources: scan order and voxel-grid order are spatially coherent and beat a re-sort; an arbitrary order costs
+    // the cell walk its L1 locality (2x slower), so in auto mode a cheap probe decides once per prepared batch
+    c->sort_now = c->sort_sources == 1;
+    if (c->sort_sources == 2 && c->n_elems > 0) {
+        launch_count_jumps(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), 1.5f, c->done_dev.as<int>(), c->stream);
+        int jumps = 0;
+        HIPCHK(c, hipMemcpyAsync(&jumps, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->sort_now = (double)jumps > 0.25 * (double)c->n_elems;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->prepared = true;
     return LISREG_OK;
@@ -602,7 +613,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
-                        c->n_elems, c->sort_sources ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
+                        c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
     const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk > 0;
     for (int it = 0; it < c->prm.bound; ++it) {

@@ -313,6 +313,24 @@ __global__ __launch_bounds__(256) void k_tseg_cell_starts(const TargetSeg* __res
         t.cell_start_out[c] = (c < t.n_cells ? bucket_start[t.bucket_base + c] : t.flat_base + t.n) - t.flat_base;
 }
 
+// Coherence probe for sort_sources = auto: how many consecutive source points are further apart than `thr`?
+// Scan order and voxel-grid order give a few per cent; an arbitrary order gives most of them.
+__global__ __launch_bounds__(kBlockQ) void k_count_jumps(const BlockDesc* __restrict__ blocks, const Segment* __restrict__ segs,
+                                                         float thr2, int* __restrict__ jumps)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const Segment sg = segs[bd.seg];
+    const int e = bd.start + threadIdx.x;
+    bool jump = false;
+    if ((int)threadIdx.x < bd.count && e + 1 < sg.n) {
+        const float4 a = sg.src[e], b = sg.src[e + 1];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        jump = dx * dx + dy * dy + dz * dz > thr2;
+    }
+    const unsigned long long m = __ballot(jump);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(jumps, __popcll(m));
+}
+
 // identity "sort": keep the caller's order (already spatially coherent scan order) — just flatten the segments
 __global__ __launch_bounds__(kBlockQ) void k_copy_sources(const BlockDesc* __restrict__ blocks,
                                                           const Segment* __restrict__ segs,
@@ -536,6 +554,12 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
 {
     k_voxel_starts<<<(n + 255) / 256, 256, 0, st>>>(n, head, slot, vstart);
     k_voxel_centroids<<<(n_vox + 255) / 256, 256, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
+}
+
+void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st)
+{
+    (void)hipMemsetAsync(jumps, 0, sizeof(int), st);
+    if (n_blocks > 0) k_count_jumps<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, thr * thr, jumps);
 }
 
 void launch_exclusive_scan(const int* in, int* out, int* tmp, int n, hipStream_t st) { exclusive_scan(in, out, tmp, n, st); }

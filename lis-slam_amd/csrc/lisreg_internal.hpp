@@ -138,6 +138,8 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
                             const int* head, const int* slot, int* vstart /* [n_vox+1] */, float4* out_pts,
                             uint32_t* out_labels /* may be null */, hipStream_t st);
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st);
+// number of consecutive source points further apart than thr (coherence probe for sort_sources = auto)
+void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st);
 // out[n+1] = exclusive scan of in[n] (out[n] = total); tmp: n/2048 + 4 ints
 void launch_exclusive_scan(const int* in, int* out, int* tmp, int n, hipStream_t st);
 

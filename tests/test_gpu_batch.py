@@ -106,7 +106,7 @@ def test_search_front_ends_agree(oracle, gpu_ctx, mode, sort):
         gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
         T, st, tr = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
     finally:
-        gpu_ctx.set_option("search_mode", 1); gpu_ctx.set_option("sort_sources", 0)
+        gpu_ctx.set_option("search_mode", 1); gpu_ctx.set_option("sort_sources", 2)
     assert st["iters"] == so["iters"] and len(tr) == len(tro)
     assert np.array_equal(tr[:, 0], tro[:, 0])            # n_corr per iteration, exactly
     rot, trn = pose_err(T, To)
