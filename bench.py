@@ -57,9 +57,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # LISREG_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, RCCL all-gather of the result blocks,
+    # MAX-reduced timing) even with one rank — lets the path the driver runs at N = 2/4/8 be exercised on a 1-GPU box.
+    use_dist = world > 1 or bool(os.environ.get("LISREG_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world
     if not torch.cuda.is_available():
@@ -112,13 +116,13 @@ def main():
 
     def step():
         ctx.batch_run()
-        if world > 1:          # RCCL all-gather of the 64 x 12-float result blocks (poses + stats) over xGMI
+        if use_dist:           # RCCL all-gather of the 64 x 12-float result blocks (poses + stats) over xGMI
             import torch.distributed as dist
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered.view(-1), local_view.view(-1))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -134,7 +138,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -218,8 +222,11 @@ def main():
                          "all_status_ok": bool(all(s["status"] == 0 for s in st_gpu))},
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
+        # the gathered block of every rank must hold every rank's poses (rank r's slice == what rank r computed)
+        g = gathered.cpu().numpy()
+        assert np.array_equal(g[rank, :, :6], T_gpu), "all-gathered result block differs from the local results"
         dist.destroy_process_group()
 
 
