@@ -12,8 +12,9 @@
 //     so they are order-independent);
 //   * selection: the greedy pick with +-5 suppression is sequential inside a ring (suppression spills into the next
 //     sector) but rings are independent: one wave per ring; the ring's picked / curvature / column arrays live in LDS,
-//     every sector is bitonic-sorted by (curvature, index) in LDS (std::sort is unstable: ties fixed by index), lane 0
-//     walks the sorted sector against LDS; picks go to per-ring lists that a last kernel concatenates in ring order.
+//     every sector is bitonic-sorted by (curvature, index) in LDS (std::sort is unstable: ties fixed by index); the
+//     greedy passes run as ballot + ffs loops over 64 sorted candidates at a time, so only actual picks cost serial
+//     time; picks go to per-ring lists that a last kernel concatenates in ring order.
 // Everything is integer/byte work plus one float stencil: HBM-streaming passes, nothing GEMM-shaped.
 // Defined behaviour where the reference has none (oracle/lisreg_oracle.h): per-frame arrays start at zero, the +-5
 // neighbour accesses are bounds-checked against the extracted cloud.
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_feat_occlude(const int* __restrict__ co
 }
 
 // extractFeatures (:610-713): one wave per ring
-__global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos, int H, int W, lisreg_feature_params P,
+__global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos, int H, int W, lisreg_feature_params P,
                                                     FeatureBuffers fb)
 {
     __shared__ int   s_picked[kMaxRingPts];
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos,
     __shared__ float s_val[kMaxSector];
     __shared__ int   s_ind[kMaxSector];
 
-    const int ring = blockIdx.x, lane = threadIdx.x;
+    const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves sort, wave 0 picks
     const int size = fb.counts[0];
     const int r0 = pos[ring * W], r1 = pos[(ring + 1) * W];           // this ring's extracted range [r0, r1)
     const int startRing = r0 - 1 + 5, endRing = r1 - 1 - 5;           // startRingIndex / endRingIndex (:521, :537)
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos,
     int n_corner = 0, n_csharp = 0, n_ssharp = 0;
     // window [lo, hi) of the extracted arrays mirrored in LDS: the ring +-6 (suppression reaches 5 beyond a pick)
     const int lo = max(r0 - 6, 0), hi = min(r1 + 6, size);
-    for (int k = lo + lane; k < hi; k += 64) { s_picked[k - lo] = fb.picked[k]; s_curv[k - lo] = fb.curv[k]; s_col[k - lo] = fb.col[k]; }
+    for (int k = lo + tid; k < hi; k += 256) { s_picked[k - lo] = fb.picked[k]; s_curv[k - lo] = fb.curv[k]; s_col[k - lo] = fb.col[k]; }
     __syncthreads();
 
     for (int j = 0; j < 6; ++j) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos,
         if (sp >= ep) continue;                                        // wave-uniform
         const int m = ep - sp;                                         // std::sort range [sp, ep)
         int np2 = 1; while (np2 < m) np2 <<= 1;
-        for (int t = lane; t < np2; t += 64) {
+        for (int t = tid; t < np2; t += 256) {
             s_val[t] = t < m ? s_curv[sp + t - lo] : 3.0e38f;
             s_ind[t] = t < m ? sp + t : 0x7fffffff;
         }
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos,
         // bitonic sort ascending by (value, index)
         for (int ksz = 2; ksz <= np2; ksz <<= 1)
             for (int jj = ksz >> 1; jj > 0; jj >>= 1) {
-                for (int t = lane; t < np2; t += 64) {
+                for (int t = tid; t < np2; t += 256) {
                     const int u = t ^ jj;
                     if (u > t) {
                         const float va = s_val[t], vb = s_val[u];
@@ -151,44 +152,77 @@ __global__ __launch_bounds__(64) void k_feat_select(const int* __restrict__ pos,
                 }
                 __syncthreads();
             }
-        if (lane == 0) {
+        // The greedy passes are sequential in the SORTED order, but a candidate only costs time when it is picked:
+        // every lane holds one sorted candidate, ballot + ffs finds the next one that qualifies and is still unpicked,
+        // that lane marks itself and its +-5 neighbours in LDS, and candidates suppressed meanwhile are skipped for
+        // free (cloudNeighborPicked only ever goes 0 -> 1, so "not eligible when reached" == "never eligible").
+        if (wave == 0) {
 #define LISREG_SUPPRESS(ind_) do { \
-                for (int l = 1; l <= 5; l++) { if ((ind_) + l >= size || (ind_) + l - 1 < 0) break; \
-                    if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l - 1 - lo]) > 10) break; \
-                    s_picked[(ind_) + l - lo] = 1; } \
-                for (int l = -1; l >= -5; l--) { if ((ind_) + l < 0 || (ind_) + l + 1 >= size) break; \
-                    if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l + 1 - lo]) > 10) break; \
-                    s_picked[(ind_) + l - lo] = 1; } } while (0)
+            for (int l = 1; l <= 5; l++) { if ((ind_) + l >= size || (ind_) + l - 1 < 0) break; \
+                if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l - 1 - lo]) > 10) break; \
+                s_picked[(ind_) + l - lo] = 1; } \
+            for (int l = -1; l >= -5; l--) { if ((ind_) + l < 0 || (ind_) + l + 1 >= size) break; \
+                if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l + 1 - lo]) > 10) break; \
+                s_picked[(ind_) + l - lo] = 1; } } while (0)
+        {   // edge features: largest curvature first (:626-661), at most 20 per sector, the first 4 are "sharp"
             int largest = 0;
-            for (int k = ep; k >= sp; k--) {                           // :626-661
-                const int ind = (k == ep) ? ep : s_ind[k - sp];        // element ep lies outside the sorted range
-                if (s_picked[ind - lo] == 0 && s_curv[ind - lo] > P.edge_threshold) {
+            bool stop = false;
+            for (int kb = ep; kb >= sp && !stop; kb -= 64) {
+                const int k = kb - lane;
+                const bool inr = k >= sp;
+                const int ind = inr ? ((k == ep) ? ep : s_ind[k - sp]) : lo;   // element ep lies outside the sorted range
+                const bool stat = inr && s_curv[ind - lo] > P.edge_threshold;
+                unsigned long long todo = __ballot(stat);
+                while (todo) {
+                    const bool elig = stat && s_picked[ind - lo] == 0;
+                    const unsigned long long m = __ballot(elig) & todo;
+                    if (!m) break;
+                    const int f = __ffsll((long long)m) - 1;
+                    todo &= ~((2ull << f) - 1ull);                             // lanes up to f have had their turn
                     largest++;
-                    if (largest <= 20) {
+                    if (largest > 20) { stop = true; break; }                  // `else break` at :641
+                    if (lane == f) {
                         fb.label[ind] = 1;
-                        lists[0 * kListCap + n_corner++] = ind;
-                        if (largest <= 4) lists[1 * kListCap + n_csharp++] = ind;
-                    } else break;
-                    s_picked[ind - lo] = 1;
-                    LISREG_SUPPRESS(ind);
+                        lists[0 * kListCap + n_corner] = ind;
+                        if (largest <= 4) lists[1 * kListCap + n_csharp] = ind;
+                        s_picked[ind - lo] = 1;
+                        LISREG_SUPPRESS(ind);
+                    }
+                    n_corner++;
+                    if (largest <= 4) n_csharp++;
                 }
             }
-            largest = 0;
-            for (int k = sp; k <= ep; k++) {                           // :663-695
-                const int ind = (k == ep) ? ep : s_ind[k - sp];
-                if (s_picked[ind - lo] == 0 && s_curv[ind - lo] < P.surf_threshold) {
-                    largest++;
-                    fb.label[ind] = -1;
-                    s_picked[ind - lo] = 1;
-                    if (largest <= 10) lists[2 * kListCap + n_ssharp++] = ind;
-                    LISREG_SUPPRESS(ind);
-                }
-            }
-#undef LISREG_SUPPRESS
         }
+        {   // planar features: smallest curvature first (:663-695), the first 10 per sector are "sharp"
+            int largest = 0;
+            for (int kb = sp; kb <= ep; kb += 64) {
+                const int k = kb + lane;
+                const bool inr = k <= ep;
+                const int ind = inr ? ((k == ep) ? ep : s_ind[k - sp]) : lo;
+                const bool stat = inr && s_curv[ind - lo] < P.surf_threshold;
+                unsigned long long todo = __ballot(stat);
+                while (todo) {
+                    const bool elig = stat && s_picked[ind - lo] == 0;
+                    const unsigned long long m = __ballot(elig) & todo;
+                    if (!m) break;
+                    const int f = __ffsll((long long)m) - 1;
+                    todo &= ~((2ull << f) - 1ull);
+                    largest++;
+                    if (lane == f) {
+                        fb.label[ind] = -1;
+                        s_picked[ind - lo] = 1;
+                        if (largest <= 10) lists[2 * kListCap + n_ssharp] = ind;
+                        LISREG_SUPPRESS(ind);
+                    }
+                    if (largest <= 10) n_ssharp++;
+                }
+            }
+        }
+#undef LISREG_SUPPRESS
+        }   // wave 0
         __syncthreads();
     }
-    if (lane == 0) {
+    if (tid == 0) {
         int* c = fb.ring_counts + ring * 4;
         c[0] = n_corner; c[1] = n_csharp; c[2] = n_ssharp;
     }
@@ -224,25 +258,27 @@ __global__ __launch_bounds__(256) void k_feat_surface_write(int hw, const int* _
     fb.lists[(size_t)1 * (hw + 16) + spos[k]] = fb.src[k];
 }
 
-// concatenate the per-ring pick lists in ring order (H <= a few hundred: one wave)
-__global__ __launch_bounds__(64) void k_feat_concat(int H, int hw, FeatureBuffers fb)
+// concatenate the per-ring pick lists in ring order: exclusive scan of the per-ring counts (one wave; ring_counts[r][3]
+// is reused for nothing else, so the offsets go to a small LDS-free strided loop), then one workgroup per ring copies.
+__global__ __launch_bounds__(64) void k_feat_offsets(int H, FeatureBuffers fb, int* __restrict__ ring_off /* [H][3] */)
 {
-    __shared__ int s_off[3];
-    if (threadIdx.x == 0) { s_off[0] = s_off[1] = s_off[2] = 0; }
-    __syncthreads();
-    const int list_of[3] = { 0, 2, 3 };                                // corner, corner_sharp, surface_sharp
-    for (int ring = 0; ring < H; ++ring) {
-        const int* c = fb.ring_counts + ring * 4;
-        for (int w = 0; w < 3; ++w) {
-            const int cnt = c[w], off = s_off[w];
-            for (int t = threadIdx.x; t < cnt; t += 64)
-                fb.lists[(size_t)list_of[w] * (hw + 16) + off + t] = fb.src[fb.ring_lists[((size_t)ring * 3 + w) * kListCap + t]];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { s_off[0] += c[0]; s_off[1] += c[1]; s_off[2] += c[2]; }
-        __syncthreads();
+    const int w = threadIdx.x;                                         // lanes 0..2: one list each
+    if (w >= 3) return;
+    int run = 0;
+    for (int ring = 0; ring < H; ++ring) { ring_off[ring * 3 + w] = run; run += fb.ring_counts[ring * 4 + w]; }
+    const int slot[3] = { 1, 3, 4 };                                   // counts[]: corner, corner_sharp, surface_sharp
+    fb.counts[slot[w]] = run;
+}
+
+__global__ __launch_bounds__(128) void k_feat_concat(int hw, FeatureBuffers fb, const int* __restrict__ ring_off)
+{
+    const int ring = blockIdx.x;
+    const int list_of[3] = { 0, 2, 3 };                                // lists[]: corner, corner_sharp, surface_sharp
+    for (int w = 0; w < 3; ++w) {
+        const int cnt = fb.ring_counts[ring * 4 + w], off = ring_off[ring * 3 + w];
+        for (int t = threadIdx.x; t < cnt; t += 128)
+            fb.lists[(size_t)list_of[w] * (hw + 16) + off + t] = fb.src[fb.ring_lists[((size_t)ring * 3 + w) * kListCap + t]];
     }
-    if (threadIdx.x == 0) { fb.counts[1] = s_off[0]; fb.counts[3] = s_off[1]; fb.counts[4] = s_off[2]; }
 }
 
 __global__ __launch_bounds__(256) void k_gather_points(const float4* __restrict__ pts, const int* __restrict__ idx, int n,
@@ -265,12 +301,14 @@ void launch_extract_features(const float4* pts, const uint32_t* rings, int n, li
     k_feat_extract<<<(hw + 16 + 255) / 256, 256, 0, st>>>(pts, fb.owner, fb.pos, H, W, fb);
     k_feat_smooth<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.curv);
     k_feat_occlude<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.col, fb.picked);
-    k_feat_select<<<H, 64, 0, st>>>(fb.pos, H, W, P, fb);
+    k_feat_select<<<H, 256, 0, st>>>(fb.pos, H, W, P, fb);
     k_feat_surface_flags<<<(hw + 16 + 255) / 256, 256, 0, st>>>(fb.pos, H, W, fb);
     // the second scan goes to the upper half of `pos`; the lower half (ring boundaries) stays valid
     launch_exclusive_scan(fb.flag, fb.pos + (hw + 17), fb.scan_tmp, hw + 16, st);
     k_feat_surface_write<<<(hw + 16 + 255) / 256, 256, 0, st>>>(hw, fb.pos + (hw + 17), fb);
-    k_feat_concat<<<1, 64, 0, st>>>(H, hw, fb);
+    int* ring_off = fb.flag;                                            // flag[] is free again after the surface scan
+    k_feat_offsets<<<1, 64, 0, st>>>(H, fb, ring_off);
+    k_feat_concat<<<H, 128, 0, st>>>(hw, fb, ring_off);
 }
 
 void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st)
