@@ -240,6 +240,20 @@ int  lisreg_extract_features(lisreg_ctx* ctx, const void* cloud, int n, int stri
                              const lisreg_feature_params* params, lisreg_feature_out* out);
 int  lisreg_default_feature_params(lisreg_feature_params* p);
 
+/* The "semantic mask": SemanticFusionNode::categoryMapping (src/node/semanticFusionNode.cpp:173-189) splits the labelled
+ * cloud, preserving order, by UsingLableMap[label] (config/label.yaml:177-196): 10 -> dynamic, 40 -> ground, 50 -> building,
+ * 81 -> pole, anything else (label 0 has no entry) -> outlier.  These five clouds are what semantic_info carries and what
+ * selects the edge (pole) and planar (ground + building + dynamic) feature sets of copies #2/#3.
+ * using_label[32]: the map indexed by label & 31, or NULL for the reference's label.yaml.  Clouds: LISREG_FMT_XYZIL host
+ * structs or LISREG_FMT_DEVICE records (label in the payload); outputs in the input's layout. */
+typedef struct lisreg_semantic_out {
+    void* cloud[5];          /* dynamic, ground, building, pole, outlier — the order of the reference's if-chain */
+    int   cap[5];
+    int   n[5];
+} lisreg_semantic_out;
+int  lisreg_semantic_split(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
+                           const uint32_t* using_label /* [32] or NULL */, lisreg_semantic_out* out);
+
 /* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
 /* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */
 void lisreg_pose_to_matrix(const float T[6], float M[12]);

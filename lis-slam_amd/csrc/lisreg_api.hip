@@ -1027,6 +1027,71 @@ int lisreg_extract_features(lisreg_ctx* c, const void* cloud, int n, int stride,
     return LISREG_OK;
 }
 
+int lisreg_semantic_split(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const uint32_t* using_label,
+                          lisreg_semantic_out* out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!out || n < 0 || (n > 0 && !cloud)) return fail(c, LISREG_ERR_ARG, "semantic_split: bad arguments");
+    if (fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_DEVICE) return fail(c, LISREG_ERR_ARG, "semantic_split: fmt must be XYZIL or DEVICE");
+    if (fmt == LISREG_FMT_XYZIL && stride < 22) return fail(c, LISREG_ERR_ARG, "semantic_split: XYZIL needs stride >= 22");
+    static const uint32_t kUsingLabel[32] = { 0, 10, 10, 10, 10, 10, 10, 10, 10, 40, 40, 40, 70, 50, 50, 70, 81, 70, 81, 81 };   // label.yaml:177-196
+    const uint32_t* map = using_label ? using_label : kUsingLabel;
+    for (int k = 0; k < 5; ++k) out->n[k] = 0;
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool dev = fmt == LISREG_FMT_DEVICE;
+    const float4* pts = nullptr;
+    const uint32_t* labels = nullptr;
+    std::vector<float4> h_pts;
+    std::vector<uint32_t> h_lab;
+    if (dev) pts = static_cast<const float4*>(cloud);
+    else {
+        h_pts.resize((size_t)n); h_lab.resize((size_t)n);
+        const unsigned char* b = static_cast<const unsigned char*>(cloud);
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* r = b + (size_t)i * (size_t)stride;
+            float v[3]; uint16_t l; memcpy(v, r, 12); memcpy(&l, r + 20, 2);
+            h_pts[(size_t)i] = make_float4(v[0], v[1], v[2], 0.f); h_lab[(size_t)i] = l;
+        }
+        HIPCHK(c, c->vox_in.ensure(sizeof(float4) * (size_t)n));
+        HIPCHK(c, c->vox_lab.ensure(sizeof(uint32_t) * (size_t)n));
+        HIPCHK(c, hipMemcpyAsync(c->vox_in.p, h_pts.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->vox_lab.p, h_lab.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        pts = c->vox_in.as<float4>(); labels = c->vox_lab.as<uint32_t>();
+    }
+    HIPCHK(c, c->vox_head.ensure(sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(c, c->vox_slot.ensure(sizeof(int) * ((size_t)n + 2)));
+    HIPCHK(c, c->scan_tmp.ensure(sizeof(int) * ((size_t)n / 2048 + 8)));
+    HIPCHK(c, c->ft_lists.ensure(sizeof(int) * 5 * (size_t)n));
+    HIPCHK(c, c->ft_counts.ensure(sizeof(int) * 8));
+    launch_semantic_split(pts, labels, n, map, c->vox_head.as<int>(), c->vox_slot.as<int>(), c->scan_tmp.as<int>(),
+                          c->ft_lists.as<int>(), c->ft_counts.as<int>(), st);
+    HIPCHK(c, hipGetLastError());
+    int counts[5];
+    HIPCHK(c, hipMemcpyAsync(counts, c->ft_counts.p, sizeof counts, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int k = 0; k < 5; ++k) out->n[k] = counts[k];
+    for (int k = 0; k < 5; ++k)
+        if (out->cloud[k] && counts[k] > out->cap[k]) return fail(c, LISREG_ERR_ARG, "semantic_split: an output buffer is too small (counts written back)");
+    std::vector<int> h_idx;
+    for (int k = 0; k < 5; ++k) {
+        if (!out->cloud[k] || counts[k] == 0) continue;
+        const int* idx = c->ft_lists.as<int>() + (size_t)k * n;
+        if (dev) launch_gather_points(pts, idx, counts[k], static_cast<float4*>(out->cloud[k]), st);
+        else {
+            h_idx.resize((size_t)counts[k]);
+            HIPCHK(c, hipMemcpyAsync(h_idx.data(), idx, sizeof(int) * (size_t)counts[k], hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            const unsigned char* b = static_cast<const unsigned char*>(cloud);
+            unsigned char* o = static_cast<unsigned char*>(out->cloud[k]);
+            for (int i = 0; i < counts[k]; ++i) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)h_idx[(size_t)i] * (size_t)stride, (size_t)stride);
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return LISREG_OK;
+}
+
 // ---- RCCL pose gather: librccl is loaded lazily so single-GPU users never pay for it ------------
 static int rccl_load(lisreg_ctx* c)
 {

@@ -281,6 +281,26 @@ __global__ __launch_bounds__(128) void k_feat_concat(int hw, FeatureBuffers fb, 
     }
 }
 
+// categoryMapping (/root/reference/src/node/semanticFusionNode.cpp:173-189): flag of "this point belongs to class k"
+struct LabelMap { uint32_t m[32]; };
+__global__ __launch_bounds__(256) void k_sem_flags(const float4* __restrict__ pts, const uint32_t* __restrict__ labels, int n,
+                                                   LabelMap map, int k, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = map.m[(labels ? labels[i] : __float_as_uint(pts[i].w)) & 31u];
+    const int c = u == 10u ? 0 : (u == 40u ? 1 : (u == 50u ? 2 : (u == 81u ? 3 : 4)));
+    flag[i] = c == k ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_sem_write(int n, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                   int* __restrict__ idx_out, int* __restrict__ count_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *count_out = pos[n];
+    if (i < n && flag[i]) idx_out[pos[i]] = i;
+}
+
 __global__ __launch_bounds__(256) void k_gather_points(const float4* __restrict__ pts, const int* __restrict__ idx, int n,
                                                        float4* __restrict__ out)
 {
@@ -309,6 +329,19 @@ void launch_extract_features(const float4* pts, const uint32_t* rings, int n, li
     int* ring_off = fb.flag;                                            // flag[] is free again after the surface scan
     k_feat_offsets<<<1, 64, 0, st>>>(H, fb, ring_off);
     k_feat_concat<<<H, 128, 0, st>>>(hw, fb, ring_off);
+}
+
+// stable five-way partition: idx_out[k*n ..] = input indices of class k in input order, counts[k] = its size
+void launch_semantic_split(const float4* pts, const uint32_t* labels, int n, const uint32_t map[32], int* flag, int* pos,
+                           int* scan_tmp, int* idx_out, int* counts, hipStream_t st)
+{
+    LabelMap lm;
+    for (int i = 0; i < 32; ++i) lm.m[i] = map[i];
+    for (int k = 0; k < 5; ++k) {
+        k_sem_flags<<<(n + 255) / 256, 256, 0, st>>>(pts, labels, n, lm, k, flag);
+        launch_exclusive_scan(flag, pos, scan_tmp, n, st);
+        k_sem_write<<<(n + 255) / 256, 256, 0, st>>>(n, flag, pos, idx_out + (size_t)k * n, counts + k);
+    }
 }
 
 void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st)

@@ -163,5 +163,8 @@ struct FeatureBuffers {
 void launch_extract_features(const float4* pts, const uint32_t* rings /* null: ring = payload & 0xffff */, int n,
                              lisreg_feature_params P, FeatureBuffers fb, hipStream_t st);
 void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st);
+void launch_semantic_split(const float4* pts, const uint32_t* labels /* null: payload */, int n, const uint32_t map[32],
+                           int* flag /* [n] */, int* pos /* [n+1] */, int* scan_tmp, int* idx_out /* [5*n] */, int* counts /* [5] */,
+                           hipStream_t st);
 
 }  // namespace lisreg

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
-    "lisreg_extract_features", "lisreg_default_feature_params",
+    "lisreg_extract_features", "lisreg_default_feature_params", "lisreg_semantic_split",
 ]
 
 
@@ -70,6 +70,10 @@ class FeatureParams(C.Structure):
 class FeatureOut(C.Structure):
     _fields_ = [(f, t) for name in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
                 for f, t in ((name, C.c_void_p), ("cap_" + name, C.c_int), ("n_" + name, C.c_int))]
+
+
+class SemanticOut(C.Structure):
+    _fields_ = [("cloud", C.c_void_p * 5), ("cap", C.c_int * 5), ("n", C.c_int * 5)]
 
 
 class LisregError(RuntimeError):
@@ -134,6 +138,7 @@ def lib():
         L.lisreg_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, vp]
         L.lisreg_extract_features.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(FeatureOut)]
         L.lisreg_default_feature_params.argtypes = [C.POINTER(FeatureParams)]
+        L.lisreg_semantic_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(SemanticOut)]
         _lib = L
     return _lib
 
@@ -355,6 +360,18 @@ class Context:
             setattr(fo, k, C.c_void_p(ptr)); setattr(fo, "cap_" + k, cap)
         self._chk(self._L.lisreg_extract_features(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, C.byref(params), C.byref(fo)))
         return {k: getattr(fo, "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")}
+
+    def semantic_split(self, cloud: np.ndarray, using_label=None) -> list:
+        """categoryMapping replacement: [dynamic, ground, building, pole, outlier] from a PointXYZIL struct array."""
+        cloud = np.ascontiguousarray(cloud)
+        bufs = [np.zeros(len(cloud), cloud.dtype) for _ in range(5)]
+        so = SemanticOut()
+        for k in range(5):
+            so.cloud[k] = bufs[k].ctypes.data_as(C.c_void_p).value if len(cloud) else None
+            so.cap[k] = len(cloud)
+        m = (C.c_uint32 * 32)(*using_label) if using_label is not None else None
+        self._chk(self._L.lisreg_semantic_split(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIL, m, C.byref(so)))
+        return [bufs[k][: so.n[k]] for k in range(5)]
 
     def set_profiling(self, on: bool):
         self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))

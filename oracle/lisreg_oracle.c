@@ -1014,3 +1014,14 @@ void orc_extract_features(const void* cloud, int n, int stride, const lisreg_fea
     free(rangeMat); free(owner); free(startRing); free(endRing); free(colInd); free(prange); free(curv); free(picked);
     free(label); free(sm);
 }
+
+/* categoryMapping (src/node/semanticFusionNode.cpp:173-189) */
+void orc_semantic_classes(const void* cloud, int n, int stride, const unsigned int using_label[32], unsigned char* cls)
+{
+    const unsigned char* src = (const unsigned char*)cloud;
+    for (int i = 0; i < n; ++i) {
+        unsigned short label; memcpy(&label, src + (size_t)i * (size_t)stride + 20, 2);
+        unsigned int u = using_label[label & 31];
+        cls[i] = u == 10 ? 0 : (u == 40 ? 1 : (u == 50 ? 2 : (u == 81 ? 3 : 4)));
+    }
+}

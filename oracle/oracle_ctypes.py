@@ -102,6 +102,8 @@ def lib():
         L.orc_transform_cloud.restype = None
         L.orc_extract_features.argtypes = [vp, C.c_int, C.c_int, C.POINTER(FeatureParams), ip, ip, ip, ip, ip, ip]
         L.orc_extract_features.restype = None
+        L.orc_semantic_classes.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_ubyte)]
+        L.orc_semantic_classes.restype = None
         _lib = L
     return _lib
 
@@ -175,3 +177,17 @@ def extract_features(cloud, params: "FeatureParams"):
     L.orc_extract_features(_vp(cloud), len(cloud), cloud.dtype.itemsize, C.byref(params), *[ip(b) for b in bufs], ip(counts))
     names = ["deskewed", "corner", "surface", "corner_sharp", "surface_sharp"]
     return {k: bufs[i][: counts[i]].copy() for i, k in enumerate(names)}
+
+
+# config/label.yaml:177-196 `using_label` (label 0 has no entry -> 0 -> outlier)
+USING_LABEL = [0, 10, 10, 10, 10, 10, 10, 10, 10, 40, 40, 40, 70, 50, 50, 70, 81, 70, 81, 81] + [0] * 12
+
+
+def semantic_split(cloud, using_label=None):
+    """Returns the five clouds (dynamic, ground, building, pole, outlier) as the stable partition by orc_semantic_classes."""
+    L = lib()
+    cloud = np.ascontiguousarray(cloud)
+    m = (C.c_uint * 32)(*(using_label or USING_LABEL))
+    cls = np.zeros(len(cloud), np.uint8)
+    L.orc_semantic_classes(_vp(cloud), len(cloud), cloud.dtype.itemsize, m, cls.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return [cloud[cls == k] for k in range(5)]

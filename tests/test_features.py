@@ -135,3 +135,40 @@ def test_full_front_end_pipeline_matches_oracle(oracle, gpu_ctx):
     Tg, sg, _ = gpu_ctx.align(ds_g["sc"], ds_g["ss"], T0, lisreg.default_params(1))
     assert so["status"] == sg["status"] == 0 and len(ds_g["ss"]) > 2000
     assert max(pose_err(Tg, To)) <= 1e-3 and max(pose_err(Tg, sc_truth)) < 3e-2
+
+
+def _labelled_cloud(seed, n=50000):
+    from lisreg import synth
+    rng = np.random.default_rng(seed)
+    c = synth.to_pcl(rng.uniform(-40, 40, (n, 3)).astype(np.float32), rng.integers(0, 20, n).astype(np.uint16),
+                     rng.uniform(0, 255, n).astype(np.float32))
+    return c
+
+
+def test_oracle_semantic_split_matches_label_yaml(oracle):
+    """categoryMapping (semanticFusionNode.cpp:173-189) with config/label.yaml:177-196."""
+    c = _labelled_cloud(1)
+    parts = oracle.semantic_split(c)
+    groups = [{1, 2, 3, 4, 5, 6, 7, 8}, {9, 10, 11}, {13, 14}, {16, 18, 19}, {0, 12, 15, 17}]   # dynamic ground building pole outlier
+    assert sum(len(p) for p in parts) == len(c)
+    for part, g in zip(parts, groups):
+        assert set(np.unique(part["label"]).tolist()) <= g
+        want = c[np.isin(c["label"], list(g))]                                 # order-preserving
+        assert same_points(part, want)
+
+
+@pytest.mark.gpu
+def test_hip_semantic_split_matches_oracle(oracle, gpu_ctx):
+    import lisreg
+    c = _labelled_cloud(2, 120000)
+    po, pg = oracle.semantic_split(c), gpu_ctx.semantic_split(c)
+    assert [len(p) for p in pg] == [len(p) for p in po]
+    for a, b in zip(pg, po):
+        assert same_points(a, b)
+    custom = [81] * 32                                                          # everything is a pole
+    pg = gpu_ctx.semantic_split(c, custom)
+    assert [len(p) for p in pg] == [0, 0, 0, len(c), 0] and same_points(pg[3], c)
+    assert [len(p) for p in gpu_ctx.semantic_split(c[:0])] == [0] * 5
+    # the split feeds copies #2/#3: edge set = pole, planar set = dynamic + building + ground (subMapOptmizationNode.cpp:856-893)
+    pg = gpu_ctx.semantic_split(c)
+    assert len(pg[3]) + len(pg[0]) + len(pg[2]) + len(pg[1]) + len(pg[4]) == len(c)
