@@ -2,8 +2,9 @@
 //
 // Creates the seam the reference lacks: each entry point replaces a piece of
 // scan2SubMapOptimization() — /root/reference/src/node/odomEstimationNode.cpp:596-626 and the copies at
-// src/node/subMapOptmizationNode.cpp:1509-1541, 4485-4540.  The GN loop is enqueued in full (index build, source
-// tile sort, `bound` x {correspondence kernel, solve kernel}, finalize) with no host synchronisation inside; a
+// src/node/subMapOptmizationNode.cpp:1509-1541, 4485-4540.  The GN loop is enqueued in full (optional index rebuild,
+// optional source sort, `bound` x {correspondence kernel, solve kernel}, finalize) with no host synchronisation inside
+// lisreg_batch_run (the synchronous entry points may stop launching early once every item has converged); a
 // context is single-threaded and owns its stream, so several contexts run concurrently (callers #2/#3).
 // There is deliberately NO CPU fallback: without a HIP device every compute entry point fails with
 // LISREG_ERR_HIP.
@@ -164,7 +165,6 @@ DevParams make_dev_params(const lisreg_params& p)
     d.edge_min = p.edge_min; d.surf_min = p.surf_min; d.use_imu = p.use_imu_blend;
     d.imu_w = p.imu_rpy_weight; d.rot_tol = p.rotation_tol; d.z_tol = p.z_tol;
     for (int i = 0; i < 32; ++i) d.wtab[i] = (float)(2.0 - (double)p.label_score[i]);   // subMapOptmizationNode.cpp:1671
-    if (const char* e = getenv("LISREG_DBG")) d.dbg = atoi(e);
     return d;
 }
 

@@ -345,8 +345,7 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
         nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
         float w = 1.f;
         if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
-        if (P.dbg & 2) { cf[0] = nb[0].x - nb[4].x; cf[1] = nb[1].y - nb[3].y; cf[2] = nb[2].z; cf[3] = w; ok = true; }
-        else ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
+        ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
     }
     row_and_reduce(ok, cf, q4, sc, P, s_acc, out);
 }
@@ -371,7 +370,6 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
     // Each step exchanges HALF of the values with the partner lane (xor 32, 16, 8, 4, 2), so 32 values need
     // 16+8+4+2+1(+1) 64-bit shuffles instead of 32 x 6; after five steps lane l holds the 32-lane sum of value
     // index bits(l)[5:1] and one last xor-1 step completes it.  Deterministic: the pairing is fixed.
-    if (P.dbg & 4) { if (lane == 0 && wave == 0) out[0] = (double)(row[0] + rb + one); return; }
     double v16[16];
     {
         const bool up = (lane & 32) != 0;
@@ -684,7 +682,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
         if (!seeded) {
             LISREG_WALK(first_pass_r2);                    // tight first pass establishes a bound cheaply
             if (!(b4 <= first_pass_r2)) LISREG_WALK(3.0e38f);
-        } else if (!(P.dbg & 1)) {
+        } else {
             LISREG_WALK(3.0e38f);
         }
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store

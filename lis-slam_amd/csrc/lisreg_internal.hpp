@@ -65,7 +65,6 @@ struct DevParams {
     int   min_corr, use_label, emulate_shadow, skip_empty, fixed_iters, bound, edge_min, surf_min, use_imu;
     float imu_w, rot_tol, z_tol;
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
-    int   dbg;                 // ablation switches for profiling ONLY (env LISREG_DBG): 1 skip walk, 2 skip fit, 4 skip reduce
 };
 
 // Mutable per-registration state (device resident for the whole GN loop — no host sync per iteration).
