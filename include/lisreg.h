@@ -254,6 +254,30 @@ typedef struct lisreg_semantic_out {
 int  lisreg_semantic_split(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
                            const uint32_t* using_label /* [32] or NULL */, lisreg_semantic_out* out);
 
+/* ---- §8 f-3: local-map maintenance (src/include/subMap.h) -------------------------------------------------- */
+/* A k = 1 search index over one cloud, kept in HBM under `slot` (its own slot space, separate from the registration
+ * targets).  Replaces pcl::search::KdTree<PointT>::setInputCloud (subMap.h:889 `local_map->tree_dynamic`,
+ * subMapOptmizationNode.cpp:2779 icp.setInputTarget).  LISREG_FMT_DEVICE clouds are referenced, not copied. */
+int  lisreg_map_index_set(lisreg_ctx* ctx, int slot, const void* cloud, int n, int stride_bytes, int fmt);
+/* nearestKSearch(query, k = 1) for a whole cloud: idx_out[i] = index into the map cloud of the nearest point, or -1 when it
+ * is farther than max_dist (pass a huge value for the reference's unbounded search); sqd_out[i] = squared distance in float,
+ * accumulated x, y, z like FLANN's L2_Simple.  Equidistant candidates resolve to the smallest index.  idx_out / sqd_out are
+ * host arrays, or device arrays when fmt is LISREG_FMT_DEVICE. */
+int  lisreg_nearest(lisreg_ctx* ctx, int slot, const void* query, int n, int stride_bytes, int fmt, float max_dist,
+                    int* idx_out, float* sqd_out);
+/* SubMapManager::map_scan_feature_pts_distance_removal (subMap.h:1064-1100): drop the points of `cloud` within
+ * center_radius (x, y) of the sensor whose nearest point of the indexed map lies at distance d with d <= near_dist_thre or
+ * dist_thre_min <= d <= dist_thre_max; order preserved.  `out` has room for n points of the input layout.  Returns
+ * LISREG_NOT_ENOUGH_FEATURES (and out = in) where the reference returns false (n <= 10). */
+int  lisreg_dynamic_filter(lisreg_ctx* ctx, int slot, const void* cloud, int n, int stride_bytes, int fmt, float center_radius,
+                           float dist_thre_min, float dist_thre_max, float near_dist_thre, void* out, int* n_out);
+/* SubMapManager::bbx_filter (subMap.h:1124-1152): bounds = {min_x, min_y, min_z, max_x, max_y, max_z} (bounds_t); keeps the
+ * points strictly inside, or the others when delete_box is set; order preserved. */
+int  lisreg_bbx_filter(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt, const double bounds[6],
+                       int delete_box, void* out, int* n_out);
+/* SubMapManager::get_cloud_bbx (subMap.h:131-163); an empty cloud yields {DBL_MAX x3, -DBL_MAX x3}. */
+int  lisreg_cloud_bounds(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt, double bounds[6]);
+
 /* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
 /* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */
 void lisreg_pose_to_matrix(const float T[6], float M[12]);

@@ -8,7 +8,7 @@
 // context is single-threaded and owns its stream, so several contexts run concurrently (callers #2/#3).
 // There is deliberately NO CPU fallback: without a HIP device every compute entry point fails with
 // LISREG_ERR_HIP.
-#include "lisreg_internal.hpp"
+#include "lisreg_ctx.hpp"
 
 #include <dlfcn.h>
 
@@ -22,107 +22,19 @@
 
 using namespace lisreg;
 
-namespace {
-
-struct DevBuf {
-    void*  p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct Target {
-    bool      valid = false;
-    int       n[2] = { 0, 0 };
-    int       n_cells[2] = { 1, 1 };
-    GridIndex g[2];
-    DevBuf    raw[2], sorted[2], cell_start[2];
-    bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
-    const float4* raw_ptr[2] = { nullptr, nullptr };
-};
-
-struct RcclApi {
-    void* handle = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value, 128 B */, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-};
-
-}  // namespace
-
-struct lisreg_ctx {
-    int          device = 0;
-    hipStream_t  own_stream = nullptr, stream = nullptr;
-    std::string  err;
-    std::vector<Target> targets;
-    DevBuf       grids_dev;
-    bool         grids_dirty = true;
-    // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
-    DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
-    // batch
-    DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
-           vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
-           ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
-           ft_lists, ft_counts, ft_rings, ft_gather;
-    int*      done_host = nullptr;          // pinned
-    int       early_stop_chunk = 3;
-    std::vector<TargetSeg> h_tsegs;
-    std::vector<BlockDesc> h_tblocks;
-    int       t_elems = 0, t_buckets = 0;
-    bool      count_searches = false;
-    int       search_mode = 1;
-    float     cert_slack = 0.10f;
-    int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
-    bool      sort_now = false;          // decision for the prepared batch
-    float     first_pass_r = 0.45f;
-    std::vector<BlockDesc> h_blocks;
-    std::vector<Segment>   h_segs;
-    std::vector<ItemState> h_items;
-    std::vector<float>     h_results;
-    int       n_items = 0, n_blocks = 0, n_segs = 0, n_elems = 0, n_buckets = 0, trace_cap = 0;
-    DevParams prm;
-    lisreg_params params;
-    bool      prepared = false;
-    bool      rebuild_targets_each_run = false;
-    std::vector<int> batch_slots;           // target slots used by the prepared batch
-    int       degenerate = 0;               // isDegenerate member (odomEstimationNode.cpp:67)
-    // profiling
-    bool      profiling = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<int>        ev_kind;        // kind of the interval STARTING at event i: 0 assoc, 1 solve, 2 index, -1 none
-    double    timing[5] = { 0, 0, 0, 0, 0 };
-    // last align trace (host copy)
-    std::vector<float> last_trace;
-    int       last_trace_n = 0;
-    // RCCL
-    RcclApi   rccl;
-    void*     comm = nullptr;
-    int       comm_nranks = 0;
-};
-
-namespace {
-
+namespace lisreg {
 thread_local std::string g_static_err;
-
-int fail(lisreg_ctx* c, int code, const std::string& msg)
+int ctx_fail(lisreg_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg; else g_static_err = msg;
     return code;
 }
+}  // namespace lisreg
 
-#define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
-    return fail((c), LISREG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+namespace {
+
+
+int fail(lisreg_ctx* c, int code, const std::string& msg) { return lisreg::ctx_fail(c, code, msg); }
 
 float env_float(const char* name, float dflt)
 {
@@ -141,6 +53,8 @@ void pose_to_matrix_host(const float T[6], float M[12])
 }
 
 // pack PCL structs (stride/format of common.h:9,25-35) into 16-B device records
+}  // namespace
+namespace lisreg {
 void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* out)
 {
     const unsigned char* b = static_cast<const unsigned char*>(cloud);
@@ -152,6 +66,8 @@ void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* ou
         out[i].payload = lab;
     }
 }
+}  // namespace lisreg
+namespace {
 
 DevParams make_dev_params(const lisreg_params& p)
 {
@@ -168,6 +84,8 @@ DevParams make_dev_params(const lisreg_params& p)
     return d;
 }
 
+}  // namespace
+namespace lisreg {
 SortBuffers sort_buffers(lisreg_ctx* c)
 {
     SortBuffers sb;
@@ -177,7 +95,11 @@ SortBuffers sort_buffers(lisreg_ctx* c)
     sb.tmp_idx = c->tmp_idx.as<int>();
     return sb;
 }
+}  // namespace lisreg
+namespace {
 
+}  // namespace
+namespace lisreg {
 int ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets)
 {
     HIPCHK(c, c->hist.ensure(sizeof(int) * (n_buckets + 1)));
@@ -190,8 +112,12 @@ int ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets)
     HIPCHK(c, c->tmp_idx.ensure(sizeof(int) * (n_elems + 1)));
     return LISREG_OK;
 }
+}  // namespace lisreg
+namespace {
 
 // grid geometry from a bounding box; cell edge grows if the box would need too many cells
+}  // namespace
+namespace lisreg {
 void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells)
 {
     memset(g, 0, sizeof *g);
@@ -209,6 +135,8 @@ void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells)
     g->cell = cell; g->inv_cell = 1.f / cell;
     *n_cells = g->nx * g->ny * g->nz;
 }
+}  // namespace lisreg
+namespace {
 
 int build_target_kind(lisreg_ctx* c, Target& t, int k)
 {
@@ -322,6 +250,9 @@ void lisreg_destroy(lisreg_ctx* c)
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
                        &c->ft_gather };
     for (auto b : bufs) b->release();
+    for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
+    DevBuf* mbufs[] = { &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out };
+    for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

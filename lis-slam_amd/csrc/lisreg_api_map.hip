@@ -1,0 +1,235 @@
+// lisreg_api_map.hip — C-ABI entry points of SURVEY.md §8 f-3 (local-map maintenance, /root/reference/src/include/subMap.h):
+// the k = 1 map index, the dynamic-point filter, the box crop and the cloud bounds.  Kernels: lisreg_nn1.hip.
+// Every filter is "flag -> exclusive scan -> index list -> gather", so the survivors keep the input order like the
+// reference's push_back loops.  No CPU fallback: without a HIP device these fail with LISREG_ERR_HIP.
+#include "lisreg_ctx.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+
+using namespace lisreg;
+
+namespace {
+
+int bad(lisreg_ctx* c, const char* msg) { return ctx_fail(c, LISREG_ERR_ARG, msg); }
+
+// the query / input cloud as 16-B device records: the caller's own memory for LISREG_FMT_DEVICE, else uploaded to mp_pts
+int stage_cloud(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const float4** out)
+{
+    if (fmt == LISREG_FMT_DEVICE) { *out = static_cast<const float4*>(cloud); return LISREG_OK; }
+    std::vector<lisreg_dpoint> h((size_t)std::max(n, 1));
+    pack_cloud(cloud, n, stride, fmt, h.data());
+    HIPCHK(c, c->mp_pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+    HIPCHK(c, hipMemcpyAsync(c->mp_pts.p, h.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // h is a local
+    *out = c->mp_pts.as<float4>();
+    return LISREG_OK;
+}
+
+int check_cloud(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const char* who)
+{
+    if (n < 0 || (n > 0 && !cloud)) return bad(c, (std::string(who) + ": NULL cloud with n > 0").c_str());
+    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_XYZI && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZIRT)
+        return bad(c, (std::string(who) + ": unknown fmt").c_str());
+    if (fmt != LISREG_FMT_DEVICE && stride < 12) return bad(c, (std::string(who) + ": stride < 12").c_str());
+    if (fmt == LISREG_FMT_XYZIL && stride < 22) return bad(c, (std::string(who) + ": XYZIL needs stride >= 22").c_str());
+    return LISREG_OK;
+}
+
+// flags (mp_flag) -> survivors of `cloud` in `out`, input layout and order
+int emit_survivors(lisreg_ctx* c, const void* cloud, const float4* pts, int n, int stride, int fmt, void* out, int* n_out)
+{
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->mp_pos.ensure(sizeof(int) * ((size_t)n + 2)));
+    HIPCHK(c, c->mp_idx.ensure(sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(c, c->mp_cnt.ensure(sizeof(int) * 4));
+    HIPCHK(c, c->scan_tmp.ensure(sizeof(int) * ((size_t)n / 2048 + 8)));
+    launch_compact(n, c->mp_flag.as<int>(), c->mp_pos.as<int>(), c->scan_tmp.as<int>(), c->mp_idx.as<int>(), c->mp_cnt.as<int>(), st);
+    HIPCHK(c, hipGetLastError());
+    int m = 0;
+    HIPCHK(c, hipMemcpyAsync(&m, c->mp_cnt.p, sizeof m, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *n_out = m;
+    if (m == 0) return LISREG_OK;
+    if (fmt == LISREG_FMT_DEVICE) {
+        if (out == cloud) {                       // in place: gather through a scratch copy
+            HIPCHK(c, c->mp_out.ensure(sizeof(float4) * (size_t)m));
+            launch_gather_points(pts, c->mp_idx.as<int>(), m, c->mp_out.as<float4>(), st);
+            HIPCHK(c, hipMemcpyAsync(out, c->mp_out.p, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, st));
+        } else launch_gather_points(pts, c->mp_idx.as<int>(), m, static_cast<float4*>(out), st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));
+        return LISREG_OK;
+    }
+    std::vector<int> idx((size_t)m);
+    HIPCHK(c, hipMemcpyAsync(idx.data(), c->mp_idx.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const unsigned char* b = static_cast<const unsigned char*>(cloud);
+    unsigned char* o = static_cast<unsigned char*>(out);
+    for (int i = 0; i < m; ++i)                    // ascending indices: safe in place (memmove)
+        memmove(o + (size_t)i * (size_t)stride, b + (size_t)idx[(size_t)i] * (size_t)stride, (size_t)stride);
+    return LISREG_OK;
+}
+
+int copy_through(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, void* out)
+{
+    if (n == 0 || out == cloud) return LISREG_OK;
+    if (fmt == LISREG_FMT_DEVICE) {
+        HIPCHK(c, hipMemcpyAsync(out, cloud, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else memmove(out, cloud, (size_t)n * (size_t)stride);
+    return LISREG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lisreg_map_index_set(lisreg_ctx* c, int slot, const void* cloud, int n, int stride, int fmt)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (slot < 0 || slot > 65535) return bad(c, "map_index_set: bad slot");
+    int rc = check_cloud(c, cloud, n, stride, fmt, "map_index_set");
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if ((size_t)slot >= c->maps.size()) c->maps.resize((size_t)slot + 1);
+    MapIndex& m = c->maps[(size_t)slot];
+    m.valid = false;
+    m.n = n;
+    float bb[6] = { 0, 0, 0, 0, 0, 0 };
+    if (fmt == LISREG_FMT_DEVICE) m.raw_ptr = static_cast<const float4*>(cloud);
+    else {
+        std::vector<lisreg_dpoint> h((size_t)std::max(n, 1));
+        pack_cloud(cloud, n, stride, fmt, h.data());
+        HIPCHK(c, m.raw.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+        if (n > 0) HIPCHK(c, hipMemcpy(m.raw.p, h.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
+        m.raw_ptr = m.raw.as<float4>();
+    }
+    if (n > 0) {
+        HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 8));
+        HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
+        launch_bbox(m.raw_ptr, n, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), st);
+        HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    make_grid(bb, n, &m.g, &m.n_cells);
+    HIPCHK(c, m.cell_start.ensure(sizeof(int) * ((size_t)m.n_cells + 2)));
+    HIPCHK(c, m.sorted.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+    rc = ensure_sort_scratch(c, (size_t)std::max(n, 1), (size_t)m.n_cells);
+    if (rc) return rc;
+    m.g.pts = m.sorted.as<float4>();
+    m.g.cell_start = m.cell_start.as<int>();
+    launch_build_target(m.raw_ptr, n, m.g, m.sorted.as<float4>(), m.cell_start.as<int>(), m.n_cells, sort_buffers(c), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, m.g_dev.ensure(sizeof(GridIndex)));
+    HIPCHK(c, hipMemcpyAsync(m.g_dev.p, &m.g, sizeof(GridIndex), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    m.valid = true;
+    return LISREG_OK;
+}
+
+int lisreg_nearest(lisreg_ctx* c, int slot, const void* query, int n, int stride, int fmt, float max_dist, int* idx_out,
+                   float* sqd_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+        return ctx_fail(c, LISREG_ERR_NO_TARGET, "nearest: no map index in this slot");
+    int rc = check_cloud(c, query, n, stride, fmt, "nearest");
+    if (rc) return rc;
+    if (!(max_dist >= 0.f)) return bad(c, "nearest: max_dist must be >= 0");
+    if (n > 0 && (!idx_out || !sqd_out)) return bad(c, "nearest: NULL output");
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const MapIndex& m = c->maps[(size_t)slot];
+    const float4* q = nullptr;
+    rc = stage_cloud(c, query, n, stride, fmt, &q);
+    if (rc) return rc;
+    max_dist = std::min(max_dist, 1.8e19f);        // squared below
+    if (fmt == LISREG_FMT_DEVICE) {
+        launch_nn1(q, n, m.g_dev.as<GridIndex>(), max_dist, idx_out, sqd_out, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));
+        return LISREG_OK;
+    }
+    HIPCHK(c, c->mp_idx.ensure(sizeof(int) * (size_t)n));
+    HIPCHK(c, c->mp_d2.ensure(sizeof(float) * (size_t)n));
+    launch_nn1(q, n, m.g_dev.as<GridIndex>(), max_dist, c->mp_idx.as<int>(), c->mp_d2.as<float>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(idx_out, c->mp_idx.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(sqd_out, c->mp_d2.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return LISREG_OK;
+}
+
+int lisreg_dynamic_filter(lisreg_ctx* c, int slot, const void* cloud, int n, int stride, int fmt, float center_radius,
+                          float dist_thre_min, float dist_thre_max, float near_dist_thre, void* out, int* n_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+        return ctx_fail(c, LISREG_ERR_NO_TARGET, "dynamic_filter: no map index in this slot");
+    int rc = check_cloud(c, cloud, n, stride, fmt, "dynamic_filter");
+    if (rc) return rc;
+    if (!n_out || (n > 0 && !out)) return bad(c, "dynamic_filter: NULL output");
+    HIPCHK(c, hipSetDevice(c->device));
+    const MapIndex& m = c->maps[(size_t)slot];
+    if (n <= 10 || m.n <= 0) {                      // subMap.h:1071-1072 returns false and leaves the cloud alone
+        *n_out = n;
+        rc = copy_through(c, cloud, n, stride, fmt, out);
+        return rc ? rc : (n <= 10 ? LISREG_NOT_ENOUGH_FEATURES : LISREG_OK);
+    }
+    const float4* pts = nullptr;
+    rc = stage_cloud(c, cloud, n, stride, fmt, &pts);
+    if (rc) return rc;
+    HIPCHK(c, c->mp_flag.ensure(sizeof(int) * ((size_t)n + 1)));
+    launch_dynamic_flags(pts, n, m.g_dev.as<GridIndex>(), center_radius, near_dist_thre, dist_thre_min, dist_thre_max,
+                         c->mp_flag.as<int>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    return emit_survivors(c, cloud, pts, n, stride, fmt, out, n_out);
+}
+
+int lisreg_bbx_filter(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const double bounds[6], int delete_box,
+                      void* out, int* n_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    int rc = check_cloud(c, cloud, n, stride, fmt, "bbx_filter");
+    if (rc) return rc;
+    if (!bounds || !n_out || (n > 0 && !out)) return bad(c, "bbx_filter: NULL argument");
+    *n_out = 0;
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const float4* pts = nullptr;
+    rc = stage_cloud(c, cloud, n, stride, fmt, &pts);
+    if (rc) return rc;
+    HIPCHK(c, c->mp_flag.ensure(sizeof(int) * ((size_t)n + 1)));
+    launch_bbx_flags(pts, n, bounds, delete_box, c->mp_flag.as<int>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    return emit_survivors(c, cloud, pts, n, stride, fmt, out, n_out);
+}
+
+int lisreg_cloud_bounds(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, double bounds[6])
+{
+    if (!c) return LISREG_ERR_ARG;
+    int rc = check_cloud(c, cloud, n, stride, fmt, "cloud_bounds");
+    if (rc) return rc;
+    if (!bounds) return bad(c, "cloud_bounds: NULL bounds");
+    for (int d = 0; d < 3; ++d) { bounds[d] = DBL_MAX; bounds[3 + d] = -DBL_MAX; }
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const float4* pts = nullptr;
+    rc = stage_cloud(c, cloud, n, stride, fmt, &pts);
+    if (rc) return rc;
+    float bb[6];
+    HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 8));
+    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
+    launch_bbox(pts, n, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int d = 0; d < 6; ++d) bounds[d] = (double)bb[d];       // float extremes widened, as the reference's double min/max
+    return LISREG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// lisreg_ctx.hpp — the context behind the C ABI (shared by the lisreg_api*.hip translation units; not installed).
+#pragma once
+#include "lisreg_internal.hpp"
+
+#include <string>
+#include <vector>
+
+namespace lisreg {
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Target {
+    bool      valid = false;
+    int       n[2] = { 0, 0 };
+    int       n_cells[2] = { 1, 1 };
+    GridIndex g[2];
+    lisreg::DevBuf    raw[2], sorted[2], cell_start[2];
+    bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
+    const float4* raw_ptr[2] = { nullptr, nullptr };
+};
+
+// k = 1 search index over one cloud (lisreg_map_index_set)
+struct MapIndex {
+    bool      valid = false;
+    int       n = 0, n_cells = 1;
+    GridIndex g;
+    DevBuf    raw, sorted, cell_start, g_dev;
+    const float4* raw_ptr = nullptr;
+};
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value, 128 B */, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+};
+
+}  // namespace lisreg
+
+struct lisreg_ctx {
+    int          device = 0;
+    hipStream_t  own_stream = nullptr, stream = nullptr;
+    std::string  err;
+    std::vector<lisreg::Target> targets;
+    lisreg::DevBuf       grids_dev;
+    bool         grids_dirty = true;
+    // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
+    lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
+    // batch
+    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
+           vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
+           ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
+           ft_lists, ft_counts, ft_rings, ft_gather;
+    std::vector<lisreg::MapIndex> maps;
+    lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out;
+    int*      done_host = nullptr;          // pinned
+    int       early_stop_chunk = 3;
+    std::vector<lisreg::TargetSeg> h_tsegs;
+    std::vector<lisreg::BlockDesc> h_tblocks;
+    int       t_elems = 0, t_buckets = 0;
+    bool      count_searches = false;
+    int       search_mode = 1;
+    float     cert_slack = 0.10f;
+    int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
+    bool      sort_now = false;          // decision for the prepared batch
+    float     first_pass_r = 0.45f;
+    std::vector<lisreg::BlockDesc> h_blocks;
+    std::vector<lisreg::Segment>   h_segs;
+    std::vector<lisreg::ItemState> h_items;
+    std::vector<float>     h_results;
+    int       n_items = 0, n_blocks = 0, n_segs = 0, n_elems = 0, n_buckets = 0, trace_cap = 0;
+    lisreg::DevParams prm;
+    lisreg_params params;
+    bool      prepared = false;
+    bool      rebuild_targets_each_run = false;
+    std::vector<int> batch_slots;           // target slots used by the prepared batch
+    int       degenerate = 0;               // isDegenerate member (odomEstimationNode.cpp:67)
+    // profiling
+    bool      profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int>        ev_kind;        // kind of the interval STARTING at event i: 0 assoc, 1 solve, 2 index, -1 none
+    double    timing[5] = { 0, 0, 0, 0, 0 };
+    // last align trace (host copy)
+    std::vector<float> last_trace;
+    int       last_trace_n = 0;
+    // RCCL
+    lisreg::RcclApi   rccl;
+    void*     comm = nullptr;
+    int       comm_nranks = 0;
+};
+
+namespace lisreg {
+int  ctx_fail(lisreg_ctx* c, int code, const std::string& msg);
+// pack PCL structs (stride/format of common.h:9,25-35) into 16-B device records
+void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* out);
+// grid geometry from a bounding box; cell edge grows if the box would need too many cells
+void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells);
+SortBuffers sort_buffers(lisreg_ctx* c);
+int  ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets);
+}  // namespace lisreg
+
+#define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return lisreg::ctx_fail((c), LISREG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)

@@ -162,6 +162,13 @@ struct FeatureBuffers {
 void launch_extract_features(const float4* pts, const uint32_t* rings /* null: ring = payload & 0xffff */, int n,
                              lisreg_feature_params P, FeatureBuffers fb, hipStream_t st);
 void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st);
+// §8 f-3 / f-4 building blocks (lisreg_nn1.hip): exact k = 1 queries on a GridIndex that lives in device memory
+void launch_nn1(const float4* q, int n, const GridIndex* grid_dev, float max_dist, int* idx_out, float* d2_out, hipStream_t st);
+void launch_dynamic_flags(const float4* pts, int n, const GridIndex* grid_dev, float center_radius, float near_thre, float dmin,
+                          float dmax, int* flag, hipStream_t st);
+void launch_bbx_flags(const float4* pts, int n, const double b[6], int delete_box, int* flag, hipStream_t st);
+// stable compaction: idx_out[0..count) = indices i with flag[i] != 0, ascending; pos [n+1]
+void launch_compact(int n, const int* flag, int* pos, int* scan_tmp, int* idx_out, int* count_out, hipStream_t st);
 void launch_semantic_split(const float4* pts, const uint32_t* labels /* null: payload */, int n, const uint32_t map[32],
                            int* flag /* [n] */, int* pos /* [n+1] */, int* scan_tmp, int* idx_out /* [5*n] */, int* counts /* [5] */,
                            hipStream_t st);

@@ -58,6 +58,21 @@ int main()
     std::printf("rc=%d iterCount=%d deltaR=%g deltaT=%g isDegenerate=%d nSel=%d T=[%g %g %g %g %g %g]\n", rc, reg.iterCount, reg.deltaR,
                 reg.deltaT, (int)reg.isDegenerate, reg.laserCloudSelNum, T[0], T[1], T[2], T[3], T[4], T[5]);
     bool ok = rc == LISREG_OK && std::fabs(T[2] - yaw) < 5e-3f && std::fabs(T[3] - tx) < 2e-2f && std::fabs(T[4] - ty) < 2e-2f && std::fabs(T[5] - tz) < 2e-2f;
+    // §8 f-3: crop the map to the padded intersection with the scan's box, then drop scan points that sit on the map
+    // (subMapOptmizationNode.cpp:1392-1405, subMap.h:889-899)
+    SubMapManager<PointType> mgr(reg.handle());
+    bounds_t bScan, bMap, bInter;
+    mgr.get_cloud_bbx(surf, bScan); mgr.get_cloud_bbx(mapSurf, bMap);
+    SubMapManager<PointType>::get_intersection_bbx(bScan, bMap, bInter, 2.0f);
+    PointCloud<PointType> cropped = mapSurf;
+    mgr.bbx_filter(cropped, bInter);
+    SearchTree<PointType> tree(reg.handle(), 0);
+    tree.setInputCloud(mapSurf);
+    PointCloud<PointType> moved = transformPointCloud(reg.handle(), surf, T), kept = moved;
+    bool applied = mgr.map_scan_feature_pts_distance_removal(kept, tree, 100.f, 0.3f, 1.0f, 0.05f);
+    std::printf("bbx_filter: map %zu -> %zu; distance_removal(applied=%d): scan %zu -> %zu\n", mapSurf.size(), cropped.size(), (int)applied,
+                moved.size(), kept.size());
+    ok = ok && applied && cropped.size() <= mapSurf.size() && cropped.size() > 0 && kept.size() < moved.size();
     std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
     return ok ? 0 : 1;
 }

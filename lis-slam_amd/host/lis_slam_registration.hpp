@@ -9,6 +9,7 @@
 // plus POD mirrors of the message surface (msg/cloud_info.msg, msg/semantic_info.msg) and a PointCloud2
 // byte-layout view, because ROS/PCL are not part of this build.  Header-only, C++17, no dependencies.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -208,6 +209,67 @@ public:
         return f;
     }
 private:
+    lisreg_ctx* ctx_;
+};
+
+// ---- the compute steps of SubMapManager (src/include/subMap.h) ---------------------------------------------
+struct bounds_t { double min_x, min_y, min_z, max_x, max_y, max_z; };     // src/include/subMap.h:32-39
+
+// pcl::search::KdTree<PointT> as SubMapManager uses it (setInputCloud once, k = 1 queries): an HBM-resident grid index.
+template <class PointT>
+class SearchTree {
+public:
+    SearchTree(lisreg_ctx* ctx, int slot) : ctx_(ctx), slot_(slot) {}
+    void setInputCloud(const PointCloud<PointT>& cloud) {
+        int rc = lisreg_map_index_set(ctx_, slot_, cloud.points.data(), (int)cloud.size(), (int)sizeof(PointT), fmt());
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+    }
+    int slot() const { return slot_; }
+    lisreg_ctx* ctx() const { return ctx_; }
+    static int fmt() { return std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI; }
+private:
+    lisreg_ctx* ctx_;
+    int slot_;
+};
+
+template <class PointT>
+class SubMapManager {
+public:
+    explicit SubMapManager(lisreg_ctx* ctx) : ctx_(ctx) {}
+    // subMap.h:131-163
+    void get_cloud_bbx(const PointCloud<PointT>& cloud, bounds_t& bound) {
+        double b[6];
+        check(lisreg_cloud_bounds(ctx_, cloud.points.data(), (int)cloud.size(), (int)sizeof(PointT), SearchTree<PointT>::fmt(), b));
+        bound = { b[0], b[1], b[2], b[3], b[4], b[5] };
+    }
+    // subMap.h:173-181 (host arithmetic)
+    static void get_intersection_bbx(const bounds_t& a, const bounds_t& b, bounds_t& out, float pad = 2.0f) {
+        out.min_x = std::max(a.min_x, b.min_x) - pad; out.min_y = std::max(a.min_y, b.min_y) - pad; out.min_z = std::max(a.min_z, b.min_z) - pad;
+        out.max_x = std::min(a.max_x, b.max_x) + pad; out.max_y = std::min(a.max_y, b.max_y) + pad; out.max_z = std::min(a.max_z, b.max_z) + pad;
+    }
+    // subMap.h:1124-1152
+    bool bbx_filter(PointCloud<PointT>& cloud_in_out, const bounds_t& bbx, bool delete_box = false) {
+        const double b[6] = { bbx.min_x, bbx.min_y, bbx.min_z, bbx.max_x, bbx.max_y, bbx.max_z };
+        int n_out = 0;
+        check(lisreg_bbx_filter(ctx_, cloud_in_out.points.data(), (int)cloud_in_out.size(), (int)sizeof(PointT), SearchTree<PointT>::fmt(), b,
+                                delete_box ? 1 : 0, cloud_in_out.points.data(), &n_out));
+        cloud_in_out.points.resize((size_t)n_out);
+        return true;
+    }
+    // subMap.h:1064-1100; returns false (cloud untouched) for <= 10 points like the reference
+    bool map_scan_feature_pts_distance_removal(PointCloud<PointT>& feature_pts, const SearchTree<PointT>& map_kdtree, float center_radius,
+                                               float dynamic_dist_thre_min = 3.402823466e38f, float dynamic_dist_thre_max = 3.402823466e38f,
+                                               float near_dist_thre = 0.0f) {
+        int n_out = 0;
+        int rc = lisreg_dynamic_filter(ctx_, map_kdtree.slot(), feature_pts.points.data(), (int)feature_pts.size(), (int)sizeof(PointT),
+                                       SearchTree<PointT>::fmt(), center_radius, dynamic_dist_thre_min, dynamic_dist_thre_max, near_dist_thre,
+                                       feature_pts.points.data(), &n_out);
+        if (rc < 0) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        feature_pts.points.resize((size_t)n_out);
+        return rc == LISREG_OK;
+    }
+private:
+    void check(int rc) { if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_)); }
     lisreg_ctx* ctx_;
 };
 

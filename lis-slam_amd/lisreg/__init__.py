@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
     "lisreg_extract_features", "lisreg_default_feature_params", "lisreg_semantic_split",
+    "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
 ]
 
 
@@ -139,6 +140,13 @@ def lib():
         L.lisreg_extract_features.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(FeatureOut)]
         L.lisreg_default_feature_params.argtypes = [C.POINTER(FeatureParams)]
         L.lisreg_semantic_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(SemanticOut)]
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.lisreg_map_index_set.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.lisreg_nearest.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+        L.lisreg_dynamic_filter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_float, vp, ip]
+        L.lisreg_bbx_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp, C.c_int, vp, ip]
+        L.lisreg_cloud_bounds.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -372,6 +380,70 @@ class Context:
         m = (C.c_uint32 * 32)(*using_label) if using_label is not None else None
         self._chk(self._L.lisreg_semantic_split(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIL, m, C.byref(so)))
         return [bufs[k][: so.n[k]] for k in range(5)]
+
+    # -- §8 f-3 -------------------------------------------------------------------------------------------
+    def map_index_set(self, slot: int, cloud: np.ndarray):
+        cloud = np.ascontiguousarray(cloud)
+        self._chk(self._L.lisreg_map_index_set(self._h, slot, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud)))
+
+    def map_index_set_device(self, slot: int, ptr: int, n: int):
+        self._chk(self._L.lisreg_map_index_set(self._h, slot, C.c_void_p(ptr), n, 16, FMT_DEVICE))
+
+    def nearest(self, slot: int, query: np.ndarray, max_dist: float = 1e18):
+        """k = 1 search: (idx [n] int32, -1 beyond max_dist; squared distance [n] float32)."""
+        query = np.ascontiguousarray(query)
+        idx = np.zeros(len(query), np.int32)
+        sqd = np.zeros(len(query), np.float32)
+        self._chk(self._L.lisreg_nearest(self._h, slot, _vp(query), len(query), query.dtype.itemsize, _fmt_of(query),
+                                         max_dist, idx.ctypes.data_as(C.c_void_p), sqd.ctypes.data_as(C.c_void_p)))
+        return idx, sqd
+
+    def nearest_device(self, slot: int, q_ptr: int, n: int, max_dist: float, idx_ptr: int, sqd_ptr: int):
+        self._chk(self._L.lisreg_nearest(self._h, slot, C.c_void_p(q_ptr), n, 16, FMT_DEVICE, max_dist,
+                                         C.c_void_p(idx_ptr), C.c_void_p(sqd_ptr)))
+
+    def dynamic_filter(self, slot: int, cloud: np.ndarray, center_radius: float, dist_thre_min: float = 3.4028234663852886e38,
+                       dist_thre_max: float = 3.4028234663852886e38, near_dist_thre: float = 0.0):
+        """map_scan_feature_pts_distance_removal: (filtered cloud, applied) — applied False where the reference returns false."""
+        cloud = np.ascontiguousarray(cloud)
+        out = np.zeros_like(cloud)
+        m = C.c_int(0)
+        rc = self._chk(self._L.lisreg_dynamic_filter(self._h, slot, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud),
+                                                     center_radius, dist_thre_min, dist_thre_max, near_dist_thre,
+                                                     out.ctypes.data_as(C.c_void_p), C.byref(m)),
+                       allow=(OK, NOT_ENOUGH_FEATURES))
+        return out[: m.value], rc == OK
+
+    def dynamic_filter_device(self, slot: int, in_ptr: int, n: int, center_radius: float, dist_thre_min: float,
+                              dist_thre_max: float, near_dist_thre: float, out_ptr: int) -> int:
+        m = C.c_int(0)
+        self._chk(self._L.lisreg_dynamic_filter(self._h, slot, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, center_radius,
+                                                dist_thre_min, dist_thre_max, near_dist_thre, C.c_void_p(out_ptr), C.byref(m)),
+                  allow=(OK, NOT_ENOUGH_FEATURES))
+        return m.value
+
+    def bbx_filter(self, cloud: np.ndarray, bounds, delete_box: bool = False) -> np.ndarray:
+        """bounds = (min_x, min_y, min_z, max_x, max_y, max_z)"""
+        cloud = np.ascontiguousarray(cloud)
+        out = np.zeros_like(cloud)
+        m = C.c_int(0)
+        b = (C.c_double * 6)(*[float(v) for v in bounds])
+        self._chk(self._L.lisreg_bbx_filter(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud), b,
+                                            1 if delete_box else 0, out.ctypes.data_as(C.c_void_p), C.byref(m)))
+        return out[: m.value]
+
+    def bbx_filter_device(self, in_ptr: int, n: int, bounds, delete_box: bool, out_ptr: int) -> int:
+        m = C.c_int(0)
+        b = (C.c_double * 6)(*[float(v) for v in bounds])
+        self._chk(self._L.lisreg_bbx_filter(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, b, 1 if delete_box else 0,
+                                            C.c_void_p(out_ptr), C.byref(m)))
+        return m.value
+
+    def cloud_bounds(self, cloud: np.ndarray) -> np.ndarray:
+        cloud = np.ascontiguousarray(cloud)
+        b = (C.c_double * 6)()
+        self._chk(self._L.lisreg_cloud_bounds(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud), b))
+        return np.array(list(b))
 
     def set_profiling(self, on: bool):
         self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))

@@ -592,7 +592,7 @@ static void unpack_cloud(const void* cloud, int n, int stride, int fmt, float* x
         memcpy(&xyz[3 * i], r, 12);
         unsigned short l = 0;
         if (fmt == LISREG_FMT_XYZIL) memcpy(&l, r + 20, 2);
-        label[i] = l;
+        if (label) label[i] = l;
     }
 }
 
@@ -1024,4 +1024,84 @@ void orc_semantic_classes(const void* cloud, int n, int stride, const unsigned i
         unsigned int u = using_label[label & 31];
         cls[i] = u == 10 ? 0 : (u == 40 ? 1 : (u == 50 ? 2 : (u == 81 ? 3 : 4)));
     }
+}
+
+/* ---- §8 f-3: local-map maintenance filters ------------------------------------------------------------------- */
+/* get_cloud_bbx (src/include/subMap.h:131-163): float coordinates widened to double; an empty cloud leaves +-DBL_MAX */
+void orc_cloud_bounds(const void* cloud, int n, int stride, double b[6])
+{
+    const unsigned char* src = (const unsigned char*)cloud;
+    b[0] = b[1] = b[2] = DBL_MAX; b[3] = b[4] = b[5] = -DBL_MAX;
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        for (int d = 0; d < 3; ++d) {
+            if (b[d] > p[d]) b[d] = p[d];
+            if (b[3 + d] < p[d]) b[3 + d] = p[d];
+        }
+    }
+}
+
+/* bbx_filter (src/include/subMap.h:1124-1152): strict inequalities, float against double; keep[] = surviving input indices */
+void orc_bbx_filter(const void* cloud, int n, int stride, const double b[6], int delete_box, int* keep, int* n_keep)
+{
+    const unsigned char* src = (const unsigned char*)cloud;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        int in = p[0] > b[0] && p[0] < b[3] && p[1] > b[1] && p[1] < b[4] && p[2] > b[2] && p[2] < b[5];
+        if (in) { if (!delete_box) keep[m++] = i; }
+        else    { if (delete_box) keep[m++] = i; }
+    }
+    *n_keep = m;
+}
+
+/* map_scan_feature_pts_distance_removal (src/include/subMap.h:1064-1100).  Returns 0 when the reference returns false
+ * (<= 10 points: cloud untouched, keep[] = identity), else 1.  pcl::search::KdTree::nearestKSearch(k = 1) -> exact
+ * nearest neighbour, squared L2 in float (FLANN L2_Simple).  An empty map is undefined behaviour in the reference
+ * (distances_square[0] of an empty vector); here it keeps every point. */
+int orc_dynamic_filter(const void* map, int n_map, const void* cloud, int n, int stride, float center_radius,
+                       float dist_thre_min, float dist_thre_max, float near_dist_thre, int* keep, int* n_keep)
+{
+    const unsigned char* src = (const unsigned char*)cloud;
+    if (n <= 10 || n_map <= 0) {
+        for (int i = 0; i < n; ++i) keep[i] = i;
+        *n_keep = n;
+        return n > 10;
+    }
+    float* mxyz = (float*)malloc(sizeof(float) * 3 * (size_t)n_map);
+    unpack_cloud(map, n_map, stride, LISREG_FMT_XYZI, mxyz, NULL);
+    orc_kdtree* tree = orc_kdtree_build(mxyz, n_map, 15);
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        if (p[0] * p[0] + p[1] * p[1] > center_radius * center_radius) keep[m++] = i;
+        else {
+            int idx; float d2;
+            orc_kdtree_knn(tree, p, 1, &idx, &d2);
+            if ((d2 > near_dist_thre * near_dist_thre && d2 < dist_thre_min * dist_thre_min) || d2 > dist_thre_max * dist_thre_max)
+                keep[m++] = i;
+        }
+    }
+    *n_keep = m;
+    orc_kdtree_free(tree); free(mxyz);
+    return 1;
+}
+
+/* k = 1 queries (test helper for the grid search): idx[i] = nearest map point (-1 if farther than max_dist), sqd[i] */
+void orc_nearest(const void* map, int n_map, const void* query, int n, int stride, float max_dist, int* idx, float* sqd)
+{
+    float* mxyz = (float*)malloc(sizeof(float) * 3 * (size_t)(n_map > 0 ? n_map : 1));
+    unpack_cloud(map, n_map, stride, LISREG_FMT_XYZI, mxyz, NULL);
+    orc_kdtree* tree = n_map > 0 ? orc_kdtree_build(mxyz, n_map, 15) : NULL;
+    const unsigned char* src = (const unsigned char*)query;
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, src + (size_t)i * (size_t)stride, 12);
+        idx[i] = -1; sqd[i] = FLT_MAX;
+        if (!tree) continue;
+        int id; float d2;
+        orc_kdtree_knn(tree, p, 1, &id, &d2);
+        if (d2 <= max_dist * max_dist) { idx[i] = id; sqd[i] = d2; }
+    }
+    if (tree) orc_kdtree_free(tree);
+    free(mxyz);
 }

@@ -106,6 +106,14 @@ void orc_extract_features(const void* cloud, int n, int stride_bytes, const lisr
  * 3 pole, 4 outlier) from using_label[label & 31]; the five output clouds are the stable partition by class. */
 void orc_semantic_classes(const void* cloud, int n, int stride_bytes, const unsigned int using_label[32], unsigned char* cls);
 
+/* ---- §8 f-3: local-map maintenance filters (src/include/subMap.h) --------------------------------------------- */
+void orc_cloud_bounds(const void* cloud, int n, int stride_bytes, double bounds[6]);                      /* :131-163 */
+void orc_bbx_filter(const void* cloud, int n, int stride_bytes, const double bounds[6], int delete_box,
+                    int* keep, int* n_keep);                                                              /* :1124-1152 */
+int  orc_dynamic_filter(const void* map, int n_map, const void* cloud, int n, int stride_bytes, float center_radius,
+                        float dist_thre_min, float dist_thre_max, float near_dist_thre, int* keep, int* n_keep); /* :1064-1100 */
+void orc_nearest(const void* map, int n_map, const void* query, int n, int stride_bytes, float max_dist, int* idx, float* sqd);
+
 #ifdef __cplusplus
 }
 #endif

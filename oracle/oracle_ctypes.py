@@ -104,6 +104,14 @@ def lib():
         L.orc_extract_features.restype = None
         L.orc_semantic_classes.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_ubyte)]
         L.orc_semantic_classes.restype = None
+        dp = C.POINTER(C.c_double)
+        L.orc_cloud_bounds.argtypes = [vp, C.c_int, C.c_int, dp]
+        L.orc_cloud_bounds.restype = None
+        L.orc_bbx_filter.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int, ip, ip]
+        L.orc_bbx_filter.restype = None
+        L.orc_dynamic_filter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, ip, ip]
+        L.orc_nearest.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, ip, fp]
+        L.orc_nearest.restype = None
         _lib = L
     return _lib
 
@@ -191,3 +199,47 @@ def semantic_split(cloud, using_label=None):
     cls = np.zeros(len(cloud), np.uint8)
     L.orc_semantic_classes(_vp(cloud), len(cloud), cloud.dtype.itemsize, m, cls.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return [cloud[cls == k] for k in range(5)]
+
+
+FLT_MAX = 3.4028234663852886e38
+
+
+def cloud_bounds(cloud):
+    cloud = np.ascontiguousarray(cloud)
+    b = (C.c_double * 6)()
+    lib().orc_cloud_bounds(_vp(cloud), len(cloud), cloud.dtype.itemsize, b)
+    return np.array(list(b))
+
+
+def bbx_filter(cloud, bounds, delete_box=False):
+    cloud = np.ascontiguousarray(cloud)
+    keep = np.zeros(max(len(cloud), 1), np.int32)
+    m = C.c_int(0)
+    b = (C.c_double * 6)(*[float(v) for v in bounds])
+    lib().orc_bbx_filter(_vp(cloud), len(cloud), cloud.dtype.itemsize, b, 1 if delete_box else 0,
+                         keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(m))
+    return cloud[keep[: m.value]]
+
+
+def dynamic_filter(map_cloud, cloud, center_radius, dist_thre_min=FLT_MAX, dist_thre_max=FLT_MAX, near_dist_thre=0.0):
+    """(filtered cloud, applied).  map_cloud and cloud must share a dtype (one stride)."""
+    cloud = np.ascontiguousarray(cloud)
+    map_cloud = np.ascontiguousarray(map_cloud)
+    assert map_cloud.dtype == cloud.dtype
+    keep = np.zeros(max(len(cloud), 1), np.int32)
+    m = C.c_int(0)
+    rc = lib().orc_dynamic_filter(_vp(map_cloud), len(map_cloud), _vp(cloud), len(cloud), cloud.dtype.itemsize, center_radius,
+                                  dist_thre_min, dist_thre_max, near_dist_thre, keep.ctypes.data_as(C.POINTER(C.c_int)),
+                                  C.byref(m))
+    return cloud[keep[: m.value]], bool(rc)
+
+
+def nearest(map_cloud, query, max_dist=1e18):
+    map_cloud = np.ascontiguousarray(map_cloud)
+    query = np.ascontiguousarray(query)
+    assert map_cloud.dtype == query.dtype
+    idx = np.zeros(max(len(query), 1), np.int32)
+    sqd = np.zeros(max(len(query), 1), np.float32)
+    lib().orc_nearest(_vp(map_cloud), len(map_cloud), _vp(query), len(query), query.dtype.itemsize, max_dist,
+                      idx.ctypes.data_as(C.POINTER(C.c_int)), _fp(sqd))
+    return idx[: len(query)], sqd[: len(query)]
