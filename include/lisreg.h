@@ -278,6 +278,44 @@ int  lisreg_bbx_filter(lisreg_ctx* ctx, const void* cloud, int n, int stride_byt
 /* SubMapManager::get_cloud_bbx (subMap.h:131-163); an empty cloud yields {DBL_MAX x3, -DBL_MAX x3}. */
 int  lisreg_cloud_bounds(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt, double bounds[6]);
 
+/* ---- §8 f-4: pcl::IterativeClosestPoint as the loop-closure / relocalisation code drives it ------------------- */
+/* Call sites: src/node/subMapOptmizationNode.cpp:2763-2833 (loop closure: 10 m, 30 iterations, 1e-4, 1e-4),
+ * :1444-1465 and :4400-4420 (0.2 m, 50 iterations, 1e-5, 1e-5); RANSAC iterations 0 everywhere, no rejectors.
+ * Point-to-point ICP: per iteration k = 1 correspondences within max_corr_dist -> closed-form rigid transform
+ * (TransformationEstimationSVD = Umeyama without scale) -> DefaultConvergenceCriteria. */
+enum {                       /* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
+    LISREG_ICP_NOT_CONVERGED      = 0,
+    LISREG_ICP_ITERATIONS         = 1,
+    LISREG_ICP_TRANSFORM          = 2,
+    LISREG_ICP_ABS_MSE            = 3,
+    LISREG_ICP_REL_MSE            = 4,
+    LISREG_ICP_NO_CORRESPONDENCES = 5
+};
+typedef struct lisreg_icp_params {
+    double max_corr_dist;               /* setMaxCorrespondenceDistance (compared squared, in double, like PCL) */
+    int    max_iters;                   /* setMaximumIterations */
+    int    reserved;
+    double transformation_epsilon;      /* setTransformationEpsilon: squared-translation bound, and 1 - eps bounds cos(angle) */
+    double euclidean_fitness_epsilon;   /* setEuclideanFitnessEpsilon -> relative MSE threshold */
+    double prev_mse;                    /* correspondences_prev_mse_: DBL_MAX on a fresh object; the reference's `static`
+                                           ICP objects carry it from one align() to the next (feed lisreg_icp_result.prev_mse back) */
+} lisreg_icp_params;
+typedef struct lisreg_icp_result {
+    float  final_transform[16];         /* getFinalTransformation(), row-major 4x4 */
+    int    converged;                   /* hasConverged() */
+    int    iters;                       /* nr_iterations_ */
+    int    state;                       /* LISREG_ICP_* */
+    int    n_corr_last;                 /* correspondences of the last iteration */
+    double fitness;                     /* getFitnessScore(): mean squared k = 1 distance of the aligned source, unbounded */
+    double prev_mse;
+} lisreg_icp_result;
+/* {10, 30, 1e-4, 1e-4} for kind 0 (loop closure), {0.2, 50, 1e-5, 1e-5} for kind 1; prev_mse = DBL_MAX */
+int  lisreg_icp_default_params(int kind, lisreg_icp_params* p);
+/* align(): target = the map index in `slot` (setInputTarget), source = `source` (setInputSource), guess = row-major 4x4 or
+ * NULL for identity.  aligned_out: NULL, or room for n points of the input layout (the `output` cloud of align()). */
+int  lisreg_icp_align(lisreg_ctx* ctx, int slot, const void* source, int n, int stride_bytes, int fmt,
+                      const lisreg_icp_params* params, const float* guess, lisreg_icp_result* result, void* aligned_out);
+
 /* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
 /* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */
 void lisreg_pose_to_matrix(const float T[6], float M[12]);

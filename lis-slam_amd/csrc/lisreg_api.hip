@@ -251,7 +251,7 @@ void lisreg_destroy(lisreg_ctx* c)
                        &c->ft_gather };
     for (auto b : bufs) b->release();
     for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
-    DevBuf* mbufs[] = { &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out };
+    DevBuf* mbufs[] = { &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
     for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);

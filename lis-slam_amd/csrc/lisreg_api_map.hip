@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 
 using namespace lisreg;
@@ -229,6 +230,91 @@ int lisreg_cloud_bounds(lisreg_ctx* c, const void* cloud, int n, int stride, int
     HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int d = 0; d < 6; ++d) bounds[d] = (double)bb[d];       // float extremes widened, as the reference's double min/max
+    return LISREG_OK;
+}
+
+// ---- §8 f-4 ------------------------------------------------------------------------------------------------------
+int lisreg_icp_default_params(int kind, lisreg_icp_params* p)
+{
+    if (!p || (kind != 0 && kind != 1)) return LISREG_ERR_ARG;
+    memset(p, 0, sizeof *p);
+    if (kind == 0) { p->max_corr_dist = 10; p->max_iters = 30; p->transformation_epsilon = 1e-4; p->euclidean_fitness_epsilon = 1e-4; }   // subMapOptmizationNode.cpp:2765-2769
+    else { p->max_corr_dist = 0.2; p->max_iters = 50; p->transformation_epsilon = 1e-5; p->euclidean_fitness_epsilon = 1e-5; }             // :1445-1449, :4401-4405
+    p->prev_mse = DBL_MAX;
+    return LISREG_OK;
+}
+
+int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int stride, int fmt, const lisreg_icp_params* P,
+                     const float* guess, lisreg_icp_result* res, void* aligned_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+        return ctx_fail(c, LISREG_ERR_NO_TARGET, "icp_align: no map index in this slot (setInputTarget)");
+    int rc = check_cloud(c, source, n, stride, fmt, "icp_align");
+    if (rc) return rc;
+    if (!P || !res) return bad(c, "icp_align: NULL params / result");
+    if (!(P->max_corr_dist >= 0) || P->max_iters < 1) return bad(c, "icp_align: bad max_corr_dist / max_iters");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const MapIndex& m = c->maps[(size_t)slot];
+    const float4* src = nullptr;
+    rc = stage_cloud(c, source, n, stride, fmt, &src);
+    if (rc) return rc;
+    IcpState h;
+    memset(&h, 0, sizeof h);
+    for (int k = 0; k < 16; ++k) h.F[k] = guess ? guess[k] : ((k % 5 == 0) ? 1.f : 0.f);
+    for (int k = 0; k < 16; ++k) h.Tm[k] = h.F[k];        // the first pass moves the working copy by the guess (icp.hpp:129-137)
+    HIPCHK(c, c->icp_cur.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->icp_cur.p, src, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    h.prev_mse = P->prev_mse; h.cur_mse = DBL_MAX;
+    const int nb = icp_blocks(n);
+    HIPCHK(c, c->icp_state.ensure(sizeof(IcpState)));
+    HIPCHK(c, c->icp_partials.ensure(sizeof(double) * 17 * (size_t)std::max(nb, 1)));
+    HIPCHK(c, hipMemcpyAsync(c->icp_state.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+    // (double) d2 > max_distance^2 rejects (correspondence_estimation.hpp): the largest float that still passes
+    const double max_d2 = P->max_corr_dist * P->max_corr_dist;
+    float cap2 = max_d2 >= 3.0e38 ? 3.0e38f : (float)max_d2;
+    if ((double)cap2 > max_d2) cap2 = std::nextafterf(cap2, 0.f);
+    IcpState* sd = c->icp_state.as<IcpState>();
+    int done = 0;
+    for (int it = 0; it < P->max_iters && !done;) {
+        const int chunk = std::min(4, P->max_iters - it);
+        for (int k = 0; k < chunk; ++k)
+            launch_icp_iteration(c->icp_cur.as<float4>(), n, m.g_dev.as<GridIndex>(), sd, cap2, c->icp_partials.as<double>(), P->max_iters,
+                                 P->transformation_epsilon, P->euclidean_fitness_epsilon, st);
+        HIPCHK(c, hipGetLastError());
+        it += chunk;
+        HIPCHK(c, hipMemcpyAsync(&done, &sd->done, sizeof done, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    launch_icp_fitness(src, n, m.g_dev.as<GridIndex>(), sd, c->icp_partials.as<double>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&h, sd, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    memcpy(res->final_transform, h.F, sizeof h.F);
+    res->converged = h.converged; res->iters = h.iters; res->state = h.state; res->n_corr_last = h.n_corr;
+    res->fitness = h.fit_n > 0 ? h.fit_sum / (double)h.fit_n : DBL_MAX;
+    res->prev_mse = h.prev_mse;
+    if (aligned_out && n > 0) {                       // `output` of align(): the source under the final transformation
+        HIPCHK(c, c->vox_M.ensure(sizeof(float) * 12));
+        HIPCHK(c, hipMemcpyAsync(c->vox_M.p, h.F, sizeof(float) * 12, hipMemcpyHostToDevice, st));     // rows 0..2 of F = [R|t]
+        if (fmt == LISREG_FMT_DEVICE) {
+            launch_transform_cloud(src, n, c->vox_M.as<float>(), static_cast<float4*>(aligned_out), st);
+            HIPCHK(c, hipStreamSynchronize(st));
+        } else {
+            HIPCHK(c, c->mp_out.ensure(sizeof(float4) * (size_t)n));
+            launch_transform_cloud(src, n, c->vox_M.as<float>(), c->mp_out.as<float4>(), st);
+            std::vector<float4> hp((size_t)n);
+            HIPCHK(c, hipMemcpyAsync(hp.data(), c->mp_out.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            const unsigned char* b = static_cast<const unsigned char*>(source);
+            unsigned char* o = static_cast<unsigned char*>(aligned_out);
+            for (int i = 0; i < n; ++i) {
+                if (o != b) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)i * (size_t)stride, (size_t)stride);
+                memcpy(o + (size_t)i * (size_t)stride, &hp[(size_t)i], 12);
+            }
+        }
+    }
     return LISREG_OK;
 }
 

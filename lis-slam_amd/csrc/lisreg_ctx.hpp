@@ -68,7 +68,7 @@ struct lisreg_ctx {
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather;
     std::vector<lisreg::MapIndex> maps;
-    lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out;
+    lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur;
     int*      done_host = nullptr;          // pinned
     int       early_stop_chunk = 3;
     std::vector<lisreg::TargetSeg> h_tsegs;

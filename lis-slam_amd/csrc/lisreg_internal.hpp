@@ -166,6 +166,19 @@ void launch_gather_points(const float4* pts, const int* idx, int n, float4* out,
 void launch_nn1(const float4* q, int n, const GridIndex* grid_dev, float max_dist, int* idx_out, float* d2_out, hipStream_t st);
 void launch_dynamic_flags(const float4* pts, int n, const GridIndex* grid_dev, float center_radius, float near_thre, float dmin,
                           float dmax, int* flag, hipStream_t st);
+// §8 f-4: device-side state of one pcl::IterativeClosestPoint::align
+struct IcpState {
+    float  F[16];            // final_transformation_ (row-major 4x4)
+    float  Tm[16];           // transformation_ of the last iteration
+    int    iters, done, state, converged, n_corr, fit_n;
+    double prev_mse, cur_mse, fit_sum;
+};
+int  icp_blocks(int n);
+// one ICP iteration on the working copy `cur` (input_transformed): apply st->Tm in place, correspondences + sums
+// (partials: icp_blocks(n) * 17 doubles), then transform estimate + convergence (st->Tm = the new transformation_)
+void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
+                          int max_iters, double eps_t, double eps_mse, hipStream_t stream);
+void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, double* partials, hipStream_t stream);
 void launch_bbx_flags(const float4* pts, int n, const double b[6], int delete_box, int* flag, hipStream_t st);
 // stable compaction: idx_out[0..count) = indices i with flag[i] != 0, ascending; pos [n+1]
 void launch_compact(int n, const int* flag, int* pos, int* scan_tmp, int* idx_out, int* count_out, hipStream_t st);

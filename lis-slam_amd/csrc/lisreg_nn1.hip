@@ -116,7 +116,228 @@ __global__ __launch_bounds__(256) void k_nn1(const float4* __restrict__ q, int n
     d2_out[i] = d2;
 }
 
+// ---- §8 f-4: point-to-point ICP (pcl::IterativeClosestPoint, subMapOptmizationNode.cpp:2763-2833) ----------------------------
+constexpr int kIcpAcc = 17;       // count, sum p (3), sum q (3), sum q_r * p_c (9), sum d2
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void apply4(const float* F, float x, float y, float z, float& ox, float& oy, float& oz)
+{
+    ox = ((F[0] * x + F[1] * y) + F[2] * z) + F[3];
+    oy = ((F[4] * x + F[5] * y) + F[6] * z) + F[7];
+    oz = ((F[8] * x + F[9] * y) + F[10] * z) + F[11];
+}
+
+// transformCloud(input_transformed, transformation_) of the previous iteration (icp.hpp applies it in place, in float, once per
+// iteration — kept that way rather than re-deriving the points from the cumulative transform), then determineCorrespondences
+// and the sums TransformationEstimationSVD needs.
+__global__ __launch_bounds__(256) void k_icp_assoc(float4* __restrict__ cur, int n, const GridIndex* __restrict__ gp,
+                                                   const IcpState* __restrict__ stp, float cap2, double* __restrict__ partials)
+{
+    __shared__ double red[4][kIcpAcc];
+    if (stp->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc[kIcpAcc];
+#pragma unroll
+    for (int k = 0; k < kIcpAcc; ++k) acc[k] = 0.0;
+    if (i < n) {
+        const GridIndex g = *gp;
+        const float4 s = cur[i];
+        float px, py, pz, d2;
+        apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
+        cur[i] = make_float4(px, py, pz, s.w);
+        const int bi = nn1_search(px, py, pz, g, cap2, &d2);
+        if (bi >= 0) {
+            const float4 q = g.pts[bi];
+            acc[0] = 1.0;
+            acc[1] = px; acc[2] = py; acc[3] = pz;
+            acc[4] = q.x; acc[5] = q.y; acc[6] = q.z;
+            acc[7] = (double)q.x * px;  acc[8] = (double)q.x * py;  acc[9] = (double)q.x * pz;
+            acc[10] = (double)q.y * px; acc[11] = (double)q.y * py; acc[12] = (double)q.y * pz;
+            acc[13] = (double)q.z * px; acc[14] = (double)q.z * py; acc[15] = (double)q.z * pz;
+            acc[16] = d2;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kIcpAcc; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kIcpAcc)
+        partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// 3x3 SVD by one-sided Jacobi (double); U S V^T = A, singular values descending, U completed to an orthogonal matrix
+__device__ void svd3(const double* Ain, double* U, double* S, double* V)
+{
+    double A[9];
+    for (int i = 0; i < 9; ++i) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int r = 0; r < 3; ++r) { a += A[3 * r + p] * A[3 * r + p]; b += A[3 * r + q] * A[3 * r + q]; c += A[3 * r + p] * A[3 * r + q]; }
+                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                off += fabs(c);
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int r = 0; r < 3; ++r) {
+                    double x = A[3 * r + p], y = A[3 * r + q];
+                    A[3 * r + p] = cs * x - sn * y; A[3 * r + q] = sn * x + cs * y;
+                    x = V[3 * r + p]; y = V[3 * r + q];
+                    V[3 * r + p] = cs * x - sn * y; V[3 * r + q] = sn * x + cs * y;
+                }
+            }
+        if (off == 0) break;
+    }
+    double nrm[3];
+    int ord[3] = { 0, 1, 2 };
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (nrm[ord[j]] > nrm[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        S[j] = nrm[ord[j]];
+        for (int r = 0; r < 3; ++r) { Vs[3 * r + j] = V[3 * r + ord[j]]; U[3 * r + j] = S[j] > 0 ? A[3 * r + ord[j]] / S[j] : 0.0; }
+    }
+    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+    const double tiny = 1e-12 * (S[0] > 0 ? S[0] : 1.0);
+    if (S[1] <= tiny) {
+        if (S[0] <= 0) { U[0] = 1; U[3] = 0; U[6] = 0; }
+        const double u0[3] = { U[0], U[3], U[6] };
+        const int k = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
+        double e[3] = { 0, 0, 0 }; e[k] = 1;
+        const double d = u0[k];
+        double u1[3] = { e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2] };
+        const double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        for (int r = 0; r < 3; ++r) U[3 * r + 1] = u1[r] / n1;
+    }
+    if (S[2] <= tiny) {
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+__device__ __forceinline__ double det3(const double* M)
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// estimateRigidTransformation (Umeyama, no scale) + final_transformation_ update + DefaultConvergenceCriteria::hasConverged
+__global__ __launch_bounds__(256) void k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st,
+                                                   int max_iters, double eps_t, double eps_mse)
+{
+    __shared__ double red[8][32];
+    __shared__ double tot[kIcpAcc];
+    if (st->done) return;
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double v = 0;
+    if (k < kIcpAcc) for (int b = grp; b < n_blocks; b += 8) v += partials[(size_t)b * kIcpAcc + k];
+    red[grp][k] = v;
+    __syncthreads();
+    if (threadIdx.x < kIcpAcc) {
+        double s = 0;
+        for (int g = 0; g < 8; ++g) s += red[g][threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double cnt = tot[0];
+    st->n_corr = (int)cnt;
+    if (cnt < 3.0) { st->state = LISREG_ICP_NO_CORRESPONDENCES; st->converged = 0; st->done = 1; return; }    // icp.hpp: min_number_correspondences_
+    const double inv = 1.0 / cnt;
+    const double ms[3] = { tot[1] * inv, tot[2] * inv, tot[3] * inv }, md[3] = { tot[4] * inv, tot[5] * inv, tot[6] * inv };
+    double sg[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sg[3 * r + c] = tot[7 + 3 * r + c] * inv - md[r] * ms[c];
+    double U[9], S[3], V[9], R[9];
+    svd3(sg, U, S, V);
+    const double s2 = det3(U) * det3(V) < 0 ? -1.0 : 1.0;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+        R[3 * r + c] = U[3 * r] * V[3 * c] + U[3 * r + 1] * V[3 * c + 1] + s2 * U[3 * r + 2] * V[3 * c + 2];
+    float Tm[16];
+    for (int i = 0; i < 16; ++i) Tm[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Tm[4 * r + c] = (float)R[3 * r + c];
+        Tm[4 * r + 3] = (float)(md[r] - (R[3 * r] * ms[0] + R[3 * r + 1] * ms[1] + R[3 * r + 2] * ms[2]));
+    }
+    float Fn[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c)
+        Fn[4 * r + c] = ((Tm[4 * r] * st->F[c] + Tm[4 * r + 1] * st->F[4 + c]) + Tm[4 * r + 2] * st->F[8 + c]) + Tm[4 * r + 3] * st->F[12 + c];
+    for (int i = 0; i < 16; ++i) { st->F[i] = Fn[i]; st->Tm[i] = Tm[i]; }
+    const int iters = ++st->iters;
+    st->state = LISREG_ICP_NOT_CONVERGED;
+    if (iters >= max_iters) { st->state = LISREG_ICP_ITERATIONS; st->converged = 1; st->done = 1; return; }
+    const double cos_angle = 0.5 * ((double)Tm[0] + (double)Tm[5] + (double)Tm[10] - 1.0);
+    const double tr2 = (double)Tm[3] * Tm[3] + (double)Tm[7] * Tm[7] + (double)Tm[11] * Tm[11];
+    if (cos_angle >= 1.0 - eps_t && tr2 <= eps_t) { st->state = LISREG_ICP_TRANSFORM; st->converged = 1; st->done = 1; return; }
+    const double cur = tot[16] * inv, prev = st->prev_mse;
+    st->cur_mse = cur;
+    if (fabs(cur - prev) < 1e-12) { st->state = LISREG_ICP_ABS_MSE; st->converged = 1; st->done = 1; return; }
+    if (fabs(cur - prev) / prev < eps_mse) { st->state = LISREG_ICP_REL_MSE; st->converged = 1; st->done = 1; return; }
+    st->prev_mse = cur;
+}
+
+// getFitnessScore(): unbounded k = 1 of the source under the final transformation
+__global__ __launch_bounds__(256) void k_icp_fitness(const float4* __restrict__ src, int n, const GridIndex* __restrict__ gp,
+                                                     const IcpState* __restrict__ stp, double* __restrict__ partials)
+{
+    __shared__ double red[4][2];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double sum = 0, cnt = 0;
+    if (i < n) {
+        const GridIndex g = *gp;
+        const float4 s = src[i];
+        float px, py, pz, d2;
+        apply4(stp->F, s.x, s.y, s.z, px, py, pz);
+        if (nn1_search(px, py, pz, g, 3.0e38f, &d2) >= 0) { sum = d2; cnt = 1; }
+    }
+    sum = wave_sum(sum); cnt = wave_sum(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = sum; red[wave][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 2) partials[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_icp_fit_reduce(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st)
+{
+    __shared__ double red[256][2];
+    double s = 0, c = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) { s += partials[(size_t)b * 2]; c += partials[(size_t)b * 2 + 1]; }
+    red[threadIdx.x][0] = s; red[threadIdx.x][1] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { st->fit_sum = red[0][0]; st->fit_n = (int)red[0][1]; }
+}
+
 }  // namespace
+
+int icp_blocks(int n) { return (n + 255) / 256; }
+
+void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
+                          int max_iters, double eps_t, double eps_mse, hipStream_t stream)
+{
+    const int nb = icp_blocks(n);
+    if (nb > 0) k_icp_assoc<<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials);
+    k_icp_solve<<<1, 256, 0, stream>>>(partials, nb, st, max_iters, eps_t, eps_mse);
+}
+
+void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, double* partials, hipStream_t stream)
+{
+    const int nb = icp_blocks(n);
+    if (nb > 0) k_icp_fitness<<<nb, 256, 0, stream>>>(src, n, grid_dev, st, partials);
+    k_icp_fit_reduce<<<1, 256, 0, stream>>>(partials, nb, st);
+}
 
 void launch_dynamic_flags(const float4* pts, int n, const GridIndex* grid_dev, float center_radius, float near_thre,
                           float dmin, float dmax, int* flag, hipStream_t st)

@@ -73,6 +73,18 @@ int main()
     std::printf("bbx_filter: map %zu -> %zu; distance_removal(applied=%d): scan %zu -> %zu\n", mapSurf.size(), cropped.size(), (int)applied,
                 moved.size(), kept.size());
     ok = ok && applied && cropped.size() <= mapSurf.size() && cropped.size() > 0 && kept.size() < moved.size();
+    // §8 f-4: ICP of the un-registered scan against the map, loop-closure settings (subMapOptmizationNode.cpp:2763-2769)
+    IterativeClosestPoint<PointType> icp(reg.handle(), 1);
+    icp.setMaxCorrespondenceDistance(10); icp.setMaximumIterations(30); icp.setTransformationEpsilon(1e-4);
+    icp.setEuclideanFitnessEpsilon(1e-4); icp.setRANSACIterations(0);
+    icp.setInputTarget(mapSurf);
+    icp.setInputSource(&surf);
+    PointCloud<PointType> unused_result;
+    icp.align(unused_result);
+    const float* Fm = icp.getFinalTransformation();
+    std::printf("ICP: converged=%d iterations=%d fitness=%g t=[%g %g %g] yaw=%g\n", (int)icp.hasConverged(), icp.nr_iterations(),
+                icp.getFitnessScore(), Fm[3], Fm[7], Fm[11], std::atan2(Fm[4], Fm[0]));
+    ok = ok && icp.hasConverged() && std::fabs(Fm[3] - tx) < 5e-2f && std::fabs(Fm[7] - ty) < 5e-2f && std::fabs(std::atan2(Fm[4], Fm[0]) - yaw) < 5e-3f;
     std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
     return ok ? 0 : 1;
 }

@@ -273,4 +273,37 @@ private:
     lisreg_ctx* ctx_;
 };
 
+// ---- pcl::IterativeClosestPoint as the loop-closure code uses it --------------------------------------------
+// (src/node/subMapOptmizationNode.cpp:2763-2833: setters, setInputTarget, setInputSource, align, getFitnessScore, hasConverged,
+// getFinalTransformation).  Like the reference's `static` objects, an instance carries correspondences_prev_mse_ across align().
+template <class PointT>
+class IterativeClosestPoint {
+public:
+    IterativeClosestPoint(lisreg_ctx* ctx, int slot) : tree_(ctx, slot) { lisreg_icp_default_params(0, &prm_); prm_.max_corr_dist = 1.3407807929942596e154; /* sqrt(DBL_MAX), PCL's default */ prm_.max_iters = 10; prm_.transformation_epsilon = 0; prm_.euclidean_fitness_epsilon = -1.7976931348623157e308; }
+    void setMaxCorrespondenceDistance(double d) { prm_.max_corr_dist = d; }
+    void setMaximumIterations(int n) { prm_.max_iters = n; }
+    void setTransformationEpsilon(double e) { prm_.transformation_epsilon = e; }
+    void setEuclideanFitnessEpsilon(double e) { prm_.euclidean_fitness_epsilon = e; }
+    void setRANSACIterations(int n) { if (n != 0) throw RegistrationError(LISREG_ERR_ARG, "ICP: the reference runs with 0 RANSAC iterations"); }
+    void setInputTarget(const PointCloud<PointT>& cloud) { tree_.setInputCloud(cloud); }
+    void setInputSource(const PointCloud<PointT>* cloud) { source_ = cloud; }
+    void align(PointCloud<PointT>& output, const float* guess = nullptr) {
+        if (!source_) throw RegistrationError(LISREG_ERR_ARG, "ICP: no input source");
+        output.points.resize(source_->size());
+        int rc = lisreg_icp_align(tree_.ctx(), tree_.slot(), source_->points.data(), (int)source_->size(), (int)sizeof(PointT),
+                                  SearchTree<PointT>::fmt(), &prm_, guess, &res_, output.points.data());
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(tree_.ctx()));
+        prm_.prev_mse = res_.prev_mse;
+    }
+    bool hasConverged() const { return res_.converged != 0; }
+    double getFitnessScore() const { return res_.fitness; }
+    const float* getFinalTransformation() const { return res_.final_transform; }     // row-major 4x4
+    int nr_iterations() const { return res_.iters; }
+private:
+    SearchTree<PointT> tree_;
+    const PointCloud<PointT>* source_ = nullptr;
+    lisreg_icp_params prm_{};
+    lisreg_icp_result res_{};
+};
+
 }  // namespace lis_slam

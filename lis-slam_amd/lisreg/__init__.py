@@ -35,7 +35,25 @@ ABI_SYMBOLS = [
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
     "lisreg_extract_features", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
+    "lisreg_icp_default_params", "lisreg_icp_align",
 ]
+
+
+ICP_NOT_CONVERGED, ICP_ITERATIONS, ICP_TRANSFORM, ICP_ABS_MSE, ICP_REL_MSE, ICP_NO_CORRESPONDENCES = range(6)
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_corr_dist", C.c_double), ("max_iters", C.c_int), ("reserved", C.c_int),
+                ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double), ("prev_mse", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("final_transform", C.c_float * 16), ("converged", C.c_int), ("iters", C.c_int), ("state", C.c_int),
+                ("n_corr_last", C.c_int), ("fitness", C.c_double), ("prev_mse", C.c_double)]
+
+    def as_dict(self):
+        return dict(T=np.array(list(self.final_transform), np.float32).reshape(4, 4), converged=bool(self.converged),
+                    iters=self.iters, state=self.state, n_corr_last=self.n_corr_last, fitness=self.fitness, prev_mse=self.prev_mse)
 
 
 class Params(C.Structure):
@@ -147,8 +165,17 @@ def lib():
                                             C.c_float, vp, ip]
         L.lisreg_bbx_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp, C.c_int, vp, ip]
         L.lisreg_cloud_bounds.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp]
+        L.lisreg_icp_default_params.argtypes = [C.c_int, C.POINTER(IcpParams)]
+        L.lisreg_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult), vp]
         _lib = L
     return _lib
+
+
+def icp_default_params(kind: int = 0) -> IcpParams:
+    p = IcpParams()
+    if lib().lisreg_icp_default_params(kind, C.byref(p)):
+        raise LisregError(ERR_ARG, "lisreg_icp_default_params")
+    return p
 
 
 def default_params(variant: int = VARIANT_ODOM) -> Params:
@@ -444,6 +471,27 @@ class Context:
         b = (C.c_double * 6)()
         self._chk(self._L.lisreg_cloud_bounds(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud), b))
         return np.array(list(b))
+
+    # -- §8 f-4 -------------------------------------------------------------------------------------------
+    def icp_align(self, slot: int, source: np.ndarray, params: "IcpParams", guess=None, want_aligned: bool = False):
+        """pcl::IterativeClosestPoint::align against the map index in `slot`; returns the result dict (+ 'aligned')."""
+        source = np.ascontiguousarray(source)
+        res = IcpResult()
+        g = None if guess is None else np.ascontiguousarray(guess, np.float32).ravel().ctypes.data_as(C.POINTER(C.c_float))
+        out = np.zeros_like(source) if want_aligned else None
+        self._chk(self._L.lisreg_icp_align(self._h, slot, _vp(source), len(source), source.dtype.itemsize, _fmt_of(source),
+                                           C.byref(params), g, C.byref(res), _vp(out) if want_aligned else None))
+        d = res.as_dict()
+        if want_aligned:
+            d["aligned"] = out
+        return d
+
+    def icp_align_device(self, slot: int, src_ptr: int, n: int, params: "IcpParams", guess=None, out_ptr: int = 0):
+        res = IcpResult()
+        g = None if guess is None else np.ascontiguousarray(guess, np.float32).ravel().ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self._L.lisreg_icp_align(self._h, slot, C.c_void_p(src_ptr), n, 16, FMT_DEVICE, C.byref(params), g,
+                                           C.byref(res), C.c_void_p(out_ptr) if out_ptr else None))
+        return res.as_dict()
 
     def set_profiling(self, on: bool):
         self._chk(self._L.lisreg_set_profiling(self._h, 1 if on else 0))

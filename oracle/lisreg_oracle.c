@@ -1105,3 +1105,184 @@ void orc_nearest(const void* map, int n_map, const void* query, int n, int strid
     if (tree) orc_kdtree_free(tree);
     free(mxyz);
 }
+
+/* ---- §8 f-4: pcl::IterativeClosestPoint as the loop-closure code drives it -------------------------------------- */
+/* 3x3 SVD by one-sided Jacobi in double (any accurate SVD yields the same R below when sigma has rank >= 2) */
+static void svd3(const double Ain[9], double U[9], double S[3], double V[9])
+{
+    double A[9]; memcpy(A, Ain, sizeof A);
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int r = 0; r < 3; ++r) { a += A[3 * r + p] * A[3 * r + p]; b += A[3 * r + q] * A[3 * r + q]; c += A[3 * r + p] * A[3 * r + q]; }
+                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                off += fabs(c);
+                double zeta = (b - a) / (2.0 * c);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int r = 0; r < 3; ++r) {
+                    double x = A[3 * r + p], y = A[3 * r + q];
+                    A[3 * r + p] = cs * x - sn * y; A[3 * r + q] = sn * x + cs * y;
+                    x = V[3 * r + p]; y = V[3 * r + q];
+                    V[3 * r + p] = cs * x - sn * y; V[3 * r + q] = sn * x + cs * y;
+                }
+            }
+        if (off == 0) break;
+    }
+    int ord[3] = { 0, 1, 2 };
+    double nrm[3];
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (nrm[ord[j]] > nrm[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        S[j] = nrm[ord[j]];
+        for (int r = 0; r < 3; ++r) { Vs[3 * r + j] = V[3 * r + ord[j]]; U[3 * r + j] = S[j] > 0 ? A[3 * r + ord[j]] / S[j] : 0.0; }
+    }
+    memcpy(V, Vs, sizeof Vs);
+    /* complete U for (numerically) vanishing singular values so that it stays orthogonal */
+    const double tiny = 1e-12 * (S[0] > 0 ? S[0] : 1.0);
+    if (S[1] <= tiny) {                       /* rank <= 1: any orthonormal completion */
+        double u0[3] = { U[0], U[3], U[6] };
+        if (S[0] <= 0) { u0[0] = 1; u0[1] = 0; u0[2] = 0; U[0] = 1; U[3] = 0; U[6] = 0; }
+        int k = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
+        double e[3] = { 0, 0, 0 }; e[k] = 1;
+        double d = e[0] * u0[0] + e[1] * u0[1] + e[2] * u0[2];
+        double u1[3] = { e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2] };
+        double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        for (int r = 0; r < 3; ++r) U[3 * r + 1] = u1[r] / n1;
+    }
+    if (S[2] <= tiny) {
+        U[2] = U[3] * U[7] - U[6] * U[4];      /* u2 = u0 x u1 */
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+static double det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+/* pcl::registration::TransformationEstimationSVD::estimateRigidTransformation -> pcl::umeyama(src, tgt, false)
+ * (PCL 1.8.1 registration/impl/transformation_estimation_svd.hpp, Eigen 3.3 Umeyama.h): means, demeaned covariance
+ * sigma = (1/n) * dst_demean * src_demean^T, SVD, S = diag(1, 1, sign(det U * det V)), R = U S V^T, t = dst_mean - R src_mean.
+ * Eigen evaluates all of it in float: the means by a sequential float sum (rowwise().sum() of a strided row), sigma by a
+ * blocked GEMM whose summation order is unspecified.  float_sums = 1 restates that (means summed in float in input order);
+ * float_sums = 0 accumulates the means in double.  A float running sum over 1e5 coordinates of ~10-50 m is only good to
+ * ~1e-4..1e-3 m and depends on the summation ORDER, so it cannot be the parity target of a parallel reduction: the GPU path
+ * is compared with float_sums = 0, and tests/test_icp.py measures how far the float_sums = 1 result sits from it (the
+ * reference's own summation noise).  Either way: float demeaned coordinates, products accumulated in double, SVD in double,
+ * result rounded to float. */
+void orc_umeyama(const float* src, const float* dst, int n, int float_sums, float T[16])
+{
+    float ms[3] = { 0, 0, 0 }, md[3] = { 0, 0, 0 };
+    const float inv = 1.0f / (float)n;
+    if (float_sums) {
+        for (int i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) { ms[d] += src[3 * i + d]; md[d] += dst[3 * i + d]; }
+        for (int d = 0; d < 3; ++d) { ms[d] *= inv; md[d] *= inv; }
+    } else {
+        double as[3] = { 0, 0, 0 }, ad[3] = { 0, 0, 0 };
+        for (int i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) { as[d] += src[3 * i + d]; ad[d] += dst[3 * i + d]; }
+        for (int d = 0; d < 3; ++d) { ms[d] = (float)(as[d] / (double)n); md[d] = (float)(ad[d] / (double)n); }
+    }
+    double sg[9] = { 0 };
+    for (int i = 0; i < n; ++i) {
+        float a[3], b[3];
+        for (int d = 0; d < 3; ++d) { a[d] = src[3 * i + d] - ms[d]; b[d] = dst[3 * i + d] - md[d]; }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sg[3 * r + c] += (double)b[r] * (double)a[c];
+    }
+    for (int k = 0; k < 9; ++k) sg[k] = (double)(float)(sg[k] * (double)inv);
+    double U[9], S[3], V[9];
+    svd3(sg, U, S, V);
+    double s2 = det3(U) * det3(V) < 0 ? -1.0 : 1.0;
+    double R[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+        R[3 * r + c] = U[3 * r + 0] * V[3 * c + 0] + U[3 * r + 1] * V[3 * c + 1] + s2 * U[3 * r + 2] * V[3 * c + 2];
+    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[4 * r + c] = (float)R[3 * r + c];
+        T[4 * r + 3] = md[r] - (T[4 * r + 0] * ms[0] + T[4 * r + 1] * ms[1] + T[4 * r + 2] * ms[2]);
+    }
+}
+
+static void mat4_mul(const float A[16], const float B[16], float C[16])
+{
+    float R[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c)
+        R[4 * r + c] = ((A[4 * r] * B[c] + A[4 * r + 1] * B[4 + c]) + A[4 * r + 2] * B[8 + c]) + A[4 * r + 3] * B[12 + c];
+    memcpy(C, R, sizeof R);
+}
+
+static void mat4_apply(const float M[16], const float p[3], float o[3])
+{
+    for (int r = 0; r < 3; ++r) o[r] = ((M[4 * r] * p[0] + M[4 * r + 1] * p[1]) + M[4 * r + 2] * p[2]) + M[4 * r + 3];
+}
+
+/* pcl::IterativeClosestPoint::align + getFitnessScore + hasConverged as called at
+ * src/node/subMapOptmizationNode.cpp:1444-1465, :2763-2833, :4400-4420 — restated from PCL 1.8.1
+ * registration/impl/icp.hpp (computeTransformation), impl/correspondence_estimation.hpp (determineCorrespondences),
+ * impl/default_convergence_criteria.hpp (hasConverged), impl/registration.hpp (getFitnessScore).
+ * prm->prev_mse is DefaultConvergenceCriteria::correspondences_prev_mse_, which the reference's `static` ICP objects carry
+ * from one align() to the next (DBL_MAX on a fresh object); res->prev_mse is its value afterwards. */
+void orc_icp_align(const void* target, int n_t, const void* source, int n_s, int stride, const lisreg_icp_params* prm,
+                   const float* guess, int float_sums, lisreg_icp_result* res)
+{
+    float* txyz = (float*)malloc(sizeof(float) * 3 * (size_t)(n_t > 0 ? n_t : 1));
+    float* sxyz = (float*)malloc(sizeof(float) * 3 * (size_t)(n_s > 0 ? n_s : 1));
+    float* cur  = (float*)malloc(sizeof(float) * 3 * (size_t)(n_s > 0 ? n_s : 1));
+    float* ca   = (float*)malloc(sizeof(float) * 3 * (size_t)(n_s > 0 ? n_s : 1));
+    float* cb   = (float*)malloc(sizeof(float) * 3 * (size_t)(n_s > 0 ? n_s : 1));
+    unpack_cloud(target, n_t, stride, LISREG_FMT_XYZI, txyz, NULL);
+    unpack_cloud(source, n_s, stride, LISREG_FMT_XYZI, sxyz, NULL);
+    orc_kdtree* tree = n_t > 0 ? orc_kdtree_build(txyz, n_t, 15) : NULL;
+    float F[16], Tm[16];
+    for (int k = 0; k < 16; ++k) F[k] = guess ? guess[k] : ((k % 5 == 0) ? 1.0f : 0.0f);
+    for (int i = 0; i < n_s; ++i) mat4_apply(F, sxyz + 3 * i, cur + 3 * i);        /* identity guess: exact copy */
+    int iters = 0, converged = 0, state = LISREG_ICP_NOT_CONVERGED, n_corr = 0;
+    double prev_mse = prm->prev_mse, cur_mse = DBL_MAX;
+    const double max_d2 = (double)prm->max_corr_dist * (double)prm->max_corr_dist;
+    for (;;) {
+        int cnt = 0;
+        double dsum = 0;
+        for (int i = 0; i < n_s && tree; ++i) {
+            int id; float d2;
+            orc_kdtree_knn(tree, cur + 3 * i, 1, &id, &d2);
+            if ((double)d2 > max_d2) continue;
+            memcpy(ca + 3 * cnt, cur + 3 * i, 12); memcpy(cb + 3 * cnt, txyz + 3 * id, 12);
+            dsum += d2; ++cnt;
+        }
+        n_corr = cnt;
+        if (cnt < 3) { state = LISREG_ICP_NO_CORRESPONDENCES; converged = 0; break; }     /* min_number_correspondences_ = 3 */
+        orc_umeyama(ca, cb, cnt, float_sums, Tm);
+        for (int i = 0; i < n_s; ++i) { float o[3]; mat4_apply(Tm, cur + 3 * i, o); memcpy(cur + 3 * i, o, 12); }
+        mat4_mul(Tm, F, F);
+        ++iters;
+        /* DefaultConvergenceCriteria::hasConverged */
+        state = LISREG_ICP_NOT_CONVERGED;
+        if (iters >= prm->max_iters) { state = LISREG_ICP_ITERATIONS; converged = 1; break; }
+        double cos_angle = 0.5 * ((double)Tm[0] + (double)Tm[5] + (double)Tm[10] - 1.0);
+        double tr2 = (double)Tm[3] * Tm[3] + (double)Tm[7] * Tm[7] + (double)Tm[11] * Tm[11];
+        if (cos_angle >= 1.0 - prm->transformation_epsilon && tr2 <= prm->transformation_epsilon) { state = LISREG_ICP_TRANSFORM; converged = 1; break; }
+        cur_mse = dsum / (double)cnt;
+        if (fabs(cur_mse - prev_mse) < 1e-12) { state = LISREG_ICP_ABS_MSE; converged = 1; break; }
+        if (fabs(cur_mse - prev_mse) / prev_mse < prm->euclidean_fitness_epsilon) { state = LISREG_ICP_REL_MSE; converged = 1; break; }
+        prev_mse = cur_mse;
+    }
+    /* getFitnessScore(): unbounded k = 1 of the source moved by the final transformation */
+    double fit = 0; int nr = 0;
+    for (int i = 0; i < n_s && tree; ++i) {
+        float p[3]; int id; float d2;
+        mat4_apply(F, sxyz + 3 * i, p);
+        orc_kdtree_knn(tree, p, 1, &id, &d2);
+        fit += d2; ++nr;
+    }
+    memcpy(res->final_transform, F, sizeof F);
+    res->converged = converged; res->iters = iters; res->state = state; res->n_corr_last = n_corr;
+    res->fitness = nr > 0 ? fit / nr : DBL_MAX;
+    res->prev_mse = prev_mse;
+    if (tree) orc_kdtree_free(tree);
+    free(txyz); free(sxyz); free(cur); free(ca); free(cb);
+}

@@ -21,6 +21,7 @@
  *   cv GEMM for CV_32F                -> float inputs, double accumulation, float result (orc_normal_equations)
  *   pcl::getTransformation            -> ZYX Euler to affine                             (orc_pose_to_matrix)
  *   tf::Quaternion setRPY/slerp, tf::Matrix3x3::getRPY                                   (orc_transform_update)
+ *   pcl::IterativeClosestPoint + Eigen::umeyama                                          (orc_icp_align, orc_umeyama)
  */
 #ifndef LISREG_ORACLE_H_
 #define LISREG_ORACLE_H_
@@ -113,6 +114,14 @@ void orc_bbx_filter(const void* cloud, int n, int stride_bytes, const double bou
 int  orc_dynamic_filter(const void* map, int n_map, const void* cloud, int n, int stride_bytes, float center_radius,
                         float dist_thre_min, float dist_thre_max, float near_dist_thre, int* keep, int* n_keep); /* :1064-1100 */
 void orc_nearest(const void* map, int n_map, const void* query, int n, int stride_bytes, float max_dist, int* idx, float* sqd);
+
+/* ---- §8 f-4: pcl::IterativeClosestPoint (PCL 1.8.1 icp.hpp / correspondence_estimation.hpp /
+ * default_convergence_criteria.hpp / transformation_estimation_svd.hpp, restated; call sites in lisreg.h) ------------ */
+/* float_sums: 1 = means by a sequential float sum like Eigen (order-dependent, ~1e-4..1e-3 m of noise at 1e5 points),
+ * 0 = means accumulated in double (the parity target of the GPU's parallel reduction) */
+void orc_umeyama(const float* src_xyz, const float* dst_xyz, int n, int float_sums, float T[16]);
+void orc_icp_align(const void* target, int n_t, const void* source, int n_s, int stride_bytes, const lisreg_icp_params* prm,
+                   const float* guess /* 16 or NULL */, int float_sums, lisreg_icp_result* res);
 
 #ifdef __cplusplus
 }

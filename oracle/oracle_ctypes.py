@@ -27,6 +27,16 @@ class Imu(C.Structure):
     _fields_ = [("imu_available", C.c_int), ("imu_roll_init", C.c_float), ("imu_pitch_init", C.c_float)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("max_corr_dist", C.c_double), ("max_iters", C.c_int), ("reserved", C.c_int),
+                ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double), ("prev_mse", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("final_transform", C.c_float * 16), ("converged", C.c_int), ("iters", C.c_int), ("state", C.c_int),
+                ("n_corr_last", C.c_int), ("fitness", C.c_double), ("prev_mse", C.c_double)]
+
+
 class FeatureParams(C.Structure):
     _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int), ("min_range", C.c_float),
                 ("max_range", C.c_float), ("edge_threshold", C.c_float), ("surf_threshold", C.c_float)]
@@ -112,6 +122,10 @@ def lib():
         L.orc_dynamic_filter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, ip, ip]
         L.orc_nearest.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, ip, fp]
         L.orc_nearest.restype = None
+        L.orc_umeyama.argtypes = [fp, fp, C.c_int, C.c_int, fp]
+        L.orc_umeyama.restype = None
+        L.orc_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.c_int, C.POINTER(IcpResult)]
+        L.orc_icp_align.restype = None
         _lib = L
     return _lib
 
@@ -243,3 +257,31 @@ def nearest(map_cloud, query, max_dist=1e18):
     lib().orc_nearest(_vp(map_cloud), len(map_cloud), _vp(query), len(query), query.dtype.itemsize, max_dist,
                       idx.ctypes.data_as(C.POINTER(C.c_int)), _fp(sqd))
     return idx[: len(query)], sqd[: len(query)]
+
+
+def icp_default_params(kind: int = 0) -> "IcpParams":
+    """subMapOptmizationNode.cpp:2765-2769 (kind 0) / :1445-1449 (kind 1)"""
+    p = IcpParams()
+    p.max_corr_dist, p.max_iters, p.transformation_epsilon, p.euclidean_fitness_epsilon = \
+        ((10.0, 30, 1e-4, 1e-4) if kind == 0 else (0.2, 50, 1e-5, 1e-5))
+    p.prev_mse = np.finfo(np.float64).max
+    return p
+
+
+def umeyama(src_xyz, dst_xyz, float_sums=False):
+    src = np.ascontiguousarray(src_xyz, np.float32); dst = np.ascontiguousarray(dst_xyz, np.float32)
+    T = np.zeros(16, np.float32)
+    lib().orc_umeyama(_fp(src), _fp(dst), len(src), 1 if float_sums else 0, _fp(T))
+    return T.reshape(4, 4)
+
+
+def icp_align(target, source, params: "IcpParams", guess=None, float_sums=False):
+    """float_sums=True: Eigen-like sequential float means (order-dependent); False: double means (the GPU parity target)."""
+    target = np.ascontiguousarray(target); source = np.ascontiguousarray(source)
+    assert target.dtype == source.dtype
+    res = IcpResult()
+    g = None if guess is None else _fp(np.ascontiguousarray(guess, np.float32).ravel())
+    lib().orc_icp_align(_vp(target), len(target), _vp(source), len(source), source.dtype.itemsize, C.byref(params), g, 1 if float_sums else 0,
+                        C.byref(res))
+    return dict(T=np.array(list(res.final_transform), np.float32).reshape(4, 4), converged=bool(res.converged), iters=res.iters,
+                state=res.state, n_corr_last=res.n_corr_last, fitness=res.fitness, prev_mse=res.prev_mse)

@@ -51,3 +51,20 @@ for n_map, (h, w) in ((200000, (64, 1800)), (1000000, (64, 1800))):
     t = timed(crop)
     t0 = time.perf_counter(); wc = oc.bbx_filter(m, b); cpu = 1e3 * (time.perf_counter() - t0)
     print(f"  bbx_filter of the map: {t:.3f} ms ({(16*len(m)+16*res['c']+8*len(m))/t/1e6:.1f} GB/s)  kept {res['c']} (oracle {len(wc)})  CPU {cpu:.1f} ms")
+
+# ---- §8 f-4: ICP (loop-closure settings) on the same clouds; source = the scan pushed off by a pose error
+import test_icp as ti                      # tests/ is this file's directory
+for n_map in (200000, 1000000):
+    tgt, src, _ = ti._case(61, n_map=n_map, trans=1.0, rot_deg=4.0, hw=(64, 1800))
+    rt, rs = lisreg.pack_device_records(tgt), lisreg.pack_device_records(src)
+    dt_, ds = lisreg.DeviceArray(rt), lisreg.DeviceArray(rs)
+    ctx.map_index_set_device(4, dt_.ptr, len(rt))
+    pg = lisreg.icp_default_params(0)
+    res = {}
+    def run():
+        res["r"] = ctx.icp_align_device(4, ds.ptr, len(rs), pg)
+    t = timed(run, 5)
+    t0 = time.perf_counter(); ro = oc.icp_align(tgt, src, oc.icp_default_params(0)); cpu = 1e3 * (time.perf_counter() - t0)
+    r = res["r"]
+    print(f"ICP target {len(tgt)} source {len(src)}: GPU {t:.3f} ms for {r['iters']} iterations + fitness ({t/(r['iters']+1):.3f} ms per k=1 pass), "
+          f"pose diff vs oracle {ti._pose_diff(r['T'], ro['T'])}, state {r['state']}, fitness {r['fitness']:.5f} | CPU oracle {cpu:.0f} ms ({ro['iters']} it, fitness {ro['fitness']:.5f})  x{cpu/t:.0f}")

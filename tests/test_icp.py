@@ -1,0 +1,219 @@
+"""pcl::IterativeClosestPoint as the loop-closure code drives it (subMapOptmizationNode.cpp:2763-2833).
+
+CPU: the oracle's Umeyama step against numpy's SVD (Kabsch) and its ICP loop against a plain numpy/cKDTree loop.
+GPU: liblisreg against the oracle (double-accumulated means: see test_oracle_float_sum_noise for why the reference's float
+running sums cannot be a parity target) — a floating-point path: the final transformation within 1e-3 m / 1e-3 rad, the same convergence state and iteration count, the fitness score within 2e-3 relative."""
+import numpy as np
+import pytest
+
+f32 = np.float32
+DBL_MAX = np.finfo(np.float64).max
+
+
+def _cat(a, b):
+    o = np.zeros(len(a) + len(b), a.dtype)
+    o[: len(a)], o[len(a):] = a, b
+    return o
+
+
+def _case(seed, n_map=40000, trans=0.6, rot_deg=3.0, hw=(32, 900)):
+    """target = submap (map frame); source = a scan of the same scene placed in the map frame with a pose error"""
+    from lisreg import synth
+    mc, ms = synth.make_submap(n_map, seed=seed, labelled=True)
+    tgt = _cat(mc, ms)
+    sc = synth.make_scan(hw[0], hw[1], seed + 1, labelled=True)
+    src = _cat(sc["corner"], sc["surf"])
+    rng = np.random.default_rng(seed)
+    T_bad = synth.perturb_pose(sc["T_true"], rng, trans=trans, rot_deg=rot_deg)
+    M = synth.pose_matrix(T_bad)
+    w = synth.pcl_xyz(src).astype(np.float64) @ M[:3, :3].T + M[:3, 3]
+    src["x"], src["y"], src["z"] = w[:, 0].astype(f32), w[:, 1].astype(f32), w[:, 2].astype(f32)
+    # the correction ICP should find: moves the mis-placed scan onto the map
+    M_fix = synth.pose_matrix(sc["T_true"]) @ np.linalg.inv(M)
+    return tgt, src, M_fix
+
+
+def _rot_angle(R):
+    v = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])      # well conditioned near 0, unlike arccos(trace)
+    return float(np.arctan2(np.linalg.norm(v), (np.trace(R) - 1) / 2))
+
+
+def _pose_diff(A, B):
+    A, B = np.asarray(A, np.float64), np.asarray(B, np.float64)
+    return _rot_angle(A[:3, :3].T @ B[:3, :3]), float(np.abs(A[:3, 3] - B[:3, 3]).max())
+
+
+# ---------------------------------------------------------------- CPU
+def test_oracle_umeyama_matches_kabsch(oracle):
+    rng = np.random.default_rng(1)
+    for planar in (False, True):
+        a = rng.normal(0, 5, (500, 3))
+        if planar:
+            a[:, 2] = 0.0                                             # rank-2 covariance
+        ang = np.array([0.2, -0.1, 0.7])
+        from lisreg import synth
+        M = synth.pose_matrix([*ang, 1.0, -2.0, 0.5])
+        b = a @ M[:3, :3].T + M[:3, 3] + rng.normal(0, 0.01, a.shape)
+        T = oracle.umeyama(a.astype(f32), b.astype(f32))
+        ac, bc = a - a.mean(0), b - b.mean(0)
+        U, S, Vt = np.linalg.svd(bc.T @ ac)
+        D = np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+        R = U @ D @ Vt
+        t = b.mean(0) - R @ a.mean(0)
+        assert np.abs(T[:3, :3] - R).max() < 2e-6 and np.abs(T[:3, 3] - t).max() < 2e-5
+        assert np.array_equal(T[3], [0, 0, 0, 1])
+        assert abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1) < 1e-6
+    # reflection case: the optimal orthogonal map is improper, Umeyama must still return a rotation
+    a = rng.normal(0, 1, (50, 3)); b = a * np.array([1, 1, -1.0])
+    T = oracle.umeyama(a.astype(f32), b.astype(f32))
+    assert abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1) < 1e-5
+
+
+def _numpy_icp(tgt, src, max_corr, max_iters, eps_t, eps_mse, prev_mse=DBL_MAX):
+    from lisreg import synth
+    from scipy.spatial import cKDTree
+    t = synth.pcl_xyz(tgt).astype(np.float64); cur = synth.pcl_xyz(src).astype(np.float64)
+    tree = cKDTree(t)
+    F = np.eye(4); iters = 0; state = 0
+    while True:
+        d, idx = tree.query(cur, k=1)
+        ok = d * d <= max_corr * max_corr
+        if ok.sum() < 3:
+            return F, iters, 5, prev_mse
+        a, b = cur[ok], t[idx[ok]]
+        ac, bc = a - a.mean(0), b - b.mean(0)
+        U, S, Vt = np.linalg.svd(bc.T @ ac)
+        R = U @ np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))]) @ Vt
+        tr = b.mean(0) - R @ a.mean(0)
+        cur = cur @ R.T + tr
+        Tm = np.eye(4); Tm[:3, :3] = R; Tm[:3, 3] = tr
+        F = Tm @ F; iters += 1
+        if iters >= max_iters:
+            return F, iters, 1, prev_mse
+        if 0.5 * (np.trace(R) - 1) >= 1 - eps_t and tr @ tr <= eps_t:
+            return F, iters, 2, prev_mse
+        mse = float((d[ok] ** 2).mean())
+        if abs(mse - prev_mse) < 1e-12:
+            return F, iters, 3, prev_mse
+        if abs(mse - prev_mse) / prev_mse < eps_mse:
+            return F, iters, 4, prev_mse
+        prev_mse = mse
+
+
+@pytest.mark.parametrize("kind,seed,trans,rot", [(0, 41, 0.6, 3.0), (0, 42, 1.5, 6.0), (1, 43, 0.05, 0.3)])
+def test_oracle_icp_matches_numpy_loop(oracle, kind, seed, trans, rot):
+    tgt, src, M_fix = _case(seed, n_map=15000, trans=trans, rot_deg=rot, hw=(16, 450))
+    p = oracle.icp_default_params(kind)
+    r = oracle.icp_align(tgt, src, p, float_sums=True)
+    F, iters, state, prev = _numpy_icp(tgt, src, p.max_corr_dist, p.max_iters, p.transformation_epsilon, p.euclidean_fitness_epsilon)
+    assert r["converged"] and r["state"] == state and r["iters"] == iters
+    dr, dt = _pose_diff(r["T"], F)
+    assert dr < 2e-4 and dt < 2e-3
+    if kind == 0:                                                     # wide gate: recovers the pose error
+        dr, dt = _pose_diff(r["T"], M_fix)
+        assert dr < 0.01 and dt < 0.1
+    assert 0 < r["fitness"] < 1.0
+
+
+def test_oracle_float_sum_noise(oracle):
+    """Eigen's umeyama sums the means sequentially in float; at scan size that is ~1e-4..1e-3 m of order-dependent noise per
+    estimate.  The GPU's parity target is the double-mean variant (which tracks an all-double numpy loop to ~1e-5 m); this test
+    pins how far the float-sum restatement of the reference sits from it."""
+    tgt, src, _ = _case(45, n_map=60000, trans=1.0, rot_deg=4.0, hw=(32, 900))
+    p = oracle.icp_default_params(0)
+    rf, rd = oracle.icp_align(tgt, src, p, float_sums=True), oracle.icp_align(tgt, src, p, float_sums=False)
+    F, iters, state, _ = _numpy_icp(tgt, src, p.max_corr_dist, p.max_iters, p.transformation_epsilon, p.euclidean_fitness_epsilon)
+    assert rd["iters"] == iters and rd["state"] == state
+    dr, dt = _pose_diff(rd["T"], F)
+    assert dr < 5e-5 and dt < 2e-4
+    dr, dt = _pose_diff(rf["T"], rd["T"])
+    assert dr < 1e-3 and dt < 1e-2                                    # the reference's own summation noise stays below 1 cm
+    assert abs(rf["iters"] - rd["iters"]) <= 1
+
+
+def test_oracle_icp_edges(oracle):
+    tgt, src, _ = _case(44, n_map=5000, hw=(8, 240))
+    p = oracle.icp_default_params(0)
+    far = src.copy(); far["x"] += 1000.0
+    r = oracle.icp_align(tgt, far, p)
+    assert not r["converged"] and r["state"] == 5 and r["iters"] == 0 and np.array_equal(r["T"], np.eye(4, dtype=f32))
+    r = oracle.icp_align(tgt, src[:2], p)                              # < 3 correspondences
+    assert not r["converged"] and r["state"] == 5
+    p.max_iters = 1
+    r = oracle.icp_align(tgt, src, p)
+    assert r["converged"] and r["state"] == 1 and r["iters"] == 1
+    # the carried correspondences_prev_mse_: a second align() on a `static` object can stop on the relative-MSE test at once
+    p = oracle.icp_default_params(0)
+    r1 = oracle.icp_align(tgt, src, p)
+    p.prev_mse = r1["prev_mse"]
+    assert r1["prev_mse"] < DBL_MAX
+    g = np.eye(4, dtype=f32)
+    r2 = oracle.icp_align(tgt, src, p, guess=g)
+    assert r2["converged"]
+
+
+# ---------------------------------------------------------------- GPU
+def _check(rg, ro):
+    assert rg["converged"] == ro["converged"] and rg["state"] == ro["state"], (rg, ro)
+    assert abs(rg["iters"] - ro["iters"]) <= 1, (rg["iters"], ro["iters"])
+    dr, dt = _pose_diff(rg["T"], ro["T"])
+    assert dr < 2e-4 and dt < 2e-4, (dr, dt)                         # measured ~1e-6 rad / ~1e-5 m; the bar is 1e-3
+    assert abs(rg["fitness"] - ro["fitness"]) <= 2e-3 * ro["fitness"] + 1e-7         # d(fitness) ~ 2 * rms distance * d(pose)
+    assert abs(rg["n_corr_last"] - ro["n_corr_last"]) <= max(3, ro["n_corr_last"] // 2000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,seed,trans,rot,n_map", [(0, 51, 0.6, 3.0, 40000), (0, 52, 1.5, 6.0, 120000), (1, 53, 0.05, 0.3, 40000),
+                                                      (0, 54, 3.0, 10.0, 40000)])
+def test_hip_icp_matches_oracle(oracle, gpu_ctx, kind, seed, trans, rot, n_map):
+    import lisreg
+    tgt, src, M_fix = _case(seed, n_map=n_map, trans=trans, rot_deg=rot)
+    gpu_ctx.map_index_set(9, tgt)
+    po, pg = oracle.icp_default_params(kind), lisreg.icp_default_params(kind)
+    assert all(getattr(po, f) == getattr(pg, f) for f, _ in pg._fields_)
+    ro = oracle.icp_align(tgt, src, po)
+    rg = gpu_ctx.icp_align(9, src, pg, want_aligned=True)
+    _check(rg, ro)
+    # `output` of align(): the source under the final transformation, other fields copied
+    from lisreg import synth
+    w = synth.pcl_xyz(src).astype(np.float64) @ rg["T"][:3, :3].astype(np.float64).T + rg["T"][:3, 3]
+    assert np.abs(synth.pcl_xyz(rg["aligned"]) - w).max() < 1e-4
+    assert np.array_equal(rg["aligned"]["label"], src["label"]) and np.array_equal(rg["aligned"]["intensity"], src["intensity"])
+
+
+@pytest.mark.gpu
+def test_hip_icp_edges_guess_and_device(oracle, gpu_ctx):
+    import lisreg
+    tgt, src, _ = _case(55, n_map=30000, hw=(16, 450))
+    gpu_ctx.map_index_set(9, tgt)
+    po, pg = oracle.icp_default_params(0), lisreg.icp_default_params(0)
+    far = src.copy(); far["x"] += 1000.0
+    rg = gpu_ctx.icp_align(9, far, pg)
+    assert not rg["converged"] and rg["state"] == lisreg.ICP_NO_CORRESPONDENCES and rg["iters"] == 0
+    assert np.array_equal(rg["T"], np.eye(4, dtype=f32))
+    _check(gpu_ctx.icp_align(9, src[:2], pg), oracle.icp_align(tgt, src[:2], po))
+    rg = gpu_ctx.icp_align(9, src[:0], pg)
+    assert not rg["converged"] and rg["fitness"] == DBL_MAX
+    po.max_iters = pg.max_iters = 1
+    _check(gpu_ctx.icp_align(9, src, pg), oracle.icp_align(tgt, src, po))
+    po.max_iters = pg.max_iters = 7
+    _check(gpu_ctx.icp_align(9, src, pg), oracle.icp_align(tgt, src, po))
+    # initial guess + carried prev_mse
+    from lisreg import synth
+    g = synth.pose_matrix([0.01, -0.02, 0.03, 0.2, -0.1, 0.05]).astype(f32)
+    po, pg = oracle.icp_default_params(0), lisreg.icp_default_params(0)
+    ro, rg = oracle.icp_align(tgt, src, po, guess=g), gpu_ctx.icp_align(9, src, pg, guess=g)
+    _check(rg, ro)
+    po.prev_mse, pg.prev_mse = ro["prev_mse"], ro["prev_mse"]
+    _check(gpu_ctx.icp_align(9, src, pg), oracle.icp_align(tgt, src, po))
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.icp_align(77, src, pg)
+    # device records
+    rs = lisreg.pack_device_records(src)
+    ds, dout = lisreg.DeviceArray(rs), lisreg.DeviceArray(np.zeros_like(rs))
+    pg = lisreg.icp_default_params(0)
+    rd = gpu_ctx.icp_align_device(9, ds.ptr, len(rs), pg, out_ptr=dout.ptr)
+    rh = gpu_ctx.icp_align(9, src, pg, want_aligned=True)
+    assert np.array_equal(rd["T"], rh["T"]) and rd["iters"] == rh["iters"] and rd["fitness"] == rh["fitness"]
+    got = lisreg.device_to_host(dout.ptr, rs.shape, np.float32)
+    assert np.array_equal(got[:, :3], synth.pcl_xyz(rh["aligned"])) and np.array_equal(got[:, 3].view(np.uint32), rs[:, 3].view(np.uint32))
