@@ -157,7 +157,7 @@ def _check(rg, ro):
     assert rg["converged"] == ro["converged"] and rg["state"] == ro["state"], (rg, ro)
     assert abs(rg["iters"] - ro["iters"]) <= 1, (rg["iters"], ro["iters"])
     dr, dt = _pose_diff(rg["T"], ro["T"])
-    assert dr < 2e-4 and dt < 2e-4, (dr, dt)                         # measured ~1e-6 rad / ~1e-5 m; the bar is 1e-3
+    assert dr < 1e-3 and dt < 1e-3, (dr, dt)      # the bar; measured ~1e-6 rad / ~1e-5 m converged, 2e-4 m when cut off mid-flight
     assert abs(rg["fitness"] - ro["fitness"]) <= 2e-3 * ro["fitness"] + 1e-7         # d(fitness) ~ 2 * rms distance * d(pose)
     assert abs(rg["n_corr_last"] - ro["n_corr_last"]) <= max(3, ro["n_corr_last"] // 2000)
 
