@@ -122,7 +122,15 @@ void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells)
 {
     memset(g, 0, sizeof *g);
     g->n = n;
-    float cell = env_float("LISREG_CELL", 0.5f);
+    // Cell edge: 0.5 m is the measured optimum for the 200 k-point submap of BASELINE configs[1]; the optimum
+    // scales with the point spacing, so denser maps get smaller cells (footprint density as the proxy: lidar maps are
+    // surfaces over a ground plane).  1 M points over the same 80 x 80 m: 0.25 m, +14 % registrations/s.  LISREG_CELL overrides.
+    float cell = 0.5f;
+    if (n > 0) {
+        const double area = std::max(1.0, (double)(bb[3] - bb[0]) * (double)(bb[4] - bb[1]));
+        cell = (float)std::min(0.5, std::max(0.25, 2.8 / std::sqrt((double)n / area)));
+    }
+    cell = env_float("LISREG_CELL", cell);
     if (n <= 0) { g->cell = cell; g->inv_cell = 1.f / cell; g->nx = g->ny = g->nz = 0; *n_cells = 1; return; }
     const double max_cells = 1 << 24;
     for (;;) {
