@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--cpu-regs", type=int, default=3, help="registrations in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-regs", type=int, default=24, help="registrations in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default, the metric's config): 64 scans 64x1800 vs one shared 200k submap, 10 iters; "

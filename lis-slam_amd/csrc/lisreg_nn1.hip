@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace lisreg {
 
@@ -22,43 +23,67 @@ typedef __attribute__((address_space(1))) const int* gptr_i32;
 
 __device__ __forceinline__ int gcoord(float v, float origin, float inv_cell) { return (int)floorf((v - origin) * inv_cell); }
 
-// nearest target point with squared distance <= max_d2 (index into g.pts, -1 if none); *d2_out = its squared distance
+// nearest target point with squared distance <= max_d2 (index into g.pts, -1 if none); *d2_out = its squared distance.
+// Q lanes (1, 4 or 8 neighbouring lanes of a wave) share one query: the (x, y) columns of every pass are dealt round-robin
+// to the Q lanes and the per-lane winners are merged with Q-wide butterflies after each pass.  A single scan is only ~1 800
+// waves of queries — a fifth of the chip's wave slots — so one-lane-per-query leaves the walk latency-bound; splitting a
+// query's columns over Q lanes shortens every dependent-load chain by Q and fills the machine (launchers pick Q from n).
+// All Q lanes of a query must call this together (same q, g, max_d2) and all of them get the merged result.
+template <int Q>
 __device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const GridIndex& g, float max_d2, float* d2_out)
 {
     constexpr float kEps = 1e-3f;
     const gptr_f4 pts = (gptr_f4)g.pts;
     const gptr_i32 cells = (gptr_i32)g.cell_start;
     float best = __uint_as_float(__float_as_uint(max_d2) + 1u);      // strictly-less test below must admit d2 == max_d2
-    int bi = -1;
+    int bi = -1, bw = 0x7fffffff;                                    // bw = original index of the best (ties: smallest wins)
     if (g.n <= 0) { *d2_out = best; return -1; }
+    const int sub = Q > 1 ? (int)(threadIdx.x & (Q - 1)) : 0;
+#define LISREG_NN1_TRY(c_, j_) do { \
+        const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
+        const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_;        /* flann::L2_Simple order */ \
+        const int w_ = __float_as_int((c_).w); \
+        if (d2_ < best || (d2_ == best && w_ < bw)) { best = d2_; bi = (j_); bw = w_; } } while (0)
     for (float r = 0.5f;; r *= 2.f) {
         const float lim = fminf(r * r, best);
         const float rad = __builtin_amdgcn_sqrtf(lim) * 1.0001f + kEps;
         const int cx0 = max(gcoord(qx - rad, g.ox, g.inv_cell), 0), cx1 = min(gcoord(qx + rad, g.ox, g.inv_cell), g.nx - 1);
         const int cy0 = max(gcoord(qy - rad, g.oy, g.inv_cell), 0), cy1 = min(gcoord(qy + rad, g.oy, g.inv_cell), g.ny - 1);
         const int cz0 = max(gcoord(qz - rad, g.oz, g.inv_cell), 0), cz1 = min(gcoord(qz + rad, g.oz, g.inv_cell), g.nz - 1);
-        if (cz0 <= cz1)
-            for (int ix = cx0; ix <= cx1; ++ix) {
-                const float xl = g.ox + (float)ix * g.cell;
+        if (cz0 <= cz1 && cx0 <= cx1 && cy0 <= cy1) {
+            const int ncy = cy1 - cy0 + 1;
+            int ix = cx0, iy = cy0 + sub;                            // lane `sub` takes columns sub, sub + Q, ... in row-major order
+            while (iy > cy1) { iy -= ncy; ++ix; }
+            while (ix <= cx1) {
+                const float xl = g.ox + (float)ix * g.cell, yl = g.oy + (float)iy * g.cell;
                 const float dx = fmaxf(fmaxf(xl - qx, qx - (xl + g.cell)) - kEps, 0.f);
-                if (dx * dx >= fminf(best, lim)) continue;
-                for (int iy = cy0; iy <= cy1; ++iy) {
-                    const float yl = g.oy + (float)iy * g.cell;
-                    const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.cell)) - kEps, 0.f);
-                    if (dx * dx + dy * dy >= fminf(best, lim)) continue;
+                const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.cell)) - kEps, 0.f);
+                if (dx * dx + dy * dy < fminf(best, lim)) {
                     const int base = (ix * g.ny + iy) * g.nz;
                     const int js = cells[base + cz0], je = cells[base + cz1 + 1];
-                    for (int j = js; j < je; ++j) {
-                        const v4f c = pts[j];
-                        const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
-                        const float d2 = ex * ex + ey * ey + ez * ez;        // flann::L2_Simple order
-                        if (d2 < best) { best = d2; bi = j; }
-                        else if (d2 == best && bi >= 0 && __float_as_int(c.w) < __float_as_int(pts[bi].w)) bi = j;   // ties: smallest original index
+                    for (int j = js; j < je; j += 4) {
+                        const int l = je - 1;
+                        const int j1 = min(j + 1, l), j2 = min(j + 2, l), j3 = min(j + 3, l);
+                        const v4f c0 = pts[j], c1 = pts[j1], c2 = pts[j2], c3 = pts[j3];     // 4 loads in flight; a clamped
+                        LISREG_NN1_TRY(c0, j); LISREG_NN1_TRY(c1, j1);                     // tail repeats the last point,
+                        LISREG_NN1_TRY(c2, j2); LISREG_NN1_TRY(c3, j3);                    // which cannot beat itself
                     }
                 }
+                iy += Q;
+                while (iy > cy1) { iy -= ncy; ++ix; }
             }
+        }
+        if (Q > 1) {
+#pragma unroll
+            for (int o = 1; o < Q; o <<= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64), ow = __shfl_xor(bw, o, 64);
+                if (ob < best || (ob == best && ow < bw)) { best = ob; bi = oi; bw = ow; }
+            }
+        }
         if (best <= r * r || r * r >= max_d2) break;       // exact: everything within min(best, r) was visited
     }
+#undef LISREG_NN1_TRY
     *d2_out = best;
     return bi;
 }
@@ -66,11 +91,12 @@ __device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const Gr
 // map_scan_feature_pts_distance_removal (subMap.h:1076-1087).  The reference's unbounded search is cut at `cap2`, the largest
 // FINITE threshold (thresholds default to FLT_MAX, whose square is +inf): beyond it the predicate no longer depends on the
 // distance and its value is `keep_far`.
+template <int Q>
 __global__ __launch_bounds__(256) void k_dynamic_flags(const float4* __restrict__ pts, int n, const GridIndex* __restrict__ gp,
                                                        float center_r2, float near2, float dmin2, float dmax2, float cap2,
                                                        int keep_far, int* __restrict__ flag)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / Q;
     if (i >= n) return;
     const float4 p = pts[i];
     int keep;
@@ -78,10 +104,10 @@ __global__ __launch_bounds__(256) void k_dynamic_flags(const float4* __restrict_
     else {
         float d2;
         const GridIndex g = *gp;
-        const int bi = nn1_search(p.x, p.y, p.z, g, cap2, &d2);
+        const int bi = nn1_search<Q>(p.x, p.y, p.z, g, cap2, &d2);
         keep = (bi < 0) ? keep_far : (((d2 > near2 && d2 < dmin2) || d2 > dmax2) ? 1 : 0);
     }
-    flag[i] = keep;
+    if ((threadIdx.x & (Q - 1)) == 0) flag[i] = keep;
 }
 
 // bbx_filter (subMap.h:1131-1144): float coordinate against double bounds
@@ -104,14 +130,16 @@ __global__ __launch_bounds__(256) void k_compact_write(int n, const int* __restr
 }
 
 // plain k = 1 query for a batch of points (exposed for tests and for the ICP row)
+template <int Q>
 __global__ __launch_bounds__(256) void k_nn1(const float4* __restrict__ q, int n, const GridIndex* __restrict__ gp, float max_d2,
                                              int* __restrict__ idx_out, float* __restrict__ d2_out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / Q;
     if (i >= n) return;
     const GridIndex g = *gp;
     float d2;
-    const int bi = nn1_search(q[i].x, q[i].y, q[i].z, g, max_d2, &d2);
+    const int bi = nn1_search<Q>(q[i].x, q[i].y, q[i].z, g, max_d2, &d2);
+    if ((threadIdx.x & (Q - 1)) != 0) return;
     idx_out[i] = bi < 0 ? -1 : __float_as_int(g.pts[bi].w);      // ORIGINAL index in the caller's map cloud
     d2_out[i] = d2;
 }
@@ -135,12 +163,14 @@ __device__ __forceinline__ void apply4(const float* F, float x, float y, float z
 // transformCloud(input_transformed, transformation_) of the previous iteration (icp.hpp applies it in place, in float, once per
 // iteration — kept that way rather than re-deriving the points from the cumulative transform), then determineCorrespondences
 // and the sums TransformationEstimationSVD needs.
+template <int Q>
 __global__ __launch_bounds__(256) void k_icp_assoc(float4* __restrict__ cur, int n, const GridIndex* __restrict__ gp,
                                                    const IcpState* __restrict__ stp, float cap2, double* __restrict__ partials)
 {
     __shared__ double red[4][kIcpAcc];
     if (stp->done) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / Q;
+    const bool lead = (threadIdx.x & (Q - 1)) == 0;
     double acc[kIcpAcc];
 #pragma unroll
     for (int k = 0; k < kIcpAcc; ++k) acc[k] = 0.0;
@@ -149,9 +179,9 @@ __global__ __launch_bounds__(256) void k_icp_assoc(float4* __restrict__ cur, int
         const float4 s = cur[i];
         float px, py, pz, d2;
         apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
-        cur[i] = make_float4(px, py, pz, s.w);
-        const int bi = nn1_search(px, py, pz, g, cap2, &d2);
-        if (bi >= 0) {
+        const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2);      // (reads cur[i] on all Q lanes before the lead lane rewrites it)
+        if (lead) cur[i] = make_float4(px, py, pz, s.w);
+        if (bi >= 0 && lead) {
             const float4 q = g.pts[bi];
             acc[0] = 1.0;
             acc[1] = px; acc[2] = py; acc[3] = pz;
@@ -184,7 +214,7 @@ __device__ void svd3(const double* Ain, double* U, double* S, double* V)
             for (int q = p + 1; q < 3; ++q) {
                 double a = 0, b = 0, c = 0;
                 for (int r = 0; r < 3; ++r) { a += A[3 * r + p] * A[3 * r + p]; b += A[3 * r + q] * A[3 * r + q]; c += A[3 * r + p] * A[3 * r + q]; }
-                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-15 * sqrt(a * b)) continue;
                 off += fabs(c);
                 const double zeta = (b - a) / (2.0 * c);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -286,18 +316,19 @@ __global__ __launch_bounds__(256) void k_icp_solve(const double* __restrict__ pa
 }
 
 // getFitnessScore(): unbounded k = 1 of the source under the final transformation
+template <int Q>
 __global__ __launch_bounds__(256) void k_icp_fitness(const float4* __restrict__ src, int n, const GridIndex* __restrict__ gp,
                                                      const IcpState* __restrict__ stp, double* __restrict__ partials)
 {
     __shared__ double red[4][2];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / Q;
     double sum = 0, cnt = 0;
     if (i < n) {
         const GridIndex g = *gp;
         const float4 s = src[i];
         float px, py, pz, d2;
         apply4(stp->F, s.x, s.y, s.z, px, py, pz);
-        if (nn1_search(px, py, pz, g, 3.0e38f, &d2) >= 0) { sum = d2; cnt = 1; }
+        if (nn1_search<Q>(px, py, pz, g, 3.0e38f, &d2) >= 0 && (threadIdx.x & (Q - 1)) == 0) { sum = d2; cnt = 1; }
     }
     sum = wave_sum(sum); cnt = wave_sum(cnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -322,20 +353,37 @@ __global__ __launch_bounds__(256) void k_icp_fit_reduce(const double* __restrict
 
 }  // namespace
 
-int icp_blocks(int n) { return (n + 255) / 256; }
+// lanes per query: a scan-sized query set (~1e5) fills the chip only when each query is spread over several lanes
+int nn1_lanes(int n)
+{
+    if (const char* e = getenv("LISREG_NN1_Q")) { const int q = atoi(e); if (q == 1 || q == 4 || q == 8) return q; }
+    return n >= 500000 ? 1 : (n >= 250000 ? 4 : 8);        // ~8 k waves fill the chip (measured at n = 115 k: 1 / 4 / 8 lanes -> 0.127 / 0.054 / 0.049 ms)
+}
+// ICP keeps to 4: every workgroup also writes a 17-double partial row that k_icp_solve has to sum
+int icp_lanes(int n) { return std::min(nn1_lanes(n), 4); }
+int nn1_blocks(int n) { return (int)(((long long)n * nn1_lanes(n) + 255) / 256); }
+int icp_blocks(int n) { return (int)(((long long)n * icp_lanes(n) + 255) / 256); }
+
+#define LISREG_DISPATCH_Q(q_, call1, call4, call8) do { if ((q_) == 1) { call1; } else if ((q_) == 4) { call4; } else { call8; } } while (0)
 
 void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
                           int max_iters, double eps_t, double eps_mse, hipStream_t stream)
 {
-    const int nb = icp_blocks(n);
-    if (nb > 0) k_icp_assoc<<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials);
+    const int nb = icp_blocks(n), q = icp_lanes(n);
+    if (nb > 0)
+        LISREG_DISPATCH_Q(q, (k_icp_assoc<1><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
+                             (k_icp_assoc<4><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
+                             (k_icp_assoc<8><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)));
     k_icp_solve<<<1, 256, 0, stream>>>(partials, nb, st, max_iters, eps_t, eps_mse);
 }
 
 void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, double* partials, hipStream_t stream)
 {
-    const int nb = icp_blocks(n);
-    if (nb > 0) k_icp_fitness<<<nb, 256, 0, stream>>>(src, n, grid_dev, st, partials);
+    const int nb = icp_blocks(n), q = icp_lanes(n);
+    if (nb > 0)
+        LISREG_DISPATCH_Q(q, (k_icp_fitness<1><<<nb, 256, 0, stream>>>(src, n, grid_dev, st, partials)),
+                             (k_icp_fitness<4><<<nb, 256, 0, stream>>>(src, n, grid_dev, st, partials)),
+                             (k_icp_fitness<8><<<nb, 256, 0, stream>>>(src, n, grid_dev, st, partials)));
     k_icp_fit_reduce<<<1, 256, 0, stream>>>(partials, nb, st);
 }
 
@@ -350,8 +398,11 @@ void launch_dynamic_flags(const float4* pts, int n, const GridIndex* grid_dev, f
     if (fmax) cap2 = std::max(cap2, dmax2);
     // farther than every finite threshold: d2 > dmax2 if that is finite; else "near2 < d2 < dmin2" holds only for dmin2 = +inf
     const int keep_far = (fmax || !fmin) ? 1 : 0;
-    k_dynamic_flags<<<(n + 255) / 256, 256, 0, st>>>(pts, n, grid_dev, center_radius * center_radius, near2, dmin2, dmax2, cap2,
-                                                    keep_far, flag);
+    const int q = nn1_lanes(n), nb = nn1_blocks(n);
+    const float cr2 = center_radius * center_radius;
+    LISREG_DISPATCH_Q(q, (k_dynamic_flags<1><<<nb, 256, 0, st>>>(pts, n, grid_dev, cr2, near2, dmin2, dmax2, cap2, keep_far, flag)),
+                         (k_dynamic_flags<4><<<nb, 256, 0, st>>>(pts, n, grid_dev, cr2, near2, dmin2, dmax2, cap2, keep_far, flag)),
+                         (k_dynamic_flags<8><<<nb, 256, 0, st>>>(pts, n, grid_dev, cr2, near2, dmin2, dmax2, cap2, keep_far, flag)));
 }
 
 void launch_bbx_flags(const float4* pts, int n, const double b[6], int delete_box, int* flag, hipStream_t st)
@@ -367,7 +418,12 @@ void launch_compact(int n, const int* flag, int* pos, int* scan_tmp, int* idx_ou
 
 void launch_nn1(const float4* q, int n, const GridIndex* grid_dev, float max_dist, int* idx_out, float* d2_out, hipStream_t st)
 {
-    if (n > 0) k_nn1<<<(n + 255) / 256, 256, 0, st>>>(q, n, grid_dev, max_dist * max_dist, idx_out, d2_out);
+    if (n <= 0) return;
+    const int lanes = nn1_lanes(n), nb = nn1_blocks(n);
+    const float m2 = max_dist * max_dist;
+    LISREG_DISPATCH_Q(lanes, (k_nn1<1><<<nb, 256, 0, st>>>(q, n, grid_dev, m2, idx_out, d2_out)),
+                             (k_nn1<4><<<nb, 256, 0, st>>>(q, n, grid_dev, m2, idx_out, d2_out)),
+                             (k_nn1<8><<<nb, 256, 0, st>>>(q, n, grid_dev, m2, idx_out, d2_out)));
 }
 
 }  // namespace lisreg

@@ -1118,7 +1118,7 @@ static void svd3(const double Ain[9], double U[9], double S[3], double V[9])
             for (int q = p + 1; q < 3; ++q) {
                 double a = 0, b = 0, c = 0;
                 for (int r = 0; r < 3; ++r) { a += A[3 * r + p] * A[3 * r + p]; b += A[3 * r + q] * A[3 * r + q]; c += A[3 * r + p] * A[3 * r + q]; }
-                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-15 * sqrt(a * b)) continue;
                 off += fabs(c);
                 double zeta = (b - a) / (2.0 * c);
                 double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

@@ -28,3 +28,11 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         print("== PMC per-dispatch averages:", os.path.relpath(f, root))
         for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:8]:
             print(f"  {k:20s} " + "  ".join(f"{c}={acc[k][c] / cnt[k][c]:.4g} (n={cnt[k][c]})" for c in sorted(acc[k])))
+
+for tag in ("next_vox", "next_feat", "next_map"):
+    for f in glob.glob(os.path.join(root, tag, "**", "*kernel_stats.csv"), recursive=True):
+        print(f"== kernel stats of the {tag} probe (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
+        for r in list(csv.DictReader(open(f)))[:18]:
+            nm = r["Name"]
+            nm = nm[nm.find("k_"):][:40] if "k_" in nm else nm[:40]
+            print(f"{nm:42s} calls={r['Calls']:>6s} total_ns={r['TotalDurationNs']:>12s} avg_ns={float(r['AverageNs']):12.1f} pct={r['Percentage']}")
