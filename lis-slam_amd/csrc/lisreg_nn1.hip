@@ -262,20 +262,29 @@ __device__ __forceinline__ double det3(const double* M)
 }
 
 // estimateRigidTransformation (Umeyama, no scale) + final_transformation_ update + DefaultConvergenceCriteria::hasConverged
-__global__ __launch_bounds__(256) void k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st,
-                                                   int max_iters, double eps_t, double eps_mse)
+__global__ __launch_bounds__(1024) void k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st,
+                                                    int max_iters, double eps_t, double eps_mse)
 {
-    __shared__ double red[8][32];
+    __shared__ double red[32][32];
     __shared__ double tot[kIcpAcc];
     if (st->done) return;
+    // fixed-order sum of the partial rows: 32 row groups x 17 columns in parallel, 4 independent loads in flight per thread
+    // (a scan at 4 lanes per query is ~1 800 rows; summing them 8 ways with one load in flight took 45 us per iteration)
     const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    double v = 0;
-    if (k < kIcpAcc) for (int b = grp; b < n_blocks; b += 8) v += partials[(size_t)b * kIcpAcc + k];
-    red[grp][k] = v;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (k < kIcpAcc) {
+        int b = grp;
+        for (; b + 96 < n_blocks; b += 128) {
+            v0 += partials[(size_t)b * kIcpAcc + k];        v1 += partials[(size_t)(b + 32) * kIcpAcc + k];
+            v2 += partials[(size_t)(b + 64) * kIcpAcc + k]; v3 += partials[(size_t)(b + 96) * kIcpAcc + k];
+        }
+        for (; b < n_blocks; b += 32) v0 += partials[(size_t)b * kIcpAcc + k];
+    }
+    red[grp][k] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (threadIdx.x < kIcpAcc) {
         double s = 0;
-        for (int g = 0; g < 8; ++g) s += red[g][threadIdx.x];
+        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
         tot[threadIdx.x] = s;
     }
     __syncthreads();
@@ -374,7 +383,7 @@ void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpStat
         LISREG_DISPATCH_Q(q, (k_icp_assoc<1><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
                              (k_icp_assoc<4><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
                              (k_icp_assoc<8><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)));
-    k_icp_solve<<<1, 256, 0, stream>>>(partials, nb, st, max_iters, eps_t, eps_mse);
+    k_icp_solve<<<1, 1024, 0, stream>>>(partials, nb, st, max_iters, eps_t, eps_mse);
 }
 
 void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, double* partials, hipStream_t stream)
