@@ -316,6 +316,23 @@ int  lisreg_icp_default_params(int kind, lisreg_icp_params* p);
 int  lisreg_icp_align(lisreg_ctx* ctx, int slot, const void* source, int n, int stride_bytes, int fmt,
                       const lisreg_icp_params* params, const float* guess, lisreg_icp_result* result, void* aligned_out);
 
+/* OptimizedICPGN (src/core/registration.cpp:19-115, src/include/registration.h:44-70): Gauss-Newton point-to-point ICP — per
+ * iteration k = 1 correspondences, J = [I, -R hat(p)], H += J^T J, B -= J^T e, delta = H^-1 B, t += delta[0:3],
+ * R = R exp(delta[3:6]) (Sophus SO3).  The class is never instantiated in the reference (commented-out call sites only); it is
+ * built because SURVEY.md §8 f-4 lists it.  Quirk kept: the squared k = 1 distance is compared with the un-squared
+ * max_correspond_distance (:50).  No convergence test (HasConverged() returns true). */
+typedef struct lisreg_icpgn_result {
+    float final_transform[16];          /* result_pose, row-major 4x4 */
+    int   steps_applied;                /* iterations whose Hessian had a non-zero determinant */
+    int   n_corr_last;
+    float fitness;                      /* GetFitnessScore() */
+    int   reserved;
+} lisreg_icpgn_result;
+/* SetTargetCloud = lisreg_map_index_set(slot); Match(source, predict_pose, transformed_out, result) + GetFitnessScore() */
+int  lisreg_icp_gn_match(lisreg_ctx* ctx, int slot, const void* source, int n, int stride_bytes, int fmt,
+                         unsigned max_iterations, float max_correspond_distance, const float predict_pose[16],
+                         lisreg_icpgn_result* result, void* transformed_out);
+
 /* ---- helpers that mirror src/core/common.cpp ------------------------------------------------------------- */
 /* trans2Affine3f (common.cpp:54-57): row-major 3x4 [R|t]. */
 void lisreg_pose_to_matrix(const float T[6], float M[12]);

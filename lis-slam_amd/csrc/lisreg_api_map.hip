@@ -318,4 +318,65 @@ int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int str
     return LISREG_OK;
 }
 
+int lisreg_icp_gn_match(lisreg_ctx* c, int slot, const void* source, int n, int stride, int fmt, unsigned max_iterations,
+                        float max_correspond_distance, const float predict_pose[16], lisreg_icpgn_result* res, void* transformed_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+        return ctx_fail(c, LISREG_ERR_NO_TARGET, "icp_gn_match: no map index in this slot (SetTargetCloud)");
+    int rc = check_cloud(c, source, n, stride, fmt, "icp_gn_match");
+    if (rc) return rc;
+    if (!predict_pose || !res) return bad(c, "icp_gn_match: NULL predict_pose / result");
+    if (max_iterations > 100000u) return bad(c, "icp_gn_match: max_iterations out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const MapIndex& m = c->maps[(size_t)slot];
+    const float4* src = nullptr;
+    rc = stage_cloud(c, source, n, stride, fmt, &src);
+    if (rc) return rc;
+    IcpState h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.F, predict_pose, sizeof h.F);
+    const int nb = icp_blocks(n);
+    HIPCHK(c, c->icp_state.ensure(sizeof(IcpState)));
+    HIPCHK(c, c->icp_partials.ensure(sizeof(double) * 22 * (size_t)std::max(nb, 1)));
+    HIPCHK(c, hipMemcpyAsync(c->icp_state.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+    IcpState* sd = c->icp_state.as<IcpState>();
+    // registration.cpp:50 compares the SQUARED distance with max_correspond_distance itself
+    const float cap2 = max_correspond_distance >= 0.f ? std::min(max_correspond_distance, 3.0e38f) : -1.f;
+    for (unsigned it = 0; it < max_iterations; ++it) {
+        if (cap2 >= 0.f) launch_icpgn_iteration(src, n, m.g_dev.as<GridIndex>(), sd, cap2, c->icp_partials.as<double>(), st);
+        if ((it & 63u) == 63u) HIPCHK(c, hipStreamSynchronize(st));      // keep the queue bounded for long runs
+    }
+    HIPCHK(c, hipGetLastError());
+    launch_icp_fitness(src, n, m.g_dev.as<GridIndex>(), sd, c->icp_partials.as<double>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&h, sd, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    memcpy(res->final_transform, h.F, sizeof h.F);
+    res->steps_applied = h.iters; res->n_corr_last = h.n_corr; res->reserved = 0;
+    res->fitness = h.fit_n > 0 ? (float)(h.fit_sum / (double)h.fit_n) : FLT_MAX;
+    if (transformed_out && n > 0) {
+        HIPCHK(c, c->vox_M.ensure(sizeof(float) * 12));
+        HIPCHK(c, hipMemcpyAsync(c->vox_M.p, h.F, sizeof(float) * 12, hipMemcpyHostToDevice, st));
+        if (fmt == LISREG_FMT_DEVICE) {
+            launch_transform_cloud(src, n, c->vox_M.as<float>(), static_cast<float4*>(transformed_out), st);
+            HIPCHK(c, hipStreamSynchronize(st));
+        } else {
+            HIPCHK(c, c->mp_out.ensure(sizeof(float4) * (size_t)n));
+            launch_transform_cloud(src, n, c->vox_M.as<float>(), c->mp_out.as<float4>(), st);
+            std::vector<float4> hp((size_t)n);
+            HIPCHK(c, hipMemcpyAsync(hp.data(), c->mp_out.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            const unsigned char* b = static_cast<const unsigned char*>(source);
+            unsigned char* o = static_cast<unsigned char*>(transformed_out);
+            for (int i = 0; i < n; ++i) {
+                if (o != b) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)i * (size_t)stride, (size_t)stride);
+                memcpy(o + (size_t)i * (size_t)stride, &hp[(size_t)i], 12);
+            }
+        }
+    }
+    return LISREG_OK;
+}
+
 }  // extern "C"

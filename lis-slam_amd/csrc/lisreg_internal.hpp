@@ -178,6 +178,9 @@ int  icp_blocks(int n);
 // (partials: icp_blocks(n) * 17 doubles), then transform estimate + convergence (st->Tm = the new transformation_)
 void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
                           int max_iters, double eps_t, double eps_mse, hipStream_t stream);
+// one OptimizedICPGN iteration (partials: icp_blocks(n) * 22 doubles); st->F is T, st->iters counts the applied steps
+void launch_icpgn_iteration(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
+                            hipStream_t stream);
 void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, double* partials, hipStream_t stream);
 void launch_bbx_flags(const float4* pts, int n, const double b[6], int delete_box, int* flag, hipStream_t st);
 // stable compaction: idx_out[0..count) = indices i with flag[i] != 0, ascending; pos [n+1]

@@ -360,6 +360,151 @@ __global__ __launch_bounds__(256) void k_icp_fit_reduce(const double* __restrict
     if (threadIdx.x == 0) { st->fit_sum = red[0][0]; st->fit_n = (int)red[0][1]; }
 }
 
+// ---- §8 f-4, second half: OptimizedICPGN (src/core/registration.cpp:19-115) ------------------------------------------------
+// J = [I | A] with A = -R hat(p), so J^T J = [[n I, sum A], [sum A^T, sum A^T A]] and J^T e = [sum e; sum A^T e]:
+// count, sum e (3), sum A (9), sum A^T A (6 unique), sum A^T e (3) = 22 sums instead of 21 + 6 + 1 generic ones.
+constexpr int kGnAcc = 22;
+
+template <int Q>
+__global__ __launch_bounds__(256) void k_icpgn_assoc(const float4* __restrict__ src, int n, const GridIndex* __restrict__ gp,
+                                                     const IcpState* __restrict__ stp, float cap2, double* __restrict__ partials)
+{
+    __shared__ double red[4][kGnAcc];
+    const int i = (blockIdx.x * 256 + threadIdx.x) / Q;
+    const bool lead = (threadIdx.x & (Q - 1)) == 0;
+    double acc[kGnAcc];
+#pragma unroll
+    for (int k = 0; k < kGnAcc; ++k) acc[k] = 0.0;
+    if (i < n) {
+        const GridIndex g = *gp;
+        const float4 p = src[i];
+        const float* F = stp->F;
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {                      // pcl::isFinite(origin_point), :37
+            float tx, ty, tz, d2;
+            apply4(F, p.x, p.y, p.z, tx, ty, tz);
+            const int bi = nn1_search<Q>(tx, ty, tz, g, cap2, &d2);
+            if (bi >= 0 && lead) {
+                const float4 q = g.pts[bi];
+                const float e[3] = { tx - q.x, ty - q.y, tz - q.z };
+                float A[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float R0 = F[4 * r], R1 = F[4 * r + 1], R2 = F[4 * r + 2];
+                    A[r][0] = -(R1 * p.z - R2 * p.y);
+                    A[r][1] = -(R2 * p.x - R0 * p.z);
+                    A[r][2] = -(R0 * p.y - R1 * p.x);
+                }
+                acc[0] = 1.0;
+                acc[1] = e[0]; acc[2] = e[1]; acc[3] = e[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[4 + 3 * r + c] = A[r][c];
+                int k = 13;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = a; b < 3; ++b) acc[k++] = (A[0][a] * A[0][b] + A[1][a] * A[1][b]) + A[2][a] * A[2][b];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[19 + a] = (A[0][a] * e[0] + A[1][a] * e[1]) + A[2][a] * e[2];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kGnAcc; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kGnAcc)
+        partials[(size_t)blockIdx.x * kGnAcc + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Hessian.determinant() == 0 -> skip; delta = Hessian.inverse() * B (Eigen PartialPivLU in float); t += delta[0:3];
+// R = R * Sophus::SO3f::exp(delta[3:6]).matrix()  (src/sophus/so3.hpp:279-312, small-angle branch as written there)
+__global__ __launch_bounds__(1024) void k_icpgn_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st)
+{
+    __shared__ double red[32][32];
+    __shared__ double tot[kGnAcc];
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (k < kGnAcc) {
+        int b = grp;
+        for (; b + 96 < n_blocks; b += 128) {
+            v0 += partials[(size_t)b * kGnAcc + k];        v1 += partials[(size_t)(b + 32) * kGnAcc + k];
+            v2 += partials[(size_t)(b + 64) * kGnAcc + k]; v3 += partials[(size_t)(b + 96) * kGnAcc + k];
+        }
+        for (; b < n_blocks; b += 32) v0 += partials[(size_t)b * kGnAcc + k];
+    }
+    red[grp][k] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (threadIdx.x < kGnAcc) {
+        double s = 0;
+        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st->n_corr = (int)tot[0];
+    float H[36], B[6];
+    for (int i = 0; i < 36; ++i) H[i] = 0.f;
+    for (int r = 0; r < 3; ++r) {
+        H[6 * r + r] = (float)tot[0];
+        B[r] = (float)(-tot[1 + r]);
+        B[3 + r] = (float)(-tot[19 + r]);
+        for (int c = 0; c < 3; ++c) { const float a = (float)tot[4 + 3 * r + c]; H[6 * r + 3 + c] = a; H[6 * (3 + c) + r] = a; }
+    }
+    { int q = 13; for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) { const float h = (float)tot[q++]; H[6 * (3 + a) + 3 + b] = h; H[6 * (3 + b) + 3 + a] = h; } }
+    // PartialPivLU
+    float A[36]; int perm[6]; float sign = 1.f;
+    for (int i = 0; i < 36; ++i) A[i] = H[i];
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    for (int c = 0; c < 6; ++c) {
+        int piv = c; float big = fabsf(A[6 * c + c]);
+        for (int r = c + 1; r < 6; ++r) if (fabsf(A[6 * r + c]) > big) { big = fabsf(A[6 * r + c]); piv = r; }
+        if (piv != c) {
+            for (int j = 0; j < 6; ++j) { const float t = A[6 * c + j]; A[6 * c + j] = A[6 * piv + j]; A[6 * piv + j] = t; }
+            const int t = perm[c]; perm[c] = perm[piv]; perm[piv] = t; sign = -sign;
+        }
+        if (A[6 * c + c] != 0.f)
+            for (int r = c + 1; r < 6; ++r) {
+                A[6 * r + c] /= A[6 * c + c];
+                for (int j = c + 1; j < 6; ++j) A[6 * r + j] -= A[6 * r + c] * A[6 * c + j];
+            }
+    }
+    float det = sign;
+    for (int c = 0; c < 6; ++c) det *= A[6 * c + c];
+    if (det == 0.f) return;                                               // :74-76
+    float inv[36];
+    for (int col = 0; col < 6; ++col) {
+        float y[6];
+        for (int r = 0; r < 6; ++r) { float s = (perm[r] == col) ? 1.f : 0.f; for (int c = 0; c < r; ++c) s -= A[6 * r + c] * y[c]; y[r] = s; }
+        for (int r = 5; r >= 0; --r) { float s = y[r]; for (int c = r + 1; c < 6; ++c) s -= A[6 * r + c] * inv[6 * c + col]; inv[6 * r + col] = s / A[6 * r + r]; }
+    }
+    float dx[6];
+    for (int r = 0; r < 6; ++r) { float s = 0.f; for (int c = 0; c < 6; ++c) s += inv[6 * r + c] * B[c]; dx[r] = s; }
+    float* T = st->F;
+    T[3] += dx[0]; T[7] += dx[1]; T[11] += dx[2];
+    const float wx = dx[3], wy = dx[4], wz = dx[5];
+    const float theta_sq = (wx * wx + wy * wy) + wz * wz;
+    const float theta = sqrtf(theta_sq), half = 0.5f * theta;
+    float imag, real;
+    if (theta < 1e-5f) {
+        const float po4 = theta_sq * theta_sq;
+        imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * po4;
+        real = 1.f - 0.5f * theta_sq + (float)(1.0 / 384.0) * po4;
+    } else { imag = sinf(half) / theta; real = cosf(half); }
+    const float qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+    const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    const float E[9] = { 1.f - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.f - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.f - (txx + tyy) };
+    float Rn[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rn[3 * r + c] = (T[4 * r] * E[c] + T[4 * r + 1] * E[3 + c]) + T[4 * r + 2] * E[6 + c];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T[4 * r + c] = Rn[3 * r + c];
+    st->iters += 1;
+}
+
 }  // namespace
 
 // lanes per query: a scan-sized query set (~1e5) fills the chip only when each query is spread over several lanes
@@ -384,6 +529,17 @@ void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpStat
                              (k_icp_assoc<4><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
                              (k_icp_assoc<8><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)));
     k_icp_solve<<<1, 1024, 0, stream>>>(partials, nb, st, max_iters, eps_t, eps_mse);
+}
+
+void launch_icpgn_iteration(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
+                            hipStream_t stream)
+{
+    const int nb = icp_blocks(n), q = icp_lanes(n);
+    if (nb > 0)
+        LISREG_DISPATCH_Q(q, (k_icpgn_assoc<1><<<nb, 256, 0, stream>>>(src, n, grid_dev, st, cap2, partials)),
+                             (k_icpgn_assoc<4><<<nb, 256, 0, stream>>>(src, n, grid_dev, st, cap2, partials)),
+                             (k_icpgn_assoc<8><<<nb, 256, 0, stream>>>(src, n, grid_dev, st, cap2, partials)));
+    k_icpgn_solve<<<1, 1024, 0, stream>>>(partials, nb, st);
 }
 
 void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, double* partials, hipStream_t stream)

@@ -85,6 +85,20 @@ int main()
     std::printf("ICP: converged=%d iterations=%d fitness=%g t=[%g %g %g] yaw=%g\n", (int)icp.hasConverged(), icp.nr_iterations(),
                 icp.getFitnessScore(), Fm[3], Fm[7], Fm[11], std::atan2(Fm[4], Fm[0]));
     ok = ok && icp.hasConverged() && std::fabs(Fm[3] - tx) < 5e-2f && std::fabs(Fm[7] - ty) < 5e-2f && std::fabs(std::atan2(Fm[4], Fm[0]) - yaw) < 5e-3f;
+    // OptimizedICPGN (registration.cpp:19-115) on the same pair
+    OptimizedICPGN<PointType> gn(reg.handle(), 2, 15, 4.0f);
+    gn.SetTargetCloud(mapSurf);
+    const float predict[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    float result_pose[16];
+    PointCloud<PointType> gnOut;
+    gn.Match(surf, predict, gnOut, result_pose);
+    std::printf("OptimizedICPGN: fitness=%g t=[%g %g %g] yaw=%g\n", gn.GetFitnessScore(), result_pose[3], result_pose[7], result_pose[11],
+                std::atan2(result_pose[4], result_pose[0]));
+    ok = ok && std::fabs(result_pose[3] - tx) < 5e-2f && std::fabs(result_pose[7] - ty) < 5e-2f && std::fabs(std::atan2(result_pose[4], result_pose[0]) - yaw) < 5e-3f;
+    bounds_t bMoved; centerpoint_t cMap, cMoved;
+    SubMapManager<PointType>::get_bound_cpt(bMap, cMap);
+    SubMapManager<PointType>::transform_bbx(bMap, cMap, bMoved, cMoved, result_pose);       // rows 0..2 of the 4x4 = [R|t]
+    ok = ok && std::fabs((bMoved.max_x - bMoved.min_x) - (bMap.max_x - bMap.min_x)) < 1e-9;
     std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
     return ok ? 0 : 1;
 }

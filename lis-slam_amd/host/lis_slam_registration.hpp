@@ -214,6 +214,7 @@ private:
 
 // ---- the compute steps of SubMapManager (src/include/subMap.h) ---------------------------------------------
 struct bounds_t { double min_x, min_y, min_z, max_x, max_y, max_z; };     // src/include/subMap.h:32-39
+struct centerpoint_t { double x, y, z; };                                  // src/include/subMap.h:11-16
 
 // pcl::search::KdTree<PointT> as SubMapManager uses it (setInputCloud once, k = 1 queries): an HBM-resident grid index.
 template <class PointT>
@@ -246,6 +247,17 @@ public:
     static void get_intersection_bbx(const bounds_t& a, const bounds_t& b, bounds_t& out, float pad = 2.0f) {
         out.min_x = std::max(a.min_x, b.min_x) - pad; out.min_y = std::max(a.min_y, b.min_y) - pad; out.min_z = std::max(a.min_z, b.min_z) - pad;
         out.max_x = std::min(a.max_x, b.max_x) + pad; out.max_y = std::min(a.max_y, b.max_y) + pad; out.max_z = std::min(a.max_z, b.max_z) + pad;
+    }
+    // subMap.h:123-128 get_bound_cpt and :214-228 transform_bbx (host arithmetic; transCur = row-major 3x4 [R|t] in float, the
+    // products are float x double like Eigen::Affine3f(i, j) * double in the reference)
+    static void get_bound_cpt(const bounds_t& b, centerpoint_t& cp) { cp = { 0.5 * (b.min_x + b.max_x), 0.5 * (b.min_y + b.max_y), 0.5 * (b.min_z + b.max_z) }; }
+    static void transform_bbx(const bounds_t& bound_in, const centerpoint_t& cp_in, bounds_t& bound_out, centerpoint_t& cp_out, const float transCur[12]) {
+        const bounds_t b = bound_in; const centerpoint_t c = cp_in;
+        cp_out.x = transCur[0] * c.x + transCur[1] * c.y + transCur[2] * c.z + transCur[3];
+        cp_out.y = transCur[4] * c.x + transCur[5] * c.y + transCur[6] * c.z + transCur[7];
+        cp_out.z = transCur[8] * c.x + transCur[9] * c.y + transCur[10] * c.z + transCur[11];
+        bound_out.max_x = b.max_x - c.x + cp_out.x; bound_out.max_y = b.max_y - c.y + cp_out.y; bound_out.max_z = b.max_z - c.z + cp_out.z;
+        bound_out.min_x = b.min_x - c.x + cp_out.x; bound_out.min_y = b.min_y - c.y + cp_out.y; bound_out.min_z = b.min_z - c.z + cp_out.z;
     }
     // subMap.h:1124-1152
     bool bbx_filter(PointCloud<PointT>& cloud_in_out, const bounds_t& bbx, bool delete_box = false) {
@@ -304,6 +316,31 @@ private:
     const PointCloud<PointT>* source_ = nullptr;
     lisreg_icp_params prm_{};
     lisreg_icp_result res_{};
+};
+
+// OptimizedICPGN (src/include/registration.h:44-70, src/core/registration.cpp:8-115): same constructor and calls
+template <class PointT>
+class OptimizedICPGN {
+public:
+    OptimizedICPGN(lisreg_ctx* ctx, int slot, unsigned max_iterations, float max_correspond_distance)
+        : tree_(ctx, slot), max_iterations_(max_iterations), max_correspond_distance_(max_correspond_distance) {}
+    bool SetTargetCloud(const PointCloud<PointT>& target_cloud) { tree_.setInputCloud(target_cloud); return true; }
+    bool Match(const PointCloud<PointT>& source_cloud, const float predict_pose[16], PointCloud<PointT>& transformed_source_cloud, float result_pose[16]) {
+        transformed_source_cloud.points.resize(source_cloud.size());
+        int rc = lisreg_icp_gn_match(tree_.ctx(), tree_.slot(), source_cloud.points.data(), (int)source_cloud.size(), (int)sizeof(PointT),
+                                     SearchTree<PointT>::fmt(), max_iterations_, max_correspond_distance_, predict_pose, &res_,
+                                     transformed_source_cloud.points.data());
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(tree_.ctx()));
+        std::memcpy(result_pose, res_.final_transform, sizeof res_.final_transform);
+        return true;
+    }
+    float GetFitnessScore() const { return res_.fitness; }
+    bool HasConverged() const { return true; }                      // registration.cpp:110-113
+private:
+    SearchTree<PointT> tree_;
+    unsigned max_iterations_;
+    float max_correspond_distance_;
+    lisreg_icpgn_result res_{};
 };
 
 }  // namespace lis_slam

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
     "lisreg_extract_features", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
-    "lisreg_icp_default_params", "lisreg_icp_align",
+    "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_gn_match",
 ]
 
 
@@ -54,6 +54,11 @@ class IcpResult(C.Structure):
     def as_dict(self):
         return dict(T=np.array(list(self.final_transform), np.float32).reshape(4, 4), converged=bool(self.converged),
                     iters=self.iters, state=self.state, n_corr_last=self.n_corr_last, fitness=self.fitness, prev_mse=self.prev_mse)
+
+
+class IcpGnResult(C.Structure):
+    _fields_ = [("final_transform", C.c_float * 16), ("steps_applied", C.c_int), ("n_corr_last", C.c_int),
+                ("fitness", C.c_float), ("reserved", C.c_int)]
 
 
 class Params(C.Structure):
@@ -166,6 +171,7 @@ def lib():
         L.lisreg_bbx_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp, C.c_int, vp, ip]
         L.lisreg_cloud_bounds.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp]
         L.lisreg_icp_default_params.argtypes = [C.c_int, C.POINTER(IcpParams)]
+        L.lisreg_icp_gn_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_float, fp, C.POINTER(IcpGnResult), vp]
         L.lisreg_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult), vp]
         _lib = L
     return _lib
@@ -484,6 +490,22 @@ class Context:
         d = res.as_dict()
         if want_aligned:
             d["aligned"] = out
+        return d
+
+    def icp_gn_match(self, slot: int, source: np.ndarray, max_iterations: int, max_correspond_distance: float, predict_pose,
+                     want_transformed: bool = False):
+        """OptimizedICPGN::Match + GetFitnessScore against the map index in `slot`."""
+        source = np.ascontiguousarray(source)
+        res = IcpGnResult()
+        g = np.ascontiguousarray(predict_pose, np.float32).ravel()
+        out = np.zeros_like(source) if want_transformed else None
+        self._chk(self._L.lisreg_icp_gn_match(self._h, slot, _vp(source), len(source), source.dtype.itemsize, _fmt_of(source),
+                                              max_iterations, max_correspond_distance, g.ctypes.data_as(C.POINTER(C.c_float)),
+                                              C.byref(res), _vp(out) if want_transformed else None))
+        d = dict(T=np.array(list(res.final_transform), np.float32).reshape(4, 4), steps_applied=res.steps_applied,
+                 n_corr_last=res.n_corr_last, fitness=res.fitness)
+        if want_transformed:
+            d["transformed"] = out
         return d
 
     def icp_align_device(self, slot: int, src_ptr: int, n: int, params: "IcpParams", guess=None, out_ptr: int = 0):

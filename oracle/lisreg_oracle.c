@@ -1286,3 +1286,129 @@ void orc_icp_align(const void* target, int n_t, const void* source, int n_s, int
     if (tree) orc_kdtree_free(tree);
     free(txyz); free(sxyz); free(cur); free(ca); free(cb);
 }
+
+/* ---- §8 f-4 (second half): OptimizedICPGN (src/core/registration.cpp:19-115; never called in the reference) ------ */
+/* 6x6 float LU with partial pivoting (Eigen::PartialPivLU, which Matrix<float,6,6>::determinant() / inverse() use):
+ * returns the determinant; inv (may be NULL) = LU.solve(Identity). */
+static float lu6_det_inv(const float Hin[36], float inv[36])
+{
+    float A[36]; int perm[6]; float sign = 1.f;
+    memcpy(A, Hin, sizeof A);
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k; float big = fabsf(A[6 * k + k]);
+        for (int r = k + 1; r < 6; ++r) if (fabsf(A[6 * r + k]) > big) { big = fabsf(A[6 * r + k]); piv = r; }
+        if (piv != k) {
+            for (int c = 0; c < 6; ++c) { float t = A[6 * k + c]; A[6 * k + c] = A[6 * piv + c]; A[6 * piv + c] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t; sign = -sign;
+        }
+        if (A[6 * k + k] != 0.f)
+            for (int r = k + 1; r < 6; ++r) {
+                A[6 * r + k] /= A[6 * k + k];
+                for (int c = k + 1; c < 6; ++c) A[6 * r + c] -= A[6 * r + k] * A[6 * k + c];
+            }
+    }
+    float det = sign;
+    for (int k = 0; k < 6; ++k) det *= A[6 * k + k];
+    if (inv && det != 0.f)
+        for (int col = 0; col < 6; ++col) {
+            float y[6];
+            for (int r = 0; r < 6; ++r) { float s = (perm[r] == col) ? 1.f : 0.f; for (int c = 0; c < r; ++c) s -= A[6 * r + c] * y[c]; y[r] = s; }
+            for (int r = 5; r >= 0; --r) { float s = y[r]; for (int c = r + 1; c < 6; ++c) s -= A[6 * r + c] * inv[6 * c + col]; inv[6 * r + col] = s / A[6 * r + r]; }
+        }
+    return det;
+}
+
+/* Sophus::SO3f::exp(omega).matrix() — src/sophus/so3.hpp:279-312 (this vendored version's small-angle real_factor uses
+ * 0.5 * theta^2 where the series has 1/8; restated as written), Constants<float>::epsilon = 1e-5 (sophus_common.hpp:146),
+ * then Eigen's Quaternion::toRotationMatrix. */
+static void so3_exp_matrix(const float w[3], float E[9])
+{
+    float theta_sq = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+    float theta = sqrtf(theta_sq), half = 0.5f * theta, imag, real;
+    if (theta < 1e-5f) {
+        float po4 = theta_sq * theta_sq;
+        imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * po4;
+        real = 1.f - 0.5f * theta_sq + (float)(1.0 / 384.0) * po4;
+    } else { imag = sinf(half) / theta; real = cosf(half); }
+    float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+    float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+    float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    E[0] = 1.f - (tyy + tzz); E[1] = txy - twz; E[2] = txz + twy;
+    E[3] = txy + twz; E[4] = 1.f - (txx + tzz); E[5] = tyz - twx;
+    E[6] = txz - twy; E[7] = tyz + twx; E[8] = 1.f - (txx + tyy);
+}
+
+/* OptimizedICPGN::Match + GetFitnessScore.  Quirk kept: the SQUARED k = 1 distance is compared with the un-squared
+ * max_correspond_distance (:50).  No convergence test: max_iterations Gauss-Newton steps, skipping a step whose Hessian has
+ * determinant exactly 0.  The reference accumulates Hessian / B / the fitness score in float in input order; as for
+ * orc_umeyama, float_sums = 1 restates that and float_sums = 0 (the GPU's parity target) accumulates them in double. */
+void orc_icp_gn(const void* target, int n_t, const void* source, int n_s, int stride, unsigned max_iterations,
+                float max_correspond_distance, const float predict_pose[16], int float_sums, lisreg_icpgn_result* res)
+{
+    float* txyz = (float*)malloc(sizeof(float) * 3 * (size_t)(n_t > 0 ? n_t : 1));
+    float* sxyz = (float*)malloc(sizeof(float) * 3 * (size_t)(n_s > 0 ? n_s : 1));
+    unpack_cloud(target, n_t, stride, LISREG_FMT_XYZI, txyz, NULL);
+    unpack_cloud(source, n_s, stride, LISREG_FMT_XYZI, sxyz, NULL);
+    orc_kdtree* tree = n_t > 0 ? orc_kdtree_build(txyz, n_t, 15) : NULL;
+    float T[16];
+    memcpy(T, predict_pose, sizeof T);
+    int n_corr = 0, applied = 0;
+    for (unsigned it = 0; it < max_iterations; ++it) {
+        double Hd[36] = { 0 }, Bd[6] = { 0 };
+        float Hf[36] = { 0 }, Bf[6] = { 0 };
+        n_corr = 0;
+        for (int j = 0; j < n_s && tree; ++j) {
+            const float* p = sxyz + 3 * j;
+            if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+            float tp[3]; int id; float d2;
+            mat4_apply(T, p, tp);
+            orc_kdtree_knn(tree, tp, 1, &id, &d2);
+            if (d2 > max_correspond_distance) continue;
+            const float* q = txyz + 3 * id;
+            float e[3] = { tp[0] - q[0], tp[1] - q[1], tp[2] - q[2] };
+            float J[18];                                       /* 3 x 6: [I | -R hat(p)] */
+            for (int r = 0; r < 3; ++r) {
+                const float R0 = T[4 * r], R1 = T[4 * r + 1], R2 = T[4 * r + 2];
+                J[6 * r + 0] = r == 0; J[6 * r + 1] = r == 1; J[6 * r + 2] = r == 2;
+                J[6 * r + 3] = -(R1 * p[2] - R2 * p[1]);
+                J[6 * r + 4] = -(R2 * p[0] - R0 * p[2]);
+                J[6 * r + 5] = -(R0 * p[1] - R1 * p[0]);
+            }
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) {
+                    float h = (J[a] * J[b] + J[6 + a] * J[6 + b]) + J[12 + a] * J[12 + b];
+                    if (float_sums) Hf[6 * a + b] += h; else Hd[6 * a + b] += h;
+                }
+                float g = -((J[a] * e[0] + J[6 + a] * e[1]) + J[12 + a] * e[2]);
+                if (float_sums) Bf[a] += g; else Bd[a] += g;
+            }
+            ++n_corr;
+        }
+        if (!float_sums) { for (int k = 0; k < 36; ++k) Hf[k] = (float)Hd[k]; for (int k = 0; k < 6; ++k) Bf[k] = (float)Bd[k]; }
+        float inv[36];
+        if (lu6_det_inv(Hf, inv) == 0.f) continue;
+        float dx[6];
+        for (int r = 0; r < 6; ++r) { float s = 0.f; for (int c = 0; c < 6; ++c) s += inv[6 * r + c] * Bf[c]; dx[r] = s; }
+        T[3] += dx[0]; T[7] += dx[1]; T[11] += dx[2];
+        float E[9], Rn[9];
+        so3_exp_matrix(dx + 3, E);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+            Rn[3 * r + c] = (T[4 * r] * E[c] + T[4 * r + 1] * E[3 + c]) + T[4 * r + 2] * E[6 + c];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T[4 * r + c] = Rn[3 * r + c];
+        ++applied;
+    }
+    double fd = 0; float ff = 0.f; int nr = 0;
+    for (int j = 0; j < n_s && tree; ++j) {
+        float tp[3]; int id; float d2;
+        mat4_apply(T, sxyz + 3 * j, tp);
+        orc_kdtree_knn(tree, tp, 1, &id, &d2);
+        if (float_sums) ff += d2; else fd += d2;
+        ++nr;
+    }
+    memcpy(res->final_transform, T, sizeof T);
+    res->n_corr_last = n_corr; res->steps_applied = applied;
+    res->fitness = nr > 0 ? (float_sums ? ff / (float)nr : (float)(fd / nr)) : FLT_MAX;
+    if (tree) orc_kdtree_free(tree);
+    free(txyz); free(sxyz);
+}

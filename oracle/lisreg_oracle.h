@@ -123,6 +123,10 @@ void orc_umeyama(const float* src_xyz, const float* dst_xyz, int n, int float_su
 void orc_icp_align(const void* target, int n_t, const void* source, int n_s, int stride_bytes, const lisreg_icp_params* prm,
                    const float* guess /* 16 or NULL */, int float_sums, lisreg_icp_result* res);
 
+/* OptimizedICPGN::Match + GetFitnessScore (src/core/registration.cpp:19-115; Sophus SO3::exp from src/sophus/so3.hpp:279-312) */
+void orc_icp_gn(const void* target, int n_t, const void* source, int n_s, int stride_bytes, unsigned max_iterations,
+                float max_correspond_distance, const float predict_pose[16], int float_sums, lisreg_icpgn_result* res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,11 @@ class IcpResult(C.Structure):
                 ("n_corr_last", C.c_int), ("fitness", C.c_double), ("prev_mse", C.c_double)]
 
 
+class IcpGnResult(C.Structure):
+    _fields_ = [("final_transform", C.c_float * 16), ("steps_applied", C.c_int), ("n_corr_last", C.c_int),
+                ("fitness", C.c_float), ("reserved", C.c_int)]
+
+
 class FeatureParams(C.Structure):
     _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("downsample_rate", C.c_int), ("min_range", C.c_float),
                 ("max_range", C.c_float), ("edge_threshold", C.c_float), ("surf_threshold", C.c_float)]
@@ -126,6 +131,8 @@ def lib():
         L.orc_umeyama.restype = None
         L.orc_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.c_int, C.POINTER(IcpResult)]
         L.orc_icp_align.restype = None
+        L.orc_icp_gn.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_uint, C.c_float, fp, C.c_int, C.POINTER(IcpGnResult)]
+        L.orc_icp_gn.restype = None
         _lib = L
     return _lib
 
@@ -285,3 +292,15 @@ def icp_align(target, source, params: "IcpParams", guess=None, float_sums=False)
                         C.byref(res))
     return dict(T=np.array(list(res.final_transform), np.float32).reshape(4, 4), converged=bool(res.converged), iters=res.iters,
                 state=res.state, n_corr_last=res.n_corr_last, fitness=res.fitness, prev_mse=res.prev_mse)
+
+
+def icp_gn_match(target, source, max_iterations, max_correspond_distance, predict_pose, float_sums=False):
+    """OptimizedICPGN::Match + GetFitnessScore (registration.cpp:19-115)"""
+    target = np.ascontiguousarray(target); source = np.ascontiguousarray(source)
+    assert target.dtype == source.dtype
+    res = IcpGnResult()
+    g = np.ascontiguousarray(predict_pose, np.float32).ravel()
+    lib().orc_icp_gn(_vp(target), len(target), _vp(source), len(source), source.dtype.itemsize, max_iterations,
+                     max_correspond_distance, _fp(g), 1 if float_sums else 0, C.byref(res))
+    return dict(T=np.array(list(res.final_transform), np.float32).reshape(4, 4), steps_applied=res.steps_applied,
+                n_corr_last=res.n_corr_last, fitness=res.fitness)

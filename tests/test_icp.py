@@ -217,3 +217,99 @@ def test_hip_icp_edges_guess_and_device(oracle, gpu_ctx):
     assert np.array_equal(rd["T"], rh["T"]) and rd["iters"] == rh["iters"] and rd["fitness"] == rh["fitness"]
     got = lisreg.device_to_host(dout.ptr, rs.shape, np.float32)
     assert np.array_equal(got[:, :3], synth.pcl_xyz(rh["aligned"])) and np.array_equal(got[:, 3].view(np.uint32), rs[:, 3].view(np.uint32))
+
+
+# ---------------------------------------------------------------- OptimizedICPGN (registration.cpp:19-115)
+def _numpy_icp_gn(tgt, src, iters, max_corr, T0):
+    """all-double Gauss-Newton point-to-point ICP with the reference's update rule (t += d[:3], R = R exp(d[3:]))"""
+    from lisreg import synth
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+    t = synth.pcl_xyz(tgt).astype(np.float64); p = synth.pcl_xyz(src).astype(np.float64)
+    tree = cKDTree(t)
+    T = np.array(T0, np.float64)
+    for _ in range(iters):
+        tp = p @ T[:3, :3].T + T[:3, 3]
+        d, idx = tree.query(tp, k=1)
+        ok = d * d <= max_corr                                     # squared distance vs un-squared threshold, as the reference
+        e = (tp - t[idx])[ok]; po = p[ok]
+        hat = np.zeros((len(po), 3, 3))
+        hat[:, 0, 1], hat[:, 0, 2], hat[:, 1, 0], hat[:, 1, 2], hat[:, 2, 0], hat[:, 2, 1] = -po[:, 2], po[:, 1], po[:, 2], -po[:, 0], -po[:, 1], po[:, 0]
+        A = -np.einsum("ij,njk->nik", T[:3, :3], hat)
+        J = np.concatenate([np.broadcast_to(np.eye(3), A.shape), A], 2)
+        H = np.einsum("nra,nrb->ab", J, J); B = -np.einsum("nra,nr->a", J, e)
+        if np.linalg.det(H) == 0:
+            continue
+        dx = np.linalg.solve(H, B)
+        T[:3, 3] += dx[:3]
+        T[:3, :3] = T[:3, :3] @ Rotation.from_rotvec(dx[3:]).as_matrix()
+    tp = p @ T[:3, :3].T + T[:3, 3]
+    d, _ = tree.query(tp, k=1)
+    return T, float((d * d).mean())
+
+
+@pytest.mark.parametrize("seed,trans,rot,iters,max_corr", [(61, 0.5, 2.0, 12, 4.0), (62, 1.0, 4.0, 20, 25.0)])
+def test_oracle_icp_gn_matches_numpy(oracle, seed, trans, rot, iters, max_corr):
+    tgt, src, M_fix = _case(seed, n_map=15000, trans=trans, rot_deg=rot, hw=(16, 450))
+    T0 = np.eye(4, dtype=f32)
+    r = oracle.icp_gn_match(tgt, src, iters, max_corr, T0)
+    T, fit = _numpy_icp_gn(tgt, src, iters, max_corr, T0)
+    assert r["steps_applied"] == iters
+    dr, dt = _pose_diff(r["T"], T)
+    assert dr < 2e-4 and dt < 2e-3, (dr, dt)          # float 6x6 inverse of a cond ~1e5 Hessian (as the reference) vs an all-double loop
+    assert abs(r["fitness"] - fit) < 5e-3 * fit
+    dr, dt = _pose_diff(r["T"], M_fix)
+    assert dr < 0.01 and dt < 0.2                     # sanity only: point-to-point on differently sampled clouds has a biased optimum
+    rf = oracle.icp_gn_match(tgt, src, iters, max_corr, T0, float_sums=True)          # the reference's float running sums
+    dr, dt = _pose_diff(rf["T"], r["T"])
+    assert dr < 1e-3 and dt < 1e-2
+
+
+def test_oracle_icp_gn_edges(oracle):
+    tgt, src, _ = _case(63, n_map=5000, hw=(8, 240))
+    T0 = np.eye(4, dtype=f32)
+    r = oracle.icp_gn_match(tgt, src, 0, 4.0, T0)
+    assert r["steps_applied"] == 0 and np.array_equal(r["T"], T0) and r["fitness"] > 0
+    far = src.copy(); far["x"] += 1000.0
+    r = oracle.icp_gn_match(tgt, far, 5, 4.0, T0)                                      # no correspondences: det(H) == 0, T untouched
+    assert r["steps_applied"] == 0 and r["n_corr_last"] == 0 and np.array_equal(r["T"], T0)
+    bad = src.copy(); bad["x"][::7] = np.nan                                             # pcl::isFinite filter
+    r1, r2 = oracle.icp_gn_match(tgt, bad, 3, 4.0, T0), oracle.icp_gn_match(tgt, np.delete(src, np.s_[::7]), 3, 4.0, T0)
+    assert np.array_equal(r1["T"], r2["T"]) and r1["n_corr_last"] == r2["n_corr_last"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,trans,rot,iters,max_corr,n_map", [(71, 0.5, 2.0, 12, 4.0, 40000), (72, 1.0, 4.0, 20, 25.0, 120000)])
+def test_hip_icp_gn_matches_oracle(oracle, gpu_ctx, seed, trans, rot, iters, max_corr, n_map):
+    tgt, src, _ = _case(seed, n_map=n_map, trans=trans, rot_deg=rot)
+    gpu_ctx.map_index_set(10, tgt)
+    from lisreg import synth
+    T0 = synth.pose_matrix([0.0, 0.0, 0.01, 0.05, -0.05, 0.0]).astype(f32)
+    ro = oracle.icp_gn_match(tgt, src, iters, max_corr, T0)
+    rg = gpu_ctx.icp_gn_match(10, src, iters, max_corr, T0, want_transformed=True)
+    assert rg["steps_applied"] == ro["steps_applied"] == iters
+    dr, dt = _pose_diff(rg["T"], ro["T"])
+    assert dr < 1e-3 and dt < 1e-3, (dr, dt)
+    assert abs(rg["fitness"] - ro["fitness"]) <= 2e-3 * ro["fitness"]
+    assert abs(rg["n_corr_last"] - ro["n_corr_last"]) <= max(3, ro["n_corr_last"] // 2000)
+    w = synth.pcl_xyz(src).astype(np.float64) @ rg["T"][:3, :3].astype(np.float64).T + rg["T"][:3, 3]
+    assert np.abs(synth.pcl_xyz(rg["transformed"]) - w).max() < 1e-4 and np.array_equal(rg["transformed"]["label"], src["label"])
+
+
+@pytest.mark.gpu
+def test_hip_icp_gn_edges(oracle, gpu_ctx):
+    import lisreg
+    tgt, src, _ = _case(73, n_map=30000, hw=(16, 450))
+    gpu_ctx.map_index_set(10, tgt)
+    T0 = np.eye(4, dtype=f32)
+    r = gpu_ctx.icp_gn_match(10, src, 0, 4.0, T0)
+    assert r["steps_applied"] == 0 and np.array_equal(r["T"], T0)
+    assert abs(r["fitness"] - oracle.icp_gn_match(tgt, src, 0, 4.0, T0)["fitness"]) < 1e-5
+    far = src.copy(); far["x"] += 1000.0
+    r = gpu_ctx.icp_gn_match(10, far, 5, 4.0, T0)
+    assert r["steps_applied"] == 0 and r["n_corr_last"] == 0 and np.array_equal(r["T"], T0)
+    bad = src.copy(); bad["x"][::7] = np.nan
+    r1, r2 = gpu_ctx.icp_gn_match(10, bad, 3, 4.0, T0), gpu_ctx.icp_gn_match(10, np.delete(src, np.s_[::7]), 3, 4.0, T0)
+    assert r1["n_corr_last"] == r2["n_corr_last"] and _pose_diff(r1["T"], r2["T"])[1] < 1e-5
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.icp_gn_match(88, src, 3, 4.0, T0)
