@@ -234,11 +234,30 @@ typedef struct lisreg_feature_out {
 } lisreg_feature_out;
 /* Replaces LaserProcessing::projectPointCloud, cloudExtraction, calculateSmoothness, markOccludedPoints and
  * extractFeatures (src/core/laserProcessing.cpp:467-510, 515-539, 544-563, 568-605, 610-713) for one scan, without the
- * IMU de-skew (deskewPoint returns the point unchanged when no IMU data is available, :404-406).  Output order is the
+ * IMU de-skew (deskewPoint returns the point unchanged when no IMU data is available, :429; lisreg_extract_features_deskew
+ * below applies it).  Output order is the
  * reference's: rings ascending, six sectors per ring, corners in pick order (largest curvature first). */
 int  lisreg_extract_features(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
                              const lisreg_feature_params* params, lisreg_feature_out* out);
 int  lisreg_default_feature_params(lisreg_feature_params* p);
+/* The IMU de-skew inside projectPointCloud (deskewPoint / findRotation, laserProcessing.cpp:368-399, 427-462, called at :501):
+ * every point that wins a range-image pixel is rotated into the frame of the first such point, with the rotation integrated from
+ * the IMU (imuDeskewInfo, :222-266 — a ~50-term prefix sum that stays on the host) interpolated at the point's time stamp.
+ * findPosition returns zeros in the reference (:405-421), so there is no positional part.  Ranges, columns and the feature
+ * selection use the raw points, hence only the coordinates of the five output clouds change. */
+typedef struct lisreg_deskew {
+    int    enabled;               /* deskewFlag == 1 && cloudInfo.imuAvailable (:429) */
+    int    imu_pointer_cur;       /* last valid index of the tables (imuPointerCur after :261) */
+    const double* imu_time;       /* host arrays [imu_pointer_cur + 1] */
+    const double* imu_rot_x;
+    const double* imu_rot_y;
+    const double* imu_rot_z;
+    double time_scan_cur;         /* timeScanCur; a point's time = time_scan_cur + its `time` field */
+    const float* time_device;     /* LISREG_FMT_DEVICE only: per-point `time` (device array [n]); host structs carry it at offset 24 */
+} lisreg_deskew;
+/* lisreg_extract_features with the de-skew applied to the output coordinates; deskew == NULL or enabled == 0 is the plain call */
+int  lisreg_extract_features_deskew(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
+                                    const lisreg_feature_params* params, const lisreg_deskew* deskew, lisreg_feature_out* out);
 
 /* The "semantic mask": SemanticFusionNode::categoryMapping (src/node/semanticFusionNode.cpp:173-189) splits the labelled
  * cloud, preserving order, by UsingLableMap[label] (config/label.yaml:177-196): 10 -> dynamic, 40 -> ground, 50 -> building,

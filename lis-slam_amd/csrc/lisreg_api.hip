@@ -256,7 +256,7 @@ void lisreg_destroy(lisreg_ctx* c)
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
-                       &c->ft_gather };
+                       &c->ft_gather, &c->ft_dsk_tab, &c->ft_dsk_pts, &c->ft_dsk_misc, &c->ft_dsk_time };
     for (auto b : bufs) b->release();
     for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
     DevBuf* mbufs[] = { &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
@@ -889,8 +889,21 @@ int lisreg_default_feature_params(lisreg_feature_params* p)
 int lisreg_extract_features(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const lisreg_feature_params* P,
                             lisreg_feature_out* out)
 {
+    return lisreg_extract_features_deskew(c, cloud, n, stride, fmt, P, nullptr, out);
+}
+
+int lisreg_extract_features_deskew(lisreg_ctx* c, const void* cloud, int n, int stride, int fmt, const lisreg_feature_params* P,
+                                   const lisreg_deskew* dk, lisreg_feature_out* out)
+{
     if (!c) return LISREG_ERR_ARG;
     if (!P || !out || n < 0 || (n > 0 && !cloud)) return fail(c, LISREG_ERR_ARG, "extract_features: bad arguments");
+    const bool deskew = dk && dk->enabled && n > 0;
+    if (deskew) {
+        if (dk->imu_pointer_cur < 1 || dk->imu_pointer_cur > (1 << 20) || !dk->imu_time || !dk->imu_rot_x || !dk->imu_rot_y || !dk->imu_rot_z)
+            return fail(c, LISREG_ERR_ARG, "extract_features: de-skew needs IMU tables with imu_pointer_cur >= 1");
+        if (fmt == LISREG_FMT_DEVICE && !dk->time_device) return fail(c, LISREG_ERR_ARG, "extract_features: de-skew of device records needs time_device");
+        if (fmt == LISREG_FMT_XYZIRT && stride < 28) return fail(c, LISREG_ERR_ARG, "extract_features: de-skew needs the time field (stride >= 28)");
+    }
     if (fmt != LISREG_FMT_XYZIRT && fmt != LISREG_FMT_DEVICE) return fail(c, LISREG_ERR_ARG, "extract_features: fmt must be XYZIRT or DEVICE");
     if (fmt == LISREG_FMT_XYZIRT && stride < 22) return fail(c, LISREG_ERR_ARG, "extract_features: XYZIRT needs stride >= 22");
     if (P->n_scan < 1 || P->n_scan > 1024 || P->horizon_scan < 16 || P->horizon_scan > 4096 || P->downsample_rate < 1)
@@ -936,6 +949,38 @@ int lisreg_extract_features(lisreg_ctx* c, const void* cloud, int n, int stride,
     }
     launch_extract_features(pts, rings, n, *P, fb, st);
     HIPCHK(c, hipGetLastError());
+    // ---- IMU de-skew: only the coordinates handed back change (ranges, columns and the selection use the raw points) ----
+    const float4* out_pts = pts;
+    std::vector<float4> h_dsk;
+    if (deskew) {
+        const size_t m = (size_t)dk->imu_pointer_cur + 1;
+        HIPCHK(c, c->ft_dsk_tab.ensure(sizeof(double) * 4 * m + 64));
+        HIPCHK(c, c->ft_dsk_pts.ensure(sizeof(float4) * (size_t)n));
+        HIPCHK(c, c->ft_dsk_misc.ensure(64));
+        double* tab = c->ft_dsk_tab.as<double>();
+        const double* srcs[4] = { dk->imu_time, dk->imu_rot_x, dk->imu_rot_y, dk->imu_rot_z };
+        for (int k = 0; k < 4; ++k) HIPCHK(c, hipMemcpyAsync(tab + (size_t)k * m, srcs[k], sizeof(double) * m, hipMemcpyHostToDevice, st));
+        const float* times_dev = dk->time_device;
+        std::vector<float> h_time;
+        if (!dev) {
+            h_time.resize((size_t)n);
+            const unsigned char* b = static_cast<const unsigned char*>(cloud);
+            for (int i = 0; i < n; ++i) memcpy(&h_time[(size_t)i], b + (size_t)i * (size_t)stride + 24, 4);
+            HIPCHK(c, c->ft_dsk_time.ensure(sizeof(float) * (size_t)n));
+            HIPCHK(c, hipMemcpyAsync(c->ft_dsk_time.p, h_time.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+            times_dev = c->ft_dsk_time.as<float>();
+        }
+        HIPCHK(c, hipMemcpyAsync(c->ft_dsk_pts.p, pts, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        DeskewTables T{ tab, tab + m, tab + 2 * m, tab + 3 * m, dk->imu_pointer_cur, dk->time_scan_cur };
+        launch_deskew(fb.owner, hw, times_dev, T, c->ft_dsk_misc.as<int>(), c->ft_dsk_misc.as<float>() + 4, c->ft_dsk_pts.as<float4>(), st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));               // h_time and the caller's tables are done with
+        out_pts = c->ft_dsk_pts.as<float4>();
+        if (!dev) {
+            h_dsk.resize((size_t)n);
+            HIPCHK(c, hipMemcpyAsync(h_dsk.data(), c->ft_dsk_pts.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, st));
+        }
+    }
     int counts[8];
     HIPCHK(c, hipMemcpyAsync(counts, fb.counts, sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -952,14 +997,17 @@ int lisreg_extract_features(lisreg_ctx* c, const void* cloud, int n, int stride,
     std::vector<int> h_idx;
     for (auto& sl : slots) {
         if (!sl.buf || sl.cnt == 0) continue;
-        if (dev) launch_gather_points(pts, sl.idx, sl.cnt, static_cast<float4*>(sl.buf), st);
+        if (dev) launch_gather_points(out_pts, sl.idx, sl.cnt, static_cast<float4*>(sl.buf), st);
         else {
             h_idx.resize((size_t)sl.cnt);
             HIPCHK(c, hipMemcpyAsync(h_idx.data(), sl.idx, sizeof(int) * (size_t)sl.cnt, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             const unsigned char* b = static_cast<const unsigned char*>(cloud);
             unsigned char* o = static_cast<unsigned char*>(sl.buf);
-            for (int i = 0; i < sl.cnt; ++i) memcpy(o + (size_t)i * (size_t)stride, b + (size_t)h_idx[(size_t)i] * (size_t)stride, (size_t)stride);
+            for (int i = 0; i < sl.cnt; ++i) {
+                memcpy(o + (size_t)i * (size_t)stride, b + (size_t)h_idx[(size_t)i] * (size_t)stride, (size_t)stride);
+                if (deskew) memcpy(o + (size_t)i * (size_t)stride, &h_dsk[(size_t)h_idx[(size_t)i]], 12);     // newPoint.x/y/z (:451-456)
+            }
         }
     }
     HIPCHK(c, hipStreamSynchronize(st));

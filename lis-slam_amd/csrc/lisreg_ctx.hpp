@@ -66,7 +66,7 @@ struct lisreg_ctx {
     lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
-           ft_lists, ft_counts, ft_rings, ft_gather;
+           ft_lists, ft_counts, ft_rings, ft_gather, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
     std::vector<lisreg::MapIndex> maps;
     lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur;
     int*      done_host = nullptr;          // pinned

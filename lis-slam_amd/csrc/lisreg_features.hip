@@ -20,6 +20,8 @@
 // neighbour accesses are bounds-checked against the extracted cloud.
 #include "lisreg_internal.hpp"
 
+#include <algorithm>
+
 namespace lisreg {
 
 namespace {
@@ -308,7 +310,98 @@ __global__ __launch_bounds__(256) void k_gather_points(const float4* __restrict_
     if (i < n) out[i] = pts[idx[i]];
 }
 
+// ---- IMU de-skew (deskewPoint / findRotation, laserProcessing.cpp:368-399, 427-462) ----------------------------------------
+__global__ __launch_bounds__(256) void k_feat_first(const int* __restrict__ owner, int hw, int* __restrict__ first)
+{
+    __shared__ int s_min[4];
+    int m = kEmpty;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) m = min(m, owner[i]);
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMin(first, min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])));
+}
+
+__device__ __forceinline__ void find_rotation(const DeskewTables& T, double pointTime, float rot[3])
+{
+    int front = 0;
+    while (front < T.imu_pointer_cur) { if (pointTime < T.time[front]) break; ++front; }
+    if (pointTime > T.time[front] || front == 0) { rot[0] = (float)T.rx[front]; rot[1] = (float)T.ry[front]; rot[2] = (float)T.rz[front]; }
+    else {
+        const int back = front - 1;
+        const double rf = (pointTime - T.time[back]) / (T.time[front] - T.time[back]);
+        const double rb = (T.time[front] - pointTime) / (T.time[front] - T.time[back]);
+        rot[0] = (float)(T.rx[front] * rf + T.rx[back] * rb);
+        rot[1] = (float)(T.ry[front] * rf + T.ry[back] * rb);
+        rot[2] = (float)(T.rz[front] * rf + T.rz[back] * rb);
+    }
+}
+
+// pcl::getTransformation(0, 0, 0, roll, pitch, yaw).linear(); cos / sin = the correctly rounded float (double evaluation)
+__device__ __forceinline__ void rot_from_rpy(float roll, float pitch, float yaw, float R[9])
+{
+    const float A = (float)cos((double)yaw), B = (float)sin((double)yaw), C = (float)cos((double)pitch), D = (float)sin((double)pitch),
+                E = (float)cos((double)roll), F = (float)sin((double)roll), DE = D * E, DF = D * F;
+    R[0] = A * C; R[1] = A * DF - B * E; R[2] = B * F + A * DE;
+    R[3] = B * C; R[4] = A * E + B * DF; R[5] = B * DE - A * F;
+    R[6] = -D;    R[7] = C * F;          R[8] = C * E;
+}
+
+// transStartInverse from the first pixel-owning point (Eigen's cofactor inverse of the 3x3 linear part)
+__global__ void k_feat_start_inverse(const float* __restrict__ times, const int* __restrict__ first, DeskewTables T, float* __restrict__ Rsi)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float m[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, inv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    const int f = *first;
+    if (f != kEmpty) {
+        float rot[3];
+        find_rotation(T, T.time_scan_cur + (double)times[f], rot);
+        rot_from_rpy(rot[0], rot[1], rot[2], m);
+#define COF(i, j) (m[3 * (((i) + 1) % 3) + ((j) + 1) % 3] * m[3 * (((i) + 2) % 3) + ((j) + 2) % 3] - m[3 * (((i) + 1) % 3) + ((j) + 2) % 3] * m[3 * (((i) + 2) % 3) + ((j) + 1) % 3])
+        const float c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);
+        const float det = (c00 * m[0] + c10 * m[3]) + c20 * m[6];
+        const float invdet = 1.0f / det;
+        inv[0] = c00 * invdet; inv[1] = c10 * invdet; inv[2] = c20 * invdet;
+        inv[3] = COF(0, 1) * invdet; inv[4] = COF(1, 1) * invdet; inv[5] = COF(2, 1) * invdet;
+        inv[6] = COF(0, 2) * invdet; inv[7] = COF(1, 2) * invdet; inv[8] = COF(2, 2) * invdet;
+#undef COF
+    }
+    for (int k = 0; k < 9; ++k) Rsi[k] = inv[k];
+}
+
+// one thread per range-image pixel: rotate its owner into the frame of the first point (coordinates only; payload kept)
+__global__ __launch_bounds__(256) void k_feat_deskew(const int* __restrict__ owner, int hw, const float* __restrict__ times,
+                                                     DeskewTables T, const float* __restrict__ Rsi, float4* __restrict__ pts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hw) return;
+    const int o = owner[i];
+    if (o == kEmpty) return;
+    float rot[3], Rf[9], Rb[9];
+    find_rotation(T, T.time_scan_cur + (double)times[o], rot);
+    rot_from_rpy(rot[0], rot[1], rot[2], Rf);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Rb[3 * a + b] = (Rsi[3 * a] * Rf[b] + Rsi[3 * a + 1] * Rf[3 + b]) + Rsi[3 * a + 2] * Rf[6 + b];
+    const float4 p = pts[o];
+    float4 q = p;
+    q.x = ((Rb[0] * p.x + Rb[1] * p.y) + Rb[2] * p.z) + 0.0f;
+    q.y = ((Rb[3] * p.x + Rb[4] * p.y) + Rb[5] * p.z) + 0.0f;
+    q.z = ((Rb[6] * p.x + Rb[7] * p.y) + Rb[8] * p.z) + 0.0f;
+    pts[o] = q;
+}
+
 }  // namespace
+
+void launch_deskew(const int* owner, int hw, const float* times_dev, DeskewTables T, int* first_dev, float* rsi_dev, float4* pts_copy,
+                   hipStream_t st)
+{
+    (void)hipMemsetAsync(first_dev, 0x7f, sizeof(int), st);
+    k_feat_first<<<std::min((hw + 255) / 256, 256), 256, 0, st>>>(owner, hw, first_dev);
+    k_feat_start_inverse<<<1, 64, 0, st>>>(times_dev, first_dev, T, rsi_dev);
+    k_feat_deskew<<<(hw + 255) / 256, 256, 0, st>>>(owner, hw, times_dev, T, rsi_dev, pts_copy);
+}
 
 void launch_extract_features(const float4* pts, const uint32_t* rings, int n, lisreg_feature_params P, FeatureBuffers fb,
                              hipStream_t st)

@@ -161,6 +161,15 @@ struct FeatureBuffers {
 };
 void launch_extract_features(const float4* pts, const uint32_t* rings /* null: ring = payload & 0xffff */, int n,
                              lisreg_feature_params P, FeatureBuffers fb, hipStream_t st);
+// IMU de-skew tables in device memory (lisreg_deskew, laserProcessing.cpp:222-266)
+struct DeskewTables {
+    const double* time; const double* rx; const double* ry; const double* rz;
+    int    imu_pointer_cur;
+    double time_scan_cur;
+};
+// rotate every pixel-owning point of pts_copy (a private copy of the sweep) into the first owner's frame
+void launch_deskew(const int* owner, int hw, const float* times_dev, DeskewTables T, int* first_dev, float* rsi_dev, float4* pts_copy,
+                   hipStream_t st);
 void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st);
 // §8 f-3 / f-4 building blocks (lisreg_nn1.hip): exact k = 1 queries on a GridIndex that lives in device memory
 void launch_nn1(const float4* q, int n, const GridIndex* grid_dev, float max_dist, int* idx_out, float* d2_out, hipStream_t st);

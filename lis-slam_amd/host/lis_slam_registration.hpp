@@ -189,7 +189,33 @@ struct ExtractedFeatures {             // what assignCouldInfo/publishClouds put
 class LaserProcessing {
 public:
     lisreg_feature_params params;
+    // de-skew state, named as in src/include/laserProcessing.h:105-123
+    std::vector<double> imuTime, imuRotX, imuRotY, imuRotZ;
+    int    imuPointerCur = 0;
+    int    deskewFlag = 1;                  // 1: the cloud has a `time` channel (:158-170)
+    bool   imuAvailable = false;            // cloudInfo.imuAvailable
+    double timeScanCur = 0.0;
     explicit LaserProcessing(lisreg_ctx* ctx) : ctx_(ctx) { lisreg_default_feature_params(&params); }
+    // imuDeskewInfo (laserProcessing.cpp:222-266): integrate the angular velocities of the IMU messages around this scan.
+    // stamp[i], (ang_x, ang_y, ang_z)[i] = header stamp and ros-frame angular velocity of message i (after imuConverter).
+    void imuDeskewInfo(const double* stamp, const double* ang_x, const double* ang_y, const double* ang_z, int n, double scanCur, double scanEnd) {
+        timeScanCur = scanCur; imuAvailable = false; imuPointerCur = 0;
+        imuTime.assign((size_t)n + 1, 0.0); imuRotX.assign((size_t)n + 1, 0.0); imuRotY.assign((size_t)n + 1, 0.0); imuRotZ.assign((size_t)n + 1, 0.0);
+        for (int i = 0; i < n; ++i) {
+            const double t = stamp[i];
+            if (t > scanEnd + 0.01) break;
+            if (imuPointerCur == 0) { imuRotX[0] = imuRotY[0] = imuRotZ[0] = 0; imuTime[0] = t; ++imuPointerCur; continue; }
+            const double dt = t - imuTime[(size_t)imuPointerCur - 1];
+            imuRotX[(size_t)imuPointerCur] = imuRotX[(size_t)imuPointerCur - 1] + ang_x[i] * dt;
+            imuRotY[(size_t)imuPointerCur] = imuRotY[(size_t)imuPointerCur - 1] + ang_y[i] * dt;
+            imuRotZ[(size_t)imuPointerCur] = imuRotZ[(size_t)imuPointerCur - 1] + ang_z[i] * dt;
+            imuTime[(size_t)imuPointerCur] = t;
+            ++imuPointerCur;
+        }
+        --imuPointerCur;
+        if (imuPointerCur <= 0) return;
+        imuAvailable = true;
+    }
     ExtractedFeatures process(const PointCloud<PointXYZIRT>& laserCloudIn) {
         ExtractedFeatures f;
         const size_t cap = (size_t)params.n_scan * (size_t)params.horizon_scan;
@@ -201,8 +227,12 @@ public:
         o.surface = f.surfaceCloud.points.data();          o.cap_surface = (int)cap;
         o.corner_sharp = f.sharpCornerCloud.points.data(); o.cap_corner_sharp = (int)cap;
         o.surface_sharp = f.SharpSurfaceCloud.points.data(); o.cap_surface_sharp = (int)cap;
-        int rc = lisreg_extract_features(ctx_, laserCloudIn.points.data(), (int)laserCloudIn.size(), (int)sizeof(PointXYZIRT),
-                                         LISREG_FMT_XYZIRT, &params, &o);
+        lisreg_deskew dk{};
+        dk.enabled = (deskewFlag == 1 && imuAvailable) ? 1 : 0;       // deskewPoint :429
+        dk.imu_pointer_cur = imuPointerCur; dk.imu_time = imuTime.data(); dk.imu_rot_x = imuRotX.data(); dk.imu_rot_y = imuRotY.data();
+        dk.imu_rot_z = imuRotZ.data(); dk.time_scan_cur = timeScanCur;
+        int rc = lisreg_extract_features_deskew(ctx_, laserCloudIn.points.data(), (int)laserCloudIn.size(), (int)sizeof(PointXYZIRT),
+                                                LISREG_FMT_XYZIRT, &params, &dk, &o);
         if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
         const int n[5] = { o.n_deskewed, o.n_corner, o.n_surface, o.n_corner_sharp, o.n_surface_sharp };
         for (int k = 0; k < 5; ++k) clouds[k]->points.resize((size_t)n[k]);

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
-    "lisreg_extract_features", "lisreg_default_feature_params", "lisreg_semantic_split",
+    "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_gn_match",
 ]
@@ -54,6 +54,25 @@ class IcpResult(C.Structure):
     def as_dict(self):
         return dict(T=np.array(list(self.final_transform), np.float32).reshape(4, 4), converged=bool(self.converged),
                     iters=self.iters, state=self.state, n_corr_last=self.n_corr_last, fitness=self.fitness, prev_mse=self.prev_mse)
+
+
+class Deskew(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("imu_pointer_cur", C.c_int), ("imu_time", C.POINTER(C.c_double)),
+                ("imu_rot_x", C.POINTER(C.c_double)), ("imu_rot_y", C.POINTER(C.c_double)), ("imu_rot_z", C.POINTER(C.c_double)),
+                ("time_scan_cur", C.c_double), ("time_device", C.POINTER(C.c_float))]
+
+
+def make_deskew(imu_time, rot_x, rot_y, rot_z, time_scan_cur, enabled=True, time_device_ptr=0):
+    """lisreg_deskew from the integrated IMU tables (imuTime / imuRotX,Y,Z of imuDeskewInfo); keeps the arrays alive."""
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (imu_time, rot_x, rot_y, rot_z)]
+    d = Deskew()
+    d.enabled = 1 if enabled else 0
+    d.imu_pointer_cur = len(arrs[0]) - 1
+    d.imu_time, d.imu_rot_x, d.imu_rot_y, d.imu_rot_z = [a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs]
+    d.time_scan_cur = float(time_scan_cur)
+    d.time_device = C.cast(C.c_void_p(time_device_ptr), C.POINTER(C.c_float)) if time_device_ptr else None
+    d._keep = arrs
+    return d
 
 
 class IcpGnResult(C.Structure):
@@ -162,6 +181,8 @@ def lib():
         L.lisreg_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, vp]
         L.lisreg_extract_features.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(FeatureOut)]
         L.lisreg_default_feature_params.argtypes = [C.POINTER(FeatureParams)]
+        L.lisreg_extract_features_deskew.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(Deskew),
+                                                     C.POINTER(FeatureOut)]
         L.lisreg_semantic_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(SemanticOut)]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
         L.lisreg_map_index_set.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
@@ -382,8 +403,8 @@ class Context:
                                                  Tf.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(out_ptr)))
 
     # -- §8 f-2 -------------------------------------------------------------------------------------------
-    def extract_features(self, cloud: np.ndarray, params: "FeatureParams") -> dict:
-        """LaserProcessing replacement on a PointXYZIRT struct array: the five clouds of cloud_info."""
+    def extract_features(self, cloud: np.ndarray, params: "FeatureParams", deskew: "Deskew | None" = None) -> dict:
+        """LaserProcessing replacement on a PointXYZIRT struct array: the five clouds of cloud_info (optionally IMU-de-skewed)."""
         cloud = np.ascontiguousarray(cloud)
         cap = params.n_scan * params.horizon_scan
         names = ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
@@ -391,15 +412,16 @@ class Context:
         fo = FeatureOut()
         for k in names:
             setattr(fo, k, bufs[k].ctypes.data_as(C.c_void_p)); setattr(fo, "cap_" + k, cap)
-        self._chk(self._L.lisreg_extract_features(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIRT,
-                                                  C.byref(params), C.byref(fo)))
+        self._chk(self._L.lisreg_extract_features_deskew(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIRT,
+                                                         C.byref(params), C.byref(deskew) if deskew is not None else None, C.byref(fo)))
         return {k: bufs[k][: getattr(fo, "n_" + k)] for k in names}
 
-    def extract_features_device(self, in_ptr: int, n: int, params: "FeatureParams", out_ptrs: dict, cap: int) -> dict:
+    def extract_features_device(self, in_ptr: int, n: int, params: "FeatureParams", out_ptrs: dict, cap: int, deskew=None) -> dict:
         fo = FeatureOut()
         for k, ptr in out_ptrs.items():
             setattr(fo, k, C.c_void_p(ptr)); setattr(fo, "cap_" + k, cap)
-        self._chk(self._L.lisreg_extract_features(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, C.byref(params), C.byref(fo)))
+        self._chk(self._L.lisreg_extract_features_deskew(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, C.byref(params),
+                                                         C.byref(deskew) if deskew is not None else None, C.byref(fo)))
         return {k: getattr(fo, "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")}
 
     def semantic_split(self, cloud: np.ndarray, using_label=None) -> list:

@@ -1412,3 +1412,78 @@ void orc_icp_gn(const void* target, int n_t, const void* source, int n_s, int st
     if (tree) orc_kdtree_free(tree);
     free(txyz); free(sxyz);
 }
+
+/* ---- §8 f-2, IMU de-skew: LaserProcessing::deskewPoint / findRotation (src/core/laserProcessing.cpp:368-399, 427-462) --- */
+/* pcl::getTransformation(0, 0, 0, roll, pitch, yaw).linear() (PCL common/impl/eigen.hpp), float */
+static void rot_from_rpy(float roll, float pitch, float yaw, float R[9])
+{
+    /* cos/sin of a float, defined here as the correctly rounded value (double evaluation rounded once): what glibc's cosf/sinf
+     * deliver, and reproducible on the device, whose single-precision library differs from glibc in the last ulp */
+    float A = (float)cos((double)yaw), B = (float)sin((double)yaw), C = (float)cos((double)pitch), D = (float)sin((double)pitch),
+          E = (float)cos((double)roll), F = (float)sin((double)roll), DE = D * E, DF = D * F;
+    R[0] = A * C; R[1] = A * DF - B * E; R[2] = B * F + A * DE;
+    R[3] = B * C; R[4] = A * E + B * DF; R[5] = B * DE - A * F;
+    R[6] = -D;    R[7] = C * F;          R[8] = C * E;
+}
+
+/* Eigen's 3x3 inverse (compute_inverse<Matrix3f>: cofactors and one division by the determinant), which
+ * Eigen::Affine3f::inverse() applies to the linear part */
+static void inv3_cofactor(const float m[9], float inv[9])
+{
+#define COF(i, j) (m[3 * (((i) + 1) % 3) + ((j) + 1) % 3] * m[3 * (((i) + 2) % 3) + ((j) + 2) % 3] - m[3 * (((i) + 1) % 3) + ((j) + 2) % 3] * m[3 * (((i) + 2) % 3) + ((j) + 1) % 3])
+    const float c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);
+    const float det = (c00 * m[0] + c10 * m[3]) + c20 * m[6];
+    const float invdet = 1.0f / det;
+    inv[0] = c00 * invdet; inv[1] = c10 * invdet; inv[2] = c20 * invdet;
+    inv[3] = COF(0, 1) * invdet; inv[4] = COF(1, 1) * invdet; inv[5] = COF(2, 1) * invdet;
+    inv[6] = COF(0, 2) * invdet; inv[7] = COF(1, 2) * invdet; inv[8] = COF(2, 2) * invdet;
+#undef COF
+}
+
+static void find_rotation(const lisreg_deskew* dk, double pointTime, float rot[3])
+{
+    int front = 0;
+    while (front < dk->imu_pointer_cur) { if (pointTime < dk->imu_time[front]) break; ++front; }
+    if (pointTime > dk->imu_time[front] || front == 0) {
+        rot[0] = (float)dk->imu_rot_x[front]; rot[1] = (float)dk->imu_rot_y[front]; rot[2] = (float)dk->imu_rot_z[front];
+    } else {
+        int back = front - 1;
+        double rf = (pointTime - dk->imu_time[back]) / (dk->imu_time[front] - dk->imu_time[back]);
+        double rb = (dk->imu_time[front] - pointTime) / (dk->imu_time[front] - dk->imu_time[back]);
+        rot[0] = (float)(dk->imu_rot_x[front] * rf + dk->imu_rot_x[back] * rb);
+        rot[1] = (float)(dk->imu_rot_y[front] * rf + dk->imu_rot_y[back] * rb);
+        rot[2] = (float)(dk->imu_rot_z[front] * rf + dk->imu_rot_z[back] * rb);
+    }
+}
+
+/* The de-skewed coordinates of the points that own a range-image pixel (idx[m] = their input indices, e.g. the `deskewed`
+ * list of orc_extract_features).  projectPointCloud calls deskewPoint in input order for exactly these points, so the one
+ * with the smallest index sets transStartInverse (firstPointFlag, :439-443).  findPosition returns zeros (:405-421).
+ * xyz_out[m][3].  With dk->enabled == 0 the points come back unchanged (:429). */
+void orc_deskew_points(const void* cloud, int stride, const lisreg_deskew* dk, const int* idx, int m, float* xyz_out)
+{
+    const unsigned char* src = (const unsigned char*)cloud;
+    int first = -1;
+    for (int k = 0; k < m; ++k) if (first < 0 || idx[k] < first) first = idx[k];
+    float Rsi[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    if (dk->enabled && first >= 0) {
+        float t, rot[3], R0[9];
+        memcpy(&t, src + (size_t)first * (size_t)stride + 24, 4);
+        find_rotation(dk, dk->time_scan_cur + (double)t, rot);
+        rot_from_rpy(rot[0], rot[1], rot[2], R0);
+        inv3_cofactor(R0, Rsi);
+    }
+    for (int k = 0; k < m; ++k) {
+        const unsigned char* r = src + (size_t)idx[k] * (size_t)stride;
+        float p[3], t;
+        memcpy(p, r, 12); memcpy(&t, r + 24, 4);
+        if (!dk->enabled) { memcpy(xyz_out + 3 * k, p, 12); continue; }
+        float rot[3], Rf[9], Rb[9];
+        find_rotation(dk, dk->time_scan_cur + (double)t, rot);
+        rot_from_rpy(rot[0], rot[1], rot[2], Rf);
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+            Rb[3 * a + b] = (Rsi[3 * a] * Rf[b] + Rsi[3 * a + 1] * Rf[3 + b]) + Rsi[3 * a + 2] * Rf[6 + b];
+        for (int a = 0; a < 3; ++a)                           /* transBt(a,3) = 0: both translations are zero */
+            xyz_out[3 * k + a] = ((Rb[3 * a] * p[0] + Rb[3 * a + 1] * p[1]) + Rb[3 * a + 2] * p[2]) + 0.0f;
+    }
+}

@@ -103,6 +103,11 @@ void orc_transform_cloud(const void* in, int n, int stride_bytes, int fmt, const
 void orc_extract_features(const void* cloud, int n, int stride_bytes, const lisreg_feature_params* p,
                           int* deskewed, int* corner, int* surface, int* corner_sharp, int* surface_sharp, int counts[5]);
 
+/* deskewPoint / findRotation (src/core/laserProcessing.cpp:368-399, 427-462) for the pixel-owning points idx[m] (input
+ * indices); xyz_out[m][3].  Float arithmetic as in the reference: pcl::getTransformation, Eigen's cofactor 3x3 inverse,
+ * the 3x3 product, then the row-by-row point transform. */
+void orc_deskew_points(const void* cloud, int stride_bytes, const lisreg_deskew* dk, const int* idx, int m, float* xyz_out);
+
 /* categoryMapping (src/node/semanticFusionNode.cpp:173-189): class of every point (0 dynamic, 1 ground, 2 building,
  * 3 pole, 4 outlier) from using_label[label & 31]; the five output clouds are the stable partition by class. */
 void orc_semantic_classes(const void* cloud, int n, int stride_bytes, const unsigned int using_label[32], unsigned char* cls);

@@ -37,6 +37,25 @@ class IcpResult(C.Structure):
                 ("n_corr_last", C.c_int), ("fitness", C.c_double), ("prev_mse", C.c_double)]
 
 
+class Deskew(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("imu_pointer_cur", C.c_int), ("imu_time", C.POINTER(C.c_double)),
+                ("imu_rot_x", C.POINTER(C.c_double)), ("imu_rot_y", C.POINTER(C.c_double)), ("imu_rot_z", C.POINTER(C.c_double)),
+                ("time_scan_cur", C.c_double), ("time_device", C.POINTER(C.c_float))]
+
+
+def make_deskew(imu_time, rot_x, rot_y, rot_z, time_scan_cur, enabled=True, time_device_ptr=0):
+    """lisreg_deskew from the integrated IMU tables (imuTime / imuRotX,Y,Z of imuDeskewInfo); keeps the arrays alive."""
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (imu_time, rot_x, rot_y, rot_z)]
+    d = Deskew()
+    d.enabled = 1 if enabled else 0
+    d.imu_pointer_cur = len(arrs[0]) - 1
+    d.imu_time, d.imu_rot_x, d.imu_rot_y, d.imu_rot_z = [a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs]
+    d.time_scan_cur = float(time_scan_cur)
+    d.time_device = C.cast(C.c_void_p(time_device_ptr), C.POINTER(C.c_float)) if time_device_ptr else None
+    d._keep = arrs
+    return d
+
+
 class IcpGnResult(C.Structure):
     _fields_ = [("final_transform", C.c_float * 16), ("steps_applied", C.c_int), ("n_corr_last", C.c_int),
                 ("fitness", C.c_float), ("reserved", C.c_int)]
@@ -119,6 +138,8 @@ def lib():
         L.orc_extract_features.restype = None
         L.orc_semantic_classes.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_ubyte)]
         L.orc_semantic_classes.restype = None
+        L.orc_deskew_points.argtypes = [vp, C.c_int, C.POINTER(Deskew), ip, C.c_int, fp]
+        L.orc_deskew_points.restype = None
         dp = C.POINTER(C.c_double)
         L.orc_cloud_bounds.argtypes = [vp, C.c_int, C.c_int, dp]
         L.orc_cloud_bounds.restype = None
@@ -304,3 +325,12 @@ def icp_gn_match(target, source, max_iterations, max_correspond_distance, predic
                      max_correspond_distance, _fp(g), 1 if float_sums else 0, C.byref(res))
     return dict(T=np.array(list(res.final_transform), np.float32).reshape(4, 4), steps_applied=res.steps_applied,
                 n_corr_last=res.n_corr_last, fitness=res.fitness)
+
+
+def deskew_points(cloud, deskew: "Deskew", idx):
+    """orc_deskew_points: de-skewed xyz [m,3] of the pixel-owning points idx (input indices) of a PointXYZIRT array"""
+    cloud = np.ascontiguousarray(cloud)
+    idx = np.ascontiguousarray(idx, np.int32)
+    out = np.zeros((max(len(idx), 1), 3), np.float32)
+    lib().orc_deskew_points(_vp(cloud), cloud.dtype.itemsize, C.byref(deskew), idx.ctypes.data_as(C.POINTER(C.c_int)), len(idx), _fp(out))
+    return out[: len(idx)]

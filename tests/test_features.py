@@ -172,3 +172,95 @@ def test_hip_semantic_split_matches_oracle(oracle, gpu_ctx):
     # the split feeds copies #2/#3: edge set = pole, planar set = dynamic + building + ground (subMapOptmizationNode.cpp:856-893)
     pg = gpu_ctx.semantic_split(c)
     assert len(pg[3]) + len(pg[0]) + len(pg[2]) + len(pg[1]) + len(pg[4]) == len(c)
+
+
+# ---------------------------------------------------------------- IMU de-skew (deskewPoint / findRotation)
+def _imu_tables(seed, t0=100.0, n=70, rate=500.0):
+    """integrated IMU rotation like imuDeskewInfo builds it: first entry zero, 500 Hz, a smooth yaw-dominant motion"""
+    rng = np.random.default_rng(seed)
+    t = t0 - 0.01 + np.arange(n) / rate
+    w = np.stack([0.05 * np.sin(6 * (t - t0)), 0.03 * np.cos(4 * (t - t0)), 0.6 + 0.2 * np.sin(3 * (t - t0))], 1) + rng.normal(0, 0.01, (n, 3))
+    rot = np.zeros((n, 3))
+    rot[1:] = np.cumsum(w[1:] * np.diff(t)[:, None], 0)
+    return t, rot
+
+
+def _numpy_deskew(c, idx, t, rot, t0):
+    """double-precision mirror: rotation interpolated at the point time, R_start^-1 R_point applied to the point"""
+    from lisreg import synth
+    def R_at(pt):
+        front = 0
+        while front < len(t) - 1 and not (pt < t[front]):
+            front += 1
+        if pt > t[front] or front == 0:
+            r = rot[front]
+        else:
+            b = front - 1
+            rf = (pt - t[b]) / (t[front] - t[b]); rb = (t[front] - pt) / (t[front] - t[b])
+            r = rot[front] * rf + rot[b] * rb
+        return synth.pose_matrix([r[0], r[1], r[2], 0, 0, 0])[:3, :3]
+    first = idx.min()
+    Rsi = np.linalg.inv(R_at(t0 + float(c["time"][first])))
+    xyz = synth.pcl_xyz(c).astype(np.float64)
+    return np.stack([Rsi @ R_at(t0 + float(c["time"][i])) @ xyz[i] for i in idx])
+
+
+def test_oracle_deskew_matches_numpy(oracle):
+    from lisreg import synth
+    c = synth.make_raw_scan(16, 450, 7400)
+    p = oracle.FeatureParams(16, 450, 1, 0.0, 70.0, 1.0, 0.1)
+    idx = oracle.extract_features(c, p)["deskewed"]
+    t, rot = _imu_tables(1)
+    dk = oracle.make_deskew(t, rot[:, 0], rot[:, 1], rot[:, 2], 100.0)
+    got = oracle.deskew_points(c, dk, idx)
+    want = _numpy_deskew(c, idx, t, rot, 100.0)
+    assert np.abs(got - want).max() < 5e-5                                   # float rotation algebra at <= 70 m
+    moved = np.linalg.norm(got - synth.pcl_xyz(c)[idx], axis=1)
+    assert moved.max() > 0.5 and moved[np.argmin(idx)] < 1e-5                # the sweep turns ~3 deg; the first point stays put
+    off = oracle.make_deskew(t, rot[:, 0], rot[:, 1], rot[:, 2], 100.0, enabled=False)
+    assert np.array_equal(oracle.deskew_points(c, off, idx), synth.pcl_xyz(c)[idx])
+    # a point time beyond the last IMU sample takes the last rotation (findRotation :382-387)
+    late = oracle.make_deskew(t[:10], rot[:10, 0], rot[:10, 1], rot[:10, 2], 100.0)
+    g2 = oracle.deskew_points(c, late, idx)
+    assert np.isfinite(g2).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,rate,seed,shuffle", [(16, 450, 1, 21, False), (64, 1800, 2, 22, False), (32, 1024, 1, 23, True)])
+def test_hip_deskew_matches_oracle(oracle, gpu_ctx, h, w, rate, seed, shuffle):
+    import lisreg
+    from lisreg import synth
+    c = synth.make_raw_scan(h, w, 7500 + seed, shuffle=shuffle)
+    po = oracle.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    pg = lisreg.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    t, rot = _imu_tables(seed)
+    dko = oracle.make_deskew(t, rot[:, 0], rot[:, 1], rot[:, 2], 100.0)
+    dkg = lisreg.make_deskew(t, rot[:, 0], rot[:, 1], rot[:, 2], 100.0)
+    ro = oracle.extract_features(c, po)
+    rg = gpu_ctx.extract_features(c, pg, dkg)
+    plain = gpu_ctx.extract_features(c, pg)
+    xyz_all = {int(i): v for i, v in zip(ro["deskewed"], oracle.deskew_points(c, dko, ro["deskewed"]))}
+    for k in NAMES:
+        assert len(rg[k]) == len(ro[k]), k
+        want = np.stack([xyz_all[int(i)] for i in ro[k]]) if len(ro[k]) else np.zeros((0, 3), np.float32)
+        assert np.array_equal(synth.pcl_xyz(rg[k]), want), k                   # coordinates bit for bit
+        for f in ("intensity", "ring", "time"):                                # everything else is the raw point's
+            assert np.array_equal(rg[k][f], c[ro[k]][f]), (k, f)
+        assert len(plain[k]) == len(rg[k])                                     # the selection does not depend on the de-skew
+    assert np.abs(synth.pcl_xyz(rg["deskewed"]) - synth.pcl_xyz(plain["deskewed"])).max() > 0.5
+    off = lisreg.make_deskew(t, rot[:, 0], rot[:, 1], rot[:, 2], 100.0, enabled=False)
+    r0 = gpu_ctx.extract_features(c, pg, off)
+    assert all(same_points(r0[k], plain[k]) for k in NAMES)
+    # device records: time as a separate device array
+    rec = np.zeros((len(c), 4), np.float32)
+    rec[:, 0], rec[:, 1], rec[:, 2] = c["x"], c["y"], c["z"]
+    rec[:, 3] = c["ring"].astype(np.uint32).view(np.float32)
+    din, dt = lisreg.DeviceArray(rec), lisreg.DeviceArray(np.ascontiguousarray(c["time"]))
+    cap = h * w
+    outs = {k: lisreg.DeviceArray(np.zeros((cap, 4), np.float32)) for k in NAMES}
+    dkd = lisreg.make_deskew(t, rot[:, 0], rot[:, 1], rot[:, 2], 100.0, time_device_ptr=dt.ptr)
+    nd = gpu_ctx.extract_features_device(din.ptr, len(c), pg, {k: v.ptr for k, v in outs.items()}, cap, dkd)
+    for k in NAMES:
+        assert nd[k] == len(rg[k])
+        got = lisreg.device_to_host(outs[k].ptr, (cap, 4), np.float32)[: nd[k]]
+        assert np.array_equal(got[:, :3], synth.pcl_xyz(rg[k])), k
