@@ -309,6 +309,23 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
     return __hiloint2double(hi, lo);
 }
 
+// gfx950 lane swaps (V_PERMLANE32_SWAP / V_PERMLANE16_SWAP): exchange the upper 32 lanes (odd 16-lane rows) of `a` with the
+// lower 32 lanes (even rows) of `b`.  After the swap a + b is the halving-butterfly step with no select and no LDS traffic:
+// lanes of the lower half hold a(l) + a(partner), lanes of the upper half hold b(partner) + b(l).
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double swap_add32(double a, double b)
+{
+    const v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double swap_add16(double a, double b)
+{
+    const v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+
 // The index arrays are reached through pointers stored in device structs, which the compiler can only treat as
 // generic (flat_load).  They are always global memory: say so, and get global_load with a scalar base.
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -371,20 +388,11 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
     // 16+8+4+2+1(+1) 64-bit shuffles instead of 32 x 6; after five steps lane l holds the 32-lane sum of value
     // index bits(l)[5:1] and one last xor-1 step completes it.  Deterministic: the pairing is fixed.
     double v16[16];
-    {
-        const bool up = (lane & 32) != 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double a = term(i), b = term(i + 16);
-            v16[i] = (up ? b : a) + shfl_xor_d(up ? a : b, 32);
-        }
-    }
+    for (int i = 0; i < 16; ++i) v16[i] = swap_add32(term(i), term(i + 16));       // lanes 0-31: term i, lanes 32-63: term i + 16
     double v8[8], v4[4], v2[2], v1;
-    {
-        const bool up = (lane & 16) != 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = (up ? v16[i + 8] : v16[i]) + shfl_xor_d(up ? v16[i] : v16[i + 8], 16);
-    }
+    for (int i = 0; i < 8; ++i) v8[i] = swap_add16(v16[i], v16[i + 8]);            // even rows: v16[i], odd rows: v16[i + 8]
     {
         const bool up = (lane & 8) != 0;
 #pragma unroll
