@@ -273,7 +273,28 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
         for (int r = 0; r < 6; ++r) s_AtB[r] = (float)s_sum[21 + r];
         solve6_qr_reg(s_AtA, s_AtB, s_X);                        // :921
         int isDeg = it->degenerate;
-        if (iter == 0) {                                         // :923-946
+        // Shortcut for the common, well-conditioned case: if AtA - shift * I is positive definite (6x6 Cholesky in double,
+        // < 1 us on one lane) every eigenvalue exceeds shift = eig_thresh + 2e-5 * trace, far enough above the threshold that
+        // cv::eigen's float Jacobi (absolute error ~ 1e-7 * norm) cannot report one below it: not degenerate, matP = V^-1 V = I.
+        // Anything closer to the threshold takes the full restatement of cv::eigen below (78 us at this size).
+        bool well_conditioned = false;
+        if (iter == 0) {
+            double L[36], trace = 0.0;
+            for (int i = 0; i < 6; ++i) trace += (double)s_AtA[i * 6 + i];
+            const double shift = (double)P.eig_thresh + 2e-5 * trace;
+            well_conditioned = trace > 0.0;
+            for (int r = 0; r < 6 && well_conditioned; ++r)
+                for (int c = 0; c <= r; ++c) {
+                    double v = (double)s_AtA[r * 6 + c] - (r == c ? shift : 0.0);
+                    for (int k = 0; k < c; ++k) v -= L[r * 6 + k] * L[c * 6 + k];
+                    if (r == c) { if (!(v > 0.0)) { well_conditioned = false; break; } L[r * 6 + r] = sqrt(v); }
+                    else L[r * 6 + c] = v / L[c * 6 + c];
+                }
+        }
+        if (iter == 0 && well_conditioned) {
+            isDeg = 0;
+            for (int i = 0; i < 36; ++i) it->P[i] = (i % 7 == 0) ? 1.f : 0.f;
+        } else if (iter == 0) {                                  // :923-946
             for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
             eigen_sym6(s_A, s_E, s_V, s_ind, s_ind + 6);
             for (int i = 0; i < 36; ++i) s_V2[i] = s_V[i];
