@@ -330,6 +330,8 @@ __device__ __forceinline__ double swap_add16(double a, double b)
 // generic (flat_load).  They are always global memory: say so, and get global_load with a scalar base.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const v4f* gptr_f4;
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef __attribute__((address_space(1))) const v3f* gptr_f3;
 typedef __attribute__((address_space(1))) const int* gptr_i32;
 typedef __attribute__((address_space(1))) int*       gptr_i32w;
 
@@ -565,56 +567,62 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 // distance (pruned per x-slab, per (x,y) column and per z-range), reading candidates straight from the
 // cell-sorted target through L1/L2 (16-B records, contiguous per cell run, 4 loads in flight per lane).
 // `lim2` caps the search radius of this pass (squared).
-#define LISREG_TEST(c_, j_) do { \
-        const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
-        const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
-        if (d2_ < b4) { \
-            const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
-            if (!dup_) LISREG_INSERT(d2_, (j_)); } } while (0)
-
 #define LISREG_TRY(d2_, j_) do { \
         if ((d2_) < b4) { \
             const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
             if (!dup_) LISREG_INSERT((d2_), (j_)); } } while (0)
 
-#define LISREG_WALK(lim2_expr) do { \
+// Flattened walk.  Nested (x, y, run) loops — the first version of this kernel — cost, per wave, the SUM over columns of the
+// longest run any lane has in that column (16.7 candidate groups in the steady state of configs[1]), although
+// the busiest lane needs 11 and the average lane 7.  Here every lane first collects the non-empty cell runs of its columns
+// into a small per-lane list in LDS (kWalkCap entries), then streams through the list in ONE loop, so a wave pays the longest TOTAL, not the sum of
+// per-column maxima.  Lists are flushed whenever a lane's list is full, which also re-prunes against the shrinking bound
+// during the wide early-iteration walks.  Same columns, same candidate order, same inserts: the result is identical.
+constexpr int kWalkCap = 8;
+#define LISREG_WALK_LIST(lim2_expr) do { \
         const float lim_ = fminf(b4, (lim2_expr)); \
-        const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps;   /* 1-ulp sqrt is fine: only a bound */ \
+        const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps; \
         const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
         const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
         const int cz0_ = max(grid_coord(qz - rad_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rad_, g.oz, g.inv_cell), g.nz - 1); \
-        if (cz0_ <= cz1_) \
-        for (int ix_ = cx0_; ix_ <= cx1_; ++ix_) { \
-            const float xl_ = g.ox + (float)ix_ * g.cell; \
-            const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
-            const float dx2_ = dx_ * dx_; \
-            if (dx2_ >= fminf(b4, lim_)) continue; \
-            for (int iy_ = cy0_; iy_ <= cy1_; ++iy_) { \
-                const float yl_ = g.oy + (float)iy_ * g.cell; \
+        int ix_ = cx0_, iy_ = cy0_; \
+        if (cz0_ > cz1_ || cy0_ > cy1_) ix_ = cx1_ + 1; \
+        while (ix_ <= cx1_) { \
+            int cnt_ = 0; \
+            /* phase 1: collect up to kWalkCap non-empty runs */ \
+            while (cnt_ < kWalkCap && ix_ <= cx1_) { \
+                const float xl_ = g.ox + (float)ix_ * g.cell, yl_ = g.oy + (float)iy_ * g.cell; \
+                const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
                 const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
-                if (dx2_ + dy_ * dy_ >= fminf(b4, lim_)) continue; \
-                const int base_ = (ix_ * g.ny + iy_) * g.nz; \
-                const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
-                for (int j_ = js_; j_ < je_; j_ += 4) { \
-                    const int l_ = je_ - 1; \
-                    const int j1_ = min(j_ + 1, l_), j2_ = min(j_ + 2, l_), j3_ = min(j_ + 3, l_); \
-                    const v4f c0_ = pts[j_], c1_ = pts[j1_], c2_ = pts[j2_], c3_ = pts[j3_]; \
-                    /* four squared distances at once (clamped tail entries repeat the last point: the index check in \
-                       the insert path drops them), one branch for the common "nothing closer" case */ \
-                    const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
-                    const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
-                    const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
-                    const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
-                    const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
-                    const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
-                    if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
-                        LISREG_TRY(e0_, j_); LISREG_TRY(e1_, j1_); LISREG_TRY(e2_, j2_); LISREG_TRY(e3_, j3_); \
-                    } \
+                if (dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
+                    const int base_ = (ix_ * g.ny + iy_) * g.nz; \
+                    const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
+                    if (js_ < je_) { s_runs[cnt_][tid] = make_int2(js_, je_); ++cnt_; } \
                 } \
+                if (++iy_ > cy1_) { iy_ = cy0_; ++ix_; } \
+            } \
+            /* phase 2: one loop over all collected candidates */ \
+            int r_ = 0, j_ = 0, e_ = 0; \
+            for (;;) { \
+                if (j_ >= e_) { if (r_ >= cnt_) break; const int2 t_ = s_runs[r_][tid]; j_ = t_.x; e_ = t_.y; ++r_; } \
+                const int l_ = e_ - 1; \
+                const int j1_ = min(j_ + 1, l_), j2_ = min(j_ + 2, l_), j3_ = min(j_ + 3, l_); \
+                /* only x, y, z take part in the search: 12-byte loads (the original index in .w is read for the final five) */ \
+                const v3f c0_ = *(gptr_f3)(pts + j_), c1_ = *(gptr_f3)(pts + j1_), c2_ = *(gptr_f3)(pts + j2_), c3_ = *(gptr_f3)(pts + j3_); \
+                const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
+                const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
+                const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
+                const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
+                const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
+                const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
+                if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
+                    LISREG_TRY(e0_, j_); LISREG_TRY(e1_, j1_); LISREG_TRY(e2_, j2_); LISREG_TRY(e3_, j3_); \
+                } \
+                j_ += 4; \
             } \
         } } while (0)
 
-__global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
+__global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
                                                         const ItemState* __restrict__ items, const DevParams P,
@@ -623,6 +631,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
                                                         double* __restrict__ partials)
 {
     __shared__ double s_acc[4][kNumAcc];
+    __shared__ int2   s_runs[kWalkCap][kBlockQ];          // per-lane list of candidate runs for the flattened walk
     constexpr float kEps = 1e-3f;
 
     const int tid = threadIdx.x;
@@ -643,11 +652,14 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
 
     const bool valid = tid < bd.count;
     const int qflat = sg.flat_base + bd.start + tid;
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) q4 = sorted_all[qflat];
-    const float qx = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
-    const float qy = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
-    const float qz = M[8] * q4.x + M[9] * q4.y + M[10] * q4.z + M[11];
+    float qx, qy, qz;
+    {
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) q0 = sorted_all[qflat];
+        qx = M[0] * q0.x + M[1] * q0.y + M[2] * q0.z + M[3];
+        qy = M[4] * q0.x + M[5] * q0.y + M[6] * q0.z + M[7];
+        qz = M[8] * q0.x + M[9] * q0.y + M[10] * q0.z + M[11];
+    }
 
     float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau;
     int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
@@ -688,10 +700,10 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
             }
         }
         if (!seeded) {
-            LISREG_WALK(first_pass_r2);                    // tight first pass establishes a bound cheaply
-            if (!(b4 <= first_pass_r2)) LISREG_WALK(3.0e38f);
+            LISREG_WALK_LIST(first_pass_r2);                    // tight first pass establishes a bound cheaply
+            if (!(b4 <= first_pass_r2)) LISREG_WALK_LIST(3.0e38f);
         } else {
-            LISREG_WALK(3.0e38f);
+            LISREG_WALK_LIST(3.0e38f);
         }
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
         // while the set is unchanged was measured twice: keeping the five ids live costs an occupancy step (8 -> 7,
@@ -700,6 +712,9 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_walk(const BlockDesc* __restr
         nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
         nn[4 * (size_t)n_elems + qflat] = i4;
     }
+    // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&sorted_all[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
     residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
 }
 
