@@ -558,7 +558,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
         launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
-                     c->items.as<ItemState>(), c->prm, c->sorted_all.as<float4>(), c->partials.as<double>(),
+                     c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>(),
                      c->search_mode, c->nn.as<int>(), c->cert.as<float4>(), c->model0.as<float4>(), c->model1.as<float4>(),
                      c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr, st);

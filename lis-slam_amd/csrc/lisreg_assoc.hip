@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 
     const bool valid = tid < bd.count;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) q4 = sorted_all[sg.flat_base + bd.start + tid];
+    if (valid) q4 = sorted_all ? sorted_all[sg.flat_base + bd.start + tid] : sg.src[bd.start + tid];
     // pointAssociateToMap (:243-258)
     float qx = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
     float qy = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
@@ -652,10 +652,13 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
 
     const bool valid = tid < bd.count;
     const int qflat = sg.flat_base + bd.start + tid;
+    // sources: the tile-sorted copy if the batch was sorted, else the caller's own records (no flattening copy).  Both are
+    // addressed with the batch-wide position qflat, so that one register serves the source and the seed arrays.
+    const float4* qsrc = sorted_all ? sorted_all : (const float4*)((uintptr_t)sg.src - (uintptr_t)sg.flat_base * sizeof(float4));
     float qx, qy, qz;
     {
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) q0 = sorted_all[qflat];
+        if (valid) q0 = qsrc[qflat];
         qx = M[0] * q0.x + M[1] * q0.y + M[2] * q0.z + M[3];
         qy = M[4] * q0.x + M[5] * q0.y + M[6] * q0.z + M[7];
         qz = M[8] * q0.x + M[9] * q0.y + M[10] * q0.z + M[11];
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&sorted_all[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
+    if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
     residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
 }
 
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
     const bool valid = tid < bd.count;
     const int qbase = sg.flat_base + bd.start;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) q4 = sorted_all[qbase + tid];
+    if (valid) q4 = sorted_all ? sorted_all[qbase + tid] : sg.src[bd.start + tid];
     const float px = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
     const float py = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
     const float pz = M[8] * q4.x + M[9] * q4.y + M[10] * q4.z + M[11];

@@ -331,19 +331,6 @@ __global__ __launch_bounds__(kBlockQ) void k_count_jumps(const BlockDesc* __rest
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(jumps, __popcll(m));
 }
 
-// identity "sort": keep the caller's order (already spatially coherent scan order) — just flatten the segments
-__global__ __launch_bounds__(kBlockQ) void k_copy_sources(const BlockDesc* __restrict__ blocks,
-                                                          const Segment* __restrict__ segs,
-                                                          float4* __restrict__ sorted_all, int* __restrict__ order_all)
-{
-    const BlockDesc bd = blocks[blockIdx.x];
-    if ((int)threadIdx.x >= bd.count) return;
-    const Segment sg = segs[bd.seg];
-    const int e = bd.start + threadIdx.x;
-    sorted_all[sg.flat_base + e] = sg.src[e];
-    order_all[sg.flat_base + e] = e;
-}
-
 // ---- §8 f-1: pcl::VoxelGrid (default settings) -----------------------------------------------------------------------
 // Same deterministic bucket sort, keyed by PCL's voxel index idx = ijk0 + ijk1*div0 + ijk2*div0*div1
 // (filters/impl/voxel_grid.hpp; call sites /root/reference/src/node/odomEstimationNode.cpp:196-201, 272-277 and
@@ -518,10 +505,7 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all,
                          int* order_all, hipStream_t st)
 {
-    if (n_buckets <= 0) {                    // sorting disabled: flatten in caller order
-        if (n_blocks > 0) k_copy_sources<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, sorted_all, order_all);
-        return;
-    }
+    if (n_buckets <= 0) return;              // sorting disabled: the kernels read the caller's records in place
     (void)hipMemsetAsync(sb.hist, 0, sizeof(int) * (size_t)n_buckets, st);
     if (n_blocks > 0)
         k_source_keys<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, items, sb.elem_bucket, sb.elem_sub, sb.hist);
