@@ -334,6 +334,8 @@ typedef float v3f __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(1))) const v3f* gptr_f3;
 typedef __attribute__((address_space(1))) const int* gptr_i32;
 typedef __attribute__((address_space(1))) int*       gptr_i32w;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4i*       gptr_i4w;
 
 __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
 {
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const gptr_f4 pts = (gptr_f4)g.pts;
     const gptr_i32 cells = (gptr_i32)g.cell_start;
     const gptr_i32w nn = (gptr_i32w)nn_;
+    const gptr_i4w nn4 = (gptr_i4w)nn_;
     const float* M = it->M;            // trans2Affine3f(T), cached by the solve kernel (uniform -> SGPRs)
 
     const bool valid = tid < bd.count;
@@ -671,12 +674,12 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (it->iter > 0) {
             // seeds: last iteration's neighbours bound the new 5th-nearest distance (any 5 points do), so the walk
             // below only has to look inside that radius.  Exactness does not depend on the seeds being right.
+            // seed layout of this kernel: ids 0..3 as one 16-byte record per query, the fifth id (-1 = no valid set) after them;
+            // both loads are issued together (one latency, two instructions instead of five)
+            const v4i s03 = nn4[qflat];
             const int s4 = nn[4 * (size_t)n_elems + qflat];
             if (s4 >= 0) {
-                int sid[5];
-                sid[4] = s4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sid[k] = nn[(size_t)k * n_elems + qflat];
+                int sid[5] = { s03.x, s03.y, s03.z, s03.w, s4 };
                 v4f sp[5];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) sp[k] = pts[sid[k]];
@@ -711,8 +714,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
         // while the set is unchanged was measured twice: keeping the five ids live costs an occupancy step (8 -> 7,
         // 4 % slower); a one-register XOR signature keeps 8 waves but gains nothing — the kernel is not HBM-bound.
-        nn[0 * (size_t)n_elems + qflat] = i0; nn[1 * (size_t)n_elems + qflat] = i1;
-        nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
+        { v4i w; w.x = i0; w.y = i1; w.z = i2; w.w = i3; nn4[qflat] = w; }
         nn[4 * (size_t)n_elems + qflat] = i4;
     }
     // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
