@@ -581,12 +581,22 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 // per-column maxima.  Lists are flushed whenever a lane's list is full, which also re-prunes against the shrinking bound
 // during the wide early-iteration walks.  Same columns, same candidate order, same inserts: the result is identical.
 constexpr int kWalkCap = 8;
-#define LISREG_WALK_LIST(lim2_expr) do { \
+// INNER: restrict this pass to the 3 x 3 columns around the query's own column and remember that box (sx0..sy1);
+// SKIP: leave out the columns of the remembered box (a preceding INNER pass covered them with a z-range at least as wide).
+// An INNER pass followed by a SKIP pass is the same walk centre-first: the bound is tight before the outer columns are
+// looked at, which then mostly fail the pruning test without touching memory (matters for the wide walks of the first
+// Gauss-Newton iterations, whose seeds are a pose step away from the truth).
+#define LISREG_WALK_LIST(lim2_expr, INNER, SKIP) do { \
         const float lim_ = fminf(b4, (lim2_expr)); \
         const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps; \
-        const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
-        const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
+        int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
+        int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
         const int cz0_ = max(grid_coord(qz - rad_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rad_, g.oz, g.inv_cell), g.nz - 1); \
+        if (INNER) { \
+            const int hx_ = grid_coord(qx, g.ox, g.inv_cell), hy_ = grid_coord(qy, g.oy, g.inv_cell); \
+            cx0_ = max(cx0_, hx_ - 1); cx1_ = min(cx1_, hx_ + 1); cy0_ = max(cy0_, hy_ - 1); cy1_ = min(cy1_, hy_ + 1); \
+            sx0_ = cx0_; sx1_ = cx1_; sy0_ = cy0_; sy1_ = cy1_; \
+        } \
         int ix_ = cx0_, iy_ = cy0_; \
         if (cz0_ > cz1_ || cy0_ > cy1_) ix_ = cx1_ + 1; \
         while (ix_ <= cx1_) { \
@@ -596,7 +606,8 @@ constexpr int kWalkCap = 8;
                 const float xl_ = g.ox + (float)ix_ * g.cell, yl_ = g.oy + (float)iy_ * g.cell; \
                 const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
                 const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
-                if (dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
+                const bool covered_ = (SKIP) && ix_ >= sx0_ && ix_ <= sx1_ && iy_ >= sy0_ && iy_ <= sy1_; \
+                if (!covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
                     const int base_ = (ix_ * g.ny + iy_) * g.nz; \
                     const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
                     if (js_ < je_) { s_runs[cnt_][tid] = make_int2(js_, je_); ++cnt_; } \
@@ -624,6 +635,7 @@ constexpr int kWalkCap = 8;
             } \
         } } while (0)
 
+template <bool kWide>
 __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
@@ -705,12 +717,17 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 seeded = true;
             }
         }
+        int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;            // columns covered by an INNER pass (empty)
         if (!seeded) {
-            LISREG_WALK_LIST(first_pass_r2);                    // tight first pass establishes a bound cheaply
-            if (!(b4 <= first_pass_r2)) LISREG_WALK_LIST(3.0e38f);
+            LISREG_WALK_LIST(first_pass_r2, false, false);      // tight first pass establishes a bound cheaply
+            if (!(b4 <= first_pass_r2)) LISREG_WALK_LIST(3.0e38f, false, false);
+        } else if (kWide) {
+            LISREG_WALK_LIST(3.0e38f, true, false);             // centre first ...
+            LISREG_WALK_LIST(3.0e38f, false, true);             // ... then whatever the tightened bound still reaches
         } else {
-            LISREG_WALK_LIST(3.0e38f);
+            LISREG_WALK_LIST(3.0e38f, false, false);
         }
+        (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
         // while the set is unchanged was measured twice: keeping the five ids live costs an occupancy step (8 -> 7,
         // 4 % slower); a one-register XOR signature keeps 8 waves but gains nothing — the kernel is not HBM-bound.
@@ -936,14 +953,18 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, unsigned long long* counters, hipStream_t st)
+                  float slack, bool wide, unsigned long long* counters, hipStream_t st)
 {
     if (n_blocks <= 0) return;
     if (mode == 0)
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
     else if (mode == 1)
-        k_assoc_walk<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                   first_pass_r2, partials);
+        if (wide)
+            k_assoc_walk<true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                             first_pass_r2, partials);
+        else
+            k_assoc_walk<false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                              first_pass_r2, partials);
     else
         k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
                                                      model1, n_elems, first_pass_r2, slack, counters, partials);

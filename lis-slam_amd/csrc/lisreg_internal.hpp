@@ -125,7 +125,8 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion certificate */,
                   int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, unsigned long long* counters /* may be null */, hipStream_t st);
+                  float slack, bool wide /* mode 1: centre-first walk for the early iterations whose seeds are stale */,
+                  unsigned long long* counters /* may be null */, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);
