@@ -240,6 +240,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_CERT_SLACK_MM")) c->cert_slack = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
+    if (const char* m = getenv("LISREG_WIDE_FROM")) c->wide_from = atoi(m);
     *out = c;
     return LISREG_OK;
 }
@@ -561,7 +562,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
                      c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>(),
                      c->search_mode, c->nn.as<int>(), c->cert.as<float4>(), c->model0.as<float4>(), c->model1.as<float4>(),
-                     c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack, it >= 1 && it <= c->wide_until,
+                     c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack, it >= c->wide_from && it <= c->wide_until,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr, st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),

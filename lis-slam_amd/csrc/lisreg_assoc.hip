@@ -718,7 +718,13 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
         int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;            // columns covered by an INNER pass (empty)
-        if (!seeded) {
+        if (!seeded && kWide) {
+            // no seeds (GN iteration 0): the 3 x 3 columns around the query over the full tau-deep z-range first, then only
+            // the columns outside that box which the bound still reaches.  A radius-limited first pass (450 ... 800 mm, with the
+            // skip only when it settles five neighbours) measured 1-2 % slower than this.
+            LISREG_WALK_LIST(3.0e38f, true, false);
+            LISREG_WALK_LIST(3.0e38f, false, true);
+        } else if (!seeded) {
             LISREG_WALK_LIST(first_pass_r2, false, false);      // tight first pass establishes a bound cheaply
             if (!(b4 <= first_pass_r2)) LISREG_WALK_LIST(3.0e38f, false, false);
         } else if (kWide) {

@@ -80,7 +80,8 @@ struct lisreg_ctx {
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch
     float     first_pass_r = 0.45f;
-    int       wide_until = 2;            // GN iterations 1..wide_until walk centre-first (their seeds are a pose step off)
+    int       wide_from = 0;
+    int       wide_until = 2;            // GN iterations wide_from..wide_until walk centre-first (no seeds, or seeds a pose step off)
     std::vector<lisreg::BlockDesc> h_blocks;
     std::vector<lisreg::Segment>   h_segs;
     std::vector<lisreg::ItemState> h_items;
