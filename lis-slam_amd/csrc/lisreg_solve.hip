@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ item
     write_pose_cache(it);
 }
 
-constexpr int kSolveThreads = 256;
+constexpr int kSolveThreads = 512;
 
 __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__ items, const DevParams P,
                                                          const double* __restrict__ partials,
