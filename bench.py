@@ -221,13 +221,22 @@ def main():
                          "vs_cpu_oracle": parity,
                          "all_status_ok": bool(all(s["status"] == 0 for s in st_gpu))},
         }
-        print(json.dumps(out))
+    else:
+        out = None
     if use_dist:
         import torch.distributed as dist
         # the gathered block of every rank must hold every rank's poses (rank r's slice == what rank r computed)
         g = gathered.cpu().numpy()
         assert np.array_equal(g[rank, :, :6], T_gpu), "all-gathered result block differs from the local results"
         dist.destroy_process_group()
+    if out is not None:                     # the ONE JSON line, after every library has said what it had to say
+        sys.stderr.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # C-level buffers (RCCL prints its version banner through stdio)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
