@@ -377,6 +377,8 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
             t.raw_external[k] = false;
             t.raw_ptr[k] = t.raw[k].as<float4>();
         }
+        for (int d = 0; d < 6; ++d)
+            if (n > 0 && !std::isfinite(bb[d])) return fail(c, LISREG_ERR_ARG, "set_target: the cloud has infinite coordinates (NaN points are ignored, Inf is not indexable)");
         make_grid(bb, n, &t.g[k], &t.n_cells[k]);
         prof_mark(c, 2);
         int rc = build_target_kind(c, t, k);

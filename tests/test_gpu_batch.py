@@ -257,3 +257,29 @@ def test_two_contexts_on_two_threads_match_sequential():
         assert len(par[k][0]) == 8
         for T, st, tr in par[k][0]:
             assert np.array_equal(T, T0) and st == st0 and np.array_equal(tr, tr0)
+
+
+@pytest.mark.gpu
+def test_non_finite_inputs_are_contained(gpu_ctx):
+    """NaN / Inf coordinates must neither hang nor fault: an Inf in a target is refused, NaN target points and non-finite
+    source points simply find no correspondences."""
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=1700)
+    p = lisreg.default_params(1)
+    bad_t = case["tgt_surf"].copy(); bad_t["x"][5] = np.inf
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.set_target(case["tgt_corner"], bad_t)
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.map_index_set(40, bad_t)
+    nan_t = case["tgt_surf"].copy(); nan_t["y"][::50] = np.nan
+    gpu_ctx.set_target(case["tgt_corner"], nan_t)
+    src = case["src_surf"].copy(); src["x"][::40] = np.nan; src["z"][7::40] = np.inf
+    T, st, _ = gpu_ctx.align(case["src_corner"], src, case["T_init"], p)
+    assert st["status"] == 0 and np.all(np.isfinite(T))
+    gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+    T0, st0, _ = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    assert max(pose_err(T, T0)) < 5e-3                                  # a few percent fewer points, same answer
+    gpu_ctx.map_index_set(40, case["tgt_surf"])
+    idx, d2 = gpu_ctx.nearest(40, src)
+    assert np.all(idx[::40] == -1) and np.all(idx[1::40] >= 0)
