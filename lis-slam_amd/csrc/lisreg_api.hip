@@ -784,6 +784,8 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
     launch_bbox(pts, n, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), st);
     HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    for (int k = 0; k < 6; ++k)       // the reference strips non-finite returns before any filter (pcl::removeNaNFromPointCloud)
+        if (!std::isfinite(bb[k])) return fail(c, LISREG_ERR_ARG, "voxel_downsample: the cloud has infinite coordinates");
     const float inv = 1.0f / leaf;
     const long long dx = (long long)((bb[3] - bb[0]) * inv) + 1, dy = (long long)((bb[4] - bb[1]) * inv) + 1,
                     dz = (long long)((bb[5] - bb[2]) * inv) + 1;

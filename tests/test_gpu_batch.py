@@ -283,3 +283,18 @@ def test_non_finite_inputs_are_contained(gpu_ctx):
     gpu_ctx.map_index_set(40, case["tgt_surf"])
     idx, d2 = gpu_ctx.nearest(40, src)
     assert np.all(idx[::40] == -1) and np.all(idx[1::40] >= 0)
+    # the rows around the path: Inf refused where a grid is sized from the bounding box, everything else runs through
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.voxel_downsample(bad_t, 0.4)
+    st_v, ds = gpu_ctx.voxel_downsample(nan_t, 0.4)
+    assert st_v == 0 and len(ds) > 1000
+    assert len(gpu_ctx.bbx_filter(bad_t, [-10, -10, -1, 10, 10, 5])) > 0
+    kept, applied = gpu_ctx.dynamic_filter(40, src, 100.0, 0.3, 1.0, 0.05)
+    assert applied and len(kept) >= len(src[::40])                      # non-finite points have no neighbour: kept
+    r = gpu_ctx.icp_align(40, src, lisreg.icp_default_params(0))
+    assert np.all(np.isfinite(r["T"]))
+    g = gpu_ctx.icp_gn_match(40, src, 4, 4.0, np.eye(4, dtype=np.float32))
+    assert np.all(np.isfinite(g["T"])) and g["steps_applied"] == 4
+    raw = synth.make_raw_scan(16, 450, 1701); raw["x"][5] = np.nan; raw["y"][6] = np.inf; raw["z"][100] = -np.inf
+    f = gpu_ctx.extract_features(raw, lisreg.FeatureParams(16, 450, 1, 0.0, 70.0, 1.0, 0.1))
+    assert len(f["deskewed"]) > 5000
