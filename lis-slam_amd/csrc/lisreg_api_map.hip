@@ -176,6 +176,8 @@ int lisreg_dynamic_filter(lisreg_ctx* c, int slot, const void* cloud, int n, int
     int rc = check_cloud(c, cloud, n, stride, fmt, "dynamic_filter");
     if (rc) return rc;
     if (!n_out || (n > 0 && !out)) return bad(c, "dynamic_filter: NULL output");
+    if (center_radius != center_radius || dist_thre_min != dist_thre_min || dist_thre_max != dist_thre_max || near_dist_thre != near_dist_thre)
+        return bad(c, "dynamic_filter: NaN threshold");
     HIPCHK(c, hipSetDevice(c->device));
     const MapIndex& m = c->maps[(size_t)slot];
     if (n <= 10 || m.n <= 0) {                      // subMap.h:1071-1072 returns false and leaves the cloud alone

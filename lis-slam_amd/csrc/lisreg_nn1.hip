@@ -81,7 +81,7 @@ __device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const Gr
                 if (ob < best || (ob == best && ow < bw)) { best = ob; bi = oi; bw = ow; }
             }
         }
-        if (best <= r * r || r * r >= max_d2) break;       // exact: everything within min(best, r) was visited
+        if (best <= r * r || !(r * r < max_d2)) break;     // exact: everything within min(best, r) was visited (a NaN cap ends the search too)
     }
 #undef LISREG_NN1_TRY
     *d2_out = best;

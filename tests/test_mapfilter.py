@@ -172,6 +172,10 @@ def test_hip_dynamic_filter_edges_and_device(oracle, gpu_ctx):
     assert same_points(got, q)
     with pytest.raises(lisreg.LisregError):
         gpu_ctx.dynamic_filter(99, q, 30.0)
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.dynamic_filter(7, q, 30.0, float("nan"), 1.0, 0.05)
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.nearest(7, q, float("nan"))
     # device records in / out, map index over device memory
     rm, rq = lisreg.pack_device_records(m), lisreg.pack_device_records(q)
     dm, dq, dout = lisreg.DeviceArray(rm), lisreg.DeviceArray(rq), lisreg.DeviceArray(np.zeros_like(rq))
