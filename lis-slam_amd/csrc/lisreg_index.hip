@@ -55,12 +55,29 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_local(const int* __restrict
     __shared__ int s_wave[4];
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     int v[kScanItems], sum = 0;
+    // full tiles of 16-byte aligned arrays move as two int4 per thread (the cell tables of a batch of targets are tens of
+    // millions of entries: this pass and k_scan_add are pure streaming)
+    const bool vec = (base + kScanItems <= n) && ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0);
+    if (vec) {
+        const int4 a = *reinterpret_cast<const int4*>(in + base), b = *reinterpret_cast<const int4*>(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; sum += v[i]; }
+        for (int i = 0; i < kScanItems; ++i) sum += v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; sum += v[i]; }
+    }
     int total;
     int ex = block_excl_scan(sum, &total, s_wave);
+    if (vec) {
+        int4 a, b;
+        a.x = ex; a.y = a.x + v[0]; a.z = a.y + v[1]; a.w = a.z + v[2];
+        b.x = a.w + v[3]; b.y = b.x + v[4]; b.z = b.y + v[5]; b.w = b.z + v[6];
+        *reinterpret_cast<int4*>(out + base) = a; *reinterpret_cast<int4*>(out + base + 4) = b;
+    } else {
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+        for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    }
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -69,12 +86,15 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tops(int* __restrict__ bloc
 {
     __shared__ int s_wave[4];
     int carry = 0;
-    for (int b0 = 0; b0 < nb; b0 += kScanBlock) {
-        int i = b0 + threadIdx.x;
-        int v = i < nb ? block_sums[i] : 0;
+    for (int b0 = 0; b0 < nb; b0 += kScanTile) {              // eight sums per thread and round
+        const int base = b0 + threadIdx.x * kScanItems;
+        int v[kScanItems], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < nb) ? block_sums[base + i] : 0; sum += v[i]; }
         int total;
-        int ex = block_excl_scan(v, &total, s_wave);
-        if (i < nb) block_sums[i] = carry + ex;
+        int ex = carry + block_excl_scan(sum, &total, s_wave);
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) { if (base + i < nb) block_sums[base + i] = ex; ex += v[i]; }
         carry += total;
     }
     if (threadIdx.x == 0) block_sums[nb] = carry;
@@ -85,8 +105,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int* __restrict__ out, 
 {
     const int off = block_sums[blockIdx.x];
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    if ((base + kScanItems <= n) && (((uintptr_t)out & 15u) == 0)) {
+        int4 a = *reinterpret_cast<int4*>(out + base), b = *reinterpret_cast<int4*>(out + base + 4);
+        a.x += off; a.y += off; a.z += off; a.w += off; b.x += off; b.y += off; b.z += off; b.w += off;
+        *reinterpret_cast<int4*>(out + base) = a; *reinterpret_cast<int4*>(out + base + 4) = b;
+    } else {
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] += off;
+        for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] += off;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
 }
 
