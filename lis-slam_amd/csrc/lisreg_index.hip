@@ -179,8 +179,9 @@ __global__ __launch_bounds__(256) void k_target_keys(const float4* __restrict__ 
     const int iz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
     const uint32_t b = (uint32_t)((ix * g.ny + iy) * g.nz + iz);
     elem_bucket[i] = b;
-    elem_sub[i] = 0u;
-    atomicAdd(&hist[b], 1);
+    // targets have no sub-key: the slot carries the point's arrival rank in its cell instead, which spares the scatter pass
+    // its own atomic (the order inside a cell is fixed afterwards by the rank pass, so which rank a point draws is irrelevant)
+    elem_sub[i] = (uint32_t)atomicAdd(&hist[b], 1);
 }
 
 // ---- source keys: (x,y) sort column of the point under the item's INITIAL pose (ItemState::M, written by the
@@ -219,14 +220,15 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ el
                                                  const uint32_t* __restrict__ elem_sub, int n,
                                                  const int* __restrict__ bucket_start, int* __restrict__ hist,
                                                  uint32_t* __restrict__ tmp_bucket, uint32_t* __restrict__ tmp_sub,
-                                                 int* __restrict__ tmp_idx)
+                                                 int* __restrict__ tmp_idx, int sub_is_rank)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t b = elem_bucket[i];
-    const int pos = bucket_start[b] + atomicSub(&hist[b], 1) - 1;
+    const uint32_t sub = elem_sub[i];
+    const int pos = bucket_start[b] + (sub_is_rank ? (int)sub : atomicSub(&hist[b], 1) - 1);
     tmp_bucket[pos] = b;
-    tmp_sub[pos] = elem_sub[i];
+    tmp_sub[pos] = sub_is_rank ? 0u : sub;
     tmp_idx[pos] = i;
 }
 
@@ -302,8 +304,7 @@ __global__ __launch_bounds__(kBlockQ) void k_tseg_keys(const BlockDesc* __restri
     const int iz = cell_coord(p.z, t.oz, t.inv_cell, t.nz);
     const uint32_t b = (uint32_t)(t.bucket_base + (ix * t.ny + iy) * t.nz + iz);
     elem_bucket[t.flat_base + e] = b;
-    elem_sub[t.flat_base + e] = 0u;
-    atomicAdd(&hist[b], 1);
+    elem_sub[t.flat_base + e] = (uint32_t)atomicAdd(&hist[b], 1);       // arrival rank in the cell (see k_target_keys)
 }
 
 __device__ __forceinline__ int find_tseg_by_flat(const TargetSeg* __restrict__ tsegs, int n, int flat)
@@ -505,7 +506,7 @@ void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_o
     exclusive_scan(sb.hist, cell_start_out, sb.scan_tmp, n_cells, st);
     if (n > 0) {
         k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, cell_start_out, sb.hist,
-                                                   sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
+                                                   sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, 1);
         k_rank_target<<<(n + 255) / 256, 256, 0, st>>>(pts, n, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx,
                                                        cell_start_out, sorted_out);
     }
@@ -520,7 +521,7 @@ void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const T
     exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
     if (n_elems > 0) {
         k_scatter<<<(n_elems + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n_elems, sb.bucket_start, sb.hist,
-                                                         sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
+                                                         sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, 1);
         k_rank_tsegs<<<(n_elems + 255) / 256, 256, 0, st>>>(tsegs, n_tsegs, n_elems, sb.tmp_bucket, sb.tmp_sub,
                                                             sb.tmp_idx, sb.bucket_start);
     }
@@ -538,7 +539,7 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
     exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
     if (n_elems > 0) {
         k_scatter<<<(n_elems + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n_elems, sb.bucket_start,
-                                                         sb.hist, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
+                                                         sb.hist, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, 0);
         k_rank_source<<<(n_elems + 255) / 256, 256, 0, st>>>(segs, n_segs, n_elems, sb.tmp_bucket, sb.tmp_sub,
                                                              sb.tmp_idx, sb.bucket_start, sorted_all, order_all);
     }
@@ -552,7 +553,7 @@ void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, Sor
     k_voxel_keys<<<(n + 255) / 256, 256, 0, st>>>(pts, n, d, sb.elem_bucket, sb.elem_sub, sb.hist);
     exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
     k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, sb.bucket_start, sb.hist, sb.tmp_bucket,
-                                               sb.tmp_sub, sb.tmp_idx);
+                                               sb.tmp_sub, sb.tmp_idx, 0);
     k_voxel_rank<<<(n + 255) / 256, 256, 0, st>>>(n, d.span, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, sb.bucket_start, order, sidx);
     k_voxel_heads<<<(n + 255) / 256, 256, 0, st>>>(n, sidx, head);
     exclusive_scan(head, slot, sb.scan_tmp, n, st);
