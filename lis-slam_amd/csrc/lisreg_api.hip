@@ -93,6 +93,7 @@ SortBuffers sort_buffers(lisreg_ctx* c)
     sb.elem_bucket = c->elem_bucket.as<uint32_t>(); sb.elem_sub = c->elem_sub.as<uint32_t>();
     sb.tmp_bucket = c->tmp_bucket.as<uint32_t>(); sb.tmp_sub = c->tmp_sub.as<uint32_t>();
     sb.tmp_idx = c->tmp_idx.as<int>();
+    sb.tmp_pts = c->tmp_pts.as<float4>();
     return sb;
 }
 }  // namespace lisreg
@@ -110,6 +111,7 @@ int ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets)
     HIPCHK(c, c->tmp_bucket.ensure(sizeof(uint32_t) * (n_elems + 1)));
     HIPCHK(c, c->tmp_sub.ensure(sizeof(uint32_t) * (n_elems + 1)));
     HIPCHK(c, c->tmp_idx.ensure(sizeof(int) * (n_elems + 1)));
+    HIPCHK(c, c->tmp_pts.ensure(sizeof(float4) * (n_elems + 1)));
     return LISREG_OK;
 }
 }  // namespace lisreg
@@ -253,7 +255,7 @@ void lisreg_destroy(lisreg_ctx* c)
     lisreg_comm_destroy(c);
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
-                       &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
+                       &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
                        &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,

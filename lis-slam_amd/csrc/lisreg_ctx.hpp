@@ -61,7 +61,7 @@ struct lisreg_ctx {
     lisreg::DevBuf       grids_dev;
     bool         grids_dirty = true;
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
-    lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, bbox_dev, bbox_scratch;
+    lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
     lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,

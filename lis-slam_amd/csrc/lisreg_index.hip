@@ -314,21 +314,41 @@ __device__ __forceinline__ int find_tseg_by_flat(const TargetSeg* __restrict__ t
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_rank_tsegs(const TargetSeg* __restrict__ tsegs, int n_tsegs, int n,
-                                                    const uint32_t* __restrict__ tmp_bucket,
-                                                    const uint32_t* __restrict__ tmp_sub,
-                                                    const int* __restrict__ tmp_idx,
-                                                    const int* __restrict__ bucket_start)
+// Batched target build, second half.  The scatter carries the point itself (x, y, z, original index) to the slot its arrival
+// rank assigns — one 16-byte write instead of three scattered 4-byte writes — and the rank pass re-derives the cell from the
+// coordinates, orders the cell's members by original index (deterministic result) and writes the final record: no gather.
+__device__ __forceinline__ uint32_t tseg_bucket(const TargetSeg& t, float x, float y, float z)
+{
+    const int ix = cell_coord(x, t.ox, t.inv_cell, t.nx), iy = cell_coord(y, t.oy, t.inv_cell, t.ny), iz = cell_coord(z, t.oz, t.inv_cell, t.nz);
+    return (uint32_t)(t.bucket_base + (ix * t.ny + iy) * t.nz + iz);
+}
+
+__global__ __launch_bounds__(kBlockQ) void k_tseg_scatter_pts(const BlockDesc* __restrict__ blocks, const TargetSeg* __restrict__ tsegs,
+                                                              const uint32_t* __restrict__ elem_rank,
+                                                              const int* __restrict__ bucket_start, float4* __restrict__ tmp_pts)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    if ((int)threadIdx.x >= bd.count) return;
+    const TargetSeg t = tsegs[bd.seg];
+    const int e = bd.start + threadIdx.x;
+    float4 p = t.raw[e];
+    const int pos = bucket_start[tseg_bucket(t, p.x, p.y, p.z)] + (int)elem_rank[t.flat_base + e];
+    p.w = __int_as_float(e);
+    tmp_pts[pos] = p;
+}
+
+__global__ __launch_bounds__(256) void k_tseg_rank_pts(const TargetSeg* __restrict__ tsegs, int n_tsegs, int n,
+                                                       const float4* __restrict__ tmp_pts, const int* __restrict__ bucket_start)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    int flat;
-    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &flat);
-    const TargetSeg t = tsegs[find_tseg_by_flat(tsegs, n_tsegs, flat)];
-    const int e = flat - t.flat_base;
-    float4 v = t.raw[e];
-    v.w = __int_as_float(e);
-    t.sorted_out[dst - t.flat_base] = v;
+    const float4 v = tmp_pts[p];
+    const TargetSeg t = tsegs[find_tseg_by_flat(tsegs, n_tsegs, p)];      // slots of a target = its flat range
+    const uint32_t b = tseg_bucket(t, v.x, v.y, v.z);
+    const int s = bucket_start[b], e = bucket_start[b + 1], idx = __float_as_int(v.w);
+    int rank = 0;
+    for (int j = s; j < e; ++j) rank += (__float_as_int(tmp_pts[j].w) < idx) ? 1 : 0;
+    t.sorted_out[s + rank - t.flat_base] = v;
 }
 
 // per-target cell_start = slice of the global bucket scan, rebased to the target's own sorted array
@@ -520,10 +540,8 @@ void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const T
     if (n_blocks > 0) k_tseg_keys<<<n_blocks, kBlockQ, 0, st>>>(blocks, tsegs, sb.elem_bucket, sb.elem_sub, sb.hist);
     exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
     if (n_elems > 0) {
-        k_scatter<<<(n_elems + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n_elems, sb.bucket_start, sb.hist,
-                                                         sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, 1);
-        k_rank_tsegs<<<(n_elems + 255) / 256, 256, 0, st>>>(tsegs, n_tsegs, n_elems, sb.tmp_bucket, sb.tmp_sub,
-                                                            sb.tmp_idx, sb.bucket_start);
+        k_tseg_scatter_pts<<<n_blocks, kBlockQ, 0, st>>>(blocks, tsegs, sb.elem_sub, sb.bucket_start, sb.tmp_pts);
+        k_tseg_rank_pts<<<(n_elems + 255) / 256, 256, 0, st>>>(tsegs, n_tsegs, n_elems, sb.tmp_pts, sb.bucket_start);
     }
     k_tseg_cell_starts<<<dim3(64, n_tsegs), 256, 0, st>>>(tsegs, n_tsegs, sb.bucket_start);
 }

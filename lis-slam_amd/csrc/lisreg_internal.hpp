@@ -106,6 +106,7 @@ struct SortBuffers {           // scratch for one deterministic bucket sort
     uint32_t* tmp_bucket;      // [n_elems] by scattered position
     uint32_t* tmp_sub;
     int*      tmp_idx;
+    float4*   tmp_pts;         // [n_elems] batched target build: the points themselves by scattered position
 };
 
 // bounding box of device records -> bbox6 = {minx,miny,minz,maxx,maxy,maxz} (device)
