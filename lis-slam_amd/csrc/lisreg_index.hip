@@ -303,7 +303,6 @@ __global__ __launch_bounds__(kBlockQ) void k_tseg_keys(const BlockDesc* __restri
     const int iy = cell_coord(p.y, t.oy, t.inv_cell, t.ny);
     const int iz = cell_coord(p.z, t.oz, t.inv_cell, t.nz);
     const uint32_t b = (uint32_t)(t.bucket_base + (ix * t.ny + iy) * t.nz + iz);
-    elem_bucket[t.flat_base + e] = b;
     elem_sub[t.flat_base + e] = (uint32_t)atomicAdd(&hist[b], 1);       // arrival rank in the cell (see k_target_keys)
 }
 
