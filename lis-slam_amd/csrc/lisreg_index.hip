@@ -178,10 +178,35 @@ __global__ __launch_bounds__(256) void k_target_keys(const float4* __restrict__ 
     const int iy = cell_coord(p.y, g.oy, g.inv_cell, g.ny);
     const int iz = cell_coord(p.z, g.oz, g.inv_cell, g.nz);
     const uint32_t b = (uint32_t)((ix * g.ny + iy) * g.nz + iz);
-    elem_bucket[i] = b;
     // targets have no sub-key: the slot carries the point's arrival rank in its cell instead, which spares the scatter pass
     // its own atomic (the order inside a cell is fixed afterwards by the rank pass, so which rank a point draws is irrelevant)
     elem_sub[i] = (uint32_t)atomicAdd(&hist[b], 1);
+}
+
+// single-target versions of the point-carrying scatter / gather-free rank (see k_tseg_scatter_pts below)
+__global__ __launch_bounds__(256) void k_target_scatter_pts(const float4* __restrict__ pts, int n, GridIndex g,
+                                                            const uint32_t* __restrict__ elem_rank,
+                                                            const int* __restrict__ cell_start, float4* __restrict__ tmp_pts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    const int b = (cell_coord(p.x, g.ox, g.inv_cell, g.nx) * g.ny + cell_coord(p.y, g.oy, g.inv_cell, g.ny)) * g.nz + cell_coord(p.z, g.oz, g.inv_cell, g.nz);
+    p.w = __int_as_float(i);
+    tmp_pts[cell_start[b] + (int)elem_rank[i]] = p;
+}
+
+__global__ __launch_bounds__(256) void k_target_rank_pts(int n, GridIndex g, const float4* __restrict__ tmp_pts,
+                                                         const int* __restrict__ cell_start, float4* __restrict__ sorted_out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float4 v = tmp_pts[p];
+    const int b = (cell_coord(v.x, g.ox, g.inv_cell, g.nx) * g.ny + cell_coord(v.y, g.oy, g.inv_cell, g.ny)) * g.nz + cell_coord(v.z, g.oz, g.inv_cell, g.nz);
+    const int s = cell_start[b], e = cell_start[b + 1], idx = __float_as_int(v.w);
+    int rank = 0;
+    for (int j = s; j < e; ++j) rank += (__float_as_int(tmp_pts[j].w) < idx) ? 1 : 0;
+    sorted_out[s + rank] = v;
 }
 
 // ---- source keys: (x,y) sort column of the point under the item's INITIAL pose (ItemState::M, written by the
@@ -220,15 +245,14 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ el
                                                  const uint32_t* __restrict__ elem_sub, int n,
                                                  const int* __restrict__ bucket_start, int* __restrict__ hist,
                                                  uint32_t* __restrict__ tmp_bucket, uint32_t* __restrict__ tmp_sub,
-                                                 int* __restrict__ tmp_idx, int sub_is_rank)
+                                                 int* __restrict__ tmp_idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t b = elem_bucket[i];
-    const uint32_t sub = elem_sub[i];
-    const int pos = bucket_start[b] + (sub_is_rank ? (int)sub : atomicSub(&hist[b], 1) - 1);
+    const int pos = bucket_start[b] + atomicSub(&hist[b], 1) - 1;
     tmp_bucket[pos] = b;
-    tmp_sub[pos] = sub_is_rank ? 0u : sub;
+    tmp_sub[pos] = elem_sub[i];
     tmp_idx[pos] = i;
 }
 
@@ -249,22 +273,6 @@ __device__ __forceinline__ int rank_in_bucket(int p, const uint32_t* __restrict_
     }
     *idx_out = idx;
     return s + rank;
-}
-
-__global__ __launch_bounds__(256) void k_rank_target(const float4* __restrict__ pts, int n,
-                                                     const uint32_t* __restrict__ tmp_bucket,
-                                                     const uint32_t* __restrict__ tmp_sub,
-                                                     const int* __restrict__ tmp_idx,
-                                                     const int* __restrict__ bucket_start,
-                                                     float4* __restrict__ sorted_out)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    int idx;
-    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &idx);
-    float4 v = pts[idx];
-    v.w = __int_as_float(idx);
-    sorted_out[dst] = v;
 }
 
 __global__ __launch_bounds__(256) void k_rank_source(const Segment* __restrict__ segs, int n_segs, int n,
@@ -524,10 +532,8 @@ void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_o
     if (n > 0) k_target_keys<<<(n + 255) / 256, 256, 0, st>>>(pts, n, g, sb.elem_bucket, sb.elem_sub, sb.hist);
     exclusive_scan(sb.hist, cell_start_out, sb.scan_tmp, n_cells, st);
     if (n > 0) {
-        k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, cell_start_out, sb.hist,
-                                                   sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, 1);
-        k_rank_target<<<(n + 255) / 256, 256, 0, st>>>(pts, n, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx,
-                                                       cell_start_out, sorted_out);
+        k_target_scatter_pts<<<(n + 255) / 256, 256, 0, st>>>(pts, n, g, sb.elem_sub, cell_start_out, sb.tmp_pts);
+        k_target_rank_pts<<<(n + 255) / 256, 256, 0, st>>>(n, g, sb.tmp_pts, cell_start_out, sorted_out);
     }
 }
 
@@ -556,7 +562,7 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
     exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
     if (n_elems > 0) {
         k_scatter<<<(n_elems + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n_elems, sb.bucket_start,
-                                                         sb.hist, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, 0);
+                                                         sb.hist, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx);
         k_rank_source<<<(n_elems + 255) / 256, 256, 0, st>>>(segs, n_segs, n_elems, sb.tmp_bucket, sb.tmp_sub,
                                                              sb.tmp_idx, sb.bucket_start, sorted_all, order_all);
     }
@@ -570,7 +576,7 @@ void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, Sor
     k_voxel_keys<<<(n + 255) / 256, 256, 0, st>>>(pts, n, d, sb.elem_bucket, sb.elem_sub, sb.hist);
     exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
     k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, sb.bucket_start, sb.hist, sb.tmp_bucket,
-                                               sb.tmp_sub, sb.tmp_idx, 0);
+                                               sb.tmp_sub, sb.tmp_idx);
     k_voxel_rank<<<(n + 255) / 256, 256, 0, st>>>(n, d.span, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, sb.bucket_start, order, sidx);
     k_voxel_heads<<<(n + 255) / 256, 256, 0, st>>>(n, sidx, head);
     exclusive_scan(head, slot, sb.scan_tmp, n, st);
