@@ -418,7 +418,12 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
         if ((lane & 1) == 0 && idx < kNumAcc) s_acc[wave][idx] = v1;
     }
     __syncthreads();
-    if (tid < kNumAcc) out[tid] = ((s_acc[0][tid] + s_acc[1][tid]) + s_acc[2][tid]) + s_acc[3][tid];
+    if (tid < kNumAcc) {
+        double v = s_acc[0][tid];
+#pragma unroll
+        for (int w = 1; w < kBlockQ / 64; ++w) v += s_acc[w][tid];        // fixed order: ((w0 + w1) + w2) + w3
+        out[tid] = v;
+    }
 }
 
 
