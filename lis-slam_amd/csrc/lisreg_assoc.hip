@@ -335,6 +335,9 @@ typedef __attribute__((address_space(1))) const v3f* gptr_f3;
 typedef __attribute__((address_space(1))) const int* gptr_i32;
 typedef __attribute__((address_space(1))) int*       gptr_i32w;
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const v4i* gptr_i4;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const v2f* gptr_f2;
 typedef __attribute__((address_space(1))) v4i*       gptr_i4w;
 
 __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
@@ -640,13 +643,67 @@ constexpr int kWalkCap = 8;
             } \
         } } while (0)
 
-template <bool kWide>
+// Graph scan (search_mode 3, GN iterations >= 1).  The target carries a k-NN graph (lisreg_index.hip: kGraphK nearest other
+// points per point, ascending, plus the coverage radius rho with "|x - a| < rho(a) => x is listed").  The query keeps ONE id
+// from the last iteration — its nearest neighbour, the anchor a — and scans {a} + list(a) in list order.  With d_a = |q - a|
+// and c5 = the current 5th-best distance (sqrt(tau) while fewer than five are known), any point not yet seen is at least
+// l - d_a away, l being the list distance reached; so the scan stops at the first entry with l > c5 + d_a, and an exhausted
+// list certifies through rho(a) > c5 + d_a.  Either way the five kept are exactly the five nearest inside sqrt(tau) (triangle
+// inequality; kEps absorbs the rounding of the recomputed list distances).  No certificate -> hop to the nearest point found
+// and rescan; still none after `graph_hops` lists -> the cell walk, seeded with what was found.  Same sets as the walk, at
+// ~10 candidate tests per query (wave maximum ~21) instead of ~27 plus ~4 column probes, with no per-column address work.
+
+#define LISREG_GRAPH_SCAN() do { \
+        int a_ = anchor; \
+        _Pragma("unroll 1") for (int hop_ = 0; hop_ < graph_hops; ++hop_) { \
+            const v4f ap_ = pts[a_]; \
+            const v2f am_ = meta[a_]; \
+            const float ux_ = qx - ap_.x, uy_ = qy - ap_.y, uz_ = qz - ap_.z; \
+            const float da2_ = ux_ * ux_ + uy_ * uy_ + uz_ * uz_; \
+            LISREG_TRY(da2_, a_); \
+            const float da_ = __builtin_amdgcn_sqrtf(da2_) * 1.0001f + kEps; \
+            const int cnt_ = __float_as_int(am_.y); \
+            const gptr_i4 L_ = (gptr_i4)(nbr + (size_t)a_ * kGraphK); \
+            bool stop_ = false; \
+            float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; \
+            float thr2_ = thr_ * thr_; \
+            _Pragma("unroll 1") for (int j_ = 0; j_ < cnt_; j_ += 4) { \
+                const v4i id_ = L_[j_ >> 2]; \
+                const int k0_ = id_.x, k1_ = id_.y < 0 ? a_ : id_.y, k2_ = id_.z < 0 ? a_ : id_.z, k3_ = id_.w < 0 ? a_ : id_.w; \
+                const v3f c0_ = *(gptr_f3)(pts + k0_), c1_ = *(gptr_f3)(pts + k1_), c2_ = *(gptr_f3)(pts + k2_), c3_ = *(gptr_f3)(pts + k3_); \
+                const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
+                const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
+                const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
+                const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
+                const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
+                const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
+                /* list distance of the LAST valid entry of the group (the list ascends; padded entries alias the anchor: 0) */ \
+                const float px_ = ap_.x - c0_.x, py_ = ap_.y - c0_.y, pz_ = ap_.z - c0_.z; \
+                const float rx_ = ap_.x - c1_.x, ry_ = ap_.y - c1_.y, rz_ = ap_.z - c1_.z; \
+                const float sx_ = ap_.x - c2_.x, sy_ = ap_.y - c2_.y, sz_ = ap_.z - c2_.z; \
+                const float tx_ = ap_.x - c3_.x, ty_ = ap_.y - c3_.y, tz_ = ap_.z - c3_.z; \
+                const float l0_ = px_ * px_ + py_ * py_ + pz_ * pz_, l1_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_; \
+                const float l2_ = sx_ * sx_ + sy_ * sy_ + sz_ * sz_, l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
+                if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
+                    LISREG_TRY(e0_, k0_); LISREG_TRY(e1_, k1_); LISREG_TRY(e2_, k2_); LISREG_TRY(e3_, k3_); \
+                    thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
+                } \
+                if (fmaxf(fmaxf(l0_, l1_), fmaxf(l2_, l3_)) > thr2_) { stop_ = true; break; } \
+            } \
+            if (!stop_) stop_ = am_.x > thr2_;                 /* list exhausted: the coverage radius decides */ \
+            if (stop_) { certified = true; break; } \
+            if (i0 == a_ || i0 < 0) break;                     /* nowhere better to hop to */ \
+            a_ = i0; \
+        } } while (0)
+
+template <bool kWide, bool kGraph>
 __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
                                                         const ItemState* __restrict__ items, const DevParams P,
                                                         const float4* __restrict__ sorted_all,
                                                         int* __restrict__ nn_, int n_elems, float first_pass_r2,
+                                                        int graph_hops, unsigned long long* __restrict__ counters,
                                                         double* __restrict__ partials)
 {
     __shared__ double s_acc[4][kNumAcc];
@@ -686,7 +743,35 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
 
     float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau;
     int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
-    if (valid) {
+    if (kGraph) {
+        // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
+        bool need_walk = valid;
+        if (valid && it->iter > 0 && g.nbr) {
+            const int anchor = nn[qflat];
+            if (anchor >= 0) {
+                const gptr_i32 nbr = (gptr_i32)g.nbr;
+                const gptr_f2 meta = (gptr_f2)g.nbr_meta;
+                bool certified = false;
+                LISREG_GRAPH_SCAN();
+                need_walk = !certified;
+            }
+        }
+        if (counters && it->iter > 0 && it->iter < 32) {       // diagnostics: lanes that fell back to the cell walk
+            const int nw = __popcll(__ballot(need_walk)), nv = __popcll(__ballot(valid));
+            if ((tid & 63) == 0) atomicAdd(&counters[it->iter], ((unsigned long long)nw << 32) | (unsigned long long)nv);
+        }
+        if (need_walk) {
+            int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;
+            if (kWide) {
+                LISREG_WALK_LIST(3.0e38f, true, false);
+                LISREG_WALK_LIST(3.0e38f, false, true);
+            } else {
+                LISREG_WALK_LIST(3.0e38f, false, false);
+            }
+            (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
+        }
+        if (valid) nn[qflat] = i0;                             // next iteration's anchor: the nearest neighbour (-1: none)
+    } else if (valid) {
         bool seeded = false;
         if (it->iter > 0) {
             // seeds: last iteration's neighbours bound the new 5th-nearest distance (any 5 points do), so the walk
@@ -964,18 +1049,25 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, bool wide, unsigned long long* counters, hipStream_t st)
+                  float slack, bool wide, int graph_hops, unsigned long long* counters, hipStream_t st)
 {
     if (n_blocks <= 0) return;
     if (mode == 0)
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
     else if (mode == 1)
         if (wide)
-            k_assoc_walk<true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                             first_pass_r2, partials);
+            k_assoc_walk<true, false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                    first_pass_r2, graph_hops, counters, partials);
         else
-            k_assoc_walk<false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                              first_pass_r2, partials);
+            k_assoc_walk<false, false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                     first_pass_r2, graph_hops, counters, partials);
+    else if (mode == 3)
+        if (wide)
+            k_assoc_walk<true, true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                   first_pass_r2, graph_hops, counters, partials);
+        else
+            k_assoc_walk<false, true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                    first_pass_r2, graph_hops, counters, partials);
     else
         k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
                                                      model1, n_elems, first_pass_r2, slack, counters, partials);

@@ -30,6 +30,8 @@ struct Target {
     int       n_cells[2] = { 1, 1 };
     GridIndex g[2];
     lisreg::DevBuf    raw[2], sorted[2], cell_start[2];
+    lisreg::DevBuf    nbr[2], nbr_meta[2];                // k-NN graph of the sorted points (search_mode 3)
+    bool      graph_valid[2] = { false, false };
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
     const float4* raw_ptr[2] = { nullptr, nullptr };
 };
@@ -75,7 +77,13 @@ struct lisreg_ctx {
     std::vector<lisreg::BlockDesc> h_tblocks;
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
-    int       search_mode = 1;
+    int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 2 walk + motion certificate, 3 k-NN graph scan,
+                                         // 4 auto: 3 when the prepared batch asks enough queries per target point to pay for the graph, else 1
+    int       mode_now = 1;              // front-end of the prepared batch
+    int       graph_min_ratio = 150;     // auto: query-iterations per target point from which the graph build pays (measured)
+    int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
+    int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
+    float     graph_radius = 1.5f;       // coverage radius of a short neighbour list (search_mode 3)
     float     cert_slack = 0.10f;
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch

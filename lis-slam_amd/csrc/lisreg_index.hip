@@ -375,6 +375,131 @@ __global__ __launch_bounds__(256) void k_tseg_cell_starts(const TargetSeg* __res
         t.cell_start_out[c] = (c < t.n_cells ? bucket_start[t.bucket_base + c] : t.flat_base + t.n) - t.flat_base;
 }
 
+
+// ---- k-NN graph over a finished target index (search_mode 3) -----------------------------------------------------------
+// For every sorted point s: up to kGraphK nearest OTHER points (sorted positions, ascending by distance) and a coverage
+// radius rho(s) with the guarantee  |x - s| < rho(s)  =>  x is in the list  (and every listed point is within rho).
+// The correspondence kernel turns that into an exact 5-NN certificate by the triangle inequality (lisreg_assoc.hip,
+// LISREG_GRAPH_SCAN): with an anchor a at distance d_a from the query and c5 the 5th-best distance found in
+// {a} + list(a), every point outside the list is at least rho(a) - d_a away.
+//
+// One WAVE per point, lanes = candidates: the candidates are the points of the 5 x 5 x 5 cell block around the point's
+// cell (25 contiguous z-runs), 64 at a time; each chunk is bitonic-sorted across the wave by (d^2, id) and merged
+// into the running 32 best.  rho = min(distance of the 32nd, distance to the nearest face of the block that has
+// cells beyond it), so nothing outside the block has to be looked at: sparse neighbourhoods simply get shorter
+// lists with rho = the block's inscribed radius (>= 2 cells).  No divergence, one coalesced 128-byte store per point.
+constexpr int kGraphPPW = 16;            // points per wave (sequential)
+
+__device__ __forceinline__ void cmpx(float& k, int& i, int j, bool take_min)
+{
+    const float pk = __shfl_xor(k, j);
+    const int   pi = __shfl_xor(i, j);
+    const bool lt = pk < k || (pk == k && pi < i);        // partner orders before me
+    const bool sw = (lt == take_min);
+    k = sw ? pk : k; i = sw ? pi : i;
+}
+
+__device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int (*s_off)[32], int (*s_js)[32])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr float kInf = __builtin_inff();
+    constexpr float kEps = 1e-3f;
+    const float4 q = g.pts[s];
+    const int hx = cell_coord(q.x, g.ox, g.inv_cell, g.nx), hy = cell_coord(q.y, g.oy, g.inv_cell, g.ny), hz = cell_coord(q.z, g.oz, g.inv_cell, g.nz);
+    const int x0 = max(hx - 2, 0), x1 = min(hx + 2, g.nx - 1), y0 = max(hy - 2, 0), y1 = min(hy + 2, g.ny - 1);
+    const int z0 = max(hz - 2, 0), z1 = min(hz + 2, g.nz - 1);
+    // inscribed radius: faces of the block that coincide with the grid boundary have nothing beyond them
+    float rc = 3.0e18f;
+    if (x0 > 0)        rc = fminf(rc, q.x - (g.ox + (float)x0 * g.cell));
+    if (x1 < g.nx - 1) rc = fminf(rc, (g.ox + (float)(x1 + 1) * g.cell) - q.x);
+    if (y0 > 0)        rc = fminf(rc, q.y - (g.oy + (float)y0 * g.cell));
+    if (y1 < g.ny - 1) rc = fminf(rc, (g.oy + (float)(y1 + 1) * g.cell) - q.y);
+    if (z0 > 0)        rc = fminf(rc, q.z - (g.oz + (float)z0 * g.cell));
+    if (z1 < g.nz - 1) rc = fminf(rc, (g.oz + (float)(z1 + 1) * g.cell) - q.z);
+    rc = fmaxf(rc - kEps, 0.f);
+    // the 25 z-runs of the block, their exclusive prefix
+    int js = 0, len = 0;
+    if (lane < 25) {
+        const int ix = hx + lane / 5 - 2, iy = hy + lane % 5 - 2;
+        if (ix >= x0 && ix <= x1 && iy >= y0 && iy <= y1) {
+            const int base = (ix * g.ny + iy) * g.nz;
+            js = g.cell_start[base + z0];
+            len = g.cell_start[base + z1 + 1] - js;
+        }
+    }
+    int inc = len;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    const int total = __shfl(inc, 31);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) { s_off[wave][lane] = inc - len; s_js[wave][lane] = js; }
+    __builtin_amdgcn_wave_barrier();
+
+    float tk = kInf; int ti = -1;                           // running 32 best in lanes 0..31, ascending
+#pragma unroll 1
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int t = c0 + lane;
+        float k = kInf; int id = -1;
+        if (t < total) {
+            int lo = 0, hi = 24;                            // last run whose offset is <= t
+#pragma unroll
+            for (int it = 0; it < 5; ++it) { const int mid = (lo + hi + 1) >> 1; if (s_off[wave][mid] <= t) lo = mid; else hi = mid - 1; }
+            const int j = s_js[wave][lo] + (t - s_off[wave][lo]);
+            const float4 c = g.pts[j];
+            const float ex = q.x - c.x, ey = q.y - c.y, ez = q.z - c.z;
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (j != s && d2 < 3.0e38f) { k = d2; id = j; }   // NaN / Inf points are never neighbours
+        }
+        // ascending bitonic sort of the 64 (k, id) pairs across the wave
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1)
+                cmpx(k, id, j, ((lane & j) == 0) == ((lane & kk) == 0 || kk == 64));
+        // lanes 32..63 <- the chunk's 32 smallest, reversed; lanes 0..31 keep the running best: a bitonic sequence
+        const float rk = __shfl(k, 63 - lane); const int ri = __shfl(id, 63 - lane);
+        float mk = lane < 32 ? tk : rk; int mi = lane < 32 ? ti : ri;
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) cmpx(mk, mi, j, (lane & j) == 0);
+        tk = mk; ti = mi;
+    }
+    const float d32 = __shfl(tk, 31);
+    const float rho2 = fminf(rc * rc, d32);
+    const bool keep = lane < 32 && ti >= 0 && tk <= rho2;
+    const int cnt = __popcll(__ballot(keep));
+    if (lane < 32) const_cast<int*>(g.nbr)[(size_t)s * kGraphK + lane] = keep ? ti : -1;
+    if (lane == 0) const_cast<float2*>(g.nbr_meta)[s] = make_float2(rho2, __int_as_float(cnt));
+}
+
+__global__ __launch_bounds__(256) void k_graph_build_one(GridIndex g)
+{
+    __shared__ int s_off[4][32], s_js[4][32];
+    const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kGraphPPW;
+#pragma unroll 1
+    for (int i = 0; i < kGraphPPW; ++i) {
+        const int s = first + i;
+        if (s >= g.n) break;
+        graph_build_wave(g, s, s_off, s_js);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __restrict__ blocks,
+                                                             const TargetSeg* __restrict__ tsegs,
+                                                             const GridIndex* __restrict__ grids)
+{
+    __shared__ int s_off[4][32], s_js[4][32];
+    constexpr int kSub = kBlockQ / (4 * kGraphPPW);         // workgroups per 256-point block descriptor
+    const BlockDesc bd = blocks[blockIdx.x / kSub];
+    const int first = ((int)(blockIdx.x % kSub) * 4 + (int)(threadIdx.x >> 6)) * kGraphPPW;
+    const GridIndex g = grids[tsegs[bd.seg].grid_id];
+#pragma unroll 1
+    for (int i = 0; i < kGraphPPW; ++i) {
+        const int e = first + i;
+        if (e >= bd.count) break;
+        graph_build_wave(g, bd.start + e, s_off, s_js);
+    }
+}
+
 // Coherence probe for sort_sources = auto: how many consecutive source points are further apart than `thr`?
 // Scan order and voxel-grid order give a few per cent; an arbitrary order gives most of them.
 __global__ __launch_bounds__(kBlockQ) void k_count_jumps(const BlockDesc* __restrict__ blocks, const Segment* __restrict__ segs,
@@ -557,6 +682,21 @@ void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const T
         k_tseg_rank_pts<<<(n_elems + 255) / 256, 256, 0, st>>>(tsegs, n_tsegs, n_elems, sb.tmp_pts, sb.bucket_start);
     }
     k_tseg_cell_starts<<<dim3(64, n_tsegs), 256, 0, st>>>(tsegs, n_tsegs, sb.bucket_start);
+}
+
+void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, float radius,
+                        hipStream_t st)
+{
+    if (n_blocks <= 0) return;
+    (void)radius;
+    k_graph_build_batched<<<n_blocks * (kBlockQ / (4 * kGraphPPW)), 256, 0, st>>>(blocks, tsegs, grids);
+}
+
+void launch_build_graph_one(GridIndex g, float radius, hipStream_t st)
+{
+    if (g.n <= 0 || !g.nbr) return;
+    (void)radius;
+    k_graph_build_one<<<(g.n + 4 * kGraphPPW - 1) / (4 * kGraphPPW), 256, 0, st>>>(g);
 }
 
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,

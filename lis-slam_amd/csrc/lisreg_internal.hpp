@@ -12,6 +12,7 @@ constexpr int kStageCap   = 1024;  // target points staged in LDS per chunk (16 
 constexpr int kNumAcc     = 28;    // 21 upper-tri AtA + 6 AtB + 1 count
 constexpr int kResultSize = 12;    // floats per item in the result block
 constexpr int kTraceStride = LISREG_TRACE_STRIDE;
+constexpr int kGraphK     = 32;    // neighbour-list length of the target's k-NN graph (search_mode 3)
 
 // Uniform-grid index over one target cloud (replaces one pcl::KdTreeFLANN, odomEstimationNode.cpp:602-603).
 // Points are bucket-sorted by cell; linear cell id = (ix*ny + iy)*nz + iz (z fastest), so a z-range of one
@@ -23,6 +24,11 @@ struct GridIndex {
     float ox, oy, oz;          // grid origin (min corner)
     float cell, inv_cell;
     int   nx, ny, nz;
+    // k-NN graph over the sorted points (search_mode 3; null otherwise): nbr[s * kGraphK + j] = sorted position of the j-th
+    // nearest other point of sorted point s (ascending by distance, -1 padded); nbr_meta[s] = (rho^2, count bits) where
+    // every point closer to s than rho is in the list.
+    const int*    nbr;
+    const float2* nbr_meta;
 };
 
 // One (item, kind) source segment; kind 0 = edge features vs corner target, 1 = planar features vs surf target.
@@ -49,6 +55,7 @@ struct TargetSeg {
     int   bucket_base;         // first bucket
     float ox, oy, oz, inv_cell;
     int   nx, ny, nz;
+    int   grid_id;             // entry of the device GridIndex array this target fills (slot * 2 + kind)
 };
 
 // One workgroup of the correspondence kernel (also the unit of the source-key kernel).
@@ -117,6 +124,10 @@ void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_o
 // several target indexes in one launch sequence (blocks: seg = TargetSeg id, start/count = point chunk)
 void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, int n_tsegs,
                                   int n_elems, int n_buckets, SortBuffers sb, hipStream_t st);
+// k-NN graph of every target in `tsegs` (grids[t.grid_id] must describe the finished index and carry nbr / nbr_meta)
+void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, float radius,
+                        hipStream_t st);
+void launch_build_graph_one(GridIndex g, float radius, hipStream_t st);
 // sources of a whole batch: tile-sort every segment under its item's initial pose
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
@@ -127,6 +138,7 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
                   int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion certificate */,
                   int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
                   float slack, bool wide /* mode 1: centre-first walk for the early iterations whose seeds are stale */,
+                  int graph_hops /* mode 3: neighbour lists scanned per query before the cell walk takes over */,
                   unsigned long long* counters /* may be null */, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);

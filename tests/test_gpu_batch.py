@@ -93,7 +93,7 @@ def test_device_resident_batch_and_rerun_is_idempotent(gpu_ctx):
     assert all(s["iters"] == 6 for s in s1)
 
 
-@pytest.mark.parametrize("mode,sort", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)])
+@pytest.mark.parametrize("mode,sort", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)])
 def test_search_front_ends_agree(oracle, gpu_ctx, mode, sort):
     """LDS-staged workgroup box search and per-lane grid walk are both exact: same correspondence counts."""
     import lisreg
@@ -106,11 +106,33 @@ def test_search_front_ends_agree(oracle, gpu_ctx, mode, sort):
         gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
         T, st, tr = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
     finally:
-        gpu_ctx.set_option("search_mode", 1); gpu_ctx.set_option("sort_sources", 2)
+        gpu_ctx.set_option("search_mode", 4); gpu_ctx.set_option("sort_sources", 2)
     assert st["iters"] == so["iters"] and len(tr) == len(tro)
     assert np.array_equal(tr[:, 0], tro[:, 0])            # n_corr per iteration, exactly
     rot, trn = pose_err(T, To)
     assert rot <= 1e-3 and trn <= 1e-3
+
+
+@pytest.mark.parametrize("variant,labelled,seed,m_points", [(1, False, 2234, 20000), (2, True, 2235, 60000), (3, True, 2236, 8000)])
+def test_graph_scan_equals_cell_walk_bitwise(gpu_ctx, variant, labelled, seed, m_points):
+    """search_mode 3 (k-NN graph scan with the triangle-inequality certificate, cell walk as the fall-back) must return the
+    same five neighbours in the same order as the cell walk for every query of every iteration: poses, traces (AtA, AtB,
+    n_corr) and stats are then bit-identical.  Sparse (8 k), default and dense (60 k) maps; tau = 1 and tau = 2."""
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=16, w=450, m_points=m_points, scan_seed=seed, labelled=labelled, trans=0.4, rot_deg=2.5)
+    p = lisreg.default_params(variant)
+    out = {}
+    for mode in (1, 3):
+        c2 = lisreg.Context(0)
+        c2.set_option("search_mode", mode)
+        c2.set_target(case["tgt_corner"], case["tgt_surf"])
+        out[mode] = c2.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        c2.close()
+    (T1, s1, tr1), (T3, s3, tr3) = out[1], out[3]
+    assert s1 == s3 and s1["status"] == 0
+    assert np.array_equal(T1, T3)
+    assert np.array_equal(tr1, tr3)
 
 
 def test_edge_cases(oracle, gpu_ctx):
