@@ -1,37 +1,71 @@
 #!/usr/bin/env python3
 """bench.py — scan-to-submap registrations/sec on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): per GPU a batch of 64 synthetic 64x1800 scans (every
+Default workload (BASELINE.json configs[1]): per GPU a batch of 64 synthetic 64x1800 scans (every
 valid pixel a feature: ~4.4 k edge + ~110.8 k planar points) against one shared 200 k-point submap, semantic mask
 off, fixed 10 Gauss-Newton iterations.  A "step" = one pass of the hot path over that batch with the inputs
 already resident in HBM: target index build (the reference rebuilds both kd-trees per registration,
 odomEstimationNode.cpp:602-603; here once per batch because the submap is shared), 10 x {correspondence +
-normal-equation kernel, solve kernel}, finalize (sources stay in caller order: scan order is already coherent).  Multi-GPU: one process per GPU, independent
-batches per rank (weak scaling), one RCCL all-gather of the 64 x 12-float result blocks per step.
+normal-equation kernel, solve kernel}, finalize.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch of the dominant kernel
-(96 B x point-iterations in the launch) / its average duration measured with HIP events on the
-library's stream inside the timed region.  `cpu_baseline` = the CPU oracle (a port of the reference path,
-kd-tree build included) timed on this host on a bounded sample of the same scans.
+  python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg4|cfg5]
+
+Multi-GPU: one process per GPU, independent batches per rank (weak scaling), one RCCL all-gather of the result
+blocks per step.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this script under
+`python -m torch.distributed.run --nproc-per-node N` (rendezvous on 127.0.0.1); under a launcher, WORLD_SIZE must
+equal N and N devices must be visible, otherwise the script exits non-zero — it never reports a 1-GPU figure as N.
+
+Prints ONE JSON line (rank 0).  `value` = registrations of all ranks / time of K steps (device-resident inputs).
+If K steps take less than --min-seconds (default 2 s) the K-step loop is repeated R times back to back inside the
+same timed bracket so that samplers see a busy GPU; `ms_per_step` is then the mean over R x K steps and
+`timed_region_s` / `step_loop_repeats` say so.
+`roofline.achieved` = algorithmic bytes per launch of the dominant kernel (96 B x point-iterations in the launch,
+BASELINE.md §3) / its average duration measured with HIP events on the library's stream inside the timed region.
+`cpu_baseline` = the CPU oracle (a port of the reference path, kd-tree build included) timed on this host on a
+bounded sample of the same scans at 1 thread (headline), 2 threads (the reference's numberOfCores,
+config/params.yaml:127) and all host cores.  `pcie_inclusive` = the same batch handed over as pinned HOST clouds in
+the reference's 32-byte PCL layout through lisreg_align_batch (H2D of the sources, device-side packing, the
+registration, D2H of poses and stats all inside the timed loop) — reported next to `value`, never as `value`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "lis-slam_amd"))
 
-import numpy as np
-import torch
-
-import lisreg
-from lisreg import synth, synth_torch
-
-H, W, M_SUBMAP, BATCH, ITERS = 64, 1800, 200_000, 64, 10
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_POINT_ITER = 96  # 16 B source read + 5 x 16 B neighbour gather
+
+WORKLOADS = {
+    # name: (H, W, submap points, batch per GPU, GN iterations, own target per item, description)
+    "cfg1": (64, 1800, 50_000, 1, 10, False,
+             "configs[0] synthetic stand-in: ONE 64x1800 scan vs a 50k-pt submap, 10 fixed GN iterations (latency-shaped)"),
+    "cfg2": (64, 1800, 200_000, 64, 10, False,
+             "configs[1]: batch=64 synthetic 64x1800 scans vs one shared 200k-pt submap per GPU, semantic mask off, "
+             "10 fixed GN iterations, target index build inside the step"),
+    "cfg3": (64, 1800, 0, 1, 0, False,
+             "configs[2] synthetic stand-in: sequential replay of a synthetic drive (previous pose as the guess, semantic "
+             "split -> per-class voxel grid -> label-weighted registration against the sliding local map, early exit)"),
+    "cfg4": (64, 1800, 200_000, 256, 10, True,
+             "configs[3] shape on one GPU: 256 independent registrations, each against its OWN 200k-pt target "
+             "(index built per item inside the step), 10 fixed GN iterations"),
+    "cfg5": (128, 2048, 1_000_000, 8, 30, False,
+             "configs[4]: 128x2048 scans vs one shared 1M-pt submap, 30 fixed GN iterations"),
+}
+
+
+def relaunch_under_torchrun(n, argv):
+    """--gpus N without a launcher: start N ranks ourselves (one per GPU) and hand back their exit code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -39,39 +73,69 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--cpu-regs", type=int, default=24, help="registrations in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--batch", type=int, default=0, help="registrations per GPU per step (0 = the workload's own)")
+    ap.add_argument("--cpu-regs", type=int, default=12, help="registrations per CPU-baseline leg (0 = skip the CPU baseline)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
-                    help="cfg2 (default, the metric's config): 64 scans 64x1800 vs one shared 200k submap, 10 iters; "
-                         "cfg4: loop-closure style, every item has its OWN 200k target (index built per item per step); "
-                         "cfg5: stress, 8 scans 128x2048 vs one shared 1M submap, 30 iters")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step loop until the timed region is this long")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
 
-    global H, W, M_SUBMAP, ITERS
-    if args.workload == "cfg5":
-        H, W, M_SUBMAP, ITERS = 128, 2048, 1_000_000, 30
-        if args.batch == BATCH:
-            args.batch = 8
-    own_targets = args.workload == "cfg4"
+    import numpy as np
+    import torch
+
+    import lisreg
+    from lisreg import synth, synth_torch
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
+                         f"report a {world}-rank figure as {args.gpus} GPUs")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    oversub = bool(os.environ.get("LISREG_BENCH_OVERSUBSCRIBE"))      # CI only: several ranks share one GPU
+    if n_dev < args.gpus and not oversub:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) visible")
+    dev_index = local_rank % n_dev
     # LISREG_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, RCCL all-gather of the result blocks,
-    # MAX-reduced timing) even with one rank — lets the path the driver runs at N = 2/4/8 be exercised on a 1-GPU box.
+    # MAX-reduced timing) even with one rank.
     use_dist = world > 1 or bool(os.environ.get("LISREG_BENCH_FORCE_DIST"))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # several ranks on ONE device (CI) cannot form an RCCL communicator: gloo carries the gather there
+        backend = "gloo" if (oversub and n_dev < world) else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
     n_gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    ctx = lisreg.Context(local_rank)
+    if args.workload == "cfg3":
+        from lisreg import replay
+        out = replay.bench_sequence(dev_index, steps=args.steps, warmup=args.warmup) if rank == 0 else None
+        if use_dist:
+            dist.barrier(); dist.destroy_process_group()
+        if out is not None:
+            out.update(n_gpus=1, scaling="replicas only (a sequential drive does not shard)")
+            print(json.dumps(out), flush=True)
+        return
+
+    H, W, M_SUBMAP, BATCH, ITERS, own_targets, wl_desc = WORKLOADS[args.workload]
+    batch = args.batch if args.batch > 0 else BATCH
+
+    ctx = lisreg.Context(dev_index)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("rebuild_targets_each_run", 1)
@@ -81,13 +145,16 @@ def main():
     # ---- synthetic inputs, generated straight into HBM ----------------------------------------------------------
     tc_dev, ts_dev, tc_host, ts_host = synth_torch.submap_device(M_SUBMAP, dev)
     scans, T_true, T_init = [], [], []
-    for i in range(args.batch):
-        seed = 1000 + rank * args.batch + i
+    n_distinct = min(batch, 64)                     # scans are reused beyond 64 (own-target batches differ in their targets)
+    for i in range(n_distinct):
+        seed = 1000 + rank * 64 + i
         c, s, tt = synth_torch.make_scan_device(H, W, seed, dev)
         if os.environ.get("LISREG_BENCH_SHUFFLE"):      # robustness probe: destroy the scan order of the sources
             c = c[torch.randperm(c.shape[0], device=dev)].contiguous(); s = s[torch.randperm(s.shape[0], device=dev)].contiguous()
         scans.append((c, s)); T_true.append(tt)
         T_init.append(synth.perturb_pose(tt, np.random.default_rng(seed + 7919)))
+    for i in range(n_distinct, batch):
+        scans.append(scans[i % n_distinct]); T_true.append(T_true[i % n_distinct]); T_init.append(T_init[i % n_distinct])
     torch.cuda.synchronize()
     T_true = np.array(T_true, np.float32); T_init = np.array(T_init, np.float32)
     n_src = sum(c.shape[0] + s.shape[0] for c, s in scans)
@@ -96,62 +163,84 @@ def main():
     params.fixed_iters = ITERS
     ctx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
     items = [dict(corner_ptr=c.data_ptr(), n_corner=c.shape[0], surf_ptr=s.data_ptr(), n_surf=s.shape[0]) for c, s in scans]
-    own = []
-    if own_targets:                      # every candidate pair gets its own copy of the submap in its own slot
-        for i in range(args.batch):
-            a, b = tc_dev.clone(), ts_dev.clone()
+    own, own_host = [], {}
+    if own_targets:                      # every candidate pair gets its own submap (distinct seeds) in its own slot
+        from lisreg import pack_device_records
+        for i in range(batch):
+            tci, tsi = synth.make_submap(M_SUBMAP, 42 + i + 1000 * rank)
+            if i < 8:
+                own_host[i] = (tci, tsi)
+            a = torch.from_numpy(pack_device_records(tci)).to(dev); b = torch.from_numpy(pack_device_records(tsi)).to(dev)
             own.append((a, b))
             ctx.set_target_device(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], slot=i)
             items[i]["target"] = i
         torch.cuda.synchronize()
     ctx.batch_prepare_device(items, T_init, params)
 
-    gathered = torch.empty((world, args.batch, lisreg.RESULT_SIZE), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, batch, lisreg.RESULT_SIZE), dtype=torch.float32, device=dev)
 
     class _DevArray:       # zero-copy torch view of the library's device result block
         def __init__(self, ptr, shape):
             self.__cuda_array_interface__ = dict(shape=shape, typestr="<f4", data=(ptr, False), version=2)
 
-    local_view = torch.as_tensor(_DevArray(ctx.result_device_ptr, (args.batch, lisreg.RESULT_SIZE)), device=dev)
+    local_view = torch.as_tensor(_DevArray(ctx.result_device_ptr, (batch, lisreg.RESULT_SIZE)), device=dev)
+    gloo_gather = use_dist and dist.get_backend() == "gloo"
 
     def step():
         ctx.batch_run()
-        if use_dist:           # RCCL all-gather of the 64 x 12-float result blocks (poses + stats) over xGMI
-            import torch.distributed as dist
+        if use_dist and not gloo_gather:   # RCCL all-gather of the result blocks (poses + stats) over xGMI
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered.view(-1), local_view.view(-1))
 
     def barrier():
         if use_dist:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     barrier()
-    if not args.no_profile:
-        ctx.set_profiling(True)
+    # how many times the K-step loop must run to fill --min-seconds (decided from a short untimed probe; all ranks agree)
+    t_probe = time.perf_counter()
+    step(); barrier()
+    per_step = max(time.perf_counter() - t_probe, 1e-5)
+    repeats = max(1, int(np.ceil(args.min_seconds / (per_step * args.steps)))) if args.min_seconds > 0 else 1
+    if use_dist:
+        rt = torch.tensor([repeats], dtype=torch.int64, device=dev if not gloo_gather else "cpu")
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        repeats = int(rt.item())
+    prof_repeats = min(repeats, max(1, 400 // max(args.steps, 1)))     # HIP events only in the first loops (bounded event count)
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for r in range(repeats):
+        if not args.no_profile:
+            if r == 0:
+                ctx.set_profiling(True)
+            elif r == prof_repeats:
+                ctx.set_profiling_paused(True)
+        for _ in range(args.steps):
+            step()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if use_dist:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if not gloo_gather else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     T_gpu, st_gpu = ctx.batch_fetch()          # also collects the event timings
     timing = ctx.timing() if not args.no_profile else None
     ctx.set_profiling(False)
+    if gloo_gather:                            # CI path: same gather, over gloo, outside the timed loop
+        parts = [torch.empty((batch, lisreg.RESULT_SIZE)) for _ in range(world)]
+        dist.all_gather(parts, local_view.cpu())
+        gathered = torch.stack(parts)
 
-    regs = n_gpus * args.batch * args.steps
+    total_steps = repeats * args.steps
+    regs = n_gpus * batch * total_steps
     value = regs / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
+    ms_per_step = 1e3 * elapsed / total_steps
 
-    # ---- roofline of the dominant kernel (k_assoc) ---------------------------------------------------------------
+    # ---- roofline of the dominant kernel (k_assoc_walk) -----------------------------------------------------------
     roof = None
     if timing and timing["assoc_launches"] > 0:
         avg_ms = timing["assoc_ms"] / timing["assoc_launches"]
@@ -159,17 +248,18 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes/launch
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "cfg2":
             try:
                 traffic = json.load(open(tpath)).get("k_assoc_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        prof_steps = min(repeats, prof_repeats) * args.steps
         roof = dict(bound="hbm", kernel="k_assoc_walk", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     avg_launch_ms=round(avg_ms, 4), launches=timing["assoc_launches"],
-                    algorithmic_bytes_per_launch=alg_bytes,
-                    time_share=dict(assoc_ms=round(timing["assoc_ms"], 3), solve_ms=round(timing["solve_ms"], 3),
-                                    index_ms=round(timing["index_ms"], 3), wall_ms=round(1e3 * elapsed, 3)))
+                    algorithmic_bytes_per_launch=alg_bytes, search_front_end=ctx.front_end(),
+                    per_step_ms=dict(assoc=round(timing["assoc_ms"] / prof_steps, 4), solve=round(timing["solve_ms"] / prof_steps, 4),
+                                     index=round(timing["index_ms"] / prof_steps, 4), wall=round(ms_per_step, 4)))
 
     # ---- accuracy: vs ground truth for all items, vs the CPU oracle on the sampled items --------------------------
     err_truth = np.abs(T_gpu.astype(np.float64) - T_true.astype(np.float64))
@@ -182,22 +272,43 @@ def main():
         import oracle_ctypes as oc                                       # checker + timed CPU baseline only
         oc.build()
         p_o = oc.default_params(1); p_o.fixed_iters = ITERS
-        k = min(args.cpu_regs, args.batch)
+        k = min(args.cpu_regs, batch)
+        if args.workload == "cfg5":
+            k = min(k, 3)
         host_scans = [(synth_torch.records_to_pcl(scans[i][0]), synth_torch.records_to_pcl(scans[i][1])) for i in range(k)]
-        tcpu0 = time.perf_counter()
-        T_cpu = []
-        for i in range(k):
-            To, so, _ = oc.align(tc_host, ts_host, host_scans[i][0], host_scans[i][1], T_init[i], p_o, n_threads=1,
-                                 use_kdtree=True, max_trace=1)
-            T_cpu.append(To)
-        tcpu = time.perf_counter() - tcpu0
-        T_cpu = np.array(T_cpu)
-        d = np.abs(T_gpu[:k].astype(np.float64) - T_cpu.astype(np.float64))
-        parity = dict(items=k, max_rot_err_rad=float(d[:, :3].max()), max_trans_err_m=float(d[:, 3:].max()))
-        cpu = dict(value=round(k / tcpu, 4), unit="registrations/s", cores=1, kind="port",
-                   sample=f"{k} of the {args.batch} scans of this batch ({H}x{W} vs {M_SUBMAP // 1000}k submap, {ITERS} GN iters, "
-                          f"kd-tree leaf 15, two tree builds per registration), 1 thread of {os.cpu_count()} host cores",
-                   seconds=round(tcpu, 2))
+        ncores = host_cores()
+        legs = {}
+        T_cpu = None
+        for threads in sorted({1, 2, ncores}):
+            tcpu0 = time.perf_counter()
+            Ts = []
+            for i in range(k if threads <= 2 else min(k, 6)):
+                tci, tsi = own_host.get(i, (tc_host, ts_host)) if own_targets else (tc_host, ts_host)
+                if own_targets and i not in own_host:
+                    break
+                To, so, _ = oc.align(tci, tsi, host_scans[i][0], host_scans[i][1], T_init[i], p_o, n_threads=threads,
+                                     use_kdtree=True, max_trace=1)
+                Ts.append(To)
+            tcpu = time.perf_counter() - tcpu0
+            legs[threads] = dict(value=round(len(Ts) / tcpu, 4), seconds=round(tcpu, 2), registrations=len(Ts))
+            if threads == 1:
+                T_cpu = np.array(Ts)
+        kk = len(T_cpu)
+        d = np.abs(T_gpu[:kk].astype(np.float64) - T_cpu.astype(np.float64))
+        parity = dict(items=kk, max_rot_err_rad=float(d[:, :3].max()), max_trans_err_m=float(d[:, 3:].max()))
+        cpu = dict(value=legs[1]["value"], unit="registrations/s", cores=1, kind="port",
+                   sample=f"{kk} of the {batch} registrations of this batch ({H}x{W} vs {M_SUBMAP // 1000}k submap, {ITERS} GN iters, "
+                          f"kd-tree leaf 15, two tree builds per registration) per leg; OpenMP over the feature points like the "
+                          f"reference's numberOfCores loops, kd-tree build single-threaded as in PCL; {ncores} host cores usable "
+                          f"(os.cpu_count() = {os.cpu_count()})",
+                   seconds=legs[1]["seconds"],
+                   by_threads={str(t): v for t, v in legs.items()})
+
+    # ---- PCIe-inclusive leg: pinned host clouds in the reference's 32-byte layout through lisreg_align_batch ------
+    pcie = None
+    if rank == 0 and n_gpus == 1 and not args.no_pcie and not own_targets:
+        pcie = pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_dev, T_init, params, T_gpu,
+                                  steps=max(3, min(args.steps, 20)))
 
     if os.environ.get("LISREG_COUNT"):
         cnt = ctx.counters()
@@ -208,14 +319,11 @@ def main():
             "value": round(value, 2), "unit": "registrations/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"cfg2": "configs[1]: batch=64 synthetic 64x1800 scans vs one shared 200k-pt submap per GPU, "
-                                            "semantic mask off, 10 fixed GN iterations, target index build inside the step",
-                                    "cfg4": "configs[3]-style: independent registrations, each against its OWN 200k-pt target "
-                                            "(index built per item inside the step), 10 fixed GN iterations",
-                                    "cfg5": "configs[4]: 128x2048 scans vs one shared 1M-pt submap, 30 fixed GN iterations"}[args.workload],
-                       "batch_per_gpu": args.batch, "scan": [H, W], "submap_points": M_SUBMAP, "gn_iters": ITERS,
+            "step_loop_repeats": repeats, "timed_region_s": round(elapsed, 3),
+            "config": {"workload": wl_desc,
+                       "batch_per_gpu": batch, "scan": [H, W], "submap_points": M_SUBMAP, "gn_iters": ITERS,
                        "source_points_per_batch": int(n_src), "parallelism": f"independent batches x{n_gpus} + RCCL all-gather of results"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "accuracy": {"max_rot_err_vs_truth_rad": float(err_truth[:, :3].max()),
                          "max_trans_err_vs_truth_m": float(err_truth[:, 3:].max()),
                          "vs_cpu_oracle": parity,
@@ -224,7 +332,6 @@ def main():
     else:
         out = None
     if use_dist:
-        import torch.distributed as dist
         # the gathered block of every rank must hold every rank's poses (rank r's slice == what rank r computed)
         g = gathered.cpu().numpy()
         assert np.array_equal(g[rank, :, :6], T_gpu), "all-gathered result block differs from the local results"
@@ -237,6 +344,72 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+
+
+def host_cores():
+    """cores this process may actually run on: scheduler affinity, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_dev, T_init, params, T_ref, steps):
+    """The same batch with the sources living in pinned HOST memory as PCL PointXYZI structs (32 B per point): every timed
+    step uploads them (hipMemcpyAsync on the context's stream), packs them on the device, runs the registration and
+    copies poses + stats back — SURVEY.md §8(d)'s "incl. H2D of sources and D2H of poses"."""
+    import ctypes as C
+    ctx = lisreg.Context(dev_index)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
+    host, n_bytes = [], 0
+    for c, s in scans:
+        pair = []
+        for rec in (c, s):
+            h = torch.zeros((rec.shape[0], 8), dtype=torch.float32).pin_memory()        # x y z pad intensity label(u16) pad pad
+            h[:, :3] = rec[:, :3].cpu()
+            pair.append(h); n_bytes += h.numel() * 4
+        host.append(pair)
+    n = len(scans)
+    arr = (lisreg.Item * n)()
+    for i, (hc, hs) in enumerate(host):
+        arr[i].src_corner = C.c_void_p(hc.data_ptr()) if hc.shape[0] else None; arr[i].n_corner = hc.shape[0]
+        arr[i].src_surf = C.c_void_p(hs.data_ptr()) if hs.shape[0] else None; arr[i].n_surf = hs.shape[0]
+        arr[i].stride_bytes = 32; arr[i].fmt = lisreg.FMT_XYZI; arr[i].target = 0
+    T = np.ascontiguousarray(T_init, np.float32).copy()
+    st = (lisreg.Stats * n)()
+
+    def one():
+        T[:] = T_init
+        rc = ctx._L.lisreg_align_batch(ctx._h, n, arr, C.byref(params), T.ctypes.data_as(C.POINTER(C.c_float)), st)
+        if rc:
+            raise RuntimeError(f"lisreg_align_batch failed: {rc}")
+
+    one(); one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(T, T_ref))
+    ctx.close()
+    return dict(value=round(n * steps / dt, 2), unit="registrations/s", ms_per_step=round(1e3 * dt / steps, 3), steps=steps,
+                h2d_bytes_per_step=int(n_bytes), d2h_bytes_per_step=int(n * 12 * 4),
+                note="pinned host PCL structs (32 B/pt) -> hipMemcpyAsync -> device-side packing -> index build + 10 GN iterations -> "
+                     "D2H of poses and stats, all inside the timed loop; one context, no copy/compute overlap",
+                poses_equal_device_resident_run=same)
 
 
 if __name__ == "__main__":

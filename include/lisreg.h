@@ -176,10 +176,15 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
 
 /* Options outside the reference's parameter surface: "rebuild_targets_each_run" (0/1: re-run the target index
  * build inside every lisreg_batch_run, as the reference rebuilds both kd-trees per registration, :602-603),
- * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (0 LDS-staged workgroup box,
- * 1 per-lane grid walk [default], 2 walk + motion certificate), "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
- * "cert_slack_mm", "first_pass_mm", "count_searches". */
+ * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (the exact 5-NN front-end
+ * that stands in for pcl::KdTreeFLANN::nearestKSearch: 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion
+ * certificate, 3 k-NN graph scan with the walk as its fall-back, 4 auto [default]: 3 when the prepared batch asks at
+ * least "graph_min_ratio" query-iterations per target point, else 1 — all return the same neighbours),
+ * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
+ * "graph_min_ratio", "graph_radius_mm", "cert_slack_mm", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
+/* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved). */
+int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
 
 /* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):
  * out[2*k] = queries re-searched at GN iteration k, out[2*k+1] = queries processed at iteration k (k < 32). */

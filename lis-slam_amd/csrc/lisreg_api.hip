@@ -276,7 +276,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
@@ -639,7 +639,7 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
     c->h_results.resize((size_t)std::max(c->n_items, 1) * kResultSize);
     if (c->n_items) HIPCHK(c, hipMemcpyAsync(c->h_results.data(), c->results.p, sizeof(float) * kResultSize * (size_t)c->n_items, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->profiling) prof_collect(c);
+    if (!c->ev.empty()) prof_collect(c);          // events of every profiled run since the last fetch (profiling may be off again by now)
     for (int i = 0; i < c->n_items; ++i) {
         const float* r = &c->h_results[(size_t)i * kResultSize];
         if (T) memcpy(T + 6 * (size_t)i, r, 24);
@@ -674,6 +674,18 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
 
+int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
+{
+    if (!c || !name || !value) return LISREG_ERR_ARG;
+    if (!strcmp(name, "search_mode")) { *value = c->search_mode; return LISREG_OK; }
+    if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }          // what the prepared batch runs (auto resolved)
+    if (!strcmp(name, "sort_sources")) { *value = c->sort_sources; return LISREG_OK; }
+    if (!strcmp(name, "sorted_now")) { *value = c->sort_now ? 1 : 0; return LISREG_OK; }
+    if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
+    if (!strcmp(name, "graph_min_ratio")) { *value = c->graph_min_ratio; return LISREG_OK; }
+    return LISREG_ERR_ARG;
+}
+
 int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, const lisreg_params* params, float* T,
                        lisreg_stats* stats)
 {
@@ -691,22 +703,38 @@ int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, con
             total += (size_t)in.n_corner + (size_t)in.n_surf;
         }
     }
-    std::vector<lisreg_dpoint> h(std::max<size_t>(total, 1));
+    // Host clouds cross PCIe as they are (the caller's structs, asynchronously on the context's stream — at full link rate
+    // when the caller's memory is pinned) and are packed to 16-byte records on the device; nothing is repacked on the CPU.
     std::vector<lisreg_item> dev_items((size_t)n_items);
     HIPCHK(c, c->src_upload.ensure(sizeof(lisreg_dpoint) * std::max<size_t>(total, 1)));
-    size_t off = 0;
+    size_t raw_bytes = 0;
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].fmt != LISREG_FMT_DEVICE) raw_bytes += ((size_t)items[i].n_corner + (size_t)items[i].n_surf) * (size_t)items[i].stride_bytes + 32;
+    HIPCHK(c, c->raw_upload.ensure(std::max<size_t>(raw_bytes, 16)));
+    size_t off = 0, roff = 0;
     for (int i = 0; i < n_items; ++i) {
         dev_items[(size_t)i] = items[i];
         const lisreg_item& in = items[i];
         if (in.fmt == LISREG_FMT_DEVICE) continue;
         lisreg_item& d = dev_items[(size_t)i];
-        if (in.n_corner > 0) pack_cloud(in.src_corner, in.n_corner, in.stride_bytes, in.fmt, &h[off]);
-        d.src_corner = c->src_upload.as<lisreg_dpoint>() + off; off += (size_t)in.n_corner;
-        if (in.n_surf > 0) pack_cloud(in.src_surf, in.n_surf, in.stride_bytes, in.fmt, &h[off]);
-        d.src_surf = c->src_upload.as<lisreg_dpoint>() + off; off += (size_t)in.n_surf;
+        const void* srcs[2] = { in.src_corner, in.src_surf };
+        const int cnts[2] = { in.n_corner, in.n_surf };
+        const void** dsts[2] = { &d.src_corner, &d.src_surf };
+        for (int k = 0; k < 2; ++k) {
+            lisreg_dpoint* dst = c->src_upload.as<lisreg_dpoint>() + off;
+            *dsts[k] = dst;
+            if (cnts[k] > 0) {
+                unsigned char* rdst = static_cast<unsigned char*>(c->raw_upload.p) + roff;
+                const size_t bytes = (size_t)cnts[k] * (size_t)in.stride_bytes;
+                HIPCHK(c, hipMemcpyAsync(rdst, srcs[k], bytes, hipMemcpyHostToDevice, c->stream));
+                launch_pack_cloud(rdst, (size_t)cnts[k], in.stride_bytes, in.fmt == LISREG_FMT_XYZIL, reinterpret_cast<float4*>(dst), c->stream);
+                roff += (bytes + 15) & ~(size_t)15;
+            }
+            off += (size_t)cnts[k];
+        }
         d.fmt = LISREG_FMT_DEVICE;
     }
-    if (total) HIPCHK(c, hipMemcpy(c->src_upload.p, h.data(), sizeof(lisreg_dpoint) * total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipGetLastError());
     int rc = lisreg_batch_prepare(c, n_items, dev_items.data(), params, T);
     if (rc) return rc;
     rc = run_impl(c, true);

@@ -634,6 +634,28 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4
     if (out_labels) out_labels[v] = best;
 }
 
+// PCL point structs as they arrive over PCIe (stride-byte records: x, y, z at 0/4/8, uint16 label at 20 for PointXYZIL,
+// src/include/common.h:9,25-35) -> 16-byte device records.  The 32-byte structs of the reference take two 16-byte loads.
+__global__ __launch_bounds__(256) void k_pack_cloud(const unsigned char* __restrict__ raw, size_t n, int stride, int has_label,
+                                                    float4* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* r = raw + i * (size_t)stride;
+    float4 o;
+    if ((stride & 15) == 0 && stride >= 32) {
+        const uint4 a = *reinterpret_cast<const uint4*>(r), b = *reinterpret_cast<const uint4*>(r + 16);
+        o = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(has_label ? (b.y & 0xffffu) : 0u));
+    } else {
+        unsigned int w[3];
+        for (int k = 0; k < 3; ++k)
+            w[k] = (unsigned)r[4 * k] | ((unsigned)r[4 * k + 1] << 8) | ((unsigned)r[4 * k + 2] << 16) | ((unsigned)r[4 * k + 3] << 24);
+        const unsigned lab = has_label ? ((unsigned)r[20] | ((unsigned)r[21] << 8)) : 0u;
+        o = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(lab));
+    }
+    out[i] = o;
+}
+
 // transformPointCloud (src/core/common.cpp:112-173): p' = R p + t, the fourth channel is copied
 __global__ __launch_bounds__(256) void k_transform_cloud(const float4* __restrict__ in, int n, const float* __restrict__ M12,
                                                          float4* __restrict__ out)
@@ -745,6 +767,11 @@ void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* se
 }
 
 void launch_exclusive_scan(const int* in, int* out, int* tmp, int n, hipStream_t st) { exclusive_scan(in, out, tmp, n, st); }
+
+void launch_pack_cloud(const void* raw_dev, size_t n, int stride, int has_label, float4* out, hipStream_t st)
+{
+    if (n > 0) k_pack_cloud<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const unsigned char*>(raw_dev), n, stride, has_label, out);
+}
 
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st)
 {

@@ -150,6 +150,8 @@ void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, Sor
 void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t* labels, int w_mode, const int* order,
                             const int* head, const int* slot, int* vstart /* [n_vox+1] */, float4* out_pts,
                             uint32_t* out_labels /* may be null */, hipStream_t st);
+// raw PCL structs already in device memory (n records of `stride` bytes) -> 16-byte records
+void launch_pack_cloud(const void* raw_dev, size_t n, int stride, int has_label, float4* out, hipStream_t st);
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st);
 // number of consecutive source points further apart than thr (coherence probe for sort_sources = auto)
 void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st);

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_counters", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
@@ -164,6 +164,7 @@ def lib():
         L.lisreg_batch_result_device.argtypes = [vp]
         L.lisreg_batch_result_device.restype = vp
         L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
         L.lisreg_set_profiling.argtypes = [vp, C.c_int]
@@ -277,6 +278,19 @@ class Context:
 
     def set_option(self, name: str, value: int):
         self._chk(self._L.lisreg_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self._chk(self._L.lisreg_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def front_end(self) -> int:
+        """search front-end of the prepared batch (1 cell walk, 3 k-NN graph scan, ...)."""
+        return self.get_option("front_end")
+
+    def set_profiling_paused(self, paused: bool):
+        """stop (or resume) recording HIP events without discarding the ones already recorded; batch_fetch collects them."""
+        self._chk(self._L.lisreg_set_profiling(self._h, 0 if paused else 1))
 
     # -- target ------------------------------------------------------------------------------------------
     def set_target(self, corner: np.ndarray, surf: np.ndarray, slot: int = 0):
