@@ -190,6 +190,14 @@ int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
  * out[2*k] = queries re-searched at GN iteration k, out[2*k+1] = queries processed at iteration k (k < 32). */
 int  lisreg_get_counters(lisreg_ctx* ctx, unsigned long long* out, int n);
 
+/* Test hook (option "dump_neighbors" = 1 before the batch is prepared; search modes 1 and 3): the five neighbours the LAST
+ * executed GN iteration used for every source point, as ORIGINAL indices into the target cloud of the point's kind, nearest
+ * first, -1 where fewer than five lie inside sqrt(knn_sq_thresh) — i.e. what nearestKSearch(5) + the `sqDist[4] < tau` test
+ * of :657 / :776 select; row 5 = 1 where the point passed every accept test and contributed a row to the normal equations
+ * (laserCloudOriFlag, :741 / :820).  out: host int[6][n_elems], n_elems = all source points of the batch in item order (corner
+ * then surf of each item). */
+int  lisreg_get_neighbors(lisreg_ctx* ctx, int* out, int n_elems);
+
 /* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
 int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);
 

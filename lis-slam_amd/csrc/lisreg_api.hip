@@ -276,7 +276,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
@@ -513,6 +513,10 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     HIPCHK(c, c->sorted_all.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->order_all.ensure(sizeof(int) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->nn.ensure(sizeof(int) * 5 * (size_t)std::max(flat, 1)));
+    if (c->dump_neighbors) {
+        HIPCHK(c, c->dbg_nn.ensure(sizeof(int) * 6 * (size_t)std::max(flat, 1)));
+        HIPCHK(c, hipMemsetAsync(c->dbg_nn.p, 0xff, sizeof(int) * 6 * (size_t)std::max(flat, 1), c->stream));
+    }
     HIPCHK(c, c->cert.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->model0.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->model1.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
@@ -609,7 +613,8 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                      c->mode_now, c->nn.as<int>(), c->cert.as<float4>(), c->model0.as<float4>(), c->model1.as<float4>(),
                      c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack,
                      it >= c->wide_from && it <= (c->mode_now == 3 ? c->graph_wide_until : c->wide_until), c->graph_hops,
-                     c->count_searches ? c->counters.as<unsigned long long>() : nullptr, st);
+                     c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
+                     c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
@@ -668,6 +673,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         if (c->count_searches) { HIPCHK(c, c->counters.ensure(64 * 8)); HIPCHK(c, hipMemset(c->counters.p, 0, 64 * 8)); }
         return LISREG_OK;
     }
+    if (!strcmp(name, "dump_neighbors")) { c->dump_neighbors = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cert_slack_mm")) { c->cert_slack = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
@@ -798,6 +804,16 @@ int lisreg_get_counters(lisreg_ctx* c, unsigned long long* out, int n)
         for (int i = 0; i < 32 && 2 * i + 1 < n; ++i) { tmp[2 * i] = out[i] >> 32; tmp[2 * i + 1] = out[i] & 0xffffffffull; }
         for (int i = 0; i < std::min(n, 64); ++i) out[i] = tmp[i];
     }
+    return LISREG_OK;
+}
+
+int lisreg_get_neighbors(lisreg_ctx* c, int* out, int n_elems)
+{
+    if (!c || !out || n_elems < 0) return LISREG_ERR_ARG;
+    if (!c->dump_neighbors || !c->dbg_nn.p || n_elems != c->n_elems || (c->mode_now != 1 && c->mode_now != 3))
+        return fail(c, LISREG_ERR_ARG, "get_neighbors: set option dump_neighbors before preparing the batch (search modes 1, 3); n_elems must be the batch's source point count");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dbg_nn.p, sizeof(int) * 6 * (size_t)n_elems, hipMemcpyDeviceToHost));
     return LISREG_OK;
 }
 

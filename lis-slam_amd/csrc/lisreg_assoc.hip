@@ -355,7 +355,7 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
                                                     const float* sc, const DevParams& P, int kind,
-                                                    double (*s_acc)[kNumAcc], double* __restrict__ out)
+                                                    double (*s_acc)[kNumAcc], double* __restrict__ out, int* dbg_ok = nullptr)
 {
     float cf[4] = { 0.f, 0.f, 0.f, 0.f };
     bool ok = false;
@@ -371,6 +371,7 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
         if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
         ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
     }
+    if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
     row_and_reduce(ok, cf, q4, sc, P, s_acc, out);
 }
 
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
                                                         const float4* __restrict__ sorted_all,
                                                         int* __restrict__ nn_, int n_elems, float first_pass_r2,
                                                         int graph_hops, unsigned long long* __restrict__ counters,
-                                                        double* __restrict__ partials)
+                                                        int* __restrict__ dbg_nn, double* __restrict__ partials)
 {
     __shared__ double s_acc[4][kNumAcc];
     __shared__ int2   s_runs[kWalkCap][kBlockQ];          // per-lane list of candidate runs for the flattened walk
@@ -830,10 +831,16 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         { v4i w; w.x = i0; w.y = i1; w.z = i2; w.w = i3; nn4[qflat] = w; }
         nn[4 * (size_t)n_elems + qflat] = i4;
     }
+    if (dbg_nn && valid) {               // "dump_neighbors" (tests): ORIGINAL indices of the five neighbours, -1 = none
+        const int ids[5] = { i0, i1, i2, i3, i4 };
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dbg_nn[(size_t)k * n_elems + qflat] = ids[k] >= 0 ? __float_as_int(pts[ids[k]].w) : -1;
+    }
     // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
-    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
+    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out,
+                        dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
 }
 
 // walk with a FIXED coverage radius: every cell that can hold a point with d^2 < cov2 is visited, so after the
@@ -1049,7 +1056,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, bool wide, int graph_hops, unsigned long long* counters, hipStream_t st)
+                  float slack, bool wide, int graph_hops, unsigned long long* counters, int* dbg_nn, hipStream_t st)
 {
     if (n_blocks <= 0) return;
     if (mode == 0)
@@ -1057,17 +1064,17 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
     else if (mode == 1)
         if (wide)
             k_assoc_walk<true, false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                    first_pass_r2, graph_hops, counters, partials);
+                                                                    first_pass_r2, graph_hops, counters, dbg_nn, partials);
         else
             k_assoc_walk<false, false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                     first_pass_r2, graph_hops, counters, partials);
+                                                                     first_pass_r2, graph_hops, counters, dbg_nn, partials);
     else if (mode == 3)
         if (wide)
             k_assoc_walk<true, true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                   first_pass_r2, graph_hops, counters, partials);
+                                                                   first_pass_r2, graph_hops, counters, dbg_nn, partials);
         else
             k_assoc_walk<false, true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                    first_pass_r2, graph_hops, counters, partials);
+                                                                    first_pass_r2, graph_hops, counters, dbg_nn, partials);
     else
         k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
                                                      model1, n_elems, first_pass_r2, slack, counters, partials);

@@ -65,7 +65,7 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
-    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
+    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
@@ -77,6 +77,7 @@ struct lisreg_ctx {
     std::vector<lisreg::BlockDesc> h_tblocks;
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
+    bool      dump_neighbors = false;   // tests: keep the five neighbour ids of every query of the last iteration run
     int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 2 walk + motion certificate, 3 k-NN graph scan,
                                          // 4 auto: 3 when the prepared batch asks enough queries per target point to pay for the graph, else 1
     int       mode_now = 1;              // front-end of the prepared batch

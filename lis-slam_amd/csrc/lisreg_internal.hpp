@@ -139,7 +139,8 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
                   int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
                   float slack, bool wide /* mode 1: centre-first walk for the early iterations whose seeds are stale */,
                   int graph_hops /* mode 3: neighbour lists scanned per query before the cell walk takes over */,
-                  unsigned long long* counters /* may be null */, hipStream_t st);
+                  unsigned long long* counters /* may be null */,
+                  int* dbg_nn /* may be null; modes 1 and 3: [5][n_elems] original indices of each query's neighbours */, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
@@ -165,6 +165,7 @@ def lib():
         L.lisreg_batch_result_device.restype = vp
         L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+        L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
         L.lisreg_get_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
         L.lisreg_set_profiling.argtypes = [vp, C.c_int]
@@ -283,6 +284,13 @@ class Context:
         v = C.c_int(0)
         self._chk(self._L.lisreg_get_option(self._h, name.encode(), C.byref(v)))
         return v.value
+
+    def neighbors(self, n_elems: int) -> np.ndarray:
+        """[6, n_elems]: rows 0-4 original target indices of every source point's neighbours in the last GN iteration run
+        (-1: none), row 5 = 1 where the point contributed a correspondence."""
+        out = np.full((6, n_elems), -1, np.int32)
+        self._chk(self._L.lisreg_get_neighbors(self._h, out.ctypes.data_as(C.POINTER(C.c_int)), n_elems))
+        return out
 
     def front_end(self) -> int:
         """search front-end of the prepared batch (1 cell walk, 3 k-NN graph scan, ...)."""

@@ -1,0 +1,90 @@
+"""Exact-neighbour parity of the search front-ends (SURVEY.md "hard parts": the grid / graph search must return the TRUE five
+nearest, as pcl::KdTreeFLANN::nearestKSearch(5) does, odomEstimationNode.cpp:655 / :774).
+
+The library's test hook (option "dump_neighbors", lisreg_get_neighbors) hands back, for every source point, the original
+target indices the last GN iteration used.  They are compared with an independent exact search (scipy cKDTree in float64 on
+the float32-transformed points): the SETS must be identical, except where two candidates are equidistant to within float32
+rounding of the squared distance (then either is a correct answer of a float32 kNN; such queries are counted and bounded).
+The cell walk (mode 1) and the k-NN graph scan (mode 3) are also compared with each other."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_sets(tgt_xyz, q, tau):
+    from scipy.spatial import cKDTree
+    tree = cKDTree(tgt_xyz.astype(np.float64))
+    d, i = tree.query(q.astype(np.float64), k=7, workers=8)
+    return d, i
+
+
+def _check(ids_gpu, src_xyz, tgt_xyz, T, tau, what):
+    """ids_gpu [5, n]; returns number of rounding-level ties tolerated"""
+    import lisreg
+    M = lisreg.pose_to_matrix(np.asarray(T, np.float32)).astype(np.float64)
+    q = src_xyz.astype(np.float64) @ M[:, :3].T + M[:, 3]
+    n = len(q)
+    if len(tgt_xyz) < 5:
+        assert (ids_gpu < 0).all()
+        return 0
+    d, i = _reference_sets(tgt_xyz, q.astype(np.float32), tau)
+    found_ref = d[:, 4] ** 2 < tau
+    found_gpu = ids_gpu[4] >= 0
+    bad = 0
+    # The device evaluates q = M p and d^2 in float32 (a couple of ulps of the coordinates apart from this float64 check),
+    # so two candidates whose squared distances differ by less than 2 d (3 ulp(|q|)) + 1e-6 d^2 may legitimately swap.
+    ulp = np.spacing(np.float32(max(1.0, float(np.abs(q).max())))).astype(np.float64)
+    # found / not found may only differ when the 5th distance sits on tau
+    diff_found = np.nonzero(found_ref != found_gpu)[0]
+    for k in diff_found:
+        assert abs(d[k, 4] ** 2 - tau) <= 2.0 * d[k, 4] * 3.0 * ulp + 1e-6 * tau, (what, "found flag", k, d[k, 4] ** 2)
+        bad += 1
+    both = np.nonzero(found_ref & found_gpu)[0]
+    g = np.sort(ids_gpu[:, both].T, axis=1)
+    r = np.sort(i[both, :5], axis=1)
+    mism = both[np.nonzero((g != r).any(1))[0]]
+    for k in mism:
+        gs, rs = set(ids_gpu[:, k].tolist()), set(i[k, :5].tolist())
+        extra, missing = sorted(gs - rs), sorted(rs - gs)
+        assert len(extra) == len(missing), (what, k)
+        de = np.sort(np.linalg.norm(tgt_xyz[extra].astype(np.float64) - q[k], axis=1) ** 2)
+        dm = np.sort(np.linalg.norm(tgt_xyz[missing].astype(np.float64) - q[k], axis=1) ** 2)
+        assert np.all(np.abs(de - dm) <= 2.0 * np.sqrt(dm) * 3.0 * ulp + 1e-6 * dm), (what, "wrong neighbour", k, de, dm)
+        bad += 1
+    assert bad <= max(2, 1e-3 * n), (what, bad, n)
+    return bad
+
+
+@pytest.mark.parametrize("h,w,m_points,variant", [(16, 450, 20000, 1), (32, 900, 60000, 2), (64, 1800, 200000, 1), (128, 2048, 1000000, 1)])
+def test_neighbour_sets_are_exact(h, w, m_points, variant):
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=h, w=w, m_points=m_points, scan_seed=4321, labelled=variant != 1)
+    tau = lisreg.default_params(variant).knn_sq_thresh
+    src = [synth.pcl_xyz(case["src_corner"]), synth.pcl_xyz(case["src_surf"])]
+    tgt = [synth.pcl_xyz(case["tgt_corner"]), synth.pcl_xyz(case["tgt_surf"])]
+    nc, ns = len(src[0]), len(src[1])
+    dumps = {}
+    for iters in (1, 4):
+        for mode in (1, 3):
+            ctx = lisreg.Context(0)
+            ctx.set_option("search_mode", mode); ctx.set_option("dump_neighbors", 1)
+            ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+            p = lisreg.default_params(variant); p.fixed_iters = iters
+            T, st, tr = ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+            assert ctx.front_end() == mode and st["iters"] == iters
+            ids = ctx.neighbors(nc + ns)[:5]
+            ctx.close()
+            T_search = case["T_init"] if iters == 1 else tr[iters - 2, 49:55]      # the pose the last iteration searched at
+            ties = _check(ids[:, :nc], src[0], tgt[0], T_search, tau, (mode, iters, "corner"))
+            ties += _check(ids[:, nc:], src[1], tgt[1], T_search, tau, (mode, iters, "surf"))
+            dumps[(mode, iters)] = (ids, tr, ties)
+        a, b = dumps[(1, iters)], dumps[(3, iters)]
+        # the two front-ends against each other: identical neighbours in identical order (up to the same rounding-level ties)
+        differing = int((a[0] != b[0]).any(0).sum())
+        print(f"{h}x{w} vs {m_points}: iteration {iters - 1}: rounding-level ties vs float64 search: walk {a[2]}, graph {b[2]}; "
+              f"queries where walk and graph differ: {differing} of {nc + ns}")
+        assert differing <= a[2] + b[2] + 2, (iters, differing)
+        if differing == 0:
+            assert np.array_equal(a[1], b[1])
