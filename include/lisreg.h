@@ -310,6 +310,47 @@ int  lisreg_bbx_filter(lisreg_ctx* ctx, const void* cloud, int n, int stride_byt
 /* SubMapManager::get_cloud_bbx (subMap.h:131-163); an empty cloud yields {DBL_MAX x3, -DBL_MAX x3}. */
 int  lisreg_cloud_bounds(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt, double bounds[6]);
 
+/* The sliding local map as ONE device-resident object (localMap_t, subMap.h:679-777): five class clouds in the map frame kept in
+ * HBM as 16-byte records, class order of append_feature / merge_feature_points: 0 dynamic, 1 pole, 2 ground, 3 building,
+ * 4 outlier.  lisreg_localmap_insert = SubMapManager::insert_local_map (subMap.h:979-1059) as makeSubMapThread calls it
+ * (subMapOptmizationNode.cpp:640-646, 708-714); lisreg_localmap_extract = extractSlidingCloud (:1369-1432) followed by the two
+ * kdtree setInputCloud calls of scan2SubMapOptimization (:1517-1518): it leaves the registration target in `target_slot`
+ * (pass -1 to skip that), so a frame loop is  extract -> lisreg_align / batch -> insert  with no cloud crossing PCIe
+ * except the incoming frame. */
+typedef struct lisreg_localmap_params {
+    int   max_num_pts;                    /* 80000: dynamic removal starts once feature_point_num > max_num_pts / 5 (:605, subMap.h:1007) */
+    int   dynamic_removal_on;             /* map_based_dynamic_removal_on = true (:608)                                         */
+    float dynamic_removal_center_radius;  /* 30.0 (:609) — compared with x^2 + y^2 of the MAP-frame point, as the reference does */
+    float dynamic_dist_thre_min;          /* 0.3  (:610)                                                                        */
+    float dynamic_dist_thre_max;          /* 3.0  (:611); widened to at least min + 0.1 like subMap.h:1006                      */
+    float near_dist_thre;                 /* 0.03 (:612)                                                                        */
+    float leaf[5];                        /* in-place voxel grids of extractSlidingCloud: 0.1, 0.05, 0.4, 0.2, 0.6 (:1385-1389)  */
+    float crop_box[6];                    /* cur_bbx = {-70,-70,-10, 70,70,20} (:1377-1379), moved by the current pose           */
+    float crop_pad;                       /* 2.0: bbx_boundary_pad of get_intersection_bbx (:1384)                               */
+} lisreg_localmap_params;
+typedef struct lisreg_localmap_info {
+    int    n[5];                          /* points per class now                                   */
+    int    feature_point_num;             /* as of the last insert (subMap.h:1039-1043)             */
+    double bound[6];                      /* localMap->bound as of the last insert (:1047-1049)     */
+    double crop[6];                       /* bbx_intersection of the last extract                   */
+    int    n_target_corner, n_target_surf;/* laserCloud{Corner,Surf}FromSubMap sizes of the last extract */
+} lisreg_localmap_info;
+int  lisreg_localmap_default_params(lisreg_localmap_params* p);
+int  lisreg_localmap_reset(lisreg_ctx* ctx, int map_id);
+/* clouds[5] / n[5]: the key frame's UN-downsampled class clouds in the sensor frame (semantic_dynamic, _pole, _ground, _building,
+ * _outlier); host PointXYZIL structs or LISREG_FMT_DEVICE records.  pose = the frame's optimized_pose {roll,pitch,yaw,x,y,z}.
+ * The outlier cloud is accepted and ignored, exactly as the reference leaves its transform commented out (subMap.h:1003). */
+int  lisreg_localmap_insert(lisreg_ctx* ctx, int map_id, const void* const clouds[5], const int n[5], int stride_bytes, int fmt,
+                            const float pose[6], const lisreg_localmap_params* params, lisreg_localmap_info* info);
+int  lisreg_localmap_extract(lisreg_ctx* ctx, int map_id, const float cur_pose[6], const lisreg_localmap_params* params,
+                             int target_slot, lisreg_localmap_info* info);
+/* Copy one cloud out as 16-byte records (host or device destination): cls 0-4 = the class clouds, 5 / 6 = the corner / surf
+ * target of the last extract.  *n_out is always set; LISREG_ERR_ARG if capacity is too small. */
+int  lisreg_localmap_get(lisreg_ctx* ctx, int map_id, int cls, void* out, int capacity, int* n_out);
+/* updateInitialGuess with neither IMU nor odometry (odomEstimationNode.cpp:351-392; subMapOptmizationNode.cpp:984-1020): the
+ * constant-velocity guess T_cur * (T_last^-1 * T_cur). */
+void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6]);
+
 /* ---- §8 f-4: pcl::IterativeClosestPoint as the loop-closure / relocalisation code drives it ------------------- */
 /* Call sites: src/node/subMapOptmizationNode.cpp:2763-2833 (loop closure: 10 m, 30 iterations, 1e-4, 1e-4),
  * :1444-1465 and :4400-4420 (0.2 m, 50 iterations, 1e-5, 1e-5); RANSAC iterations 0 everywhere, no rejectors.

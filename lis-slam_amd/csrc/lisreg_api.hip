@@ -283,7 +283,8 @@ void lisreg_destroy(lisreg_ctx* c)
                        &c->ft_gather, &c->ft_dsk_tab, &c->ft_dsk_pts, &c->ft_dsk_misc, &c->ft_dsk_time };
     for (auto b : bufs) b->release();
     for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
-    DevBuf* mbufs[] = { &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
+    for (auto& m : c->localmaps) { for (auto& b : m.cls) b.release(); m.tgt[0].release(); m.tgt[1].release(); }
+    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
     for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);

@@ -1,0 +1,290 @@
+// lisreg_api_localmap.hip — the device-resident sliding local map of SURVEY.md §8 f-3: SubMapManager::insert_local_map
+// (/root/reference/src/include/subMap.h:979-1059) and SubMapOptmizationNode::extractSlidingCloud
+// (src/node/subMapOptmizationNode.cpp:1369-1432) as ONE chain over 16-byte device records, ending in the registration
+// target of scan2SubMapOptimization (:1509-1541).  Between frames the five class clouds never leave HBM; per call the host
+// sees only counts and bounding boxes.  Every step is one of the primitives of lisreg_api.hip / lisreg_api_map.hip in
+// LISREG_FMT_DEVICE form, in the reference's order:
+//   insert : transformPointCloud of the frame's dynamic / pole / ground / building clouds (the outlier transform is commented
+//            out in the reference, :1003, so nothing is appended to that class) -> optional map-based dynamic removal of the
+//            frame's dynamic points against tree_dynamic (:1007-1026) -> append_feature -> feature_point_num -> bound
+//   extract: cur_bbx moved by the current pose (transform_bbx) -> intersection with the map bound + 2 m -> in-place voxel
+//            grids 0.1 / 0.05 / 0.4 / 0.2 / 0.6 -> bbx_filter of every class -> corner target = pole,
+//            surf target = ground + building + dynamic (:1408-1419) -> both target indexes built.
+// No CPU fallback: without a HIP device these fail with LISREG_ERR_HIP.
+#include "lisreg_ctx.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+using namespace lisreg;
+
+namespace {
+
+constexpr int kMapSlotBase = 60000;      // lisreg_map_index_set slots 60000.. are the local maps' tree_dynamic
+
+int bad(lisreg_ctx* c, const char* msg) { return ctx_fail(c, LISREG_ERR_ARG, msg); }
+
+// grow a device buffer, keeping its first `keep` bytes
+int grow_keep(lisreg_ctx* c, DevBuf& b, size_t bytes, size_t keep)
+{
+    if (bytes <= b.cap) return LISREG_OK;
+    DevBuf nb;
+    HIPCHK(c, nb.ensure(bytes + bytes / 2));
+    if (keep > 0 && b.p) HIPCHK(c, hipMemcpyAsync(nb.p, b.p, keep, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.release();
+    b = nb;
+    return LISREG_OK;
+}
+
+LocalMap* get_map(lisreg_ctx* c, int id, bool create)
+{
+    if (id < 0 || id > 1023) return nullptr;
+    if ((size_t)id >= c->localmaps.size()) { if (!create) return nullptr; c->localmaps.resize((size_t)id + 1); }
+    return &c->localmaps[(size_t)id];
+}
+
+void fill_info(const LocalMap& m, lisreg_localmap_info* info)
+{
+    if (!info) return;
+    for (int k = 0; k < 5; ++k) info->n[k] = m.n[k];
+    info->feature_point_num = m.feature_point_num;
+    for (int d = 0; d < 6; ++d) info->bound[d] = m.bound[d];
+    info->n_target_corner = m.n_tgt[0]; info->n_target_surf = m.n_tgt[1];
+}
+
+// get_cloud_bbx over the five classes (merge_feature_points + get_cloud_bbx_cpt, subMap.h:1047-1049): float extremes
+// widened to double, {DBL_MAX, -DBL_MAX} when the map is empty
+int update_bound(lisreg_ctx* c, LocalMap& m)
+{
+    for (int d = 0; d < 3; ++d) { m.bound[d] = DBL_MAX; m.bound[3 + d] = -DBL_MAX; }
+    HIPCHK(c, c->lm_bbox.ensure(sizeof(float) * 6 * 5));
+    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
+    float bb[30];
+    bool any = false;
+    for (int k = 0; k < 5; ++k)
+        if (m.n[k] > 0) { launch_bbox(m.cls[k].as<float4>(), m.n[k], c->lm_bbox.as<float>() + 6 * k, c->bbox_scratch.as<float>(), c->stream); any = true; }
+    if (!any) return LISREG_OK;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(bb, c->lm_bbox.p, sizeof bb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 5; ++k)
+        if (m.n[k] > 0)
+            for (int d = 0; d < 3; ++d) {
+                m.bound[d] = std::min(m.bound[d], (double)bb[6 * k + d]);
+                m.bound[3 + d] = std::max(m.bound[3 + d], (double)bb[6 * k + 3 + d]);
+            }
+    return LISREG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lisreg_localmap_default_params(lisreg_localmap_params* p)
+{
+    if (!p) return LISREG_ERR_ARG;
+    memset(p, 0, sizeof *p);
+    p->max_num_pts = 80000;                          // subMapOptmizationNode.cpp:605
+    p->dynamic_removal_on = 1;                       // :608
+    p->dynamic_removal_center_radius = 30.0f;        // :609
+    p->dynamic_dist_thre_min = 0.3f;                 // :610
+    p->dynamic_dist_thre_max = 3.0f;                 // :611
+    p->near_dist_thre = 0.03f;                       // :612
+    const float leaf[5] = { 0.1f, 0.05f, 0.4f, 0.2f, 0.6f };            // :1385-1389 (dynamic, pole, ground, building, outlier)
+    const float box[6] = { -70.f, -70.f, -10.f, 70.f, 70.f, 20.f };     // :1377-1379
+    memcpy(p->leaf, leaf, sizeof leaf);
+    memcpy(p->crop_box, box, sizeof box);
+    p->crop_pad = 2.0f;                              // :1384
+    return LISREG_OK;
+}
+
+int lisreg_localmap_reset(lisreg_ctx* c, int map_id)
+{
+    if (!c) return LISREG_ERR_ARG;
+    LocalMap* m = get_map(c, map_id, true);
+    if (!m) return bad(c, "localmap_reset: bad map id");
+    for (int k = 0; k < 5; ++k) m->n[k] = 0;
+    m->n_tgt[0] = m->n_tgt[1] = 0;
+    m->feature_point_num = 0;
+    for (int d = 0; d < 3; ++d) { m->bound[d] = DBL_MAX; m->bound[3 + d] = -DBL_MAX; }
+    m->valid = true;
+    return LISREG_OK;
+}
+
+int lisreg_localmap_insert(lisreg_ctx* c, int map_id, const void* const clouds[5], const int n[5], int stride, int fmt,
+                           const float pose[6], const lisreg_localmap_params* P, lisreg_localmap_info* info)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!clouds || !n || !pose || !P) return bad(c, "localmap_insert: NULL argument");
+    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return bad(c, "localmap_insert: unknown fmt");
+    if (fmt != LISREG_FMT_DEVICE && (stride < 12 || (fmt == LISREG_FMT_XYZIL && stride < 22))) return bad(c, "localmap_insert: bad stride");
+    for (int k = 0; k < 5; ++k) if (n[k] < 0 || (n[k] > 0 && !clouds[k])) return bad(c, "localmap_insert: NULL cloud with n > 0");
+    LocalMap* m = get_map(c, map_id, true);
+    if (!m) return bad(c, "localmap_insert: bad map id");
+    if (!m->valid) { int rc = lisreg_localmap_reset(c, map_id); if (rc) return rc; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // the reference widens the band first (subMap.h:1006): max(dynamic_dist_thre_max, (float)(dynamic_dist_thre_min + 0.1))
+    const float thre_max = std::max(P->dynamic_dist_thre_max, (float)((double)P->dynamic_dist_thre_min + 0.1));
+    for (int k = 0; k < 4; ++k) {                    // dynamic, pole, ground, building (outlier: not inserted, :1003)
+        if (n[k] == 0) continue;
+        // stage the frame's class cloud as device records, then transformPointCloud(.., &optimized_pose) into lm_tmp
+        const float4* src = nullptr;
+        if (fmt == LISREG_FMT_DEVICE) src = static_cast<const float4*>(clouds[k]);
+        else {
+            const size_t bytes = (size_t)n[k] * (size_t)stride;
+            HIPCHK(c, c->raw_upload.ensure(bytes + 32));
+            HIPCHK(c, c->lm_in.ensure(sizeof(float4) * (size_t)n[k]));
+            HIPCHK(c, hipMemcpyAsync(c->raw_upload.p, clouds[k], bytes, hipMemcpyHostToDevice, st));
+            launch_pack_cloud(c->raw_upload.p, (size_t)n[k], stride, fmt == LISREG_FMT_XYZIL, c->lm_in.as<float4>(), st);
+            HIPCHK(c, hipStreamSynchronize(st));     // pageable sources are free to change after the call
+            src = c->lm_in.as<float4>();
+        }
+        HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)n[k]));
+        int rc = lisreg_transform_cloud(c, src, n[k], 16, LISREG_FMT_DEVICE, pose, c->lm_tmp.p);
+        if (rc) return rc;
+        int n_add = n[k];
+        if (k == 0 && P->dynamic_removal_on && m->feature_point_num > P->max_num_pts / 5) {
+            // tree_dynamic->setInputCloud(submap_dynamic) + map_scan_feature_pts_distance_removal (:1008-1012)
+            rc = lisreg_map_index_set(c, kMapSlotBase + map_id, m->cls[0].p, m->n[0], 16, LISREG_FMT_DEVICE);
+            if (rc) return rc;
+            rc = lisreg_dynamic_filter(c, kMapSlotBase + map_id, c->lm_tmp.p, n[k], 16, LISREG_FMT_DEVICE,
+                                       P->dynamic_removal_center_radius, P->dynamic_dist_thre_min, thre_max, P->near_dist_thre,
+                                       c->lm_tmp.p, &n_add);
+            if (rc != LISREG_OK && rc != LISREG_NOT_ENOUGH_FEATURES) return rc;
+        }
+        // append_feature (subMap.h:742-753)
+        rc = grow_keep(c, m->cls[k], sizeof(float4) * ((size_t)m->n[k] + (size_t)n_add + 1), sizeof(float4) * (size_t)m->n[k]);
+        if (rc) return rc;
+        if (n_add > 0)
+            HIPCHK(c, hipMemcpyAsync(m->cls[k].as<float4>() + m->n[k], c->lm_tmp.p, sizeof(float4) * (size_t)n_add, hipMemcpyDeviceToDevice, st));
+        m->n[k] += n_add;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    m->feature_point_num = m->n[0] + m->n[1] + m->n[2] + m->n[3] + m->n[4];
+    int rc = update_bound(c, *m);
+    if (rc) return rc;
+    fill_info(*m, info);
+    return LISREG_OK;
+}
+
+int lisreg_localmap_extract(lisreg_ctx* c, int map_id, const float cur_pose[6], const lisreg_localmap_params* P, int target_slot,
+                            lisreg_localmap_info* info)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!cur_pose || !P) return bad(c, "localmap_extract: NULL argument");
+    LocalMap* m = get_map(c, map_id, false);
+    if (!m || !m->valid) return ctx_fail(c, LISREG_ERR_NO_TARGET, "localmap_extract: no such local map");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // cur_bbx / get_bound_cpt / transform_bbx (:1376-1382, subMap.h:122-127, 235-249): double boxes, float matrix entries
+    float M[12];
+    lisreg_pose_to_matrix(cur_pose, M);
+    double bx[6], cp[3], cpo[3];
+    for (int d = 0; d < 6; ++d) bx[d] = (double)P->crop_box[d];
+    for (int d = 0; d < 3; ++d) cp[d] = 0.5 * (bx[d] + bx[3 + d]);
+    for (int r = 0; r < 3; ++r) cpo[r] = M[4 * r + 0] * cp[0] + M[4 * r + 1] * cp[1] + M[4 * r + 2] * cp[2] + M[4 * r + 3];
+    double cur[6];
+    for (int d = 0; d < 3; ++d) { cur[3 + d] = bx[3 + d] - cp[d] + cpo[d]; cur[d] = bx[d] - cp[d] + cpo[d]; }
+    // get_intersection_bbx(cur_bbx, localMap->bound, bbx_intersection, 2.0) (subMap.h:176-184)
+    double isect[6];
+    for (int d = 0; d < 3; ++d) {
+        isect[d] = std::max(cur[d], m->bound[d]) - (double)P->crop_pad;
+        isect[3 + d] = std::min(cur[3 + d], m->bound[3 + d]) + (double)P->crop_pad;
+    }
+    // voxel_downsample_pcl(cls, cls, leaf) in place (:1385-1389; an empty class returns false and stays empty), then bbx_filter
+    for (int k = 0; k < 5; ++k) {
+        if (m->n[k] > 0) {
+            HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)m->n[k]));
+            int nv = 0;
+            int rc = lisreg_voxel_downsample(c, m->cls[k].p, m->n[k], 16, LISREG_FMT_DEVICE, P->leaf[k], c->lm_tmp.p, m->n[k], &nv);
+            if (rc != LISREG_OK && rc != LISREG_LEAF_TOO_SMALL) return rc;
+            HIPCHK(c, hipMemcpyAsync(m->cls[k].p, c->lm_tmp.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            m->n[k] = nv;
+        }
+    }
+    for (int k = 0; k < 5; ++k) {
+        if (m->n[k] > 0) {
+            int nk = 0;
+            int rc = lisreg_bbx_filter(c, m->cls[k].p, m->n[k], 16, LISREG_FMT_DEVICE, isect, 0, m->cls[k].p, &nk);
+            if (rc) return rc;
+            m->n[k] = nk;
+        }
+    }
+    // laserCloudCornerFromSubMap = pole; laserCloudSurfFromSubMap = ground + building + dynamic (:1408-1419)
+    m->n_tgt[0] = m->n[1];
+    m->n_tgt[1] = m->n[2] + m->n[3] + m->n[0];
+    HIPCHK(c, m->tgt[0].ensure(sizeof(float4) * (size_t)std::max(m->n_tgt[0], 1)));
+    HIPCHK(c, m->tgt[1].ensure(sizeof(float4) * (size_t)std::max(m->n_tgt[1], 1)));
+    if (m->n[1] > 0) HIPCHK(c, hipMemcpyAsync(m->tgt[0].p, m->cls[1].p, sizeof(float4) * (size_t)m->n[1], hipMemcpyDeviceToDevice, st));
+    size_t off = 0;
+    const int order[3] = { 2, 3, 0 };
+    for (int j = 0; j < 3; ++j) {
+        const int k = order[j];
+        if (m->n[k] > 0) HIPCHK(c, hipMemcpyAsync(m->tgt[1].as<float4>() + off, m->cls[k].p, sizeof(float4) * (size_t)m->n[k], hipMemcpyDeviceToDevice, st));
+        off += (size_t)m->n[k];
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (target_slot >= 0) {                          // kdtree{Corner,Surf}FromSubMap->setInputCloud (:1517-1518)
+        int rc = lisreg_set_target_slot(c, target_slot, m->tgt[0].p, m->n_tgt[0], m->tgt[1].p, m->n_tgt[1], 16, LISREG_FMT_DEVICE);
+        if (rc) return rc;
+    }
+    fill_info(*m, info);
+    if (info) for (int d = 0; d < 6; ++d) info->crop[d] = isect[d];
+    return LISREG_OK;
+}
+
+int lisreg_localmap_get(lisreg_ctx* c, int map_id, int cls, void* out, int capacity, int* n_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    LocalMap* m = get_map(c, map_id, false);
+    if (!m || !m->valid) return ctx_fail(c, LISREG_ERR_NO_TARGET, "localmap_get: no such local map");
+    if (cls < 0 || cls > 6 || !n_out) return bad(c, "localmap_get: bad class / NULL count");
+    const void* src = cls < 5 ? m->cls[cls].p : m->tgt[cls - 5].p;
+    const int n = cls < 5 ? m->n[cls] : m->n_tgt[cls - 5];
+    *n_out = n;
+    if (n > capacity) return bad(c, "localmap_get: capacity too small (see *n_out)");
+    if (n > 0 && !out) return bad(c, "localmap_get: NULL out");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0) HIPCHK(c, hipMemcpy(out, src, sizeof(float4) * (size_t)n, hipMemcpyDefault));      // host or device destination
+    return LISREG_OK;
+}
+
+// updateInitialGuess without IMU / odometry input (odomEstimationNode.cpp:351-392, subMapOptmizationNode.cpp:984-1020): the last
+// frame-to-frame increment applied once more, T_guess = T_cur * (T_last^-1 * T_cur), in Eigen's float arithmetic
+// (pcl::getTransformation, Affine3f::inverse, getTranslationAndEulerAngles).
+void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6])
+{
+    float A[12], B[12];
+    lisreg_pose_to_matrix(T_last, A);
+    lisreg_pose_to_matrix(T_cur, B);
+    // inverse of the rigid A as Eigen's Affine inverse computes it: linear part by the cofactor 3x3 inverse, t' = -L^-1 t
+    const float a = A[0], b = A[1], cc = A[2], d = A[4], e = A[5], f = A[6], g = A[8], h = A[9], i = A[10];
+    const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const float det = a * c00 + b * c01 + cc * c02, id = 1.f / det;
+    float L[9] = { c00 * id, (cc * h - b * i) * id, (b * f - cc * e) * id,
+                   c01 * id, (a * i - cc * g) * id, (cc * d - a * f) * id,
+                   c02 * id, (b * g - a * h) * id, (a * e - b * d) * id };
+    float ti[3];
+    for (int r = 0; r < 3; ++r) ti[r] = -(L[3 * r] * A[3] + L[3 * r + 1] * A[7] + L[3 * r + 2] * A[11]);
+    float Inc[12], F[12];                              // Inc = A^-1 * B ; F = B * Inc
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 3; ++q) Inc[4 * r + q] = L[3 * r] * B[q] + L[3 * r + 1] * B[4 + q] + L[3 * r + 2] * B[8 + q];
+        Inc[4 * r + 3] = L[3 * r] * B[3] + L[3 * r + 1] * B[7] + L[3 * r + 2] * B[11] + ti[r];
+    }
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 3; ++q) F[4 * r + q] = B[4 * r] * Inc[q] + B[4 * r + 1] * Inc[4 + q] + B[4 * r + 2] * Inc[8 + q];
+        F[4 * r + 3] = B[4 * r] * Inc[3] + B[4 * r + 1] * Inc[7] + B[4 * r + 2] * Inc[11] + B[4 * r + 3];
+    }
+    // pcl::getTranslationAndEulerAngles: x,y,z = t; roll = atan2(m21, m22); pitch = asin(-m20); yaw = atan2(m10, m00)
+    T_guess[3] = F[3]; T_guess[4] = F[7]; T_guess[5] = F[11];
+    T_guess[0] = atan2f(F[9], F[10]);
+    T_guess[1] = asinf(-F[8]);
+    T_guess[2] = atan2f(F[4], F[0]);
+}
+
+}  // extern "C"

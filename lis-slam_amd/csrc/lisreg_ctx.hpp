@@ -45,6 +45,17 @@ struct MapIndex {
     const float4* raw_ptr = nullptr;
 };
 
+// device-resident sliding local map (lisreg_api_localmap.hip)
+struct LocalMap {
+    bool   valid = false;
+    DevBuf cls[5];                 // dynamic, pole, ground, building, outlier (map frame)
+    int    n[5] = { 0, 0, 0, 0, 0 };
+    DevBuf tgt[2];                 // corner / surf registration targets of the last extract
+    int    n_tgt[2] = { 0, 0 };
+    int    feature_point_num = 0;
+    double bound[6] = { 0, 0, 0, 0, 0, 0 };
+};
+
 struct RcclApi {
     void* handle = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
@@ -70,6 +81,8 @@ struct lisreg_ctx {
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
     std::vector<lisreg::MapIndex> maps;
+    std::vector<lisreg::LocalMap> localmaps;
+    lisreg::DevBuf lm_in, lm_tmp, lm_bbox;
     lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur;
     int*      done_host = nullptr;          // pinned
     int       early_stop_chunk = 3;

@@ -663,9 +663,16 @@ __global__ __launch_bounds__(256) void k_transform_cloud(const float4* __restric
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 p = in[i];
-    out[i] = make_float4(M12[0] * p.x + M12[1] * p.y + M12[2] * p.z + M12[3],
-                         M12[4] * p.x + M12[5] * p.y + M12[6] * p.z + M12[7],
-                         M12[8] * p.x + M12[9] * p.y + M12[10] * p.z + M12[11], p.w);
+    // ((m0 x + m1 y) + m2 z) + m3 with every product and sum rounded on its own, like the reference's x86 build (no FMA
+    // contraction): the transformed clouds feed voxel grids and box crops whose parity bar is exact.  HBM-bound either way.
+    auto row = [&](int r) {
+#pragma clang fp contract(off)
+        const float a = M12[4 * r] * p.x, b = M12[4 * r + 1] * p.y, cc = M12[4 * r + 2] * p.z;
+        const float s1 = a + b;
+        const float s2 = s1 + cc;
+        return s2 + M12[4 * r + 3];
+    };
+    out[i] = make_float4(row(0), row(1), row(2), p.w);
 }
 
 }  // namespace

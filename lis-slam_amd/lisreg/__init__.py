@@ -35,6 +35,8 @@ ABI_SYMBOLS = [
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
     "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
+    "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
+    "lisreg_localmap_get", "lisreg_predict_pose",
     "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_gn_match",
 ]
 
@@ -103,6 +105,20 @@ class Item(C.Structure):
     _fields_ = [("src_corner", C.c_void_p), ("n_corner", C.c_int), ("src_surf", C.c_void_p), ("n_surf", C.c_int),
                 ("stride_bytes", C.c_int), ("fmt", C.c_int), ("target", C.c_int), ("degenerate_in", C.c_int),
                 ("imu", Imu)]
+
+
+class LocalMapParams(C.Structure):
+    _fields_ = [("max_num_pts", C.c_int), ("dynamic_removal_on", C.c_int), ("dynamic_removal_center_radius", C.c_float),
+                ("dynamic_dist_thre_min", C.c_float), ("dynamic_dist_thre_max", C.c_float), ("near_dist_thre", C.c_float),
+                ("leaf", C.c_float * 5), ("crop_box", C.c_float * 6), ("crop_pad", C.c_float)]
+
+
+class LocalMapInfo(C.Structure):
+    _fields_ = [("n", C.c_int * 5), ("feature_point_num", C.c_int), ("bound", C.c_double * 6), ("crop", C.c_double * 6),
+                ("n_target_corner", C.c_int), ("n_target_surf", C.c_int)]
+
+
+LOCALMAP_CLASSES = ("dynamic", "pole", "ground", "building", "outlier")      # class order of localMap_t (subMap.h:742-753)
 
 
 class FeatureParams(C.Structure):
@@ -193,11 +209,39 @@ def lib():
                                             C.c_float, vp, ip]
         L.lisreg_bbx_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp, C.c_int, vp, ip]
         L.lisreg_cloud_bounds.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp]
+        L.lisreg_localmap_default_params.argtypes = [C.POINTER(LocalMapParams)]
+        L.lisreg_localmap_reset.argtypes = [vp, C.c_int]
+        L.lisreg_localmap_insert.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, fp,
+                                             C.POINTER(LocalMapParams), C.POINTER(LocalMapInfo)]
+        L.lisreg_localmap_extract.argtypes = [vp, C.c_int, fp, C.POINTER(LocalMapParams), C.c_int, C.POINTER(LocalMapInfo)]
+        L.lisreg_localmap_get.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
+        L.lisreg_predict_pose.argtypes = [fp, fp, fp]
+        L.lisreg_predict_pose.restype = None
         L.lisreg_icp_default_params.argtypes = [C.c_int, C.POINTER(IcpParams)]
         L.lisreg_icp_gn_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_float, fp, C.POINTER(IcpGnResult), vp]
         L.lisreg_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult), vp]
         _lib = L
     return _lib
+
+
+def localmap_default_params() -> LocalMapParams:
+    p = LocalMapParams()
+    if lib().lisreg_localmap_default_params(C.byref(p)):
+        raise LisregError(ERR_ARG, "lisreg_localmap_default_params")
+    return p
+
+
+def predict_pose(T_last, T_cur) -> np.ndarray:
+    a = np.ascontiguousarray(T_last, np.float32); b = np.ascontiguousarray(T_cur, np.float32)
+    out = np.zeros(6, np.float32)
+    f = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    lib().lisreg_predict_pose(f(a), f(b), f(out))
+    return out
+
+
+def _info_dict(info: LocalMapInfo) -> dict:
+    return dict(n=list(info.n), feature_point_num=info.feature_point_num, bound=np.array(list(info.bound)),
+                crop=np.array(list(info.crop)), n_target_corner=info.n_target_corner, n_target_surf=info.n_target_surf)
 
 
 def icp_default_params(kind: int = 0) -> IcpParams:
@@ -457,6 +501,45 @@ class Context:
         m = (C.c_uint32 * 32)(*using_label) if using_label is not None else None
         self._chk(self._L.lisreg_semantic_split(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIL, m, C.byref(so)))
         return [bufs[k][: so.n[k]] for k in range(5)]
+
+    # -- §8 f-3: device-resident sliding local map -----------------------------------------------------------
+    def localmap_reset(self, map_id: int = 0):
+        self._chk(self._L.lisreg_localmap_reset(self._h, map_id))
+
+    def localmap_insert(self, map_id: int, clouds, pose, params: LocalMapParams) -> dict:
+        """clouds: five PCL PointXYZIL struct arrays in LOCALMAP_CLASSES order (sensor frame, un-downsampled)."""
+        arrs = [np.ascontiguousarray(a) for a in clouds]
+        ptrs = (C.c_void_p * 5)(*[a.ctypes.data if len(a) else None for a in arrs])
+        cnt = (C.c_int * 5)(*[len(a) for a in arrs])
+        T = np.ascontiguousarray(pose, np.float32)
+        info = LocalMapInfo()
+        self._chk(self._L.lisreg_localmap_insert(self._h, map_id, ptrs, cnt, arrs[0].dtype.itemsize, _fmt_of(arrs[0]),
+                                                 T.ctypes.data_as(C.POINTER(C.c_float)), C.byref(params), C.byref(info)))
+        return _info_dict(info)
+
+    def localmap_insert_device(self, map_id: int, ptrs, counts, pose, params: LocalMapParams) -> dict:
+        p = (C.c_void_p * 5)(*[C.c_void_p(int(x)) if c else None for x, c in zip(ptrs, counts)])
+        cnt = (C.c_int * 5)(*[int(x) for x in counts])
+        T = np.ascontiguousarray(pose, np.float32)
+        info = LocalMapInfo()
+        self._chk(self._L.lisreg_localmap_insert(self._h, map_id, p, cnt, 16, FMT_DEVICE,
+                                                 T.ctypes.data_as(C.POINTER(C.c_float)), C.byref(params), C.byref(info)))
+        return _info_dict(info)
+
+    def localmap_extract(self, map_id: int, cur_pose, params: LocalMapParams, target_slot: int = 0) -> dict:
+        T = np.ascontiguousarray(cur_pose, np.float32)
+        info = LocalMapInfo()
+        self._chk(self._L.lisreg_localmap_extract(self._h, map_id, T.ctypes.data_as(C.POINTER(C.c_float)), C.byref(params),
+                                                  target_slot, C.byref(info)))
+        return _info_dict(info)
+
+    def localmap_get(self, map_id: int, cls: int) -> np.ndarray:
+        """[n, 4] float32 records (x, y, z, label bits) of class cls (0-4) or of the corner / surf target (5 / 6)."""
+        n = C.c_int(0)
+        self._L.lisreg_localmap_get(self._h, map_id, cls, None, 0, C.byref(n))
+        out = np.zeros((max(n.value, 1), 4), np.float32)
+        self._chk(self._L.lisreg_localmap_get(self._h, map_id, cls, out.ctypes.data_as(C.c_void_p), max(n.value, 1), C.byref(n)))
+        return out[: n.value]
 
     # -- §8 f-3 -------------------------------------------------------------------------------------------
     def map_index_set(self, slot: int, cloud: np.ndarray):

@@ -1,0 +1,175 @@
+"""Sequential replay on the HIP path (BASELINE.json configs[2]): the frame loop of SubMapOptmizationNode::makeSubMapThread
+(/root/reference/src/node/subMapOptmizationNode.cpp:597-755) with every cloud operation done by liblisreg on the GPU:
+
+  per frame   semantic split (categoryMapping, semanticFusionNode.cpp:173-189) -> per-class voxel grids (keyframeInit :806-811)
+              -> pose guess (updateInitialGuess :984-1020) -> lisreg_localmap_extract (extractSlidingCloud :1369-1432 + both
+              target indexes) -> label-weighted registration, copy #2 (:1509-1541) -> lisreg_localmap_insert
+              (SubMapManager::insert_local_map, subMap.h:979-1059)
+
+The local map lives in HBM from the first frame to the last.  Also here: the synthetic drive used when no dataset is mounted,
+the KITTI / SemanticKITTI readers, and the trajectory writer in the reference's format (transformFusion, :5079-5179).
+This module is host-side driver code (the reference's ROS node, minus ROS); it computes nothing itself."""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from . import synth
+
+CLASSES = ("dynamic", "pole", "ground", "building", "outlier")
+FRAME_LEAF = dict(dynamic=0.2, pole=0.05, ground=0.6, building=0.4, outlier=0.6)      # keyframeInit :806-811
+
+# config/label.yaml:110-144 `learning_map`: SemanticKITTI raw ids -> the 20 RangeNet++ classes the reference's nodes see
+LEARNING_MAP = {0: 0, 1: 0, 10: 1, 11: 2, 13: 5, 15: 3, 16: 5, 18: 4, 20: 5, 30: 6, 31: 7, 32: 8, 40: 9, 44: 10, 48: 11, 49: 12,
+                50: 13, 51: 14, 52: 0, 60: 9, 70: 15, 71: 16, 72: 17, 80: 18, 81: 19, 99: 0, 252: 1, 253: 7, 254: 6, 255: 8,
+                256: 5, 257: 5, 258: 4, 259: 5}
+
+
+# ---- inputs ---------------------------------------------------------------------------------------------------------
+def synthetic_drive(n_frames: int, h: int = 64, w: int = 1800, step: float = 0.45, seed: int = 7, car: bool = True):
+    """A labelled drive through the synthetic room of synth.py: frame k is an H x W sweep from a pose that advances `step`
+    metres per frame on a gently curving path (first pose level, yaw 0, so the map frame equals the first sensor frame).
+    Labels are RangeNet classes: pole 18, road 9, building 13; floor returns inside a rectangle that moves with the frames
+    are relabelled car (1) so that the dynamic class and the map-based dynamic removal are exercised.
+    Yields (cloud PointXYZIL struct array, T_true relative to frame 0)."""
+    x0, y0 = -14.0, -6.0
+    for k in range(n_frames):
+        yaw = 0.35 * np.sin(0.08 * k)
+        x = x0 + step * k * np.cos(0.12) - 0.0
+        y = y0 + step * k * np.sin(0.12) + 1.5 * np.sin(0.05 * k)
+        T_world = np.array([0.0, 0.0, yaw, x, y, synth.SENSOR_Z])
+        sc = synth.make_scan(h, w, seed * 1000 + k, labelled=True, T_true=T_world)
+        cloud = synth.concat_clouds([sc["corner"], sc["surf"]])
+        if car:
+            M = synth.pose_matrix(T_world)
+            xyz = synth.pcl_xyz(cloud).astype(np.float64) @ M[:3, :3].T + M[:3, 3]
+            cx, cy = x + 6.0 + 0.5 * k * 0.2, y + 2.5
+            in_car = (np.abs(xyz[:, 0] - cx) < 2.0) & (np.abs(xyz[:, 1] - cy) < 0.9) & (cloud["label"] == synth.LABEL_GROUND)
+            cloud["label"][in_car] = 1
+        T_rel = np.array([0.0, 0.0, yaw, x - x0, y - y0, 0.0])                 # frame 0 has yaw 0
+        yield cloud, T_rel
+
+
+def read_kitti_frame(bin_path: str, label_path: str | None):
+    """velodyne/*.bin (float32 x y z remission) + labels/*.label (uint32: low 16 bits = SemanticKITTI class) ->
+    PointXYZIL struct array carrying the RangeNet class id the reference's semantic node would publish."""
+    raw = np.fromfile(bin_path, np.float32).reshape(-1, 4)
+    lab = np.zeros(len(raw), np.uint16)
+    if label_path and os.path.exists(label_path):
+        sem = np.fromfile(label_path, np.uint32) & 0xFFFF
+        lut = np.zeros(65536, np.uint16)
+        for k, v in LEARNING_MAP.items():
+            lut[k] = v
+        lab = lut[sem]
+    return synth.to_pcl(raw[:, :3].copy(), lab, raw[:, 3].copy())
+
+
+def kitti_sequence(root: str, seq: str, max_frames: int | None = None):
+    """Yields labelled frames of <root>/sequences/<seq>/{velodyne,labels} in order."""
+    d = os.path.join(root, "sequences", seq)
+    names = sorted(f[:-4] for f in os.listdir(os.path.join(d, "velodyne")) if f.endswith(".bin"))
+    for i, nm in enumerate(names):
+        if max_frames is not None and i >= max_frames:
+            return
+        yield read_kitti_frame(os.path.join(d, "velodyne", nm + ".bin"), os.path.join(d, "labels", nm + ".label")), None
+
+
+def write_trajectory(path: str, poses):
+    """transformFusion's file format (:5079-5179): per pose one line with the 12 entries of H_init^-1 * H (row-major 3 x 4),
+    scientific notation, 6 digits."""
+    H0 = None
+    with open(path, "w") as f:
+        for T in poses:
+            H = synth.pose_matrix(np.asarray(T, np.float64))
+            if H0 is None:
+                H0 = np.linalg.inv(H)
+            R = H0 @ H
+            f.write(" ".join(f"{R[i, j]:.6e}" for i in range(3) for j in range(4)) + "\n")
+
+
+# ---- the frame loop -------------------------------------------------------------------------------------------------
+class Replayer:
+    """makeSubMapThread's state: transformTobeSubMapped, the previous pose, the local map (device object `map_id` of `ctx`)."""
+
+    def __init__(self, ctx, variant: int = 2, map_id: int = 0, target_slot: int = 0):
+        import lisreg
+        self.ctx, self.map_id, self.slot = ctx, map_id, target_slot
+        self.params = lisreg.default_params(variant)
+        self.lm_params = lisreg.localmap_default_params()
+        self.T = np.zeros(6, np.float32)
+        self.T_last = None
+        self.k = 0
+        ctx.localmap_reset(map_id)
+
+    def _split_and_downsample(self, cloud):
+        parts = self.ctx.semantic_split(cloud)                      # dynamic, ground, building, pole, outlier
+        full = dict(dynamic=parts[0], ground=parts[1], building=parts[2], pole=parts[3], outlier=parts[4])
+        down = {k: (self.ctx.voxel_downsample(c, FRAME_LEAF[k])[1] if len(c) else c) for k, c in full.items()}
+        return full, down
+
+    def step(self, cloud) -> dict:
+        import lisreg
+        t0 = time.perf_counter()
+        full, down = self._split_and_downsample(cloud)
+        rec = dict(frame=self.k)
+        if self.k == 0:                                             # subMapFirstFlag branch (:634-651)
+            rec.update(T=self.T.copy(), guess=self.T.copy(), stats=None)
+        else:
+            if self.T_last is None:                                 # updateInitialGuess: the first call only records (:1003-1011)
+                self.T_last = self.T.copy()
+                guess = self.T.copy()
+            else:
+                guess = lisreg.predict_pose(self.T_last, self.T)
+                self.T_last = self.T.copy()
+            info = self.ctx.localmap_extract(self.map_id, guess, self.lm_params, self.slot)
+            src_c = down["pole"]                                                              # currentCloudInit :866-868
+            src_s = synth.concat_clouds([down["dynamic"], down["building"], down["ground"]])   # :873-889
+            T, st, _ = self.ctx.align(src_c, src_s, guess, self.params)
+            self.T = T.astype(np.float32)
+            rec.update(T=self.T.copy(), guess=guess.copy(), stats=st, n_target_corner=info["n_target_corner"],
+                       n_target_surf=info["n_target_surf"], n_src_corner=len(src_c), n_src_surf=len(src_s), crop=info["crop"])
+        info = self.ctx.localmap_insert(self.map_id, [full[c] for c in CLASSES], self.T, self.lm_params)
+        rec.update(n_map=info["n"], feature_point_num=info["feature_point_num"], bound=info["bound"], ms=1e3 * (time.perf_counter() - t0))
+        self.k += 1
+        return rec
+
+
+def replay(ctx, frames, variant: int = 2, on_frame=None):
+    r = Replayer(ctx, variant)
+    out = []
+    for cloud in frames:
+        rec = r.step(cloud)
+        out.append(rec)
+        if on_frame:
+            on_frame(rec)
+    return out
+
+
+def bench_sequence(device: int, steps: int = 20, warmup: int = 2) -> dict:
+    """bench.py --workload cfg3: frames/s of the synthetic drive on the HIP chain (host-inclusive: every frame's sweep crosses
+    PCIe, as in the reference's node), with the CPU oracle chain timed on the first frames as the baseline."""
+    import lisreg
+    n = max(steps, 2) + warmup
+    frames = [c for c, _ in synthetic_drive(n)]
+    truth = [t for _, t in synthetic_drive(n)]
+    ctx = lisreg.Context(device)
+    r = Replayer(ctx, 2)
+    recs = []
+    t0 = None
+    for k, cloud in enumerate(frames):
+        if k == warmup:
+            t0 = time.perf_counter()
+        recs.append(r.step(cloud))
+    dt = time.perf_counter() - t0
+    err = max(float(np.abs(np.asarray(rec["T"], np.float64)[3:5] - truth[rec["frame"]][3:5]).max()) for rec in recs)
+    ctx.close()
+    return {"metric": "sequential scan-to-local-map registrations/sec (synthetic drive, semantic mask on)",
+            "value": round((n - warmup) / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / (n - warmup), 3), "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": "configs[2] synthetic stand-in: 64x1800 labelled sweeps, host clouds in, "
+                                                        "device-resident sliding local map, copy #2 parameters, early exit"},
+            "roofline": None, "cpu_baseline": None,
+            "accuracy": {"max_xy_err_vs_truth_m": err, "frames": n,
+                         "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]}}

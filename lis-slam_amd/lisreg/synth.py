@@ -46,6 +46,20 @@ def to_pcl(xyz: np.ndarray, label=None, intensity=None) -> np.ndarray:
     return out
 
 
+def concat_clouds(clouds, dtype=None) -> np.ndarray:
+    """`*a += *b` for PCL struct arrays.  np.concatenate would re-pack a padded struct dtype (32-byte PCL points become 18-byte
+    records with the label at another offset); this keeps the layout of the first cloud."""
+    clouds = list(clouds)
+    dtype = dtype or clouds[0].dtype
+    out = np.zeros(sum(len(c) for c in clouds), dtype)
+    o = 0
+    for c in clouds:
+        assert c.dtype == dtype, (c.dtype, dtype)
+        out[o:o + len(c)] = c
+        o += len(c)
+    return out
+
+
 def pcl_xyz(cloud: np.ndarray) -> np.ndarray:
     return np.stack([cloud["x"], cloud["y"], cloud["z"]], 1).astype(np.float32)
 
@@ -209,7 +223,7 @@ def make_raw_scan(h: int, w: int, seed: int, scene_seed: int = 1234, dup_fractio
     plus a few jittered duplicates so that several points compete for one range-image pixel (first one must win)."""
     rng = np.random.default_rng(seed + 31)
     sc = make_scan(h, w, seed, scene_seed)
-    both = np.concatenate([sc["corner"], sc["surf"]])
+    both = concat_clouds([sc["corner"], sc["surf"]])
     xyz = pcl_xyz(both)
     el = np.degrees(np.arctan2(xyz[:, 2], np.hypot(xyz[:, 0], xyz[:, 1])))
     ring = np.clip(np.rint((el + 24.8) / (26.8 / (h - 1))), 0, h - 1).astype(np.uint16)

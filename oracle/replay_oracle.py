@@ -1,0 +1,138 @@
+"""CPU restatement of the reference's sequential frame loop — TEST INFRASTRUCTURE ONLY (see lisreg_oracle.h).
+
+Composes the C restatement's primitives (oracle_ctypes) in the order of
+  SubMapOptmizationNode::makeSubMapThread     /root/reference/src/node/subMapOptmizationNode.cpp:597-755
+  keyframeInit (per-class voxel grids)        :758-852
+  currentCloudInit (source assembly)          :856-893
+  updateInitialGuess (no IMU, no odometry)    :984-1020 (same arithmetic as odomEstimationNode.cpp:351-392)
+  extractTargetCloud -> extractSlidingCloud   :1146-1200, 1369-1432
+  scan2SubMapOptimization (copy #2)           :1509-1541  -> oracle_ctypes.align(variant 2)
+  SubMapManager::insert_local_map             src/include/subMap.h:979-1059
+on host clouds in the reference's PointXYZIL layout.  Only tests/, bench.py's cpu_baseline leg and tools/kitti_replay.py
+--check may import this module."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_ctypes as oc
+
+CLASSES = ("dynamic", "pole", "ground", "building", "outlier")        # append_feature / merge_feature_points order
+FRAME_LEAF = dict(dynamic=0.2, pole=0.05, ground=0.6, building=0.4, outlier=0.6)     # keyframeInit :806-811
+MAP_LEAF = (0.1, 0.05, 0.4, 0.2, 0.6)                                                 # extractSlidingCloud :1385-1389
+CROP_BOX = (-70.0, -70.0, -10.0, 70.0, 70.0, 20.0)                                    # :1377-1379
+
+
+def cat(clouds):
+    """`*a += *b` on PCL struct arrays, keeping the padded 32-byte layout (np.concatenate would re-pack the dtype)."""
+    out = np.zeros(sum(len(c) for c in clouds), clouds[0].dtype)
+    o = 0
+    for c in clouds:
+        out[o:o + len(c)] = c
+        o += len(c)
+    return out
+
+
+def pose_matrix_f32(T):
+    """pcl::getTransformation in float (trans2Affine3f, common.cpp:54-57) via the oracle's own restatement."""
+    Tf = np.ascontiguousarray(T, np.float32)
+    M = np.zeros(12, np.float32)
+    oc.lib().orc_pose_to_matrix(oc._fp(Tf), oc._fp(M))
+    return M.reshape(3, 4)
+
+
+def predict_pose(T_last, T_cur):
+    """updateInitialGuess, constant-velocity branch: transFinal = transTobe * (transLast^-1 * transBack), float arithmetic."""
+    A = np.vstack([pose_matrix_f32(T_last), np.array([[0, 0, 0, 1]], np.float32)]).astype(np.float32)
+    B = np.vstack([pose_matrix_f32(T_cur), np.array([[0, 0, 0, 1]], np.float32)]).astype(np.float32)
+    inc = (np.linalg.inv(A.astype(np.float64)) @ B.astype(np.float64)).astype(np.float32)
+    F = (B @ inc).astype(np.float32)
+    # pcl::getTranslationAndEulerAngles
+    return np.array([np.arctan2(F[2, 1], F[2, 2]), np.arcsin(-F[2, 0]), np.arctan2(F[1, 0], F[0, 0]), F[0, 3], F[1, 3], F[2, 3]], np.float32)
+
+
+class LocalMapOracle:
+    """localMap_t + insert_local_map + extractSlidingCloud on host struct arrays."""
+
+    def __init__(self, dtype):
+        self.cls = [np.zeros(0, dtype) for _ in range(5)]
+        self.feature_point_num = 0
+        self.bound = np.array([np.finfo(np.float64).max] * 3 + [-np.finfo(np.float64).max] * 3)
+
+    def insert(self, clouds, pose, max_num_pts=80000, dynamic_removal_on=True, center_radius=30.0, thre_min=0.3, thre_max=3.0,
+               near_thre=0.03):
+        """subMap.h:979-1059.  clouds: five un-downsampled class clouds (CLASSES order) in the sensor frame."""
+        thre_max = max(np.float32(thre_max), np.float32(np.float64(np.float32(thre_min)) + 0.1))           # :1006
+        moved = [oc.transform_cloud(c, pose, fmt=1) if len(c) else c for c in clouds[:4]]                # outlier: commented out (:1003)
+        if dynamic_removal_on and self.feature_point_num > max_num_pts // 5 and len(self.cls[0]) > 0:
+            moved[0], _ = oc.dynamic_filter(self.cls[0], moved[0], center_radius, float(np.float32(thre_min)), float(thre_max),
+                                            float(np.float32(near_thre)))
+        for k in range(4):
+            self.cls[k] = cat([self.cls[k], moved[k]])
+        self.feature_point_num = sum(len(c) for c in self.cls)
+        allpts = cat(self.cls)
+        self.bound = oc.cloud_bounds(allpts)
+
+    def extract(self, cur_pose, leaf=MAP_LEAF, crop_box=CROP_BOX, pad=2.0):
+        """subMapOptmizationNode.cpp:1369-1432.  Returns (corner target, surf target, bbx_intersection)."""
+        M = pose_matrix_f32(cur_pose).astype(np.float64)             # float entries, double arithmetic (transform_bbx)
+        bx = np.array(crop_box, np.float64)
+        cp = 0.5 * (bx[:3] + bx[3:])
+        cpo = M[:, 0] * cp[0] + M[:, 1] * cp[1] + M[:, 2] * cp[2] + M[:, 3]
+        cur = np.concatenate([bx[:3] - cp + cpo, bx[3:] - cp + cpo])
+        isect = np.concatenate([np.maximum(cur[:3], self.bound[:3]) - pad, np.minimum(cur[3:], self.bound[3:]) + pad])
+        for k in range(5):
+            if len(self.cls[k]):
+                rc, ds = oc.voxel_grid(self.cls[k], float(np.float32(leaf[k])), fmt=1)
+                self.cls[k] = ds
+        for k in range(5):
+            if len(self.cls[k]):
+                self.cls[k] = oc.bbx_filter(self.cls[k], isect)
+        return self.cls[1].copy(), cat([self.cls[2], self.cls[3], self.cls[0]]), isect
+
+
+def split_and_downsample(labelled_cloud):
+    """SemanticFusionNode::categoryMapping + keyframeInit's per-class voxel grids.  Returns (full, down) dicts keyed by class."""
+    dyn, ground, building, pole, outlier = oc.semantic_split(labelled_cloud)
+    full = dict(dynamic=dyn, pole=pole, ground=ground, building=building, outlier=outlier)
+    down = {}
+    for k, c in full.items():
+        down[k] = oc.voxel_grid(c, FRAME_LEAF[k], fmt=1)[1] if len(c) else c
+    return full, down
+
+
+def replay(frames, n_threads=8, params=None, on_frame=None):
+    """frames: iterable of labelled PointXYZIL clouds (one sweep each).  Returns a list of per-frame dicts
+    (T = transformTobeSubMapped after the frame, guess, stats, n_target_corner / n_target_surf, n_src_corner / n_src_surf)."""
+    p = params or oc.default_params(2)
+    out = []
+    lm = None
+    T = np.zeros(6, np.float32)
+    T_last = None
+    have_last = False
+    for k, cloud in enumerate(frames):
+        full, down = split_and_downsample(cloud)
+        if lm is None:
+            lm = LocalMapOracle(cloud.dtype)
+        rec = dict(frame=k)
+        if k == 0:                                             # subMapFirstFlag branch (:634-651)
+            rec.update(T=T.copy(), guess=T.copy(), stats=None)
+        else:
+            if not have_last:                                  # updateInitialGuess: the first call only records (:1003-1011)
+                T_last = T.copy(); have_last = True
+                guess = T.copy()
+            else:
+                guess = predict_pose(T_last, T)
+                T_last = T.copy()
+            tc, ts, isect = lm.extract(guess)
+            src_c = down["pole"]                                                                  # currentCloudInit :866-868
+            src_s = cat([down["dynamic"], down["building"], down["ground"]])                     # :873-889
+            Tn, st, _ = oc.align(tc, ts, src_c, src_s, guess, p, n_threads=n_threads, max_trace=1)
+            T = Tn.astype(np.float32)
+            rec.update(T=T.copy(), guess=guess.copy(), stats=st, n_target_corner=len(tc), n_target_surf=len(ts),
+                       n_src_corner=len(src_c), n_src_surf=len(src_s), crop=isect)
+        lm.insert([full[c] for c in CLASSES], T)
+        rec.update(n_map=[len(c) for c in lm.cls], feature_point_num=lm.feature_point_num, bound=lm.bound.copy())
+        out.append(rec)
+        if on_frame:
+            on_frame(rec)
+    return out

@@ -1,0 +1,186 @@
+"""BASELINE configs[2] (sequential replay, semantic mask on) on the synthetic drive, and the device-resident sliding local map.
+
+CPU (-m "not gpu"): the oracle chain (oracle/replay_oracle.py: the reference's frame loop restated over the C restatement's
+primitives) tracks the known trajectory of a short drive; its pose-guess helper agrees with the library's host helper.
+GPU: (1) lisreg_localmap_insert / _extract against the oracle's LocalMapOracle with IDENTICAL poses fed to both — every class
+cloud, the bound, the crop box and both targets must then be bit-identical; (2) the HIP frame loop (lisreg.replay) against the
+oracle frame loop, frame by frame: same iteration counts, poses within 1e-3 m / 1e-3 rad, and the trajectory file format."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import pose_err
+
+
+def _records(cloud):
+    import lisreg
+    return lisreg.pack_device_records(cloud)
+
+
+def test_oracle_chain_tracks_the_synthetic_drive(oracle):
+    import replay_oracle as ro
+    from lisreg import replay
+    frames, truth = zip(*replay.synthetic_drive(5, h=16, w=450, step=0.15))
+    recs = ro.replay(frames, n_threads=8)
+    assert len(recs) == 5 and recs[0]["stats"] is None
+    for rec, t in zip(recs[1:], truth[1:]):
+        assert rec["stats"]["status"] == 0
+        assert np.abs(rec["T"][3:5] - t[3:5]).max() < 0.05 and abs(rec["T"][2] - t[2]) < 0.01, (rec["frame"], rec["T"], t)
+    # the local map is the union of what was inserted, cropped and down-sampled: non-empty static classes, no outliers
+    assert recs[-1]["n_map"][1] > 0 and recs[-1]["n_map"][2] > 0 and recs[-1]["n_map"][3] > 0 and recs[-1]["n_map"][4] == 0
+    assert recs[-1]["feature_point_num"] == sum(recs[-1]["n_map"])
+
+
+def test_predict_pose_helper_matches_oracle():
+    import lisreg
+    import replay_oracle as ro
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        a = np.concatenate([rng.uniform(-0.1, 0.1, 2), rng.uniform(-3, 3, 1), rng.uniform(-50, 50, 3)]).astype(np.float32)
+        b = (a + np.concatenate([rng.uniform(-0.01, 0.01, 3), rng.uniform(-1, 1, 3)])).astype(np.float32)
+        g1, g2 = lisreg.predict_pose(a, b), ro.predict_pose(a, b)
+        assert max(pose_err(g1, g2)) < 2e-5, (g1, g2)
+    assert max(pose_err(lisreg.predict_pose(a, a), a)) < 1e-6          # no motion -> the same pose
+
+
+def test_trajectory_file_format(tmp_path):
+    from lisreg import replay
+    poses = [np.array([0, 0, 0.1 * k, 1.0 * k, 0.5 * k, 0], np.float32) for k in range(3)]
+    p = tmp_path / "traj.txt"
+    replay.write_trajectory(str(p), poses)
+    rows = [l.split() for l in open(p).read().strip().split("\n")]
+    assert len(rows) == 3 and all(len(r) == 12 for r in rows)
+    first = np.array(rows[0], np.float64).reshape(3, 4)
+    assert np.allclose(first, np.eye(4)[:3], atol=1e-9) and "e" in rows[1][0]          # H_init^-1 H, scientific notation
+
+
+@pytest.mark.gpu
+def test_localmap_composite_equals_oracle_bitwise(oracle, gpu_ctx):
+    """insert / extract / insert ... with the SAME poses on both sides: the device-resident map must equal the host restatement
+    exactly (class clouds incl. labels, feature_point_num, bound, crop box, targets) — including the dynamic removal, which
+    starts once feature_point_num > 16000."""
+    import lisreg
+    import replay_oracle as ro
+    from lisreg import replay
+    frames, truth = zip(*replay.synthetic_drive(6, h=32, w=900))
+    lm = None
+    P = lisreg.localmap_default_params()
+    gpu_ctx.localmap_reset(3)
+    removed_any = False
+    for k, (cloud, T) in enumerate(zip(frames, truth)):
+        T = T.astype(np.float32)
+        parts = oracle.semantic_split(cloud)
+        full = dict(dynamic=parts[0], ground=parts[1], building=parts[2], pole=parts[3], outlier=parts[4])
+        clouds = [full[c] for c in ro.CLASSES]
+        if lm is None:
+            lm = ro.LocalMapOracle(cloud.dtype)
+        if k > 0:
+            tc, ts, isect = lm.extract(T)
+            info = gpu_ctx.localmap_extract(3, T, P, target_slot=0)
+            assert np.array_equal(info["crop"], isect)
+            assert info["n_target_corner"] == len(tc) and info["n_target_surf"] == len(ts)
+            assert np.array_equal(gpu_ctx.localmap_get(3, 5), _records(tc))
+            assert np.array_equal(gpu_ctx.localmap_get(3, 6), _records(ts))
+        n_dyn_before = len(lm.cls[0])
+        lm.insert(clouds, T)
+        removed_any |= len(lm.cls[0]) - n_dyn_before < len(full["dynamic"])
+        info = gpu_ctx.localmap_insert(3, clouds, T, P)
+        assert info["n"] == [len(c) for c in lm.cls] and info["feature_point_num"] == lm.feature_point_num
+        assert np.array_equal(info["bound"], lm.bound)
+        for c in range(5):
+            assert np.array_equal(gpu_ctx.localmap_get(3, c), _records(lm.cls[c])), (k, c)
+    assert removed_any, "the drive never exercised the map-based dynamic removal"
+    # the extracted target is a registration target like any other
+    T, st, _ = gpu_ctx.align(*[lisreg.synth.to_pcl(np.zeros((0, 3), np.float32), np.zeros(0, np.uint16))] * 2, truth[-1].astype(np.float32),
+                             lisreg.default_params(2))
+    assert st["status"] == lisreg.NOT_ENOUGH_FEATURES
+
+
+@pytest.mark.gpu
+def test_sequential_replay_matches_oracle_frame_by_frame(oracle):
+    """configs[2] on the synthetic drive at full scan size: 20 frames of 64x1800 labelled sweeps, label-weighted copy #2
+    registration against the sliding local map, early exit — HIP chain vs oracle chain."""
+    import lisreg
+    import replay_oracle as ro
+    from lisreg import replay
+    n = 20
+    frames, truth = zip(*replay.synthetic_drive(n))
+    ref = ro.replay(frames, n_threads=16)
+    ctx = lisreg.Context(0)
+    got = replay.replay(ctx, frames)
+    ctx.close()
+    assert len(got) == len(ref) == n
+    worst = 0.0
+    for g, r, t in zip(got, ref, truth):
+        if r["stats"] is None:
+            assert g["stats"] is None
+            continue
+        assert g["stats"]["status"] == r["stats"]["status"] == 0, (g["frame"], g["stats"], r["stats"])
+        assert abs(g["stats"]["iters"] - r["stats"]["iters"]) <= 1, (g["frame"], g["stats"], r["stats"])
+        e = max(pose_err(g["T"], r["T"]))
+        worst = max(worst, e)
+        assert e <= 1e-3, (g["frame"], e, g["T"], r["T"])
+        assert max(pose_err(g["guess"], r["guess"])) <= 1e-3
+        # map sizes: identical up to the points a sub-0.1-mm pose difference moves across a voxel / crop boundary
+        for a, b in zip(g["n_map"], r["n_map"]):
+            assert abs(a - b) <= max(3, 0.002 * b), (g["frame"], g["n_map"], r["n_map"])
+        assert abs(g["n_target_surf"] - r["n_target_surf"]) <= max(3, 0.002 * r["n_target_surf"])
+        assert np.abs(np.asarray(g["T"], np.float64)[3:5] - t[3:5]).max() < 0.05          # and both follow the drive
+    print(f"replay: worst pose difference HIP vs oracle over {n} frames: {worst:.2e}; iterations per frame "
+          f"{[g['stats']['iters'] for g in got[1:]]}")
+
+
+def _write_kitti_dir(root, frames):
+    """frames as a KITTI odometry / SemanticKITTI tree: velodyne/%06d.bin (x y z remission), labels/%06d.label (uint32)."""
+    inv = {1: 10, 9: 40, 13: 50, 18: 80}                 # RangeNet class -> a SemanticKITTI raw id that learning_map sends back to it
+    vd, ld = os.path.join(root, "sequences", "05", "velodyne"), os.path.join(root, "sequences", "05", "labels")
+    os.makedirs(vd); os.makedirs(ld)
+    for k, cloud in enumerate(frames):
+        raw = np.zeros((len(cloud), 4), np.float32)
+        raw[:, 0], raw[:, 1], raw[:, 2] = cloud["x"], cloud["y"], cloud["z"]
+        raw.tofile(os.path.join(vd, f"{k:06d}.bin"))
+        sem = np.array([inv[int(l)] for l in cloud["label"]], np.uint32) | (np.uint32(7) << 16)       # instance id in the high half
+        sem.tofile(os.path.join(ld, f"{k:06d}.label"))
+
+
+def test_kitti_reader_round_trip(tmp_path):
+    from lisreg import replay
+    frames, _ = zip(*replay.synthetic_drive(2, h=16, w=450))
+    _write_kitti_dir(str(tmp_path), frames)
+    got = [c for c, _ in replay.kitti_sequence(str(tmp_path), "05")]
+    assert len(got) == 2
+    for a, b in zip(got, frames):
+        assert a.dtype == b.dtype and np.array_equal(a["label"], b["label"])
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["z"], b["z"])
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "kitti_replay.py")
+    rc = subprocess.call([sys.executable, tool, "--root", str(tmp_path / "nowhere"), "--seq", "05"], stderr=subprocess.DEVNULL)
+    assert rc == 2                                         # no dataset -> says so, no traceback, no fake numbers
+
+
+@pytest.mark.gpu
+def test_kitti_tool_end_to_end_on_a_synthesised_sequence(tmp_path):
+    """tools/kitti_replay.py on a KITTI-format directory written from the synthetic drive: it must reproduce lisreg.replay on
+    the same frames bit for bit, write the trajectory in the reference's format and agree with the CPU restatement."""
+    import json
+    import subprocess
+    import sys
+    import lisreg
+    from lisreg import replay
+    frames, truth = zip(*replay.synthetic_drive(6, h=32, w=900))
+    _write_kitti_dir(str(tmp_path), frames)
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "kitti_replay.py")
+    out = tmp_path / "traj.txt"
+    res = subprocess.run([sys.executable, tool, "--root", str(tmp_path), "--seq", "05", "--out", str(out), "--check-oracle", "6"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    summary = json.loads(res.stdout.strip().split("\n")[-1])
+    assert summary["frames"] == 6 and summary["oracle_check"]["max_trans_diff_m"] <= 1e-3 and summary["oracle_check"]["max_rot_diff_rad"] <= 1e-3
+    ctx = lisreg.Context(0)
+    direct = replay.replay(ctx, frames)
+    ctx.close()
+    assert np.allclose(summary["final_pose"], direct[-1]["T"], rtol=0, atol=0)
+    rows = np.loadtxt(out)
+    assert rows.shape == (6, 12) and np.allclose(rows[0].reshape(3, 4), np.eye(4)[:3])
+    assert abs(rows[-1, 3] - truth[-1][3]) < 0.05 and abs(rows[-1, 7] - truth[-1][4]) < 0.05

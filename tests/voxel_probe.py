@@ -24,7 +24,7 @@ cases.append(("200k submap surf, leaf 0.4", ts, 0.4))
 sc = synth.make_scan(64, 1800, 1000, labelled=True)
 cases.append(("64x1800 scan surf (110k), leaf 0.4", sc["surf"], 0.4))
 cases.append(("64x1800 scan surf (110k), leaf 0.2", sc["surf"], 0.2))
-big = np.concatenate([synth.make_submap(200000, 100 + k, labelled=True)[1] for k in range(10)])
+big = synth.concat_clouds([synth.make_submap(200000, 100 + k, labelled=True)[1] for k in range(10)])
 cases.append(("assembled local map 1.9M (10 keyframe-sized clouds), leaf 0.4", big, 0.4))
 for name, cloud, leaf in cases:
     rec = lisreg.pack_device_records(cloud); n = len(cloud)
