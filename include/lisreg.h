@@ -73,7 +73,8 @@ typedef struct lisreg_params {
     float plane_tol;            /* |n.p + d| > 0.2 invalidates the plane (:798)                                */
     float accept_s;             /* keep correspondence iff s > 0.1 (:734,814)                                  */
     int   use_label_weight;     /* w = 2 - LabelSorce[label] (subMapOptmizationNode.cpp:1671,1795)             */
-    float label_score[32];      /* LabelSorce table, config/label.yaml:214-234; index = label & 31             */
+    float label_score[32];      /* LabelSorce table, config/label.yaml:214-234, indexed by label; 20..31 default to 0 and labels
+                                 * >= 32 read as 0: std::map::operator[] on a label the yaml does not list gives w = 2.0      */
     int   emulate_matp_shadow;  /* 1: reproduce the local-matP quirk; 0: keep P from iter 0 */
     int   skip_empty_target;    /* variant #3 skips a stage whose target cloud is empty (:4505-4509)           */
     int   use_imu_blend;        /* transformUpdate slerps roll/pitch toward IMU (#1,#2) or not (#3)            */

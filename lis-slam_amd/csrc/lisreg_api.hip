@@ -276,7 +276,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
@@ -288,6 +288,9 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);
+    if (c->stage_host) (void)hipHostFree(c->stage_host);
+    if (c->fetch_host) (void)hipHostFree(c->fetch_host);
+    if (c->stage_done) (void)hipEventDestroy(c->stage_done);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -318,7 +321,7 @@ int lisreg_default_params(int variant, lisreg_params* p)
     p->min_corr = 50; p->eig_thresh = 100.f; p->edge_min = -1; p->surf_min = 100;
     p->line_ratio = 3.f; p->plane_tol = 0.2f; p->accept_s = 0.1f;
     p->use_label_weight = variant == 1 ? 0 : 1;
-    for (int i = 0; i < 32; ++i) p->label_score[i] = i < 20 ? score[i] : 1.0f;
+    for (int i = 0; i < 32; ++i) p->label_score[i] = i < 20 ? score[i] : 0.0f;    // a label the std::map does not hold reads as 0 (:1671)
     p->emulate_matp_shadow = 1;
     p->skip_empty_target = variant == 3 ? 1 : 0;
     p->use_imu_blend = variant == 3 ? 0 : 1;
@@ -402,6 +405,8 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
         }
         for (int d = 0; d < 6; ++d)
             if (n > 0 && !std::isfinite(bb[d])) return fail(c, LISREG_ERR_ARG, "set_target: the cloud has infinite coordinates (NaN points are ignored, Inf is not indexable)");
+        if (n > 0 && !(bb[0] <= bb[3] && bb[1] <= bb[4] && bb[2] <= bb[5]))
+            return fail(c, LISREG_ERR_ARG, "set_target: the cloud has no finite point (every coordinate is NaN)");
         make_grid(bb, n, &t.g[k], &t.n_cells[k]);
         prof_mark(c, 2);
         int rc = build_target_kind(c, t, k);
@@ -461,7 +466,46 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
-    const float tile = env_float("LISREG_TILE", 0.25f);   // 2-D sort columns
+    // 2-D sort columns of the (optional) source sort: 0.25 m tiles over every item's target footprint.  The bucket count is kept
+    // in 64 bits and the tile grows until the whole batch fits 2^26 buckets (km-scale submaps x large batches would otherwise
+    // overflow the int32 bucket numbering and ask for gigabytes of histogram).
+    float tile = env_float("LISREG_TILE", 0.25f);
+    for (;;) {
+        long long total = 0;
+        for (int i = 0; i < n_items; ++i) {
+            if (items[i].target < 0 || (size_t)items[i].target >= c->targets.size()) continue;
+            for (int k = 0; k < 2; ++k) {
+                const GridIndex& g = c->targets[(size_t)items[i].target].g[k];
+                total += (long long)std::max(1.0, std::ceil((double)g.nx * g.cell / tile)) * (long long)std::max(1.0, std::ceil((double)g.ny * g.cell / tile));
+            }
+        }
+        if (total <= (1LL << 26)) break;
+        tile *= 1.5f;
+    }
+    // front-end of this batch.  The k-NN graph costs ~2 ns per target point and saves ~0.014 ns per query-iteration
+    // (MI355X, DESIGN.md §5): it pays for shared / long-lived targets (a batch of scans against one submap), not for
+    // one-shot targets (a loop-closure candidate pair, a single odometry frame).
+    {
+        long long total_src = 0;
+        double t_pts = 0;
+        std::vector<int> seen;
+        for (int i = 0; i < n_items; ++i) {
+            total_src += (long long)std::max(items[i].n_corner, 0) + (long long)std::max(items[i].n_surf, 0);
+            const int sl = items[i].target;
+            if (sl >= 0 && (size_t)sl < c->targets.size() && std::find(seen.begin(), seen.end(), sl) == seen.end()) {
+                seen.push_back(sl);
+                t_pts += (double)c->targets[(size_t)sl].n[0] + (double)c->targets[(size_t)sl].n[1];
+            }
+        }
+        if (total_src > 2000000000LL) return fail(c, LISREG_ERR_ARG, "batch_prepare: more than 2e9 source points in one batch");
+        c->mode_now = c->search_mode;
+        if (c->search_mode == 4)
+            c->mode_now = (t_pts > 0 && (double)total_src * (double)c->prm.bound >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
+        // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
+        c->lanes_q = (c->mode_now == 1 && c->lanes_per_query_auto && total_src > 0 && total_src <= 131072) ? 8 : 1;
+    }
+    const int qpb = kBlockQ / c->lanes_q;                  // queries per workgroup of the kQ-lane search (h_blocks_q)
+    c->h_blocks_q.clear();
     int flat = 0, bucket = 0;
     for (int i = 0; i < n_items; ++i) {
         const lisreg_item& in = items[i];
@@ -497,6 +541,9 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             c->h_segs.push_back(sg);
             for (int s = 0; s < sg.n; s += kBlockQ)
                 c->h_blocks.push_back(BlockDesc{ seg_id, s, std::min(kBlockQ, sg.n - s), i });
+            if (c->lanes_q > 1)
+                for (int s = 0; s < sg.n; s += qpb)
+                    c->h_blocks_q.push_back(BlockDesc{ seg_id, s, std::min(qpb, sg.n - s), i });
             flat += sg.n;
             bucket += sg.tnx * sg.tny;
         }
@@ -506,14 +553,18 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->n_segs = (int)c->h_segs.size();
     c->n_elems = flat;
     c->n_buckets = std::max(bucket, 1);
-    int rc = ensure_sort_scratch(c, (size_t)std::max(flat, 1), (size_t)c->n_buckets);
-    if (rc) return rc;
+    int rc = LISREG_OK;
     HIPCHK(c, c->blocks.ensure(sizeof(BlockDesc) * (size_t)std::max(c->n_blocks, 1)));
     HIPCHK(c, c->segs.ensure(sizeof(Segment) * (size_t)std::max(c->n_segs, 1)));
     HIPCHK(c, c->items.ensure(sizeof(ItemState) * (size_t)std::max(n_items, 1)));
     HIPCHK(c, c->sorted_all.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->order_all.ensure(sizeof(int) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->nn.ensure(sizeof(int) * 5 * (size_t)std::max(flat, 1)));
+    if (c->lanes_q > 1) {
+        HIPCHK(c, c->blocks_q.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_blocks_q.size(), 1)));
+        HIPCHK(c, c->coef.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
+        HIPCHK(c, c->coef_ok.ensure(sizeof(int) * (size_t)std::max(flat, 1)));
+    }
     if (c->dump_neighbors) {
         HIPCHK(c, c->dbg_nn.ensure(sizeof(int) * 6 * (size_t)std::max(flat, 1)));
         HIPCHK(c, hipMemsetAsync(c->dbg_nn.p, 0xff, sizeof(int) * 6 * (size_t)std::max(flat, 1), c->stream));
@@ -524,18 +575,6 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     HIPCHK(c, c->partials.ensure(sizeof(double) * kNumAcc * (size_t)std::max(c->n_blocks, 1)));
     HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * (size_t)std::max(n_items, 1)));
     if (c->trace_cap > 0) HIPCHK(c, c->trace.ensure(sizeof(float) * kTraceStride * (size_t)c->trace_cap * (size_t)std::max(n_items, 1)));
-    if (c->n_blocks) HIPCHK(c, hipMemcpyAsync(c->blocks.p, c->h_blocks.data(), sizeof(BlockDesc) * (size_t)c->n_blocks, hipMemcpyHostToDevice, c->stream));
-    if (c->n_segs) HIPCHK(c, hipMemcpyAsync(c->segs.p, c->h_segs.data(), sizeof(Segment) * (size_t)c->n_segs, hipMemcpyHostToDevice, c->stream));
-    if (n_items) HIPCHK(c, hipMemcpyAsync(c->items.p, c->h_items.data(), sizeof(ItemState) * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
-    // front-end of this batch.  The k-NN graph costs ~2 ns per target point and saves ~0.014 ns per query-iteration
-    // (MI355X, DESIGN.md §5): it pays for shared / long-lived targets (a batch of scans against one submap), not for
-    // one-shot targets (a loop-closure candidate pair, a single odometry frame).
-    c->mode_now = c->search_mode;
-    if (c->search_mode == 4) {
-        double q_iters = (double)flat * (double)c->prm.bound, t_pts = 0;
-        for (int slot : c->batch_slots) t_pts += (double)c->targets[(size_t)slot].n[0] + (double)c->targets[(size_t)slot].n[1];
-        c->mode_now = (t_pts > 0 && q_iters >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
-    }
     if (c->mode_now == 3)                        // the mode may have been chosen after the targets were set
         for (int slot : c->batch_slots)
             for (int k = 0; k < 2; ++k) {
@@ -563,23 +602,56 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             tflat += ts.n; tbucket += ts.n_cells;
         }
     c->t_elems = tflat; c->t_buckets = std::max(tbucket, 1);
-    rc = ensure_sort_scratch(c, (size_t)std::max(std::max(flat, tflat), 1), (size_t)std::max(c->n_buckets, c->t_buckets));
-    if (rc) return rc;
     HIPCHK(c, c->tseg_dev.ensure(sizeof(TargetSeg) * std::max<size_t>(c->h_tsegs.size(), 1)));
     HIPCHK(c, c->tblk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tblocks.size(), 1)));
-    if (!c->h_tsegs.empty()) HIPCHK(c, hipMemcpyAsync(c->tseg_dev.p, c->h_tsegs.data(), sizeof(TargetSeg) * c->h_tsegs.size(), hipMemcpyHostToDevice, c->stream));
-    if (!c->h_tblocks.empty()) HIPCHK(c, hipMemcpyAsync(c->tblk_dev.p, c->h_tblocks.data(), sizeof(BlockDesc) * c->h_tblocks.size(), hipMemcpyHostToDevice, c->stream));
-    // sort_sources: scan order and voxel-grid order are spatially coherent and beat a re-sort; an arbitrary order costs
-    // the cell walk its L1 locality (2x slower), so in auto mode a cheap probe decides once per prepared batch
-    c->sort_now = c->sort_sources == 1;
-    if (c->sort_sources == 2 && c->n_elems > 0) {
-        launch_count_jumps(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), 1.5f, c->done_dev.as<int>(), c->stream);
-        int jumps = 0;
-        HIPCHK(c, hipMemcpyAsync(&jumps, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->sort_now = (double)jumps > 0.25 * (double)c->n_elems;
+    // every table crosses PCIe from ONE pinned staging buffer: five asynchronous copies, no host synchronisation
+    // (pageable sources would make each hipMemcpyAsync a blocking staged copy — most of a single registration's latency)
+    {
+        struct Part { const void* src; size_t bytes; void* dst; };
+        const Part parts[6] = {
+            { c->h_blocks_q.data(), sizeof(BlockDesc) * c->h_blocks_q.size(), c->blocks_q.p },
+            { c->h_blocks.data(), sizeof(BlockDesc) * (size_t)c->n_blocks, c->blocks.p },
+            { c->h_segs.data(), sizeof(Segment) * (size_t)c->n_segs, c->segs.p },
+            { c->h_items.data(), sizeof(ItemState) * (size_t)n_items, c->items.p },
+            { c->h_tsegs.data(), sizeof(TargetSeg) * c->h_tsegs.size(), c->tseg_dev.p },
+            { c->h_tblocks.data(), sizeof(BlockDesc) * c->h_tblocks.size(), c->tblk_dev.p } };
+        size_t total = 0;
+        for (const Part& pt : parts) total += (pt.bytes + 63) & ~(size_t)63;
+        if (c->stage_done) HIPCHK(c, hipEventSynchronize(c->stage_done));      // the previous batch's copies have left the buffer
+        else HIPCHK(c, hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming));
+        if (total > c->stage_cap) {
+            if (c->stage_host) (void)hipHostFree(c->stage_host);
+            c->stage_host = nullptr; c->stage_cap = 0;
+            HIPCHK(c, hipHostMalloc((void**)&c->stage_host, total + total / 2 + 4096, hipHostMallocDefault));
+            c->stage_cap = total + total / 2 + 4096;
+        }
+        size_t off = 0;
+        for (const Part& pt : parts) {
+            if (pt.bytes) {
+                memcpy(c->stage_host + off, pt.src, pt.bytes);
+                HIPCHK(c, hipMemcpyAsync(pt.dst, c->stage_host + off, pt.bytes, hipMemcpyHostToDevice, c->stream));
+            }
+            off += (pt.bytes + 63) & ~(size_t)63;
+        }
+        HIPCHK(c, hipEventRecord(c->stage_done, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // sort_sources: scan order and voxel-grid order are spatially coherent and beat a re-sort; an arbitrary order costs
+    // the cell walk its L1 locality (2x slower), so in auto mode a cheap probe decides once per prepared batch.  Small batches
+    // (a single odometry frame) skip the probe and its host round trip: a sort could not pay for itself there.
+    c->sort_now = c->sort_sources == 1;
+    if (c->sort_sources == 2 && c->n_elems >= 65536) {
+        launch_count_jumps(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), 1.5f, c->done_dev.as<int>(), c->stream);
+        HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->sort_now = (double)*c->done_host > 0.25 * (double)c->n_elems;
+    }
+    // scratch of the bucket sorts: the target rebuild (if the batch does that) and the source sort (only if it will run)
+    {
+        const size_t se = (size_t)std::max(c->rebuild_targets_each_run ? tflat : 1, c->sort_now ? flat : 1);
+        const size_t sbk = (size_t)std::max(c->rebuild_targets_each_run ? c->t_buckets : 1, c->sort_now ? c->n_buckets : 1);
+        rc = ensure_sort_scratch(c, se, sbk);
+        if (rc) return rc;
+    }
     c->prepared = true;
     return LISREG_OK;
 }
@@ -606,7 +678,11 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
-    const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk > 0;
+    const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk != 0;
+    // how often the host looks at the "registrations finished" counter: a skipped launch of a big batch still dispatches tens of
+    // thousands of workgroups (check every 3 iterations), a skipped launch of a single frame costs ~2 us (check every 6: one
+    // round trip for the typical 3-6 iteration registration)
+    const int chunk = c->early_stop_chunk > 0 ? c->early_stop_chunk : (c->n_blocks <= 1024 ? 6 : 3);
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
         launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
@@ -615,12 +691,13 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                      c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack,
                      it >= c->wide_from && it <= (c->mode_now == 3 ? c->graph_wide_until : c->wide_until), c->graph_hops,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
-                     c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, st);
+                     c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, c->lanes_q,
+                     c->blocks_q.as<BlockDesc>(), (int)c->h_blocks_q.size(), c->coef.as<float4>(), c->coef_ok.as<int>(), st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
         prof_mark(c, -1);
-        if (can_stop && (it + 1) % c->early_stop_chunk == 0 && it + 1 < c->prm.bound) {
+        if (can_stop && (it + 1) % chunk == 0 && it + 1 < c->prm.bound) {
             HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (*c->done_host >= c->n_items) break;
@@ -642,9 +719,20 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
     if (!c) return LISREG_ERR_ARG;
     if (!c->prepared) return fail(c, LISREG_ERR_ARG, "batch_fetch: no prepared batch");
     HIPCHK(c, hipSetDevice(c->device));
-    c->h_results.resize((size_t)std::max(c->n_items, 1) * kResultSize);
-    if (c->n_items) HIPCHK(c, hipMemcpyAsync(c->h_results.data(), c->results.p, sizeof(float) * kResultSize * (size_t)c->n_items, hipMemcpyDeviceToHost, c->stream));
+    // results (and, for lisreg_align, the trace) land in pinned memory: asynchronous copies, ONE synchronisation
+    const size_t res_floats = (size_t)std::max(c->n_items, 1) * kResultSize;
+    const size_t trace_floats = c->fetch_trace_records > 0 ? (size_t)kTraceStride * (size_t)c->fetch_trace_records : 0;
+    if ((res_floats + trace_floats) * sizeof(float) > c->fetch_cap) {
+        if (c->fetch_host) (void)hipHostFree(c->fetch_host);
+        c->fetch_host = nullptr; c->fetch_cap = 0;
+        const size_t want = (res_floats + trace_floats) * sizeof(float) * 2 + 4096;
+        HIPCHK(c, hipHostMalloc((void**)&c->fetch_host, want, hipHostMallocDefault));
+        c->fetch_cap = want;
+    }
+    if (c->n_items) HIPCHK(c, hipMemcpyAsync(c->fetch_host, c->results.p, sizeof(float) * kResultSize * (size_t)c->n_items, hipMemcpyDeviceToHost, c->stream));
+    if (trace_floats && c->trace.p) HIPCHK(c, hipMemcpyAsync(c->fetch_host + res_floats, c->trace.p, sizeof(float) * trace_floats, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_results.assign(c->fetch_host, c->fetch_host + res_floats);
     if (!c->ev.empty()) prof_collect(c);          // events of every profiled run since the last fetch (profiling may be off again by now)
     for (int i = 0; i < c->n_items; ++i) {
         const float* r = &c->h_results[(size_t)i * kResultSize];
@@ -663,7 +751,14 @@ void* lisreg_batch_result_device(const lisreg_ctx* c) { return c ? c->results.p 
 int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
 {
     if (!c || !name) return LISREG_ERR_ARG;
-    if (!strcmp(name, "rebuild_targets_each_run")) { c->rebuild_targets_each_run = value != 0; return LISREG_OK; }
+    if (!strcmp(name, "rebuild_targets_each_run")) {
+        c->rebuild_targets_each_run = value != 0;
+        if (c->prepared && c->rebuild_targets_each_run) {      // the rebuild needs its sort scratch
+            int rc = ensure_sort_scratch(c, (size_t)std::max(c->t_elems, 1), (size_t)std::max(c->t_buckets, 1));
+            if (rc) return rc;
+        }
+        return LISREG_OK;
+    }
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
     if (!strcmp(name, "search_mode")) { c->search_mode = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
@@ -674,6 +769,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         if (c->count_searches) { HIPCHK(c, c->counters.ensure(64 * 8)); HIPCHK(c, hipMemset(c->counters.p, 0, 64 * 8)); }
         return LISREG_OK;
     }
+    if (!strcmp(name, "lanes_per_query")) { c->lanes_per_query_auto = value != 1; c->prepared = false; return LISREG_OK; }   // 1 forces one lane per query, anything else = auto
     if (!strcmp(name, "dump_neighbors")) { c->dump_neighbors = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cert_slack_mm")) { c->cert_slack = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
@@ -685,7 +781,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
 {
     if (!c || !name || !value) return LISREG_ERR_ARG;
     if (!strcmp(name, "search_mode")) { *value = c->search_mode; return LISREG_OK; }
-    if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }          // what the prepared batch runs (auto resolved)
+    if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }
+    if (!strcmp(name, "lanes_per_query")) { *value = c->lanes_q; return LISREG_OK; }          // what the prepared batch runs (auto resolved)
     if (!strcmp(name, "sort_sources")) { *value = c->sort_sources; return LISREG_OK; }
     if (!strcmp(name, "sorted_now")) { *value = c->sort_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
@@ -767,16 +864,16 @@ int lisreg_align(lisreg_ctx* c, const void* src_corner, int n_corner, const void
     c->trace_cap = std::max(bound, 1);
     lisreg_stats st;
     memset(&st, 0, sizeof st);
+    c->fetch_trace_records = c->trace_cap;             // the trace rides along with the result copy (one synchronisation)
     int rc = lisreg_align_batch(c, 1, &item, params, T, &st);
+    c->fetch_trace_records = 0;
     if (rc == LISREG_OK) {
         c->degenerate = st.degenerate;
         c->last_trace_n = std::min(bound, st.iters + 1);
         if (st.status == LISREG_NOT_ENOUGH_FEATURES) c->last_trace_n = 0;
         c->last_trace.assign((size_t)kTraceStride * (size_t)std::max(c->last_trace_n, 1), 0.f);
-        if (c->last_trace_n > 0) {
-            hipError_t e = hipMemcpy(c->last_trace.data(), c->trace.p, sizeof(float) * kTraceStride * (size_t)c->last_trace_n, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { c->trace_cap = saved_cap; return fail(c, LISREG_ERR_HIP, "align: trace copy failed"); }
-        }
+        if (c->last_trace_n > 0 && c->fetch_host)
+            memcpy(c->last_trace.data(), c->fetch_host + (size_t)kResultSize, sizeof(float) * kTraceStride * (size_t)c->last_trace_n);
         if (stats) *stats = st;
         rc = st.status;
     }

@@ -117,6 +117,7 @@ int lisreg_map_index_set(lisreg_ctx* c, int slot, const void* cloud, int n, int 
     }
     for (int d = 0; d < 6; ++d)
         if (n > 0 && !std::isfinite(bb[d])) return bad(c, "map_index_set: the cloud has infinite coordinates");
+    if (n > 0 && !(bb[0] <= bb[3] && bb[1] <= bb[4] && bb[2] <= bb[5])) return bad(c, "map_index_set: the cloud has no finite point (every coordinate is NaN)");
     make_grid(bb, n, &m.g, &m.n_cells);
     HIPCHK(c, m.cell_start.ensure(sizeof(int) * ((size_t)m.n_cells + 2)));
     HIPCHK(c, m.sorted.ensure(sizeof(float4) * (size_t)std::max(n, 1)));

@@ -345,6 +345,14 @@ __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
     return (int)floorf((v - origin) * inv_cell);
 }
 
+// w = 2.0 - LabelSorce[label] (subMapOptmizationNode.cpp:1671, :1795).  LabelSorce is a std::map read with operator[]: a label
+// that is not in config/label.yaml:214-234 yields 0, i.e. w = 2.0 — wtab carries that for 20..31, labels >= 32 get it here.
+__device__ __forceinline__ float label_weight(const DevParams& P, float payload)
+{
+    const unsigned lab = __float_as_uint(payload) & 0xffffu;
+    return lab < 32u ? P.wtab[lab] : 2.0f;
+}
+
 // Jacobian row + fixed-order fp64 reduction of the 28 normal-equation terms: wave halving butterfly -> LDS ->
 // one partial row per workgroup.  `ok` = this lane contributes a correspondence with coefficients cf.
 __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* sc,
@@ -352,12 +360,11 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
 
 // Residual model shared by the search front-ends that re-fit every iteration.
 // (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
-__device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
-                                                    const GridIndex& g, const float4 q4, float qx, float qy, float qz,
-                                                    const float* sc, const DevParams& P, int kind,
-                                                    double (*s_acc)[kNumAcc], double* __restrict__ out, int* dbg_ok = nullptr)
+__device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int i2, int i3, int i4, const GridIndex& g,
+                                                const float4 q4, float qx, float qy, float qz, const DevParams& P, int kind,
+                                                float cf[4])
 {
-    float cf[4] = { 0.f, 0.f, 0.f, 0.f };
+    cf[0] = cf[1] = cf[2] = cf[3] = 0.f;
     bool ok = false;
     const bool found = valid && (i4 >= 0);          // five neighbours with sqDist < tau  (:657 / :776)
     if (found) {
@@ -368,9 +375,19 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
         nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
         nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
         float w = 1.f;
-        if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
+        if (P.use_label) w = label_weight(P, q4.w);
         ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
     }
+    return ok;
+}
+
+__device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
+                                                    const GridIndex& g, const float4 q4, float qx, float qy, float qz,
+                                                    const float* sc, const DevParams& P, int kind,
+                                                    double (*s_acc)[kNumAcc], double* __restrict__ out, int* dbg_ok = nullptr)
+{
+    float cf[4];
+    const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
     row_and_reduce(ok, cf, q4, sc, P, s_acc, out);
 }
@@ -607,6 +624,7 @@ constexpr int kWalkCap = 8;
             sx0_ = cx0_; sx1_ = cx1_; sy0_ = cy0_; sy1_ = cy1_; \
         } \
         int ix_ = cx0_, iy_ = cy0_; \
+        int ccol_ = 0; (void)ccol_; \
         if (cz0_ > cz1_ || cy0_ > cy1_) ix_ = cx1_ + 1; \
         while (ix_ <= cx1_) { \
             int cnt_ = 0; \
@@ -616,7 +634,9 @@ constexpr int kWalkCap = 8;
                 const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
                 const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
                 const bool covered_ = (SKIP) && ix_ >= sx0_ && ix_ <= sx1_ && iy_ >= sy0_ && iy_ <= sy1_; \
-                if (!covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
+                /* kQ lanes per query: the columns of the pass are dealt round-robin (the box is the same for all of them) */ \
+                const bool mine_ = kQ == 1 || ((ccol_++) & (kQ - 1)) == sub_q; \
+                if (mine_ && !covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
                     const int base_ = (ix_ * g.ny + iy_) * g.nz; \
                     const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
                     if (js_ < je_) { s_runs[cnt_][tid] = make_int2(js_, je_); ++cnt_; } \
@@ -643,6 +663,17 @@ constexpr int kWalkCap = 8;
                 j_ += 4; \
             } \
         } } while (0)
+
+// kQ lanes per query (small batches, see k_assoc_walk): after a pass every lane holds the best five of ITS columns; a butterfly
+// over the kQ lanes leaves all of them with the best five of the union, so the next pass starts from one common bound (and one
+// common column box).  Entries travel as (distance, index) pairs; empty slots carry tau and never insert.
+#define LISREG_GROUP_MERGE() do { \
+        if (kQ > 1) { \
+            _Pragma("unroll") for (int d_ = 1; d_ < kQ; d_ <<= 1) { \
+                const float p0_ = __shfl_xor(b0, d_), p1_ = __shfl_xor(b1, d_), p2_ = __shfl_xor(b2, d_), p3_ = __shfl_xor(b3, d_), p4_ = __shfl_xor(b4, d_); \
+                const int   j0_ = __shfl_xor(i0, d_), j1_ = __shfl_xor(i1, d_), j2_ = __shfl_xor(i2, d_), j3_ = __shfl_xor(i3, d_), j4_ = __shfl_xor(i4, d_); \
+                LISREG_TRY(p0_, j0_); LISREG_TRY(p1_, j1_); LISREG_TRY(p2_, j2_); LISREG_TRY(p3_, j3_); LISREG_TRY(p4_, j4_); \
+            } } } while (0)
 
 // Graph scan (search_mode 3, GN iterations >= 1).  The target carries a k-NN graph (lisreg_index.hip: kGraphK nearest other
 // points per point, ascending, plus the coverage radius rho with "|x - a| < rho(a) => x is listed").  The query keeps ONE id
@@ -697,7 +728,11 @@ constexpr int kWalkCap = 8;
             a_ = i0; \
         } } while (0)
 
-template <bool kWide, bool kGraph>
+// kQ = lanes per query.  1 for big batches (every lane its own query: throughput).  A single odometry-sized registration is a
+// few hundred waves on a chip with 8192 wave slots, i.e. one wave per SIMD with nothing to hide its dependent cell -> candidate
+// loads behind: there kQ = 8 lanes share one query (columns dealt round-robin, five-best lists merged by butterfly), which cuts
+// the serial chain of the walk by the same factor.  The five neighbours, and everything computed from them, are identical.
+template <bool kWide, bool kGraph, int kQ>
 __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
@@ -705,7 +740,8 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
                                                         const float4* __restrict__ sorted_all,
                                                         int* __restrict__ nn_, int n_elems, float first_pass_r2,
                                                         int graph_hops, unsigned long long* __restrict__ counters,
-                                                        int* __restrict__ dbg_nn, double* __restrict__ partials)
+                                                        int* __restrict__ dbg_nn, float4* __restrict__ coef, int* __restrict__ coef_ok,
+                                                        double* __restrict__ partials)
 {
     __shared__ double s_acc[4][kNumAcc];
     __shared__ int2   s_runs[kWalkCap][kBlockQ];          // per-lane list of candidate runs for the flattened walk
@@ -719,7 +755,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const GridIndex g = grids[sg.target];
     double* out = partials + (size_t)blockIdx.x * kNumAcc;
     if (g.n < 5) {
-        if (tid < kNumAcc) out[tid] = 0.0;
+        if (kQ == 1 && tid < kNumAcc) out[tid] = 0.0;      // kQ > 1: k_rows_reduce owns the partial rows
         return;
     }
     const gptr_f4 pts = (gptr_f4)g.pts;
@@ -728,8 +764,9 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const gptr_i4w nn4 = (gptr_i4w)nn_;
     const float* M = it->M;            // trans2Affine3f(T), cached by the solve kernel (uniform -> SGPRs)
 
-    const bool valid = tid < bd.count;
-    const int qflat = sg.flat_base + bd.start + tid;
+    const int sub_q = tid & (kQ - 1); (void)sub_q;
+    const bool valid = tid / kQ < bd.count;
+    const int qflat = sg.flat_base + bd.start + tid / kQ;
     // sources: the tile-sorted copy if the batch was sorted, else the caller's own records (no flattening copy).  Both are
     // addressed with the batch-wide position qflat, so that one register serves the source and the seed arrays.
     const float4* qsrc = sorted_all ? sorted_all : (const float4*)((uintptr_t)sg.src - (uintptr_t)sg.flat_base * sizeof(float4));
@@ -814,24 +851,30 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
             // the columns outside that box which the bound still reaches.  A radius-limited first pass (450 ... 800 mm, with the
             // skip only when it settles five neighbours) measured 1-2 % slower than this.
             LISREG_WALK_LIST(3.0e38f, true, false);
+            LISREG_GROUP_MERGE();
             LISREG_WALK_LIST(3.0e38f, false, true);
         } else if (!seeded) {
             LISREG_WALK_LIST(first_pass_r2, false, false);      // tight first pass establishes a bound cheaply
+            LISREG_GROUP_MERGE();
             if (!(b4 <= first_pass_r2)) LISREG_WALK_LIST(3.0e38f, false, false);
         } else if (kWide) {
             LISREG_WALK_LIST(3.0e38f, true, false);             // centre first ...
+            LISREG_GROUP_MERGE();
             LISREG_WALK_LIST(3.0e38f, false, true);             // ... then whatever the tightened bound still reaches
         } else {
             LISREG_WALK_LIST(3.0e38f, false, false);
         }
+        LISREG_GROUP_MERGE();
         (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
         // while the set is unchanged was measured twice: keeping the five ids live costs an occupancy step (8 -> 7,
         // 4 % slower); a one-register XOR signature keeps 8 waves but gains nothing — the kernel is not HBM-bound.
-        { v4i w; w.x = i0; w.y = i1; w.z = i2; w.w = i3; nn4[qflat] = w; }
-        nn[4 * (size_t)n_elems + qflat] = i4;
+        if (kQ == 1 || sub_q == 0) {
+            { v4i w; w.x = i0; w.y = i1; w.z = i2; w.w = i3; nn4[qflat] = w; }
+            nn[4 * (size_t)n_elems + qflat] = i4;
+        }
     }
-    if (dbg_nn && valid) {               // "dump_neighbors" (tests): ORIGINAL indices of the five neighbours, -1 = none
+    if (dbg_nn && valid && (kQ == 1 || sub_q == 0)) {     // "dump_neighbors" (tests): ORIGINAL indices of the five neighbours, -1 = none
         const int ids[5] = { i0, i1, i2, i3, i4 };
 #pragma unroll
         for (int k = 0; k < 5; ++k) dbg_nn[(size_t)k * n_elems + qflat] = ids[k] >= 0 ? __float_as_int(pts[ids[k]].w) : -1;
@@ -839,8 +882,54 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
-    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out,
-                        dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
+    if (kQ == 1) {
+        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out,
+                            dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
+    } else {
+        // kQ lanes per query: the coefficients go to memory and k_rows_reduce builds the partial rows with the SAME 256-query
+        // workgroups and the SAME reduction tree as the kQ = 1 kernel, so the normal equations — hence every pose — are
+        // bit-identical whichever variant a batch runs with (a frame gives the same result alone and inside a big batch)
+        float cf[4];
+        const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, sg.kind, cf);
+        if (valid && sub_q == 0) {
+            coef[qflat] = make_float4(cf[0], cf[1], cf[2], cf[3]);
+            coef_ok[qflat] = ok ? 1 : 0;
+            if (dbg_nn) dbg_nn[5 * (size_t)n_elems + qflat] = ok ? 1 : 0;
+        }
+    }
+}
+
+// Second half of the kQ > 1 path: Jacobian rows and the partial normal equations from the stored coefficients, on the 256-query
+// block descriptors — identical code and order to the tail of k_assoc_walk<.., 1>.
+__global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __restrict__ blocks, const Segment* __restrict__ segs,
+                                                         const GridIndex* __restrict__ grids, const ItemState* __restrict__ items,
+                                                         const DevParams P, const float4* __restrict__ sorted_all,
+                                                         const float4* __restrict__ coef, const int* __restrict__ coef_ok,
+                                                         double* __restrict__ partials)
+{
+    __shared__ double s_acc[4][kNumAcc];
+    const int tid = threadIdx.x;
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ItemState* it = &items[bd.item];
+    if (it->done) return;
+    const Segment sg = segs[bd.seg];
+    double* out = partials + (size_t)blockIdx.x * kNumAcc;
+    if (grids[sg.target].n < 5) {
+        if (tid < kNumAcc) out[tid] = 0.0;
+        return;
+    }
+    const bool valid = tid < bd.count;
+    const int qflat = sg.flat_base + bd.start + tid;
+    const float4* qsrc = sorted_all ? sorted_all : (const float4*)((uintptr_t)sg.src - (uintptr_t)sg.flat_base * sizeof(float4));
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool ok = false;
+    if (valid) {
+        const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w);
+        c4 = coef[qflat];
+        ok = coef_ok[qflat] != 0;
+    }
+    const float cf[4] = { c4.x, c4.y, c4.z, c4.w };
+    row_and_reduce(ok, cf, q4, it->sc, P, s_acc, out);
 }
 
 // walk with a FIXED coverage radius: every cell that can hold a point with d^2 < cov2 is visited, so after the
@@ -1044,7 +1133,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
     bool ok = false;
     if (valid) {
         float w = 1.f;
-        if (P.use_label) w = P.wtab[__float_as_uint(q4.w) & 31u];
+        if (P.use_label) w = label_weight(P, q4.w);
         if (kind == 0) { if (m0.w == 1.f) ok = corner_eval(m0, m1, px, py, pz, w, P, cf); }
         else           { if (m0.w == m0.w) ok = surf_eval(m0, px, py, pz, w, P, cf); }
     }
@@ -1056,25 +1145,36 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, bool wide, int graph_hops, unsigned long long* counters, int* dbg_nn, hipStream_t st)
+                  float slack, bool wide, int graph_hops, unsigned long long* counters, int* dbg_nn, int lanes_q,
+                  const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, hipStream_t st)
 {
     if (n_blocks <= 0) return;
+    if (mode == 1 && lanes_q == 8) {
+        if (wide)
+            k_assoc_walk<true, false, 8><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                         first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+        else
+            k_assoc_walk<false, false, 8><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                          first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+        k_rows_reduce<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, coef, coef_ok, partials);
+        return;
+    }
     if (mode == 0)
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
     else if (mode == 1)
         if (wide)
-            k_assoc_walk<true, false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                    first_pass_r2, graph_hops, counters, dbg_nn, partials);
+            k_assoc_walk<true, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
         else
-            k_assoc_walk<false, false><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                     first_pass_r2, graph_hops, counters, dbg_nn, partials);
+            k_assoc_walk<false, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
     else if (mode == 3)
         if (wide)
-            k_assoc_walk<true, true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                   first_pass_r2, graph_hops, counters, dbg_nn, partials);
+            k_assoc_walk<true, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                      first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
         else
-            k_assoc_walk<false, true><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                    first_pass_r2, graph_hops, counters, dbg_nn, partials);
+            k_assoc_walk<false, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
     else
         k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
                                                      model1, n_elems, first_pass_r2, slack, counters, partials);

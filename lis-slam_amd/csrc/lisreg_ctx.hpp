@@ -76,7 +76,7 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
-    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
+    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
@@ -85,7 +85,13 @@ struct lisreg_ctx {
     lisreg::DevBuf lm_in, lm_tmp, lm_bbox;
     lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur;
     int*      done_host = nullptr;          // pinned
-    int       early_stop_chunk = 3;
+    unsigned char* stage_host = nullptr;    // pinned staging of the per-batch tables
+    size_t    stage_cap = 0;
+    hipEvent_t stage_done = nullptr;
+    float*    fetch_host = nullptr;         // pinned landing area of results (+ trace)
+    size_t    fetch_cap = 0;
+    int       early_stop_chunk = -1;        // iterations between host looks at the finished-counter; -1 auto, 0 never
+    int       fetch_trace_records = 0;      // lisreg_align: trace records copied out together with the results
     std::vector<lisreg::TargetSeg> h_tsegs;
     std::vector<lisreg::BlockDesc> h_tblocks;
     int       t_elems = 0, t_buckets = 0;
@@ -94,6 +100,8 @@ struct lisreg_ctx {
     int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 2 walk + motion certificate, 3 k-NN graph scan,
                                          // 4 auto: 3 when the prepared batch asks enough queries per target point to pay for the graph, else 1
     int       mode_now = 1;              // front-end of the prepared batch
+    int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
+    bool      lanes_per_query_auto = true;
     int       graph_min_ratio = 150;     // auto: query-iterations per target point from which the graph build pays (measured)
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
@@ -104,7 +112,8 @@ struct lisreg_ctx {
     float     first_pass_r = 0.45f;
     int       wide_from = 0;
     int       wide_until = 2;            // GN iterations wide_from..wide_until walk centre-first (no seeds, or seeds a pose step off)
-    std::vector<lisreg::BlockDesc> h_blocks;
+    std::vector<lisreg::BlockDesc> h_blocks;      // 256-query workgroups: partial rows, sorts, probes
+    std::vector<lisreg::BlockDesc> h_blocks_q;    // lanes_q > 1: kBlockQ / lanes_q queries per workgroup of the search kernel
     std::vector<lisreg::Segment>   h_segs;
     std::vector<lisreg::ItemState> h_items;
     std::vector<float>     h_results;

@@ -140,7 +140,10 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
                   float slack, bool wide /* mode 1: centre-first walk for the early iterations whose seeds are stale */,
                   int graph_hops /* mode 3: neighbour lists scanned per query before the cell walk takes over */,
                   unsigned long long* counters /* may be null */,
-                  int* dbg_nn /* may be null; modes 1 and 3: [5][n_elems] original indices of each query's neighbours */, hipStream_t st);
+                  int* dbg_nn /* may be null; modes 1 and 3: [6][n_elems] original indices of each query's neighbours + accept flag */,
+                  int lanes_q /* mode 1: 1, or 8 lanes per query (small batches) */,
+                  const BlockDesc* blocks_q, int n_blocks_q /* lanes_q = 8: descriptors of kBlockQ / 8 queries for the search */,
+                  float4* coef, int* coef_ok /* lanes_q = 8: per-query coefficients handed to k_rows_reduce */, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);

@@ -130,7 +130,9 @@ def label_weights(labels, p):
     if not p["use_label_weight"]:
         return np.ones(len(labels), f32)
     score = np.asarray(p["label_score"], f32)
-    return (2.0 - score[labels & 31].astype(np.float64)).astype(f32)
+    lab = np.asarray(labels).astype(np.int64)
+    sc = np.where(lab < 32, score[np.minimum(lab, 31)], 0.0)          # std::map::operator[] on a missing label -> 0 -> w = 2
+    return (2.0 - sc.astype(np.float64)).astype(f32)
 
 
 def align(tgt_c, tgt_s, src_c, src_s, lab_c, lab_s, T_init, p, degenerate_in=0):

@@ -599,7 +599,9 @@ static void unpack_cloud(const void* cloud, int n, int stride, int fmt, float* x
 static float label_weight(const lisreg_params* p, unsigned short label)
 {
     if (!p->use_label_weight) return 1.f;
-    return (float)(2.0 - (double)p->label_score[label & 31]);   /* subMapOptmizationNode.cpp:1671 */
+    /* subMapOptmizationNode.cpp:1671: LabelSorce is a std::map<uint16_t,float> read with operator[] — a label outside
+     * config/label.yaml:214-234 default-constructs 0.f, so its weight is 2.0 (label_score[20..31] are 0 by default) */
+    return label < 32 ? (float)(2.0 - (double)p->label_score[label]) : 2.0f;
 }
 
 typedef struct {

@@ -89,7 +89,7 @@ def default_params(variant: int = 1) -> Params:
     p.line_ratio, p.plane_tol, p.accept_s = 3.0, 0.2, 0.1
     p.use_label_weight = 0 if variant == 1 else 1
     for i in range(32):
-        p.label_score[i] = LABEL_SCORE[i] if i < 20 else 1.0
+        p.label_score[i] = LABEL_SCORE[i] if i < 20 else 0.0      # unknown label: std::map::operator[] yields 0 -> w = 2
     p.emulate_matp_shadow = 1
     p.skip_empty_target = 1 if variant == 3 else 0
     p.use_imu_blend = 0 if variant == 3 else 1

@@ -202,3 +202,48 @@ def test_random_sweep_matches_oracle(oracle, gpu_ctx, seed):
         assert r <= TOL_ROT and t <= TOL_TRANS, (seed, i, r, t)
     rot, tr = pose_err(Tg, To)
     assert rot <= TOL_ROT and tr <= TOL_TRANS, (seed, rot, tr, sg, so)
+
+
+def test_unknown_labels_weigh_two(oracle, gpu_ctx):
+    """A label outside config/label.yaml:214-234 (RangeNet classes 0..19) reads 0 from the reference's std::map, i.e. the
+    correspondence weight is 2.0 - 0 (subMapOptmizationNode.cpp:1671); labels 25 and 40 (a raw SemanticKITTI id) must be
+    weighted like that on both sides — not aliased onto another class."""
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=1500, labelled=True)
+    src_s = case["src_surf"].copy()
+    src_s["label"][::3] = 25
+    src_s["label"][1::7] = 40
+    p_o = oracle.default_params(2)
+    p_g = copy_params(p_o, lisreg.Params)
+    assert p_g.label_score[25] == 0.0 and lisreg.default_params(2).label_score[25] == 0.0
+    To, so, tro = oracle.align(case["tgt_corner"], case["tgt_surf"], case["src_corner"], src_s, case["T_init"], p_o)
+    gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+    Tg, sg, trg = gpu_ctx.align(case["src_corner"], src_s, case["T_init"], p_g)
+    assert sg["iters"] == so["iters"] and sg["status"] == so["status"] == 0
+    assert max(pose_err(Tg, To)) <= 1e-3
+    scale = np.abs(tro[0, 1:37]).max()
+    assert np.abs(trg[0, 1:37] - tro[0, 1:37]).max() <= 2e-3 * scale
+    # and the weights matter: the same run with every label known differs
+    T2, _, tr2 = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p_g)
+    assert not np.array_equal(tr2[0, 1:37], trg[0, 1:37])
+
+
+def test_lanes_per_query_variants_are_bit_identical(gpu_ctx):
+    """Small batches run the search with eight lanes per query (and build the rows in a second kernel), big ones with one:
+    poses, traces and stats must not depend on it, so that a frame registers identically alone and inside a large batch."""
+    import lisreg
+    from lisreg import synth
+    for variant, labelled, seed in ((1, False, 1600), (2, True, 1601)):
+        case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=seed, labelled=labelled)
+        p = lisreg.default_params(variant)
+        out = []
+        for lanes in (0, 1):                                   # 0 = auto (eight lanes for a batch this small), 1 = forced single
+            c = lisreg.Context(0)
+            c.set_option("lanes_per_query", lanes)
+            c.set_target(case["tgt_corner"], case["tgt_surf"])
+            out.append(c.align(case["src_corner"], case["src_surf"], case["T_init"], p))
+            assert c.get_option("lanes_per_query") == (8 if lanes == 0 else 1)
+            c.close()
+        (Ta, sa, tra), (Tb, sb, trb) = out
+        assert sa == sb and np.array_equal(Ta, Tb) and np.array_equal(tra, trb)
