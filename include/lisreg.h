@@ -130,9 +130,12 @@ int  lisreg_default_params(int variant, lisreg_params* p);
 
 /* ---- target (local map / submap) ------------------------------------------------------------------------- */
 /* Replaces kdtreeCornerFromMap->setInputCloud / kdtreeSurfFromMap->setInputCloud
- * (odomEstimationNode.cpp:602-603 | subMapOptmizationNode.cpp:1516-1517 | :4496-4497): uploads the two target
- * clouds and builds the device search index.  The index persists until the next call for that slot, so a
- * target shared by many registrations is built once.  Slot 0 is what lisreg_align uses. */
+ * (odomEstimationNode.cpp:602-603 | subMapOptmizationNode.cpp:1516-1517 | :4496-4497): builds the device search index
+ * of the two target clouds.  Host clouds are copied to the device; LISREG_FMT_DEVICE clouds are REFERENCED, not copied —
+ * the caller's records must stay valid and unchanged until the slot is set again or the context is destroyed (with the
+ * option "rebuild_targets_each_run" every lisreg_batch_run re-reads them).  The index persists until the next call for
+ * that slot, so a target shared by many registrations is built once.  Slot 0 is what lisreg_align uses.  A cloud with an
+ * infinite coordinate, or with no finite point at all, is refused (LISREG_ERR_ARG); NaN points are simply never neighbours. */
 int  lisreg_set_target(lisreg_ctx* ctx, const void* corner, int n_corner,
                        const void* surf, int n_surf, int stride_bytes, int fmt);
 int  lisreg_set_target_slot(lisreg_ctx* ctx, int slot, const void* corner, int n_corner,
@@ -164,9 +167,12 @@ int  lisreg_align_batch(lisreg_ctx* ctx, int n_items, const lisreg_item* items,
 
 /* Asynchronous form for device-resident batches (all items LISREG_FMT_DEVICE): enqueue on the context's
  * stream with poses/stats left on the device; lisreg_batch_fetch synchronises and copies them out.
- * `prepare` does all per-batch allocation and item-table upload; `run` only launches kernels (no host sync,
- * graph-replayed), so it can be timed with events on lisreg_get_stream(). T_init is copied at prepare time
- * and re-applied on the device at the start of every run. */
+ * `prepare` does all per-batch allocation and the item-table upload (one pinned staging buffer, asynchronous copies);
+ * `run` only launches kernels — optional index rebuild, then `bound` x {correspondence kernel, solve kernel}, finalize:
+ * eager launches, no host synchronisation, registrations that have converged make their workgroups exit at once — so
+ * it can be timed with events on lisreg_get_stream().  T_init is copied at prepare time and re-applied on the device at
+ * the start of every run.  (The synchronous entry points lisreg_align / lisreg_align_batch additionally read a 4-byte
+ * finished-counter every few iterations and stop launching once every item is done.) */
 int  lisreg_batch_prepare(lisreg_ctx* ctx, int n_items, const lisreg_item* items,
                           const lisreg_params* params, const float* T_init);
 int  lisreg_batch_run(lisreg_ctx* ctx);

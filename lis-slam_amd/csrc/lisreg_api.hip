@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -795,6 +796,7 @@ int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, con
 {
     if (!c) return LISREG_ERR_ARG;
     if (n_items < 0 || (n_items > 0 && (!items || !T)) || !params) return fail(c, LISREG_ERR_ARG, "align_batch: bad arguments");
+    const auto t_in = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     // stage host clouds into one device buffer of 16-B records; device items pass through
     size_t total = 0;
@@ -839,11 +841,22 @@ int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, con
         d.fmt = LISREG_FMT_DEVICE;
     }
     HIPCHK(c, hipGetLastError());
+    static const bool host_prof = getenv("LISREG_HOST_PROF") != nullptr;      // where a synchronous call spends its host time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
     int rc = lisreg_batch_prepare(c, n_items, dev_items.data(), params, T);
     if (rc) return rc;
+    const auto t1 = now();
     rc = run_impl(c, true);
     if (rc) return rc;
-    return lisreg_batch_fetch(c, T, stats);
+    const auto t2 = now();
+    rc = lisreg_batch_fetch(c, T, stats);
+    if (host_prof) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[lisreg host] upload %.1f us, prepare %.1f us, enqueue %.1f us, fetch (incl. GPU wait) %.1f us\n",
+                us(t_in, t0), us(t0, t1), us(t1, t2), us(t2, now()));
+    }
+    return rc;
 }
 
 int lisreg_align(lisreg_ctx* c, const void* src_corner, int n_corner, const void* src_surf, int n_surf, int stride,

@@ -1,9 +1,12 @@
 // host_smoke.cpp — C++ caller of liblisreg through the reference-shaped host mirror (plain g++, no HIP headers).
 // With a GPU: registers a small synthetic scene (two walls + floor + poles) and checks the pose moved toward truth.
 // Without a GPU: verifies the loud failure path (no CPU fallback) and exits 0.
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <vector>
 
 #include "lis_slam_registration.hpp"
 
@@ -57,6 +60,18 @@ int main()
     const float* T = reg.transformTobeMapped;
     std::printf("rc=%d iterCount=%d deltaR=%g deltaT=%g isDegenerate=%d nSel=%d T=[%g %g %g %g %g %g]\n", rc, reg.iterCount, reg.deltaR,
                 reg.deltaT, (int)reg.isDegenerate, reg.laserCloudSelNum, T[0], T[1], T[2], T[3], T[4], T[5]);
+    {   // host-inclusive latency of one registration through the mirror (pageable host clouds in, pose out), same problem re-run
+        std::vector<double> us;
+        for (int rep = 0; rep < 40; ++rep) {
+            for (int k = 0; k < 6; ++k) reg.transformTobeMapped[k] = 0.f;
+            const auto t0 = std::chrono::steady_clock::now();
+            reg.scan2SubMapOptimization(corner, surf, info);
+            us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        std::sort(us.begin(), us.end());
+        std::printf("latency: scan2SubMapOptimization (%zu + %zu source points vs %zu + %zu, %d iterations): median %.1f us, min %.1f us\n",
+                    corner.size(), surf.size(), mapCorner.size(), mapSurf.size(), reg.iterCount + 1, us[us.size() / 2], us[0]);
+    }
     bool ok = rc == LISREG_OK && std::fabs(T[2] - yaw) < 5e-3f && std::fabs(T[3] - tx) < 2e-2f && std::fabs(T[4] - ty) < 2e-2f && std::fabs(T[5] - tz) < 2e-2f;
     // §8 f-3: crop the map to the padded intersection with the scan's box, then drop scan points that sit on the map
     // (subMapOptmizationNode.cpp:1392-1405, subMap.h:889-899)
@@ -99,6 +114,22 @@ int main()
     SubMapManager<PointType>::get_bound_cpt(bMap, cMap);
     SubMapManager<PointType>::transform_bbx(bMap, cMap, bMoved, cMoved, result_pose);       // rows 0..2 of the 4x4 = [R|t]
     ok = ok && std::fabs((bMoved.max_x - bMoved.min_x) - (bMap.max_x - bMap.min_x)) < 1e-9;
+    // §8 f-3 composite: the device-resident sliding local map (insert_local_map / extractSlidingCloud), labelled clouds
+    {
+        Scan2SubMapRegistration<PointXYZIL> reg2(Variant::SubMap);
+        LocalMap<PointXYZIL> localMap(reg2.handle(), 0);
+        PointCloud<PointXYZIL> cls[5];                       // dynamic, pole, ground, building, outlier
+        for (size_t i = 0; i < mapSurf.size(); ++i) { PointXYZIL p{}; p.x = mapSurf.points[i].x; p.y = mapSurf.points[i].y; p.z = mapSurf.points[i].z; p.label = p.z < 0.05f ? 9 : 13; cls[p.label == 9 ? 2 : 3].push_back(p); }
+        for (size_t i = 0; i < mapCorner.size(); ++i) { PointXYZIL p{}; p.x = mapCorner.points[i].x; p.y = mapCorner.points[i].y; p.z = mapCorner.points[i].z; p.label = 18; cls[1].push_back(p); }
+        const float pose0[6] = { 0, 0, 0, 0, 0, 0 };
+        lisreg_localmap_info inf = localMap.insert_local_map(cls, pose0);
+        const float cur[6] = { 0, 0, 0.01f, 0.1f, 0, 0 };
+        lisreg_localmap_info ex = localMap.extractSlidingCloud(cur, 0);           // leaves the registration target in slot 0
+        std::printf("LocalMap: inserted %d points, bound x [%g, %g]; extract -> corner %d, surf %d\n", inf.feature_point_num, inf.bound[0],
+                    inf.bound[3], ex.n_target_corner, ex.n_target_surf);
+        ok = ok && inf.feature_point_num == (int)(mapSurf.size() + mapCorner.size()) && ex.n_target_corner > 0 && ex.n_target_surf > 0 &&
+             ex.n_target_surf <= (int)mapSurf.size();
+    }
     std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
     return ok ? 0 : 1;
 }

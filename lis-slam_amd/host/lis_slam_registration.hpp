@@ -373,4 +373,47 @@ private:
     lisreg_icpgn_result res_{};
 };
 
+// ---- SURVEY.md §8 f-3 composite: the sliding local map kept in HBM -------------------------------------------------------
+// localMap_t + SubMapManager::insert_local_map (src/include/subMap.h:979-1059) + SubMapOptmizationNode::extractSlidingCloud
+// (src/node/subMapOptmizationNode.cpp:1369-1432).  Class order of the arrays: dynamic, pole, ground, building, outlier
+// (append_feature, subMap.h:742-753).  The makeSubMapThread loop (:597-755) becomes
+//     localMap.extractSlidingCloud(transformTobeSubMapped);  reg.scan2SubMapOptimization(...);  localMap.insert_local_map(cls, pose);
+template <class PointT = PointXYZIL>
+class LocalMap {
+public:
+    lisreg_localmap_params params;          // local_map_radius etc. of makeSubMapThread (:603-612) that the path actually reads
+    LocalMap(lisreg_ctx* ctx, int map_id = 0) : ctx_(ctx), id_(map_id) {
+        lisreg_localmap_default_params(&params);
+        int rc = lisreg_localmap_reset(ctx_, id_);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+    }
+    // this->insert_local_map(localMap, currentKeyFrame, ...): the key frame's un-downsampled class clouds + its optimized_pose
+    lisreg_localmap_info insert_local_map(const PointCloud<PointT> cls[5], const float optimized_pose[6]) {
+        const void* ptr[5]; int n[5];
+        for (int k = 0; k < 5; ++k) { ptr[k] = cls[k].points.data(); n[k] = (int)cls[k].size(); }
+        lisreg_localmap_info info{};
+        int rc = lisreg_localmap_insert(ctx_, id_, ptr, n, (int)sizeof(PointT), fmt(), optimized_pose, &params, &info);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        return info;
+    }
+    // extractSlidingCloud(currentKeyFrame, cur_pose) + both kd-tree setInputCloud calls: the target lands in `target_slot`
+    lisreg_localmap_info extractSlidingCloud(const float cur_pose[6], int target_slot = 0) {
+        lisreg_localmap_info info{};
+        int rc = lisreg_localmap_extract(ctx_, id_, cur_pose, &params, target_slot, &info);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        return info;
+    }
+private:
+    static constexpr int fmt() { return std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI; }
+    lisreg_ctx* ctx_;
+    int id_;
+};
+
+// updateInitialGuess with neither IMU nor odometry (odomEstimationNode.cpp:351-392): constant-velocity pose guess
+inline void updateInitialGuess(const float lastTransformTobeMapped[6], float transformTobeMapped[6]) {
+    float g[6];
+    lisreg_predict_pose(lastTransformTobeMapped, transformTobeMapped, g);
+    for (int k = 0; k < 6; ++k) transformTobeMapped[k] = g[k];
+}
+
 }  // namespace lis_slam
