@@ -685,48 +685,87 @@ constexpr int kWalkCap = 8;
 // and rescan; still none after `graph_hops` lists -> the cell walk, seeded with what was found.  Same sets as the walk, at
 // ~10 candidate tests per query (wave maximum ~21) instead of ~27 plus ~4 column probes, with no per-column address work.
 
+// insertion without the duplicate test: inside ONE neighbour list (plus its anchor) every id occurs once
+#define LISREG_TRY_ND(d2_, j_) do { if ((d2_) < b4) LISREG_INSERT((d2_), (j_)); } while (0)
+
+// one group of four list entries: ids IDV (padded with -1), list distance LMAX of the group's last entry (squared, from the
+// build).  Candidates are tested against the running five best; the scan stops once the list has moved past c5 + d_a.
+#define LISREG_GRAPH_GROUP(IDV, TRYM) do { \
+        const int k0_ = (IDV).x, k1_ = (IDV).y < 0 ? a_ : (IDV).y, k2_ = (IDV).z < 0 ? a_ : (IDV).z, k3_ = (IDV).w < 0 ? a_ : (IDV).w; \
+        const v3f c0_ = *(gptr_f3)(pts + k0_), c1_ = *(gptr_f3)(pts + k1_), c2_ = *(gptr_f3)(pts + k2_), c3_ = *(gptr_f3)(pts + k3_); \
+        const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
+        const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
+        const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
+        const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
+        const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_; \
+        const float e1_ = (IDV).y < 0 ? 3.0e38f : bx_ * bx_ + by_ * by_ + bz_ * bz_; \
+        const float e2_ = (IDV).z < 0 ? 3.0e38f : gx_ * gx_ + gy_ * gy_ + gz_ * gz_; \
+        const float e3_ = (IDV).w < 0 ? 3.0e38f : hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
+        /* list distance of the group's entries (the list ascends; padded entries alias the anchor: 0) */ \
+        const float px_ = ap_.x - c0_.x, py_ = ap_.y - c0_.y, pz_ = ap_.z - c0_.z; \
+        const float rx_ = ap_.x - c1_.x, ry_ = ap_.y - c1_.y, rz_ = ap_.z - c1_.z; \
+        const float sx_ = ap_.x - c2_.x, sy_ = ap_.y - c2_.y, sz_ = ap_.z - c2_.z; \
+        const float tx_ = ap_.x - c3_.x, ty_ = ap_.y - c3_.y, tz_ = ap_.z - c3_.z; \
+        const float l0_ = px_ * px_ + py_ * py_ + pz_ * pz_, l1_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_; \
+        const float l2_ = sx_ * sx_ + sy_ * sy_ + sz_ * sz_, l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
+        if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
+            TRYM(e0_, k0_); TRYM(e1_, k1_); TRYM(e2_, k2_); TRYM(e3_, k3_); \
+            const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
+        } \
+        if (fmaxf(fmaxf(l0_, l1_), fmaxf(l2_, l3_)) > thr2_) stop_ = true; } while (0)
+
+// The first two id groups, the row's (rho^2, count) and the anchor point are fetched together; anchor + first four candidates
+// seed the five-best list through a 9-comparator network; later groups are streamed.
 #define LISREG_GRAPH_SCAN() do { \
         int a_ = anchor; \
         _Pragma("unroll 1") for (int hop_ = 0; hop_ < graph_hops; ++hop_) { \
-            const v4f ap_ = pts[a_]; \
+            const gptr_i4 R4_ = (gptr_i4)(nbr + (size_t)a_ * kGraphK); \
+            const v4i id0_ = R4_[0], id1_ = R4_[1]; \
             const v2f am_ = meta[a_]; \
+            const v4f ap_ = pts[a_]; \
+            const float rho2_ = am_.x; \
+            const int cnt_ = __float_as_int(am_.y); \
             const float ux_ = qx - ap_.x, uy_ = qy - ap_.y, uz_ = qz - ap_.z; \
             const float da2_ = ux_ * ux_ + uy_ * uy_ + uz_ * uz_; \
-            LISREG_TRY(da2_, a_); \
             const float da_ = __builtin_amdgcn_sqrtf(da2_) * 1.0001f + kEps; \
-            const int cnt_ = __float_as_int(am_.y); \
-            const gptr_i4 L_ = (gptr_i4)(nbr + (size_t)a_ * kGraphK); \
             bool stop_ = false; \
-            float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; \
-            float thr2_ = thr_ * thr_; \
-            _Pragma("unroll 1") for (int j_ = 0; j_ < cnt_; j_ += 4) { \
-                const v4i id_ = L_[j_ >> 2]; \
-                const int k0_ = id_.x, k1_ = id_.y < 0 ? a_ : id_.y, k2_ = id_.z < 0 ? a_ : id_.z, k3_ = id_.w < 0 ? a_ : id_.w; \
-                const v3f c0_ = *(gptr_f3)(pts + k0_), c1_ = *(gptr_f3)(pts + k1_), c2_ = *(gptr_f3)(pts + k2_), c3_ = *(gptr_f3)(pts + k3_); \
-                const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
-                const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
-                const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
-                const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
-                const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
-                const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
-                /* list distance of the LAST valid entry of the group (the list ascends; padded entries alias the anchor: 0) */ \
-                const float px_ = ap_.x - c0_.x, py_ = ap_.y - c0_.y, pz_ = ap_.z - c0_.z; \
-                const float rx_ = ap_.x - c1_.x, ry_ = ap_.y - c1_.y, rz_ = ap_.z - c1_.z; \
-                const float sx_ = ap_.x - c2_.x, sy_ = ap_.y - c2_.y, sz_ = ap_.z - c2_.z; \
-                const float tx_ = ap_.x - c3_.x, ty_ = ap_.y - c3_.y, tz_ = ap_.z - c3_.z; \
-                const float l0_ = px_ * px_ + py_ * py_ + pz_ * pz_, l1_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_; \
-                const float l2_ = sx_ * sx_ + sy_ * sy_ + sz_ * sz_, l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
-                if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
-                    LISREG_TRY(e0_, k0_); LISREG_TRY(e1_, k1_); LISREG_TRY(e2_, k2_); LISREG_TRY(e3_, k3_); \
-                    thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
-                } \
-                if (fmaxf(fmaxf(l0_, l1_), fmaxf(l2_, l3_)) > thr2_) { stop_ = true; break; } \
+            float thr2_; \
+            if (hop_ == 0 && cnt_ >= 4) { \
+                /* anchor + the first four entries: all distinct, nothing in the list yet -> sort the five and take what is inside tau */ \
+                const v3f c0_ = *(gptr_f3)(pts + id0_.x), c1_ = *(gptr_f3)(pts + id0_.y), c2_ = *(gptr_f3)(pts + id0_.z), c3_ = *(gptr_f3)(pts + id0_.w); \
+                float sd[5]; int sid[5] = { a_, id0_.x, id0_.y, id0_.z, id0_.w }; \
+                sd[0] = da2_; \
+                { const float x_ = qx - c0_.x, y_ = qy - c0_.y, z_ = qz - c0_.z; sd[1] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - c1_.x, y_ = qy - c1_.y, z_ = qz - c1_.z; sd[2] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - c2_.x, y_ = qy - c2_.y, z_ = qz - c2_.z; sd[3] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - c3_.x, y_ = qy - c3_.y, z_ = qz - c3_.z; sd[4] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                const float lx_ = ap_.x - c3_.x, ly_ = ap_.y - c3_.y, lz_ = ap_.z - c3_.z; \
+                const float l3_ = lx_ * lx_ + ly_ * ly_ + lz_ * lz_; \
+                LISREG_CE5(0, 1); LISREG_CE5(3, 4); LISREG_CE5(2, 4); LISREG_CE5(2, 3); LISREG_CE5(0, 3); \
+                LISREG_CE5(0, 2); LISREG_CE5(1, 4); LISREG_CE5(1, 3); LISREG_CE5(1, 2); \
+                b0 = fminf(sd[0], P.tau); b1 = fminf(sd[1], P.tau); b2 = fminf(sd[2], P.tau); b3 = fminf(sd[3], P.tau); b4 = fminf(sd[4], P.tau); \
+                i0 = sd[0] < P.tau ? sid[0] : -1; i1 = sd[1] < P.tau ? sid[1] : -1; i2 = sd[2] < P.tau ? sid[2] : -1; \
+                i3 = sd[3] < P.tau ? sid[3] : -1; i4 = sd[4] < P.tau ? sid[4] : -1; \
+                const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
+                if (l3_ > thr2_) stop_ = true; \
+            } else { \
+                LISREG_TRY(da2_, a_); \
+                const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
+                if (cnt_ > 0) LISREG_GRAPH_GROUP(id0_, LISREG_TRY); \
             } \
-            if (!stop_) stop_ = am_.x > thr2_;                 /* list exhausted: the coverage radius decides */ \
+            if (!stop_ && cnt_ > 4) { if (hop_ == 0) LISREG_GRAPH_GROUP(id1_, LISREG_TRY_ND); else LISREG_GRAPH_GROUP(id1_, LISREG_TRY); } \
+            _Pragma("unroll 1") for (int g_ = 2; !stop_ && 4 * g_ < cnt_; ++g_) { \
+                const v4i idg_ = R4_[g_]; \
+                if (hop_ == 0) LISREG_GRAPH_GROUP(idg_, LISREG_TRY_ND); else LISREG_GRAPH_GROUP(idg_, LISREG_TRY); \
+            } \
+            if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
             if (stop_) { certified = true; break; } \
             if (i0 == a_ || i0 < 0) break;                     /* nowhere better to hop to */ \
             a_ = i0; \
         } } while (0)
+
+#define LISREG_CE5(a, b) do { const bool sw_ = sd[b] < sd[a]; const float ta_ = sd[a]; const int ia_ = sid[a]; \
+                              sd[a] = sw_ ? sd[b] : ta_; sd[b] = sw_ ? ta_ : sd[b]; sid[a] = sw_ ? sid[b] : ia_; sid[b] = sw_ ? ia_ : sid[b]; } while (0)
 
 // kQ = lanes per query.  1 for big batches (every lane its own query: throughput).  A single odometry-sized registration is a
 // few hundred waves on a chip with 8192 wave slots, i.e. one wave per SIMD with nothing to hide its dependent cell -> candidate
