@@ -390,19 +390,56 @@ __global__ __launch_bounds__(256) void k_tseg_cell_starts(const TargetSeg* __res
 // lists with rho = the block's inscribed radius (>= 2 cells).  No divergence, one coalesced 128-byte store per point.
 constexpr int kGraphPPW = 16;            // points per wave (sequential)
 
-__device__ __forceinline__ void cmpx(float& k, int& i, int j, bool take_min)
+// value of lane (l ^ M).  The sort below is bound by cross-lane traffic, and ds_bpermute (the LDS crossbar, 4 LDS cycles per
+// wave-instruction) was 40 % of the build's wave time; most masks of the network have a pure-VALU form on gfx950: quad
+// permutes (1, 2, 3), row mirrors (7, 15), a row rotation (8) — DPP moves.  The masks 4, 16, 31, 32, 63 stay on the
+// LDS crossbar: moving them to VALU forms too (row_ror pairs, V_PERMLANE16/32_SWAP) measured slower (0.29 vs 0.256 ms per 200 k
+// points) — the two pipes are balanced as it is.
+template <int M> __device__ __forceinline__ int lane_xor(int v)
 {
-    const float pk = __shfl_xor(k, j);
-    const int   pi = __shfl_xor(i, j);
-    const bool lt = pk < k || (pk == k && pi < i);        // partner orders before me
-    const bool sw = (lt == take_min);
-    k = sw ? pk : k; i = sw ? pi : i;
+    if constexpr (M == 1)       return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    else if constexpr (M == 2)  return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 3)  return __builtin_amdgcn_mov_dpp(v, 0x1B, 0xF, 0xF, true);     // quad_perm [3,2,1,0]
+    else if constexpr (M == 7)  return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    else if constexpr (M == 15) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);    // row_mirror
+    else if constexpr (M == 8)  return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);    // row_ror:8
+    else return __shfl_xor(v, M);
+}
+
+// compare-exchange of 64-bit keys (squared distance bits << 32 | id: positive floats order like unsigned integers, the id breaks
+// ties) with the lane M away; lanes whose bit `LowBit` is clear keep the smaller key.  Every stage of the network below has
+// this one direction, so a stage is two cross-lane moves, one 64-bit compare and two selects.
+template <int M, int LowBit> __device__ __forceinline__ unsigned long long cmpx64(unsigned long long k, int lane)
+{
+    const unsigned lo = (unsigned)lane_xor<M>((int)(unsigned)k), hi = (unsigned)lane_xor<M>((int)(unsigned)(k >> 32));
+    const unsigned long long pk = ((unsigned long long)hi << 32) | lo;
+    const bool take_min = (lane & LowBit) == 0;
+    return ((pk < k) == take_min) ? pk : k;
+}
+
+template <int H> __device__ __forceinline__ unsigned long long half_cleaners(unsigned long long k, int lane)
+{
+    if constexpr (H > 0) { k = cmpx64<H, H>(k, lane); return half_cleaners<(H >> 1)>(k, lane); }
+    else return k;
+}
+// merge sorted blocks of H into sorted blocks of 2H, in the "mirror" form: the first stage pairs lane i with the lane mirrored
+// inside the block, the rest are half-cleaners — the lower lane always keeps the minimum
+template <int H> __device__ __forceinline__ unsigned long long merge_blocks(unsigned long long k, int lane)
+{
+    k = cmpx64<2 * H - 1, H>(k, lane);
+    return half_cleaners<(H >> 1)>(k, lane);
+}
+// ascending sort of one key per lane across the wave
+__device__ __forceinline__ unsigned long long sort64(unsigned long long k, int lane)
+{
+    k = merge_blocks<1>(k, lane); k = merge_blocks<2>(k, lane); k = merge_blocks<4>(k, lane);
+    k = merge_blocks<8>(k, lane); k = merge_blocks<16>(k, lane); k = merge_blocks<32>(k, lane);
+    return k;
 }
 
 __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int (*s_off)[32], int (*s_js)[32])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr float kInf = __builtin_inff();
     constexpr float kEps = 1e-3f;
     const float4 q = g.pts[s];
     const int hx = cell_coord(q.x, g.ox, g.inv_cell, g.nx), hy = cell_coord(q.y, g.oy, g.inv_cell, g.ny), hz = cell_coord(q.z, g.oz, g.inv_cell, g.nz);
@@ -435,11 +472,12 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
     if (lane < 32) { s_off[wave][lane] = inc - len; s_js[wave][lane] = js; }
     __builtin_amdgcn_wave_barrier();
 
-    float tk = kInf; int ti = -1;                           // running 32 best in lanes 0..31, ascending
+    constexpr unsigned long long kEmpty = ((unsigned long long)0x7f800000u << 32) | 0xffffffffull;      // (+inf, id -1)
+    unsigned long long top = kEmpty;                        // running 32 best in lanes 0..31, ascending
 #pragma unroll 1
     for (int c0 = 0; c0 < total; c0 += 64) {
         const int t = c0 + lane;
-        float k = kInf; int id = -1;
+        unsigned long long k = kEmpty;
         if (t < total) {
             int lo = 0, hi = 24;                            // last run whose offset is <= t
 #pragma unroll
@@ -448,21 +486,17 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
             const float4 c = g.pts[j];
             const float ex = q.x - c.x, ey = q.y - c.y, ez = q.z - c.z;
             const float d2 = ex * ex + ey * ey + ez * ez;
-            if (j != s && d2 < 3.0e38f) { k = d2; id = j; }   // NaN / Inf points are never neighbours
+            if (j != s && d2 < 3.0e38f) k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;   // NaN / Inf points are never neighbours
         }
-        // ascending bitonic sort of the 64 (k, id) pairs across the wave
-#pragma unroll
-        for (int kk = 2; kk <= 64; kk <<= 1)
-#pragma unroll
-            for (int j = kk >> 1; j > 0; j >>= 1)
-                cmpx(k, id, j, ((lane & j) == 0) == ((lane & kk) == 0 || kk == 64));
-        // lanes 32..63 <- the chunk's 32 smallest, reversed; lanes 0..31 keep the running best: a bitonic sequence
-        const float rk = __shfl(k, 63 - lane); const int ri = __shfl(id, 63 - lane);
-        float mk = lane < 32 ? tk : rk; int mi = lane < 32 ? ti : ri;
-#pragma unroll
-        for (int j = 32; j > 0; j >>= 1) cmpx(mk, mi, j, (lane & j) == 0);
-        tk = mk; ti = mi;
+        k = sort64(k, lane);
+        // lanes 32..63 <- the chunk's 32 smallest, reversed; lanes 0..31 keep the running best: one bitonic sequence, merged
+        // by the half-cleaners alone
+        const unsigned rlo = (unsigned)__shfl((int)(unsigned)k, 63 - lane), rhi = (unsigned)__shfl((int)(unsigned)(k >> 32), 63 - lane);
+        unsigned long long m = lane < 32 ? top : (((unsigned long long)rhi << 32) | rlo);
+        top = half_cleaners<32>(m, lane);
     }
+    const float tk = __uint_as_float((unsigned)(top >> 32));
+    const int ti = (int)(unsigned)top;
     const float d32 = __shfl(tk, 31);
     const float rho2 = fminf(rc * rc, d32);
     const bool keep = lane < 32 && ti >= 0 && tk <= rho2;
