@@ -483,7 +483,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         if (total <= (1LL << 26)) break;
         tile *= 1.5f;
     }
-    // front-end of this batch.  The k-NN graph costs ~2 ns per target point and saves ~0.014 ns per query-iteration
+    // front-end of this batch.  The k-NN graph costs ~1 ns per target point and saves ~0.015 ns per query-iteration
     // (MI355X): it pays for shared / long-lived targets (a batch of scans against one submap), not for
     // one-shot targets (a loop-closure candidate pair, a single odometry frame).
     {

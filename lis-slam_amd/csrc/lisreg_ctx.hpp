@@ -102,7 +102,7 @@ struct lisreg_ctx {
     int       mode_now = 1;              // front-end of the prepared batch
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
     bool      lanes_per_query_auto = true;
-    int       graph_min_ratio = 150;     // auto: query-iterations per target point from which the graph build pays (measured)
+    int       graph_min_ratio = 100;     // auto: query-iterations per target point from which the graph build pays (measured break-even ~75)
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
     float     graph_radius = 1.5f;       // coverage radius of a short neighbour list (search_mode 3)

@@ -1,18 +1,17 @@
 #!/bin/bash
 # rocprofv3 recipe used for profiles/: kernel-trace stats pass + separate PMC passes (never combined with tracing).
-# usage: tests/prof.sh <tag> [bench args]
+# usage (on the GPU box, repo root): tests/prof.sh <tag> [bench args]     e.g.  tests/prof.sh r02
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --cpu-regs 0 --no-profile $*"
+ARGS="--steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 $*"
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_sq.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD -d $OUT/pmc_sq2 -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES -d $OUT/pmc_lanes -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_lanes.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU -d $OUT/pmc_sq2 -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_sq2.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --output-format csv --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum -d $OUT/pmc_tcp -o pmc -- python $REPO/bench.py $ARGS > $OUT/pmc_tcp.log 2>&1
@@ -21,8 +20,7 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/next_vox -o trace -
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/next_feat -o trace -- python $REPO/tests/feature_probe.py > $OUT/next_feat.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/next_map -o trace -- python $REPO/tests/mapfilter_probe.py > $OUT/next_map.log 2>&1
 cd $REPO
-find $OUT -name "*.csv" | head -50
-python tests/prof_summarize.py $OUT > $OUT/summary.txt 2>&1
+python tests/prof_summarize.py $OUT $TAG > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small files
 find $OUT -size +2M -delete

@@ -1,38 +1,89 @@
-"""Summarise rocprofv3 output dirs written by tests/prof.sh: per-kernel time stats + per-kernel PMC averages."""
-import csv, glob, os, sys
+"""Summarise rocprofv3 output dirs written by tests/prof.sh: per-kernel time stats + per-kernel PMC averages of the lisreg
+kernels (the torch at::native::* rows are bench.py's synthetic-scene generator, outside the timed region, and are dropped).
+Also writes <root>/kernel_stats.csv (lisreg rows of the --stats table), <root>/traffic.json (HBM bytes per launch of the dominant
+kernel: FETCH_SIZE x 2 (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KB)."""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 root = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+
 
 def short(name):
-    for k in ("k_assoc_walk", "k_assoc_staged", "k_solve", "k_finalize", "k_reset_items", "k_rank_source", "k_rank_target",
-              "k_scatter", "k_source_keys", "k_target_keys", "k_scan_local", "k_scan_tops", "k_scan_add", "k_bbox"):
-        if k in name:
-            return k
-    return name[:60]
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def is_ours(name):
+    return "lisreg" in name
+
 
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
-    rows = list(csv.DictReader(open(f)))
-    for r in rows[:25]:
-        print(f"{short(r['Name']):28s} calls={r['Calls']:>6s} total_ns={r['TotalDurationNs']:>12s} avg_ns={float(r['AverageNs']):12.1f} pct={r['Percentage']}")
+    print("== kernel stats (rocprofv3 --kernel-trace --stats), lisreg kernels:", os.path.relpath(f, root))
+    rows = [r for r in csv.DictReader(open(f)) if is_ours(r["Name"])]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(os.path.join(root, "kernel_stats.csv"), "w") as o:
+        w = csv.writer(o)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct_of_lisreg_time"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r.get("MinNs", ""), r.get("MaxNs", ""),
+                        round(100 * float(r["TotalDurationNs"]) / tot, 2)])
+    for r in rows[:30]:
+        print(f"{short(r['Name']):36s} calls={r['Calls']:>6s} total_ns={r['TotalDurationNs']:>12s} avg_ns={float(r['AverageNs']):12.1f} "
+              f"pct={100 * float(r['TotalDurationNs']) / tot:.2f}")
 
+pm = defaultdict(lambda: defaultdict(float)); pc = defaultdict(lambda: defaultdict(int))
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
         for r in csv.DictReader(open(f)):
+            if not is_ours(r["Kernel_Name"]):
+                continue
             k = short(r["Kernel_Name"]); c = r["Counter_Name"]
-            acc[k][c] += float(r["Counter_Value"]); cnt[k][c] += 1
-        print("== PMC per-dispatch averages:", os.path.relpath(f, root))
-        for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:8]:
-            print(f"  {k:20s} " + "  ".join(f"{c}={acc[k][c] / cnt[k][c]:.4g} (n={cnt[k][c]})" for c in sorted(acc[k])))
+            pm[k][c] += float(r["Counter_Value"]); pc[k][c] += 1
+print("== PMC per-dispatch averages (separate --pmc passes, no tracing)")
+for k in sorted(pm, key=lambda k: -pm[k].get("SQ_WAVE_CYCLES", 0)):
+    if pc[k].get("SQ_WAVES", 0) == 0:
+        continue
+    a = {c: pm[k][c] / pc[k][c] for c in pm[k]}
+    print(f"  {k}  (dispatches per pass: {pc[k]['SQ_WAVES']})")
+    print("     " + "  ".join(f"{c}={a[c]:.4g}" for c in sorted(a)))
+    w = max(a.get("SQ_WAVES", 0), 1)
+    extra = [f"VALU/wave {a.get('SQ_INSTS_VALU', 0) / w:.0f}", f"SALU/wave {a.get('SQ_INSTS_SALU', 0) / w:.0f}",
+             f"VMEM_RD/wave {a.get('SQ_INSTS_VMEM_RD', 0) / w:.1f}", f"LDS/wave {a.get('SQ_INSTS_LDS', 0) / w:.1f}"]
+    if a.get("SQ_ACTIVE_INST_VALU"):
+        extra.append(f"lane use {a.get('SQ_THREAD_CYCLES_VALU', 0) / (a['SQ_ACTIVE_INST_VALU'] * 64):.3f}")
+    if a.get("TCC_HIT_sum") is not None and a.get("TCC_MISS_sum") is not None and a["TCC_HIT_sum"] + a["TCC_MISS_sum"] > 0:
+        extra.append(f"L2 hit {a['TCC_HIT_sum'] / (a['TCC_HIT_sum'] + a['TCC_MISS_sum']):.3f}")
+    if a.get("FETCH_SIZE") is not None:
+        extra.append(f"HBM-side bytes/launch {(2 * a['FETCH_SIZE'] + a.get('WRITE_SIZE', 0)) * 1024:.4g}")
+    print("     -> " + ", ".join(extra))
 
-for tag in ("next_vox", "next_feat", "next_map"):
-    for f in glob.glob(os.path.join(root, tag, "**", "*kernel_stats.csv"), recursive=True):
-        print(f"== kernel stats of the {tag} probe (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
-        for r in list(csv.DictReader(open(f)))[:18]:
-            nm = r["Name"]
-            nm = nm[nm.find("k_"):][:40] if "k_" in nm else nm[:40]
-            print(f"{nm:42s} calls={r['Calls']:>6s} total_ns={r['TotalDurationNs']:>12s} avg_ns={float(r['AverageNs']):12.1f} pct={r['Percentage']}")
+# traffic of the dominant kernel (all k_assoc_walk instantiations together, weighted by dispatch count)
+f_sum = w_sum = n_f = n_w = 0
+for k in pm:
+    if k.startswith("k_assoc_walk"):
+        f_sum += pm[k].get("FETCH_SIZE", 0); n_f += pc[k].get("FETCH_SIZE", 0)
+        w_sum += pm[k].get("WRITE_SIZE", 0); n_w += pc[k].get("WRITE_SIZE", 0)
+if n_f and n_w:
+    fetch_kb, write_kb = f_sum / n_f, w_sum / n_w
+    tj = {"k_assoc_hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
+          "source": f"profiles/{tag}_rocprofv3_summary.txt: FETCH_SIZE={fetch_kb:.4g} KB (x2 gfx950 correction), WRITE_SIZE={write_kb:.4g} KB, "
+                    f"average over {n_f} dispatches of k_assoc_walk (all instantiations)",
+          "note": "compulsory streams per launch (graph front-end): 118 MB source read twice (the record is re-read after the search "
+                  "instead of being held in registers) + 29 MB anchor read + 29 MB anchor write; the submap, its cell table and the "
+                  "neighbour lists are served from L2 / Infinity Cache"}
+    json.dump(tj, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+    print("== traffic.json:", json.dumps(tj))
+
+for t in ("next_vox", "next_feat", "next_map"):
+    for f in glob.glob(os.path.join(root, t, "**", "*kernel_stats.csv"), recursive=True):
+        print(f"== kernel stats of the {t} probe (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
+        rows = [r for r in csv.DictReader(open(f)) if is_ours(r["Name"]) or "rocclr" in r["Name"]]
+        with open(os.path.join(root, f"{t}_kernel_stats.csv"), "w") as o:
+            w = csv.writer(o); w.writerow(["kernel", "calls", "total_ns", "avg_ns"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"]])
+        for r in rows[:18]:
+            print(f"{short(r['Name']):42s} calls={r['Calls']:>6s} total_ns={r['TotalDurationNs']:>12s} avg_ns={float(r['AverageNs']):12.1f}")
