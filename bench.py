@@ -368,11 +368,11 @@ def host_cores():
 def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_dev, T_init, params, T_ref, steps):
     """The same batch with the sources living in pinned HOST memory as PCL PointXYZI structs (32 B per point): every timed
     step uploads them (hipMemcpyAsync on the context's stream), packs them on the device, runs the registration and
-    copies poses + stats back — SURVEY.md §8(d)'s "incl. H2D of sources and D2H of poses"."""
+    copies poses + stats back — SURVEY.md §8(d)'s "incl. H2D of sources and D2H of poses".  Measured twice: one context (copy and
+    compute in series) and two contexts on two host threads / two streams (the next batch's upload overlaps this batch's kernels;
+    contexts are independent and thread-safe per context, like the reference's concurrently running node objects)."""
     import ctypes as C
-    ctx = lisreg.Context(dev_index)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
+    import threading
     host, n_bytes = [], 0
     for c, s in scans:
         pair = []
@@ -387,29 +387,55 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
         arr[i].src_corner = C.c_void_p(hc.data_ptr()) if hc.shape[0] else None; arr[i].n_corner = hc.shape[0]
         arr[i].src_surf = C.c_void_p(hs.data_ptr()) if hs.shape[0] else None; arr[i].n_surf = hs.shape[0]
         arr[i].stride_bytes = 32; arr[i].fmt = lisreg.FMT_XYZI; arr[i].target = 0
-    T = np.ascontiguousarray(T_init, np.float32).copy()
-    st = (lisreg.Stats * n)()
 
-    def one():
-        T[:] = T_init
-        rc = ctx._L.lisreg_align_batch(ctx._h, n, arr, C.byref(params), T.ctypes.data_as(C.POINTER(C.c_float)), st)
-        if rc:
-            raise RuntimeError(f"lisreg_align_batch failed: {rc}")
+    class Lane:
+        def __init__(self):
+            self.ctx = lisreg.Context(dev_index)
+            self.ctx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
+            self.T = np.ascontiguousarray(T_init, np.float32).copy()
+            self.st = (lisreg.Stats * n)()
 
-    one(); one()
+        def one(self):
+            self.T[:] = T_init
+            rc = self.ctx._L.lisreg_align_batch(self.ctx._h, n, arr, C.byref(params), self.T.ctypes.data_as(C.POINTER(C.c_float)), self.st)
+            if rc:
+                raise RuntimeError(f"lisreg_align_batch failed: {rc}")
+
+    a = Lane()
+    a.one(); a.one()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        one()
+        a.one()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    same = bool(np.array_equal(T, T_ref))
-    ctx.close()
+    same = bool(np.array_equal(a.T, T_ref))
+    # two contexts, two host threads: the batches alternate between them
+    b = Lane()
+    b.one()
+    torch.cuda.synchronize()
+
+    def worker(lane, k):
+        for _ in range(k):
+            lane.one()
+    th = [threading.Thread(target=worker, args=(a, steps)), threading.Thread(target=worker, args=(b, steps))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t0
+    same2 = bool(np.array_equal(a.T, T_ref) and np.array_equal(b.T, T_ref))
+    a.ctx.close(); b.ctx.close()
     return dict(value=round(n * steps / dt, 2), unit="registrations/s", ms_per_step=round(1e3 * dt / steps, 3), steps=steps,
                 h2d_bytes_per_step=int(n_bytes), d2h_bytes_per_step=int(n * 12 * 4),
                 note="pinned host PCL structs (32 B/pt) -> hipMemcpyAsync -> device-side packing -> index build + 10 GN iterations -> "
-                     "D2H of poses and stats, all inside the timed loop; one context, no copy/compute overlap",
-                poses_equal_device_resident_run=same)
+                     "D2H of poses and stats, all inside the timed loop; `value`: one context, copy and compute in series; "
+                     "`two_contexts`: two contexts on two host threads, uploads overlapping the other context's kernels",
+                poses_equal_device_resident_run=same,
+                two_contexts=dict(value=round(2 * n * steps / dt2, 2), ms_per_step=round(1e3 * dt2 / (2 * steps), 3), steps=2 * steps,
+                                  poses_equal_device_resident_run=same2))
 
 
 if __name__ == "__main__":

@@ -279,6 +279,14 @@ typedef struct lisreg_deskew {
 int  lisreg_extract_features_deskew(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
                                     const lisreg_feature_params* params, const lisreg_deskew* deskew, lisreg_feature_out* out);
 
+/* lisreg_extract_features for n_sweeps sweeps at once — the throughput form: the sweeps are stacked into one range image (the
+ * selection kernel's grid is sweeps x rings) and every pass of the pipeline runs once.  sweeps[s] / n[s]: DEVICE lisreg_dpoint
+ * records (ring in the low 16 bits of the payload); outs[s]: device buffers as in lisreg_extract_features.  No IMU de-skew.
+ * The five clouds of every sweep are identical to what a single call on that sweep returns.  At most 256 sweeps and
+ * n_sweeps x n_scan <= 32768 per call. */
+int  lisreg_extract_features_batch(lisreg_ctx* ctx, int n_sweeps, const void* const* sweeps, const int* n,
+                                   const lisreg_feature_params* params, lisreg_feature_out* outs);
+
 /* The "semantic mask": SemanticFusionNode::categoryMapping (src/node/semanticFusionNode.cpp:173-189) splits the labelled
  * cloud, preserving order, by UsingLableMap[label] (config/label.yaml:177-196): 10 -> dynamic, 40 -> ground, 50 -> building,
  * 81 -> pole, anything else (label 0 has no entry) -> outlier.  These five clouds are what semantic_info carries and what

@@ -281,7 +281,7 @@ void lisreg_destroy(lisreg_ctx* c)
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
-                       &c->ft_gather, &c->ft_dsk_tab, &c->ft_dsk_pts, &c->ft_dsk_misc, &c->ft_dsk_time };
+                       &c->ft_gather, &c->ft_cat, &c->ft_bounds, &c->ft_dsk_tab, &c->ft_dsk_pts, &c->ft_dsk_misc, &c->ft_dsk_time };
     for (auto b : bufs) b->release();
     for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
     for (auto& m : c->localmaps) { for (auto& b : m.cls) b.release(); m.tgt[0].release(); m.tgt[1].release(); }
@@ -1223,6 +1223,89 @@ int lisreg_extract_features_deskew(lisreg_ctx* c, const void* cloud, int n, int 
         }
     }
     HIPCHK(c, hipStreamSynchronize(st));
+    return LISREG_OK;
+}
+
+// S sweeps in one pass: the sweeps are stacked into ONE range image of S x H rows (grid of the selection kernel = sweeps x
+// rings), every flat pass of the single-sweep pipeline runs once over the stack with per-sweep end guards, and one gather per
+// output list hands every sweep its slice.  Device records in, device records out; the only host round trip is the (S + 1) x 5
+// list boundaries the caller needs anyway.  Results are identical to S single calls (tests/test_features.py).
+int lisreg_extract_features_batch(lisreg_ctx* c, int n_sweeps, const void* const* sweeps, const int* n, const lisreg_feature_params* P,
+                                  lisreg_feature_out* outs)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n_sweeps < 0 || (n_sweeps > 0 && (!sweeps || !n || !outs)) || !P) return fail(c, LISREG_ERR_ARG, "extract_features_batch: bad arguments");
+    if (n_sweeps == 0) return LISREG_OK;
+    if (P->n_scan < 1 || P->n_scan > 1024 || P->horizon_scan < 16 || P->horizon_scan > 4096 || P->downsample_rate < 1)
+        return fail(c, LISREG_ERR_ARG, "extract_features_batch: n_scan in [1,1024], horizon_scan in [16,4096], downsample_rate >= 1");
+    if (n_sweeps > 256 || (long long)n_sweeps * P->n_scan > 32768) return fail(c, LISREG_ERR_ARG, "extract_features_batch: at most 256 sweeps and 32768 rows per call");
+    std::vector<int> off((size_t)n_sweeps + 1, 0);
+    for (int s = 0; s < n_sweeps; ++s) {
+        if (n[s] < 0 || (n[s] > 0 && !sweeps[s])) return fail(c, LISREG_ERR_ARG, "extract_features_batch: NULL sweep with n > 0");
+        if ((long long)off[(size_t)s] + n[s] > 2000000000LL) return fail(c, LISREG_ERR_ARG, "extract_features_batch: too many points");
+        off[(size_t)s + 1] = off[(size_t)s] + n[s];
+    }
+    const int N = off[(size_t)n_sweeps];
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int Hs = P->n_scan, W = P->horizon_scan, H = Hs * n_sweeps, hw = H * W, hw_sweep = Hs * W;
+    const size_t L = (size_t)hw + 16;
+    HIPCHK(c, c->ft_owner.ensure(sizeof(int) * (size_t)hw));      HIPCHK(c, c->ft_flag.ensure(sizeof(int) * L));
+    HIPCHK(c, c->ft_pos.ensure(sizeof(int) * 2 * (L + 1)));       HIPCHK(c, c->ft_scan.ensure(sizeof(int) * (L / 2048 + 8)));
+    HIPCHK(c, c->ft_col.ensure(sizeof(int) * L));                 HIPCHK(c, c->ft_range.ensure(sizeof(float) * L));
+    HIPCHK(c, c->ft_src.ensure(sizeof(int) * L));                 HIPCHK(c, c->ft_curv.ensure(sizeof(float) * L));
+    HIPCHK(c, c->ft_picked.ensure(sizeof(int) * L));              HIPCHK(c, c->ft_label.ensure(sizeof(int) * L));
+    HIPCHK(c, c->ft_rlists.ensure(sizeof(int) * (size_t)H * 3 * 128));
+    HIPCHK(c, c->ft_rcounts.ensure(sizeof(int) * (size_t)H * 4)); HIPCHK(c, c->ft_lists.ensure(sizeof(int) * 4 * L));
+    HIPCHK(c, c->ft_counts.ensure(sizeof(int) * 8));
+    HIPCHK(c, c->ft_cat.ensure(sizeof(float4) * (size_t)std::max(N, 1)));
+    HIPCHK(c, c->ft_rings.ensure(sizeof(uint32_t) * (size_t)std::max(N, 1)));
+    HIPCHK(c, c->ft_bounds.ensure(sizeof(int) * 5 * ((size_t)n_sweeps + 1) + 16 * 5 * (size_t)n_sweeps));
+    FeatureBuffers fb;
+    fb.owner = c->ft_owner.as<int>(); fb.flag = c->ft_flag.as<int>(); fb.pos = c->ft_pos.as<int>(); fb.scan_tmp = c->ft_scan.as<int>();
+    fb.col = c->ft_col.as<int>(); fb.range = c->ft_range.as<float>(); fb.src = c->ft_src.as<int>(); fb.curv = c->ft_curv.as<float>();
+    fb.picked = c->ft_picked.as<int>(); fb.label = c->ft_label.as<int>(); fb.ring_lists = c->ft_rlists.as<int>();
+    fb.ring_counts = c->ft_rcounts.as<int>(); fb.lists = c->ft_lists.as<int>(); fb.counts = c->ft_counts.as<int>();
+    float4* cat = c->ft_cat.as<float4>();
+    for (int s = 0; s < n_sweeps; ++s)
+        if (n[s] > 0) HIPCHK(c, hipMemcpyAsync(cat + off[(size_t)s], sweeps[s], sizeof(float4) * (size_t)n[s], hipMemcpyDeviceToDevice, st));
+    launch_feature_batch_rows(cat, N, off.data(), n_sweeps, Hs, P->downsample_rate, c->ft_rings.as<uint32_t>(), st);
+    lisreg_feature_params Pst = *P;
+    Pst.n_scan = H; Pst.downsample_rate = 1;                    // rows are stack rows; the ring filter was applied by k_feat_batch_rows
+    launch_extract_features(cat, c->ft_rings.as<uint32_t>(), N, Pst, fb, st, n_sweeps);
+    int* Bdev = c->ft_bounds.as<int>();
+    launch_feature_batch_bounds(n_sweeps, Hs, hw_sweep, fb, hw, Bdev, st);
+    HIPCHK(c, hipGetLastError());
+    std::vector<int> B(5 * ((size_t)n_sweeps + 1));
+    HIPCHK(c, hipMemcpyAsync(B.data(), Bdev, sizeof(int) * B.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // ---- per sweep: counts, capacity check, one gather job per list ---------------------------------------------------------
+    struct Job { void* dst; int begin, count; };
+    std::vector<Job> jobs(5 * (size_t)n_sweeps);
+    int max_count[5] = { 0, 0, 0, 0, 0 };
+    for (int s = 0; s < n_sweeps; ++s) {
+        lisreg_feature_out& o = outs[s];
+        // B columns: extracted, corner, corner_sharp, surface_sharp, surface
+        const int cnt[5] = { B[(s + 1) * 5 + 0] - B[s * 5 + 0], B[(s + 1) * 5 + 1] - B[s * 5 + 1], B[(s + 1) * 5 + 4] - B[s * 5 + 4],
+                             B[(s + 1) * 5 + 2] - B[s * 5 + 2], B[(s + 1) * 5 + 3] - B[s * 5 + 3] };      // deskewed, corner, surface, corner_sharp, surface_sharp
+        const int beg[5] = { B[s * 5 + 0], B[s * 5 + 1], B[s * 5 + 4], B[s * 5 + 2], B[s * 5 + 3] };
+        void* bufs[5] = { o.deskewed, o.corner, o.surface, o.corner_sharp, o.surface_sharp };
+        const int caps[5] = { o.cap_deskewed, o.cap_corner, o.cap_surface, o.cap_corner_sharp, o.cap_surface_sharp };
+        o.n_deskewed = cnt[0]; o.n_corner = cnt[1]; o.n_surface = cnt[2]; o.n_corner_sharp = cnt[3]; o.n_surface_sharp = cnt[4];
+        for (int k = 0; k < 5; ++k) {
+            if (bufs[k] && cnt[k] > caps[k]) return fail(c, LISREG_ERR_ARG, "extract_features_batch: an output buffer is too small (counts written back)");
+            jobs[(size_t)k * n_sweeps + s] = Job{ bufs[k], beg[k], bufs[k] ? cnt[k] : 0 };
+            if (bufs[k]) max_count[k] = std::max(max_count[k], cnt[k]);
+        }
+    }
+    Job* jobs_dev = reinterpret_cast<Job*>(Bdev + 5 * ((size_t)n_sweeps + 1) + 3) ;     // 16-byte slots behind the bounds
+    jobs_dev = reinterpret_cast<Job*>(((uintptr_t)jobs_dev + 15) & ~(uintptr_t)15);
+    HIPCHK(c, hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
+    const int* idx[5] = { fb.src, fb.lists + 0 * L, fb.lists + 1 * L, fb.lists + 2 * L, fb.lists + 3 * L };
+    for (int k = 0; k < 5; ++k)
+        launch_feature_batch_gather(cat, idx[k], jobs_dev + (size_t)k * n_sweeps, n_sweeps, max_count[k], st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));           // `jobs` is a local
     return LISREG_OK;
 }
 

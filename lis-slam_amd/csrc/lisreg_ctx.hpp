@@ -79,7 +79,7 @@ struct lisreg_ctx {
     lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
-           ft_lists, ft_counts, ft_rings, ft_gather, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
+           ft_lists, ft_counts, ft_rings, ft_gather, ft_cat, ft_bounds, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
     std::vector<lisreg::MapIndex> maps;
     std::vector<lisreg::LocalMap> localmaps;
     lisreg::DevBuf lm_in, lm_tmp, lm_bbox;

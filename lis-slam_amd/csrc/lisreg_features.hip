@@ -78,13 +78,25 @@ __global__ __launch_bounds__(256) void k_feat_extract(const float4* __restrict__
     fb.src[e] = o;
 }
 
+// Batched extraction stacks S sweeps into one range image of S x H rows.  The reference's flat loops over the extracted cloud
+// (smoothness, occlusion) stop 5 / 6 entries short of the cloud's two ends: in the stack those ends are the sweep's own
+// [lo, hi) — the extracted positions of its first pixel and of the next sweep's first pixel.
+__device__ __forceinline__ void sweep_range(const int* __restrict__ pos, int hw_sweep, int n_sweeps, int i, int& lo, int& hi)
+{
+    int a = 0, b = n_sweeps - 1;                                     // last sweep whose first extracted position is <= i
+    while (a < b) { const int mid = (a + b + 1) >> 1; if (pos[(size_t)mid * hw_sweep] <= i) a = mid; else b = mid - 1; }
+    lo = pos[(size_t)a * hw_sweep]; hi = pos[(size_t)(a + 1) * hw_sweep];
+}
+
 // calculateSmoothness (:544-563)
 __global__ __launch_bounds__(256) void k_feat_smooth(const int* __restrict__ counts, const float* __restrict__ r,
-                                                     float* __restrict__ curv)
+                                                     float* __restrict__ curv, const int* __restrict__ pos, int hw_sweep, int n_sweeps)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int size = counts[0];
-    if (i < 5 || i >= size - 5) return;
+    if (i >= counts[0]) return;
+    int lo, size;
+    sweep_range(pos, hw_sweep, n_sweeps, i, lo, size);
+    if (i < lo + 5 || i >= size - 5) return;
     const float d = r[i - 5] + r[i - 4] + r[i - 3] + r[i - 2] + r[i - 1] - r[i] * 10 + r[i + 1] + r[i + 2] + r[i + 3] +
                     r[i + 4] + r[i + 5];
     curv[i] = d * d;
@@ -92,11 +104,14 @@ __global__ __launch_bounds__(256) void k_feat_smooth(const int* __restrict__ cou
 
 // markOccludedPoints (:568-605): only ever stores 1 -> order-independent
 __global__ __launch_bounds__(256) void k_feat_occlude(const int* __restrict__ counts, const float* __restrict__ r,
-                                                      const int* __restrict__ col, int* __restrict__ picked)
+                                                      const int* __restrict__ col, int* __restrict__ picked,
+                                                      const int* __restrict__ pos, int hw_sweep, int n_sweeps)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int size = counts[0];
-    if (i < 5 || i >= size - 6) return;
+    if (i >= counts[0]) return;
+    int lo, size;
+    sweep_range(pos, hw_sweep, n_sweeps, i, lo, size);
+    if (i < lo + 5 || i >= size - 6) return;
     const float depth1 = r[i], depth2 = r[i + 1];
     const int columnDiff = abs(col[i + 1] - col[i]);
     if (columnDiff < 10) {
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(256) void k_feat_occlude(const int* __restrict__ co
 
 // extractFeatures (:610-713): one wave per ring
 __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos, int H, int W, lisreg_feature_params P,
-                                                    FeatureBuffers fb)
+                                                    FeatureBuffers fb, int rows_per_sweep)
 {
     __shared__ int   s_picked[kMaxRingPts];
     __shared__ float s_curv[kMaxRingPts];
@@ -118,13 +133,15 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
     __shared__ int   s_ind[kMaxSector];
 
     const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves sort, wave 0 picks
-    const int size = fb.counts[0];
+    // the extracted cloud this ring belongs to: [base, size) — the whole cloud for one sweep, the sweep's own slice in a batch
+    const int sweep = ring / rows_per_sweep;
+    const int base = pos[(size_t)sweep * rows_per_sweep * W], size = pos[(size_t)(sweep + 1) * rows_per_sweep * W];
     const int r0 = pos[ring * W], r1 = pos[(ring + 1) * W];           // this ring's extracted range [r0, r1)
     const int startRing = r0 - 1 + 5, endRing = r1 - 1 - 5;           // startRingIndex / endRingIndex (:521, :537)
     int* lists = fb.ring_lists + (size_t)ring * 3 * kListCap;
     int n_corner = 0, n_csharp = 0, n_ssharp = 0;
     // window [lo, hi) of the extracted arrays mirrored in LDS: the ring +-6 (suppression reaches 5 beyond a pick)
-    const int lo = max(r0 - 6, 0), hi = min(r1 + 6, size);
+    const int lo = max(r0 - 6, base), hi = min(r1 + 6, size);
     for (int k = lo + tid; k < hi; k += 256) { s_picked[k - lo] = fb.picked[k]; s_curv[k - lo] = fb.curv[k]; s_col[k - lo] = fb.col[k]; }
     __syncthreads();
 
@@ -160,10 +177,10 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
         // free (cloudNeighborPicked only ever goes 0 -> 1, so "not eligible when reached" == "never eligible").
         if (wave == 0) {
 #define LISREG_SUPPRESS(ind_) do { \
-            for (int l = 1; l <= 5; l++) { if ((ind_) + l >= size || (ind_) + l - 1 < 0) break; \
+            for (int l = 1; l <= 5; l++) { if ((ind_) + l >= size || (ind_) + l - 1 < base) break; \
                 if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l - 1 - lo]) > 10) break; \
                 s_picked[(ind_) + l - lo] = 1; } \
-            for (int l = -1; l >= -5; l--) { if ((ind_) + l < 0 || (ind_) + l + 1 >= size) break; \
+            for (int l = -1; l >= -5; l--) { if ((ind_) + l < base || (ind_) + l + 1 >= size) break; \
                 if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l + 1 - lo]) > 10) break; \
                 s_picked[(ind_) + l - lo] = 1; } } while (0)
         {   // edge features: largest curvature first (:626-661), at most 20 per sector, the first 4 are "sharp"
@@ -262,14 +279,25 @@ __global__ __launch_bounds__(256) void k_feat_surface_write(int hw, const int* _
 
 // concatenate the per-ring pick lists in ring order: exclusive scan of the per-ring counts (one wave; ring_counts[r][3]
 // is reused for nothing else, so the offsets go to a small LDS-free strided loop), then one workgroup per ring copies.
-__global__ __launch_bounds__(64) void k_feat_offsets(int H, FeatureBuffers fb, int* __restrict__ ring_off /* [H][3] */)
+__global__ __launch_bounds__(256) void k_feat_offsets(int H, FeatureBuffers fb, int* __restrict__ ring_off /* [H + 1][3] */)
 {
-    const int w = threadIdx.x;                                         // lanes 0..2: one list each
-    if (w >= 3) return;
-    int run = 0;
-    for (int ring = 0; ring < H; ++ring) { ring_off[ring * 3 + w] = run; run += fb.ring_counts[ring * 4 + w]; }
-    const int slot[3] = { 1, 3, 4 };                                   // counts[]: corner, corner_sharp, surface_sharp
-    fb.counts[slot[w]] = run;
+    // exclusive scan of the three per-ring counts over H rings (H up to tens of thousands in a batch): 256 threads, each owning a
+    // contiguous chunk of rings; chunk sums are scanned through LDS
+    __shared__ int s_sum[3][256];
+    const int t = threadIdx.x;
+    const int per = (H + 255) / 256, r_begin = t * per, r_end = min(H, r_begin + per);
+    int acc[3] = { 0, 0, 0 };
+    for (int ring = r_begin; ring < r_end; ++ring)
+        for (int w = 0; w < 3; ++w) acc[w] += fb.ring_counts[ring * 4 + w];
+    for (int w = 0; w < 3; ++w) s_sum[w][t] = acc[w];
+    __syncthreads();
+    if (t < 3) { int run = 0; for (int k = 0; k < 256; ++k) { const int v = s_sum[t][k]; s_sum[t][k] = run; run += v; }
+                 const int slot[3] = { 1, 3, 4 };                      // counts[]: corner, corner_sharp, surface_sharp
+                 fb.counts[slot[t]] = run; ring_off[H * 3 + t] = run; }
+    __syncthreads();
+    int run[3] = { s_sum[0][t], s_sum[1][t], s_sum[2][t] };
+    for (int ring = r_begin; ring < r_end; ++ring)
+        for (int w = 0; w < 3; ++w) { ring_off[ring * 3 + w] = run[w]; run[w] += fb.ring_counts[ring * 4 + w]; }
 }
 
 __global__ __launch_bounds__(128) void k_feat_concat(int hw, FeatureBuffers fb, const int* __restrict__ ring_off)
@@ -281,6 +309,42 @@ __global__ __launch_bounds__(128) void k_feat_concat(int hw, FeatureBuffers fb, 
         for (int t = threadIdx.x; t < cnt; t += 128)
             fb.lists[(size_t)list_of[w] * (hw + 16) + off + t] = fb.src[fb.ring_lists[((size_t)ring * 3 + w) * kListCap + t]];
     }
+}
+
+// ---- batched extraction: S sweeps as one stack of S x H rows ------------------------------------------------------------
+struct SweepOffsets { int off[258]; };          // first point of each sweep in the concatenated cloud; off[S] = total
+
+// row of every point in the stack (its ring + sweep * H), or 0xffff for points the single-sweep kernel would drop by ring
+__global__ __launch_bounds__(256) void k_feat_batch_rows(const float4* __restrict__ cat, int n, SweepOffsets so, int n_sweeps, int H,
+                                                         int rate, uint32_t* __restrict__ rows)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int a = 0, b = n_sweeps - 1;
+    while (a < b) { const int mid = (a + b + 1) >> 1; if (so.off[mid] <= i) a = mid; else b = mid - 1; }
+    const int ring = (int)(__float_as_uint(cat[i].w) & 0xffffu);
+    rows[i] = (ring < H && ring % rate == 0) ? (uint32_t)(a * H + ring) : 0xffffu;
+}
+
+// per sweep: where its slice of each output list begins — B[s] = { extracted, corner, corner_sharp, surface_sharp, surface }
+__global__ void k_feat_batch_bounds(int n_sweeps, int H, int hw_sweep, const int* __restrict__ pos, const int* __restrict__ spos,
+                                    const int* __restrict__ ring_off, int* __restrict__ B)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_sweeps) return;
+    const int e = pos[(size_t)s * hw_sweep];
+    B[s * 5 + 0] = e;
+    for (int w = 0; w < 3; ++w) B[s * 5 + 1 + w] = ring_off[(size_t)s * H * 3 + w];
+    B[s * 5 + 4] = spos[e];
+}
+
+// one launch hands every sweep its slice of one list: grid.y = sweep
+struct GatherJob { float4* dst; int begin, count; };
+__global__ __launch_bounds__(256) void k_feat_batch_gather(const float4* __restrict__ cat, const int* __restrict__ idx,
+                                                           const GatherJob* __restrict__ jobs)
+{
+    const GatherJob j = jobs[blockIdx.y];
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < j.count; t += gridDim.x * 256) j.dst[t] = cat[idx[j.begin + t]];
 }
 
 // categoryMapping (/root/reference/src/node/semanticFusionNode.cpp:173-189): flag of "this point belongs to class k"
@@ -404,24 +468,47 @@ void launch_deskew(const int* owner, int hw, const float* times_dev, DeskewTable
 }
 
 void launch_extract_features(const float4* pts, const uint32_t* rings, int n, lisreg_feature_params P, FeatureBuffers fb,
-                             hipStream_t st)
+                             hipStream_t st, int n_sweeps)
 {
+    // n_sweeps > 1: P.n_scan is the height of the whole stack (n_sweeps x rings per sweep), `rings` holds stack rows
     const int H = P.n_scan, W = P.horizon_scan, hw = H * W;
+    const int rows_per_sweep = H / n_sweeps, hw_sweep = rows_per_sweep * W;
     (void)hipMemsetAsync(fb.owner, 0x7f, sizeof(int) * (size_t)hw, st);             // every pixel = kEmpty
     if (n > 0) k_feat_project<<<(n + 255) / 256, 256, 0, st>>>(pts, rings, n, P, fb.owner);
     k_feat_valid<<<(hw + 255) / 256, 256, 0, st>>>(fb.owner, hw, fb.flag);
     launch_exclusive_scan(fb.flag, fb.pos, fb.scan_tmp, hw, st);
     k_feat_extract<<<(hw + 16 + 255) / 256, 256, 0, st>>>(pts, fb.owner, fb.pos, H, W, fb);
-    k_feat_smooth<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.curv);
-    k_feat_occlude<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.col, fb.picked);
-    k_feat_select<<<H, 256, 0, st>>>(fb.pos, H, W, P, fb);
+    k_feat_smooth<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.curv, fb.pos, hw_sweep, n_sweeps);
+    k_feat_occlude<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.col, fb.picked, fb.pos, hw_sweep, n_sweeps);
+    k_feat_select<<<H, 256, 0, st>>>(fb.pos, H, W, P, fb, rows_per_sweep);            // grid = sweeps x rings
     k_feat_surface_flags<<<(hw + 16 + 255) / 256, 256, 0, st>>>(fb.pos, H, W, fb);
     // the second scan goes to the upper half of `pos`; the lower half (ring boundaries) stays valid
     launch_exclusive_scan(fb.flag, fb.pos + (hw + 17), fb.scan_tmp, hw + 16, st);
     k_feat_surface_write<<<(hw + 16 + 255) / 256, 256, 0, st>>>(hw, fb.pos + (hw + 17), fb);
     int* ring_off = fb.flag;                                            // flag[] is free again after the surface scan
-    k_feat_offsets<<<1, 64, 0, st>>>(H, fb, ring_off);
+    k_feat_offsets<<<1, 256, 0, st>>>(H, fb, ring_off);
     k_feat_concat<<<H, 128, 0, st>>>(hw, fb, ring_off);
+}
+
+void launch_feature_batch_rows(const float4* cat, int n, const int* offsets /* host [n_sweeps + 1] */, int n_sweeps, int H, int rate,
+                               uint32_t* rows, hipStream_t st)
+{
+    SweepOffsets so;
+    for (int s = 0; s <= n_sweeps; ++s) so.off[s] = offsets[s];
+    if (n > 0) k_feat_batch_rows<<<(n + 255) / 256, 256, 0, st>>>(cat, n, so, n_sweeps, H, rate, rows);
+}
+
+void launch_feature_batch_bounds(int n_sweeps, int H, int hw_sweep, FeatureBuffers fb, int hw_total, int* B, hipStream_t st)
+{
+    // ring offsets were left in fb.flag by launch_extract_features; the surface scan in the upper half of fb.pos
+    k_feat_batch_bounds<<<(n_sweeps + 1 + 63) / 64, 64, 0, st>>>(n_sweeps, H, hw_sweep, fb.pos, fb.pos + (hw_total + 17), fb.flag, B);
+}
+
+void launch_feature_batch_gather(const float4* cat, const int* idx, const void* jobs_dev, int n_sweeps, int max_count, hipStream_t st)
+{
+    if (max_count <= 0) return;
+    const int gx = std::min(64, (max_count + 255) / 256);
+    k_feat_batch_gather<<<dim3(gx, n_sweeps), 256, 0, st>>>(cat, idx, static_cast<const GatherJob*>(jobs_dev));
 }
 
 // stable five-way partition: idx_out[k*n ..] = input indices of class k in input order, counts[k] = its size

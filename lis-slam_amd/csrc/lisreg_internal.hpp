@@ -180,7 +180,13 @@ struct FeatureBuffers {
     int*   counts;     // [8]       deskewed, corner, surface, corner_sharp, surface_sharp
 };
 void launch_extract_features(const float4* pts, const uint32_t* rings /* null: ring = payload & 0xffff */, int n,
-                             lisreg_feature_params P, FeatureBuffers fb, hipStream_t st);
+                             lisreg_feature_params P, FeatureBuffers fb, hipStream_t st, int n_sweeps = 1);
+// batched extraction (S sweeps stacked into one range image of S x H rows; ring offsets need [H_total + 1][3] ints in fb.flag)
+void launch_feature_batch_rows(const float4* cat, int n, const int* offsets /* host [n_sweeps + 1] */, int n_sweeps, int H, int rate,
+                               uint32_t* rows, hipStream_t st);
+void launch_feature_batch_bounds(int n_sweeps, int H, int hw_sweep, FeatureBuffers fb, int hw_total, int* B /* [n_sweeps + 1][5] */, hipStream_t st);
+void launch_feature_batch_gather(const float4* cat, const int* idx, const void* jobs_dev /* {float4* dst; int begin, count} per sweep */,
+                                 int n_sweeps, int max_count, hipStream_t st);
 // IMU de-skew tables in device memory (lisreg_deskew, laserProcessing.cpp:222-266)
 struct DeskewTables {
     const double* time; const double* rx; const double* ry; const double* rz;

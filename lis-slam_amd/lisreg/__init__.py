@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
-    "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_default_feature_params", "lisreg_semantic_split",
+    "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_extract_features_batch", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
     "lisreg_localmap_get", "lisreg_predict_pose",
@@ -199,6 +199,8 @@ def lib():
         L.lisreg_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, vp]
         L.lisreg_extract_features.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(FeatureOut)]
         L.lisreg_default_feature_params.argtypes = [C.POINTER(FeatureParams)]
+        L.lisreg_extract_features_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(FeatureParams),
+                                                    C.POINTER(FeatureOut)]
         L.lisreg_extract_features_deskew.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(Deskew),
                                                      C.POINTER(FeatureOut)]
         L.lisreg_semantic_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(SemanticOut)]
@@ -489,6 +491,19 @@ class Context:
         self._chk(self._L.lisreg_extract_features_deskew(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, C.byref(params),
                                                          C.byref(deskew) if deskew is not None else None, C.byref(fo)))
         return {k: getattr(fo, "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")}
+
+    def extract_features_batch_device(self, in_ptrs, counts, params: "FeatureParams", out_ptrs: list, cap: int) -> list:
+        """lisreg_extract_features_batch: in_ptrs / counts per sweep (device records), out_ptrs = one dict of five device buffers
+        per sweep (capacity `cap` points each).  Returns the per-sweep count dicts."""
+        S = len(in_ptrs)
+        ptrs = (C.c_void_p * S)(*[C.c_void_p(int(p)) if n else None for p, n in zip(in_ptrs, counts)])
+        ns = (C.c_int * S)(*[int(x) for x in counts])
+        fos = (FeatureOut * S)()
+        for s in range(S):
+            for k, ptr in out_ptrs[s].items():
+                setattr(fos[s], k, C.c_void_p(ptr)); setattr(fos[s], "cap_" + k, cap)
+        self._chk(self._L.lisreg_extract_features_batch(self._h, S, ptrs, ns, C.byref(params), fos))
+        return [{k: getattr(fos[s], "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")} for s in range(S)]
 
     def semantic_split(self, cloud: np.ndarray, using_label=None) -> list:
         """categoryMapping replacement: [dynamic, ground, building, pole, outlier] from a PointXYZIL struct array."""

@@ -27,3 +27,19 @@ for h, w, rate in ((64, 1800, 2), (64, 1800, 1), (128, 2048, 1)):
     ms = timed(run, 20)
     t0 = time.perf_counter(); ro = oc.extract_features(c, po); cpu = 1e3 * (time.perf_counter() - t0)
     print(f"{h}x{w} rate {rate}: {len(c)} pts -> {res['c']}  GPU {ms:.3f} ms ({len(c)/ms/1e3:.0f} Mpts/s)  CPU oracle {cpu:.2f} ms  x{cpu/ms:.1f}")
+
+# batched: 8 sweeps in one pass (grid = sweeps x rings)
+h, w, rate, S = 64, 1800, 2, 8
+sweeps = [synth.make_raw_scan(h, w, 8100 + k) for k in range(S)]
+recs = []
+for c in sweeps:
+    rec = np.zeros((len(c), 4), np.float32); rec[:, 0], rec[:, 1], rec[:, 2] = c["x"], c["y"], c["z"]
+    rec[:, 3] = c["ring"].astype(np.uint32).view(np.float32); recs.append(rec)
+dins = [lisreg.DeviceArray(r) for r in recs]; cap = h * w
+names = ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
+outs = [{k: lisreg.DeviceArray(np.zeros((cap, 4), np.float32)) for k in names} for _ in range(S)]
+pg = lisreg.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+def runb(): ctx.extract_features_batch_device([d.ptr for d in dins], [len(r) for r in recs], pg, [{k: v.ptr for k, v in o.items()} for o in outs], cap)
+ms = timed(runb, 20)
+t0 = time.perf_counter(); runb(); wall = 1e3 * (time.perf_counter() - t0)
+print(f"batched {S} x {h}x{w} rate {rate}: GPU {ms:.3f} ms total ({ms / S:.3f} ms per sweep), host-inclusive call {wall:.3f} ms")

@@ -264,3 +264,44 @@ def test_hip_deskew_matches_oracle(oracle, gpu_ctx, h, w, rate, seed, shuffle):
         assert nd[k] == len(rg[k])
         got = lisreg.device_to_host(outs[k].ptr, (cap, 4), np.float32)[: nd[k]]
         assert np.array_equal(got[:, :3], synth.pcl_xyz(rg[k])), k
+
+
+def _records(c):
+    rec = np.zeros((len(c), 4), np.float32)
+    rec[:, 0], rec[:, 1], rec[:, 2] = c["x"], c["y"], c["z"]
+    rec[:, 3] = c["ring"].astype(np.uint32).view(np.float32)
+    return rec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,rate", [(16, 450, 1), (64, 1800, 2)])
+def test_batched_extraction_equals_single_calls_and_oracle(oracle, gpu_ctx, h, w, rate):
+    """lisreg_extract_features_batch stacks the sweeps into one range image (grid = sweeps x rings).  Every sweep's five clouds
+    must be exactly what a single call — and the oracle — give for that sweep alone: the flat loops of the reference stop 5 / 6
+    entries short of the CLOUD's ends, which in the stack are the sweep's own ends.  Includes an empty sweep, a sweep too small for
+    the stencil, shuffled input and a sweep whose last ring is empty."""
+    import lisreg
+    from lisreg import synth
+    sweeps = [synth.make_raw_scan(h, w, 7400 + k, shuffle=(k == 2)) for k in range(6)]
+    sweeps[1] = sweeps[1][:0]
+    sweeps[3] = sweeps[3][:30]
+    sweeps[4] = sweeps[4][sweeps[4]["ring"] < h - 2]
+    sweeps.append(synth.make_raw_scan(h, w, 7410))
+    sweeps.append(synth.make_raw_scan(h, w, 7411))
+    pg = lisreg.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    po = oracle.FeatureParams(h, w, rate, 0.0, 70.0, 1.0, 0.1)
+    recs = [_records(c) for c in sweeps]
+    dins = [lisreg.DeviceArray(r) if len(r) else None for r in recs]
+    cap = h * w
+    outs = [{k: lisreg.DeviceArray(np.zeros((cap, 4), np.float32)) for k in NAMES} for _ in sweeps]
+    counts = gpu_ctx.extract_features_batch_device([d.ptr if d else 0 for d in dins], [len(r) for r in recs], pg,
+                                                   [{k: v.ptr for k, v in o.items()} for o in outs], cap)
+    one = {k: lisreg.DeviceArray(np.zeros((cap, 4), np.float32)) for k in NAMES}
+    for s, c in enumerate(sweeps):
+        ro = oracle.extract_features(c, po)
+        single = gpu_ctx.extract_features_device(dins[s].ptr if dins[s] else 0, len(c), pg, {k: v.ptr for k, v in one.items()}, cap)
+        for k in NAMES:
+            assert counts[s][k] == single[k] == len(ro[k]), (s, k, counts[s][k], single[k], len(ro[k]))
+            got = lisreg.device_to_host(outs[s][k].ptr, (cap, 4))[: counts[s][k]]
+            assert got.tobytes() == recs[s][ro[k]].tobytes(), (s, k)
+    assert sum(c["corner"] for c in counts) > 0
