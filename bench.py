@@ -139,8 +139,13 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("rebuild_targets_each_run", 1)
+    for kv in filter(None, os.environ.get("LISREG_OPTS", "").split(",")):        # tuning experiments: LISREG_OPTS=name=value,...
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     if os.environ.get("LISREG_COUNT"):
         ctx.set_option("count_searches", 1)
+        if os.environ.get("LISREG_COUNT") == "2":
+            ctx.set_option("dump_neighbors", 1)
 
     # ---- synthetic inputs, generated straight into HBM ----------------------------------------------------------
     tc_dev, ts_dev, tc_host, ts_host = synth_torch.submap_device(M_SUBMAP, dev)
@@ -313,6 +318,10 @@ def main():
     if os.environ.get("LISREG_COUNT"):
         cnt = ctx.counters()
         print("searched fraction per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in cnt[:ITERS]], file=sys.stderr)
+        print("wavefronts with a walking lane per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in ctx.wave_counters()[:ITERS]], file=sys.stderr)
+        if os.environ.get("LISREG_COUNT") == "2":
+            raw = ctx.raw_counters()[96:96 + ITERS]
+            print("queries with an unchanged ordered neighbour set / wavefronts where all are unchanged:", [(int(r >> 32), int(r & 0xffffffff)) for r in raw], file=sys.stderr)
     if rank == 0:
         out = {
             "metric": "scan-to-submap registrations/sec (64x1800 pts, 200k submap)",

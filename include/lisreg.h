@@ -194,7 +194,8 @@ int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
 
 /* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):
- * out[2*k] = queries re-searched at GN iteration k, out[2*k+1] = queries processed at iteration k (k < 32). */
+ * out[2*k] = queries re-searched at GN iteration k, out[2*k+1] = queries processed at iteration k (k < 32).
+ * Graph front-end, n > 64: out[64+k] = (wavefronts with a walking lane) << 32 | wavefronts, of iteration k. */
 int  lisreg_get_counters(lisreg_ctx* ctx, unsigned long long* out, int n);
 
 /* Test hook (option "dump_neighbors" = 1 before the batch is prepared; search modes 1 and 3): the five neighbours the LAST
@@ -204,6 +205,13 @@ int  lisreg_get_counters(lisreg_ctx* ctx, unsigned long long* out, int n);
  * (laserCloudOriFlag, :741 / :820).  out: host int[6][n_elems], n_elems = all source points of the batch in item order (corner
  * then surf of each item). */
 int  lisreg_get_neighbors(lisreg_ctx* ctx, int* out, int n_elems);
+
+/* Diagnostics (tests): the search index of target `slot`, kind 0 = corner / 1 = surf, as it stands in HBM after the work queued on
+ * the context's stream: dims = {n, nx, ny, nz, n_cells}, geom = {ox, oy, oz, cell edge}, the cell-sorted records
+ * (x, y, z, bit-cast original index; ordered by cell (ix * ny + iy) * nz + iz, then original index) and cell_start[n_cells + 1].
+ * Any output pointer may be NULL. */
+int  lisreg_get_target_index(lisreg_ctx* ctx, int slot, int kind, int* dims, float* geom,
+                             float* sorted_out, int sorted_capacity, int* cell_start_out, int cell_capacity);
 
 /* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
 int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);

@@ -277,7 +277,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
@@ -584,8 +584,10 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             }
     if (c->grids_dirty) { rc = upload_grids(c); if (rc) return rc; }
     // table for rebuilding every target index of this batch in ONE launch sequence (rebuild_targets_each_run)
-    c->h_tsegs.clear(); c->h_tblocks.clear();
-    int tflat = 0, tbucket = 0;
+    c->h_tsegs.clear(); c->h_tblocks.clear(); c->h_tchunks.clear();
+    int tflat = 0, tbucket = 0, tstrip = 0;
+    c->t_max_units = 0; c->t_max_ucells = 0;
+    bool strips_fit = true;
     for (int slot : c->batch_slots)
         for (int k = 0; k < 2; ++k) {
             Target& t = c->targets[(size_t)slot];
@@ -597,19 +599,37 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             ts.ox = t.g[k].ox; ts.oy = t.g[k].oy; ts.oz = t.g[k].oz; ts.inv_cell = t.g[k].inv_cell;
             ts.nx = t.g[k].nx; ts.ny = t.g[k].ny; ts.nz = t.g[k].nz;
             ts.grid_id = slot * 2 + k;
+            ts.strip_base = tstrip;
+            ts.ystrip = std::max(1, std::min(ts.ny, (c->strip_cells + ts.nz / 2) / std::max(ts.nz, 1)));
+            ts.nstrips = (ts.ny + ts.ystrip - 1) / ts.ystrip;
             const int id = (int)c->h_tsegs.size();
             c->h_tsegs.push_back(ts);
             for (int s = 0; s < ts.n; s += kBlockQ) c->h_tblocks.push_back(BlockDesc{ id, s, std::min(kBlockQ, ts.n - s), 0 });
+            for (int s = 0; s < ts.n; s += kPartChunkHost) c->h_tchunks.push_back(BlockDesc{ id, s, std::min(kPartChunkHost, ts.n - s), 0 });
             tflat += ts.n; tbucket += ts.n_cells;
+            if (ts.n > 0) {
+                const int units = ts.nx * ts.nstrips;
+                tstrip += units; c->t_max_units = std::max(c->t_max_units, units); c->t_max_ucells = std::max(c->t_max_ucells, ts.ystrip * ts.nz);
+                strips_fit = strips_fit && units <= kMaxStrips;
+            }
         }
-    c->t_elems = tflat; c->t_buckets = std::max(tbucket, 1);
+    c->t_elems = tflat; c->t_buckets = std::max(tbucket, 1); c->t_strips = tstrip;
+    strips_fit = strips_fit && ((size_t)c->t_max_ucells + 1) * 4 + (size_t)c->strip_cap * 6 + 8192 <= kStripLdsLarge;
+    // auto = the strip form whenever the grids fit it: measured faster from 2 own-target items up (index 0.063 vs 0.078 ms) to 256
+    // (2.2 vs 5.3 ms), and equal for the single shared submap of configs[1]
+    c->strip_now = strips_fit && c->index_build != 0;
+    if (c->index_build == 1 && !c->strip_now)
+        return fail(c, LISREG_ERR_ARG, "index_build 1: a target grid of this batch does not fit the strip form (strips per target or cells per strip)");
+    HIPCHK(c, c->tchunk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tchunks.size(), 1)));
+    HIPCHK(c, c->strip_tab.ensure(sizeof(int) * (3 * ((size_t)tstrip + 4) + (size_t)tstrip / 2048 + 8)));
     HIPCHK(c, c->tseg_dev.ensure(sizeof(TargetSeg) * std::max<size_t>(c->h_tsegs.size(), 1)));
     HIPCHK(c, c->tblk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tblocks.size(), 1)));
     // every table crosses PCIe from ONE pinned staging buffer: five asynchronous copies, no host synchronisation
     // (pageable sources would make each hipMemcpyAsync a blocking staged copy — most of a single registration's latency)
     {
         struct Part { const void* src; size_t bytes; void* dst; };
-        const Part parts[6] = {
+        const Part parts[7] = {
+            { c->h_tchunks.data(), sizeof(BlockDesc) * c->h_tchunks.size(), c->tchunk_dev.p },
             { c->h_blocks_q.data(), sizeof(BlockDesc) * c->h_blocks_q.size(), c->blocks_q.p },
             { c->h_blocks.data(), sizeof(BlockDesc) * (size_t)c->n_blocks, c->blocks.p },
             { c->h_segs.data(), sizeof(Segment) * (size_t)c->n_segs, c->segs.p },
@@ -667,8 +687,17 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     hipStream_t st = c->stream;
     if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
         prof_mark(c, 2);
-        launch_build_targets_batched(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
-                                     (int)c->h_tsegs.size(), c->t_elems, c->t_buckets, sort_buffers(c), st);
+        if (c->strip_now) {
+            StripBuffers sl;
+            sl.cnt = c->strip_tab.as<int>(); sl.fill = sl.cnt + (c->t_strips + 1); sl.start = sl.fill + (c->t_strips + 1);
+            sl.scan_tmp = sl.start + (c->t_strips + 2);
+            sl.tmp_pts = c->tmp_pts.as<float4>(); sl.slot_idx = c->elem_bucket.as<uint32_t>(); sl.slot_pos = c->elem_sub.as<uint32_t>();
+            if (launch_build_targets_strips(c->tchunk_dev.as<BlockDesc>(), (int)c->h_tchunks.size(), c->tseg_dev.as<TargetSeg>(),
+                                            (int)c->h_tsegs.size(), c->t_strips, c->t_max_units, c->t_max_ucells, c->strip_cap, sl, st))
+                return fail(c, LISREG_ERR_HIP, "strip index build: LDS configuration refused");
+        } else
+            launch_build_targets_batched(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
+                                         (int)c->h_tsegs.size(), c->t_elems, c->t_buckets, sort_buffers(c), st);
         if (c->mode_now == 3)
             launch_build_graph(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
                                c->grids_dev.as<GridIndex>(), c->graph_radius, st);
@@ -765,9 +794,16 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "graph_radius_mm")) { c->graph_radius = 1e-3f * (float)value; for (auto& t : c->targets) t.graph_valid[0] = t.graph_valid[1] = false; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
+    if (!strcmp(name, "index_build")) {
+        if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "index_build: 0 bucket sort, 1 strip form, 2 auto");
+        c->index_build = value; c->prepared = false;
+        return LISREG_OK;
+    }
+    if (!strcmp(name, "index_strip_cells")) { c->strip_cells = std::max(value, 1); c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "index_strip_cap")) { c->strip_cap = std::min(std::max(value, 64), 16384); c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "count_searches")) {
         c->count_searches = value != 0;
-        if (c->count_searches) { HIPCHK(c, c->counters.ensure(64 * 8)); HIPCHK(c, hipMemset(c->counters.p, 0, 64 * 8)); }
+        if (c->count_searches) { HIPCHK(c, c->counters.ensure(128 * 8)); HIPCHK(c, hipMemset(c->counters.p, 0, 128 * 8)); }
         return LISREG_OK;
     }
     if (!strcmp(name, "lanes_per_query")) { c->lanes_per_query_auto = value != 1; c->prepared = false; return LISREG_OK; }   // 1 forces one lane per query, anything else = auto
@@ -782,6 +818,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
 {
     if (!c || !name || !value) return LISREG_ERR_ARG;
     if (!strcmp(name, "search_mode")) { *value = c->search_mode; return LISREG_OK; }
+    if (!strcmp(name, "index_build")) { *value = c->index_build; return LISREG_OK; }
+    if (!strcmp(name, "index_build_now")) { *value = c->strip_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }
     if (!strcmp(name, "lanes_per_query")) { *value = c->lanes_q; return LISREG_OK; }          // what the prepared batch runs (auto resolved)
     if (!strcmp(name, "sort_sources")) { *value = c->sort_sources; return LISREG_OK; }
@@ -909,11 +947,32 @@ int lisreg_get_counters(lisreg_ctx* c, unsigned long long* out, int n)
     for (int i = 0; i < n; ++i) out[i] = 0;
     if (!c->counters.p) return LISREG_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->counters.p, sizeof(unsigned long long) * (size_t)std::min(n, 64), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->counters.p, sizeof(unsigned long long) * (size_t)std::min(n, 128), hipMemcpyDeviceToHost));
     if (c->mode_now == 3) {              // the graph scan packs (walked << 32 | valid) per GN iteration: unpack to the pair layout
         unsigned long long tmp[64] = { 0 };
         for (int i = 0; i < 32 && 2 * i + 1 < n; ++i) { tmp[2 * i] = out[i] >> 32; tmp[2 * i + 1] = out[i] & 0xffffffffull; }
         for (int i = 0; i < std::min(n, 64); ++i) out[i] = tmp[i];
+    }
+    return LISREG_OK;
+}
+
+int lisreg_get_target_index(lisreg_ctx* c, int slot, int kind, int* dims /* n, nx, ny, nz, n_cells */, float* geom /* ox, oy, oz, cell */,
+                            float* sorted_out, int sorted_capacity, int* cell_start_out, int cell_capacity)
+{
+    if (!c || slot < 0 || (size_t)slot >= c->targets.size() || kind < 0 || kind > 1 || !c->targets[(size_t)slot].valid)
+        return fail(c, LISREG_ERR_ARG, "get_target_index: no such target");
+    const Target& t = c->targets[(size_t)slot];
+    const GridIndex& g = t.g[kind];
+    if (dims) { dims[0] = t.n[kind]; dims[1] = g.nx; dims[2] = g.ny; dims[3] = g.nz; dims[4] = t.n_cells[kind]; }
+    if (geom) { geom[0] = g.ox; geom[1] = g.oy; geom[2] = g.oz; geom[3] = g.cell; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sorted_out) {
+        if (sorted_capacity < t.n[kind]) return fail(c, LISREG_ERR_ARG, "get_target_index: sorted_capacity too small");
+        if (t.n[kind] > 0) HIPCHK(c, hipMemcpy(sorted_out, t.sorted[kind].p, sizeof(float4) * (size_t)t.n[kind], hipMemcpyDeviceToHost));
+    }
+    if (cell_start_out) {
+        if (cell_capacity < t.n_cells[kind] + 1) return fail(c, LISREG_ERR_ARG, "get_target_index: cell_capacity too small");
+        HIPCHK(c, hipMemcpy(cell_start_out, t.cell_start[kind].p, sizeof(int) * ((size_t)t.n_cells[kind] + 1), hipMemcpyDeviceToHost));
     }
     return LISREG_OK;
 }

@@ -388,7 +388,18 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
 {
     float cf[4];
     const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
+    // ablation builds (-DLISREG_ABL_FIT2 / -DLISREG_ABL_RED2, tests/pmc_periter.sh): the model fit resp. the row + reduction run
+    // twice with identical results, so the difference in VALU instructions and time per launch is that stage's cost
+#ifdef LISREG_ABL_FIT2
+    { float cf2[4]; float qx2 = qx; int j0 = i0; asm volatile("" : "+v"(qx2), "+v"(j0));
+      const bool ok2 = residual_coeffs(valid, j0, i1, i2, i3, i4, g, q4, qx2, qy, qz, P, kind, cf2);
+      if (ok2 && cf2[0] == 12345.f && cf2[3] == 54321.f) cf[0] += 1.f; }
+#endif
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
+#ifdef LISREG_ABL_RED2
+    { float cf2[4] = { cf[0], cf[1], cf[2], cf[3] }; asm volatile("" : "+v"(cf2[0]), "+v"(cf2[1]), "+v"(cf2[2]), "+v"(cf2[3]));
+      row_and_reduce(ok, cf2, q4, sc, P, s_acc, out); __syncthreads(); }
+#endif
     row_and_reduce(ok, cf, q4, sc, P, s_acc, out);
 }
 
@@ -835,7 +846,10 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
         if (counters && it->iter > 0 && it->iter < 32) {       // diagnostics: lanes that fell back to the cell walk
             const int nw = __popcll(__ballot(need_walk)), nv = __popcll(__ballot(valid));
-            if ((tid & 63) == 0) atomicAdd(&counters[it->iter], ((unsigned long long)nw << 32) | (unsigned long long)nv);
+            if ((tid & 63) == 0) {
+                atomicAdd(&counters[it->iter], ((unsigned long long)nw << 32) | (unsigned long long)nv);
+                atomicAdd(&counters[64 + it->iter], ((unsigned long long)(nw > 0) << 32) | (unsigned long long)(nv > 0));   // waves
+            }
         }
         if (need_walk) {
             int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;
@@ -915,8 +929,18 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     if (dbg_nn && valid && (kQ == 1 || sub_q == 0)) {     // "dump_neighbors" (tests): ORIGINAL indices of the five neighbours, -1 = none
         const int ids[5] = { i0, i1, i2, i3, i4 };
+        bool same = true;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dbg_nn[(size_t)k * n_elems + qflat] = ids[k] >= 0 ? __float_as_int(pts[ids[k]].w) : -1;
+        for (int k = 0; k < 5; ++k) {
+            const int o = ids[k] >= 0 ? __float_as_int(pts[ids[k]].w) : -1;
+            same = same && dbg_nn[(size_t)k * n_elems + qflat] == o;
+            dbg_nn[(size_t)k * n_elems + qflat] = o;
+        }
+        if (counters && it->iter > 0 && it->iter < 32) {       // diagnostics: queries whose ordered neighbour set did not change
+            const unsigned long long m = __ballot(same);
+            if (__ffsll((long long)__ballot(true)) - 1 == (tid & 63))
+                atomicAdd(&counters[96 + it->iter], ((unsigned long long)__popcll(m) << 32) | (unsigned long long)(m == __ballot(true)));
+        }
     }
     // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);

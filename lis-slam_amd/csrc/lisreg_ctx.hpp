@@ -76,7 +76,7 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
-    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, done_dev,
+    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, tchunk_dev, strip_tab, done_dev,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_cat, ft_bounds, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
@@ -94,6 +94,11 @@ struct lisreg_ctx {
     int       fetch_trace_records = 0;      // lisreg_align: trace records copied out together with the results
     std::vector<lisreg::TargetSeg> h_tsegs;
     std::vector<lisreg::BlockDesc> h_tblocks;
+    std::vector<lisreg::BlockDesc> h_tchunks;          // the same targets in chunks of kPartChunkHost points (strip form of the build)
+    int       t_strips = 0, t_max_units = 0, t_max_ucells = 0;
+    int       index_build = 2;                          // 0 bucket sort, 1 strip form (error if a grid does not fit it), 2 strip form whenever it fits
+    int       strip_cells = 2048, strip_cap = 2048;     // cells per strip aimed at; points per strip of the small-workgroup variant
+    bool      strip_now = false;
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
     bool      dump_neighbors = false;   // tests: keep the five neighbour ids of every query of the last iteration run

@@ -376,6 +376,175 @@ __global__ __launch_bounds__(256) void k_tseg_cell_starts(const TargetSeg* __res
 }
 
 
+// ---- batched target builds, strip form ----------------------------------------------------------------------------------
+// The bucket sort above pays one global atomic per point on a random cell: 12.8 M of them take 0.51-0.55 ms on an MI355X
+// whatever the table size (0.4 MB or 172 MB, tests/probes/atomic_probe.hip) — the L2 atomic units serve ~24 G scattered
+// requests/s — while the same count on consecutive addresses takes 0.036 ms and a 4096-bin LDS histogram per 4096 points
+// 0.09 ms.  So the points are first partitioned into STRIPS — the cells of one ix and a run of `ystrip` consecutive iy, i.e. a
+// contiguous range of cell ids ((ix * ny + iy) * nz + iz) — with an LDS histogram per 4096-point chunk and one global atomic
+// per chunk and non-empty strip; then ONE workgroup per (target, strip) finishes its strip entirely in LDS: cell histogram,
+// scan, placement, order inside the cells by original index, the strip's stretch of cell_start, the sorted records.  Strip
+// offsets + in-strip offsets ARE the global cell starts: no pass over the cell table of the whole batch (43 M cells for
+// 64 x 2 targets), no memset of it, no scan beyond the strip counts.  Same output as the bucket sort, bit for bit.
+constexpr int kPartChunk   = kPartChunkHost;   // points per workgroup of the partition passes
+constexpr int kPartThreads = 1024;
+
+__device__ __forceinline__ int strip_of(const TargetSeg& t, float x, float y)
+{
+    return cell_coord(x, t.ox, t.inv_cell, t.nx) * t.nstrips + cell_coord(y, t.oy, t.inv_cell, t.ny) / t.ystrip;
+}
+
+// kScatter = false: strip populations (cnt);  true: move the records (x, y, z, original index) to their strip's stretch of tmp_pts
+template <bool kScatter>
+__global__ __launch_bounds__(kPartThreads) void k_strip_partition(const BlockDesc* __restrict__ chunks, const TargetSeg* __restrict__ tsegs,
+                                                                  int* __restrict__ cnt, const int* __restrict__ start,
+                                                                  int* __restrict__ fill, float4* __restrict__ tmp_pts)
+{
+    __shared__ int s_hist[kMaxStrips];
+    const BlockDesc bd = chunks[blockIdx.x];
+    const TargetSeg t = tsegs[bd.seg];
+    const int tid = threadIdx.x, n_units = t.nx * t.nstrips;
+    for (int k = tid; k < n_units; k += kPartThreads) s_hist[k] = 0;
+    __syncthreads();
+    float4 p[kPartChunk / kPartThreads];
+    int u[kPartChunk / kPartThreads], r[kPartChunk / kPartThreads];
+#pragma unroll
+    for (int k = 0; k < kPartChunk / kPartThreads; ++k) {
+        const int e = k * kPartThreads + tid;
+        u[k] = -1; r[k] = 0;
+        if (e < bd.count) {
+            p[k] = t.raw[bd.start + e];
+            u[k] = strip_of(t, p[k].x, p[k].y);
+            if (kScatter) r[k] = atomicAdd(&s_hist[u[k]], 1); else atomicAdd(&s_hist[u[k]], 1);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < n_units; k += kPartThreads) {
+        const int c = s_hist[k];
+        if (c) {
+            if (kScatter) s_hist[k] = start[t.strip_base + k] + atomicAdd(&fill[t.strip_base + k], c);
+            else atomicAdd(&cnt[t.strip_base + k], c);
+        }
+    }
+    if (kScatter) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPartChunk / kPartThreads; ++k)
+            if (u[k] >= 0) {
+                float4 v = p[k];
+                v.w = __int_as_float(bd.start + k * kPartThreads + tid);
+                tmp_pts[s_hist[u[k]] + r[k]] = v;
+            }
+    }
+}
+
+// slot tables of one strip: in LDS (16-bit positions: a strip in LDS holds < 65536 points), or — a strip too big for LDS — in
+// global scratch, read back past the L1 (the workgroup reads what other wavefronts of it wrote)
+struct SlotsLds {
+    uint32_t* idx; uint16_t* pos;
+    __device__ __forceinline__ void put(int s, uint32_t i, int p) const { idx[s] = i; pos[s] = (uint16_t)p; }
+    __device__ __forceinline__ uint32_t get_idx(int s) const { return idx[s]; }
+    __device__ __forceinline__ int get_pos(int s) const { return pos[s]; }
+};
+struct SlotsGlobal {
+    uint32_t* idx; uint32_t* pos;
+    __device__ __forceinline__ void put(int s, uint32_t i, int p) const { idx[s] = i; pos[s] = (uint32_t)p; }
+    __device__ __forceinline__ uint32_t get_idx(int s) const { return __hip_atomic_load(&idx[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ int get_pos(int s) const { return (int)__hip_atomic_load(&pos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+
+// exclusive scan of one value per thread across an NT-thread workgroup
+template <int NT>
+__device__ __forceinline__ int block_excl_scan_nt(int v, int* s_wave /* [NT / 64] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) if (w < wave) base += s_wave[w];
+    __syncthreads();
+    return base + inc - v;
+}
+
+template <int NT, typename Slots>
+__device__ __forceinline__ void strip_build_body(const TargetSeg& t, int y0, int cell0, int ucells, int s0, int n_s,
+                                                 int* hist /* LDS [ucells + 1] */, const Slots sl, const float4* __restrict__ tmp, int* s_wave)
+{
+    const int tid = threadIdx.x;
+    auto ucell = [&](const float4& v) { return (cell_coord(v.y, t.oy, t.inv_cell, t.ny) - y0) * t.nz + cell_coord(v.z, t.oz, t.inv_cell, t.nz); };
+    for (int c = tid; c <= ucells; c += NT) hist[c] = 0;
+    __syncthreads();
+    for (int p = tid; p < n_s; p += NT) atomicAdd(&hist[ucell(tmp[s0 + p])], 1);
+    __syncthreads();
+    {   // in-place INCLUSIVE scan (cell ends): every thread owns a run of cells
+        const int L = (ucells + NT - 1) / NT, b = tid * L;
+        int sum = 0;
+        for (int i = 0; i < L; ++i) if (b + i < ucells) sum += hist[b + i];
+        int run = block_excl_scan_nt<NT>(sum, s_wave);
+        for (int i = 0; i < L; ++i) if (b + i < ucells) { run += hist[b + i]; hist[b + i] = run; }
+        if (tid == 0) hist[ucells] = n_s;
+    }
+    __syncthreads();
+    // placement from the cell ends downwards (arrival order inside a cell is arbitrary; the last pass orders it): afterwards
+    // hist[c] is the cell's START
+    for (int p = tid; p < n_s; p += NT) {
+        const float4 v = tmp[s0 + p];
+        const int slot = atomicSub(&hist[ucell(v)], 1) - 1;
+        sl.put(slot, (uint32_t)__float_as_int(v.w), p);
+    }
+    __syncthreads();
+    const int rel = s0 - t.flat_base;                       // the strip's first record in the target's own sorted array
+    {
+        int* cs = t.cell_start_out + cell0;
+        for (int c = tid; c < ucells; c += NT) cs[c] = rel + hist[c];
+        if (cell0 + ucells == t.n_cells && tid == 0) t.cell_start_out[t.n_cells] = t.n;
+    }
+    for (int s = tid; s < n_s; s += NT) {
+        const float4 v = tmp[s0 + sl.get_pos(s)];
+        const int c = ucell(v);
+        const int a = hist[c], e = hist[c + 1];
+        const uint32_t idx = (uint32_t)__float_as_int(v.w);
+        int rank = 0;
+        for (int j = a; j < e; ++j) rank += sl.get_idx(j) < idx ? 1 : 0;
+        t.sorted_out[rel + a + rank] = v;
+    }
+}
+
+// kLarge = false: strips of at most cap_small points, 256 threads, several workgroups per CU;  true: the rest, 1024 threads and as
+// much LDS as a workgroup can have — and global slot tables for a strip that still does not fit
+template <bool kLarge>
+__global__ __launch_bounds__(kLarge ? 1024 : 256) void k_strip_build(const TargetSeg* __restrict__ tsegs, const int* __restrict__ start,
+                                                                     const float4* __restrict__ tmp_pts, int cap_small, int cap_large,
+                                                                     uint32_t* __restrict__ g_slot_idx, uint32_t* __restrict__ g_slot_pos)
+{
+    constexpr int NT = kLarge ? 1024 : 256;
+    extern __shared__ int s_dyn[];
+    __shared__ int s_wave[NT / 64];
+    const TargetSeg t = tsegs[blockIdx.y];
+    const int unit = blockIdx.x;
+    if (t.n <= 0) { if (!kLarge && unit == 0 && threadIdx.x == 0) t.cell_start_out[0] = 0; return; }
+    if (unit >= t.nx * t.nstrips) return;
+    const int s0 = start[t.strip_base + unit], n_s = start[t.strip_base + unit + 1] - s0;
+    if (kLarge ? (n_s <= cap_small) : (n_s > cap_small)) return;
+    const int ix = unit / t.nstrips, ys = unit - ix * t.nstrips;
+    const int y0 = ys * t.ystrip, y1 = min(t.ny, y0 + t.ystrip);
+    const int cell0 = (ix * t.ny + y0) * t.nz, ucells = (y1 - y0) * t.nz;
+    const int ucap = t.ystrip * t.nz;                       // table size the launch was dimensioned for
+    const int cap = kLarge ? cap_large : cap_small;
+    if (!kLarge || n_s <= cap) {
+        SlotsLds sl;
+        sl.idx = (uint32_t*)(s_dyn + ucap + 1);
+        sl.pos = (uint16_t*)(sl.idx + cap);
+        strip_build_body<NT>(t, y0, cell0, ucells, s0, n_s, s_dyn, sl, tmp_pts, s_wave);
+    } else {
+        SlotsGlobal sl;
+        sl.idx = g_slot_idx + s0; sl.pos = g_slot_pos + s0;
+        strip_build_body<NT>(t, y0, cell0, ucells, s0, n_s, s_dyn, sl, tmp_pts, s_wave);
+    }
+}
+
 // ---- k-NN graph over a finished target index (search_mode 3) -----------------------------------------------------------
 // For every sorted point s: up to kGraphK nearest OTHER points (sorted positions, ascending by distance) and a coverage
 // radius rho(s) with the guarantee  |x - s| < rho(s)  =>  x is in the list  (and every listed point is within rho).
@@ -745,6 +914,32 @@ void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const T
         k_tseg_rank_pts<<<(n_elems + 255) / 256, 256, 0, st>>>(tsegs, n_tsegs, n_elems, sb.tmp_pts, sb.bucket_start);
     }
     k_tseg_cell_starts<<<dim3(64, n_tsegs), 256, 0, st>>>(tsegs, n_tsegs, sb.bucket_start);
+}
+
+int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const TargetSeg* tsegs, int n_tsegs, int n_strips, int max_units,
+                                int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st)
+{
+    if (n_tsegs <= 0) return 0;
+    const size_t hist_bytes = (size_t)(max_strip_cells + 1) * 4;
+    const size_t lds_small = hist_bytes + (size_t)cap_small * 6;
+    if (hist_bytes + 6 * 1024 > kStripLdsLarge || lds_small > kStripLdsLarge) return 2;
+    const int cap_large = (int)std::min<size_t>((kStripLdsLarge - hist_bytes) / 6, 65535);
+    const size_t lds_large = hist_bytes + (size_t)cap_large * 6;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_build<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsLarge);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_build<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsLarge);
+        if (e1 != hipSuccess || e2 != hipSuccess) return 1;
+        attr_set = true;
+    }
+    (void)hipMemsetAsync(sb.cnt, 0, sizeof(int) * 2 * (size_t)(n_strips + 1), st);          // cnt and fill are one allocation
+    if (n_chunks > 0) k_strip_partition<false><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, sb.cnt, nullptr, nullptr, nullptr);
+    exclusive_scan(sb.cnt, sb.start, sb.scan_tmp, n_strips, st);
+    if (n_chunks > 0) k_strip_partition<true><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, nullptr, sb.start, sb.fill, sb.tmp_pts);
+    const dim3 grid((unsigned)std::max(max_units, 1), (unsigned)n_tsegs);
+    k_strip_build<false><<<grid, 256, lds_small, st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
+    k_strip_build<true><<<grid, 1024, lds_large, st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
+    return 0;
 }
 
 void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, float radius,

@@ -56,6 +56,8 @@ struct TargetSeg {
     float ox, oy, oz, inv_cell;
     int   nx, ny, nz;
     int   grid_id;             // entry of the device GridIndex array this target fills (slot * 2 + kind)
+    int   strip_base;          // strip form of the build (lisreg_index.hip): first strip of this target in the batch-wide tables,
+    int   ystrip, nstrips;     // iy cells per strip, strips per ix
 };
 
 // One workgroup of the correspondence kernel (also the unit of the source-key kernel).
@@ -124,6 +126,22 @@ void launch_build_target(const float4* pts, int n, GridIndex g, float4* sorted_o
 // several target indexes in one launch sequence (blocks: seg = TargetSeg id, start/count = point chunk)
 void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, int n_tsegs,
                                   int n_elems, int n_buckets, SortBuffers sb, hipStream_t st);
+// the same build in strip form (lisreg_index.hip): partition into strips (one ix, a run of iy), then one workgroup per
+// (target, strip) in LDS.  chunks: seg = TargetSeg id, start/count = point chunk of at most kPartChunkHost points.
+constexpr int    kPartChunkHost = 4096;
+constexpr int    kMaxStrips     = 8192;          // strips of one target the partition histogram holds
+constexpr size_t kStripLdsLarge = 150 * 1024;    // LDS budget of the one-per-CU variant: cell table of a strip + 6 bytes per point
+struct StripBuffers {
+    int*      cnt;             // [n_strips + 1] populations       } one allocation, zeroed per build
+    int*      fill;            // [n_strips + 1] scatter cursors   }
+    int*      start;           // [n_strips + 1] first flat position of every strip
+    int*      scan_tmp;        // [n_strips / 2048 + 4]
+    float4*   tmp_pts;         // [n_elems] records by strip
+    uint32_t* slot_idx;        // [n_elems] } slot tables of strips too big for LDS
+    uint32_t* slot_pos;        // [n_elems] }
+};
+int  launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const TargetSeg* tsegs, int n_tsegs, int n_strips, int max_units,
+                                 int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st);
 // k-NN graph of every target in `tsegs` (grids[t.grid_id] must describe the finished index and carry nbr / nbr_meta)
 void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, float radius,
                         hipStream_t st);

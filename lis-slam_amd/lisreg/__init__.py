@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
@@ -182,6 +182,7 @@ def lib():
         L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+        L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lisreg_get_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
         L.lisreg_set_profiling.argtypes = [vp, C.c_int]
@@ -438,6 +439,28 @@ class Context:
         out = (C.c_ulonglong * 64)()
         self._chk(self._L.lisreg_get_counters(self._h, out, 64))
         return np.array(out[:], np.int64).reshape(32, 2)
+
+    def target_index(self, slot: int = 0, kind: int = 1) -> dict:
+        """Diagnostics: the device search index of a target (see lisreg_get_target_index)."""
+        dims = (C.c_int * 5)(); geom = (C.c_float * 4)()
+        self._chk(self._L.lisreg_get_target_index(self._h, slot, kind, dims, geom, None, 0, None, 0))
+        n, nx, ny, nz, nc = [int(v) for v in dims]
+        pts = np.zeros((max(n, 1), 4), np.float32); cs = np.zeros(nc + 1, np.int32)
+        self._chk(self._L.lisreg_get_target_index(self._h, slot, kind, dims, geom, pts.ctypes.data, n, cs.ctypes.data, nc + 1))
+        return dict(n=n, nx=nx, ny=ny, nz=nz, n_cells=nc, origin=np.array(geom[:3], np.float32), cell=float(geom[3]),
+                    sorted=pts[:n], cell_start=cs)
+
+    def raw_counters(self):
+        out = (C.c_ulonglong * 128)()
+        self._chk(self._L.lisreg_get_counters(self._h, out, 128))
+        return [int(v) for v in out]
+
+    def wave_counters(self) -> np.ndarray:
+        """Graph front-end only: per GN iteration (wavefronts with at least one lane in the cell walk, wavefronts)."""
+        out = (C.c_ulonglong * 128)()
+        self._chk(self._L.lisreg_get_counters(self._h, out, 128))
+        raw = np.array(out[64:96], np.uint64)
+        return np.stack([(raw >> np.uint64(32)).astype(np.int64), (raw & np.uint64(0xffffffff)).astype(np.int64)], 1)
 
     # -- §8 f-1 -------------------------------------------------------------------------------------------
     def voxel_downsample(self, cloud: np.ndarray, leaf: float):

@@ -1,0 +1,80 @@
+"""The target search index (uniform grid, records ordered by (cell, original index), cell_start) in both device build forms —
+the bucket sort (one global atomic per point) and the slab form (x-slab partition + one workgroup per slab in LDS) — against a
+numpy restatement of the ordering, bit for bit.  Covers many targets per launch sequence (own-target batches, BASELINE configs[3]),
+empty and tiny targets, a cloud that lives in ONE x-slab (the slab too big for LDS: global slot tables), and clouds with points
+outside the grid's clamped range.  This replaces the two pcl::KdTreeFLANN::setInputCloud calls per registration
+(/root/reference/src/node/odomEstimationNode.cpp:602-603)."""
+import numpy as np
+import pytest
+
+
+def _expected(idx, cloud_xyz):
+    """numpy restatement: cell of every point (float32 arithmetic as on the device), stable order by cell then index."""
+    o, inv = idx["origin"], np.float32(1.0) / np.float32(idx["cell"])
+    dims = (idx["nx"], idx["ny"], idx["nz"])
+    c = []
+    for a in range(3):
+        v = np.floor((cloud_xyz[:, a].astype(np.float32) - o[a]) * inv).astype(np.int64)
+        c.append(np.clip(v, 0, dims[a] - 1))
+    cell = (c[0] * dims[1] + c[1]) * dims[2] + c[2]
+    order = np.lexsort((np.arange(len(cell)), cell))
+    cs = np.zeros(idx["n_cells"] + 1, np.int64)
+    np.add.at(cs, cell + 1, 1)
+    return order, np.cumsum(cs)
+
+
+def _check(ctx, slot, kind, cloud):
+    import lisreg
+    idx = ctx.target_index(slot, kind)
+    xyz = lisreg.synth.pcl_xyz(cloud)
+    assert idx["n"] == len(cloud)
+    if len(cloud) == 0:
+        return
+    order, cs = _expected(idx, xyz)
+    assert np.array_equal(idx["cell_start"], cs), "cell_start"
+    assert np.array_equal(idx["sorted"][:, 3].view(np.int32), order.astype(np.int32)), "record order (cell, original index)"
+    assert np.array_equal(idx["sorted"][:, :3], xyz[order].astype(np.float32))
+
+
+def _clouds(seed):
+    from lisreg import synth
+    rng = np.random.default_rng(seed)
+    tc, ts = synth.make_submap(30000 + 1000 * seed, 300 + seed)
+    wall = np.zeros((40000, 3), np.float32)                     # one x-slab, 40 k points: beyond the LDS capacity of a slab
+    wall[:, 0] = 3.0 + rng.uniform(0, 0.2, len(wall)); wall[:, 1] = rng.uniform(-30, 30, len(wall)); wall[:, 2] = rng.uniform(-1, 6, len(wall))
+    thick = np.concatenate([rng.uniform(-40, 40, (20000, 3)).astype(np.float32) * np.array([1, 1, 0.1], np.float32), wall[:25000]])
+    return tc, ts, synth.to_pcl(wall, np.zeros(len(wall), np.uint16)), synth.to_pcl(thick, np.zeros(len(thick), np.uint16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [0, 1])
+def test_batched_index_build_is_exactly_cell_then_index_order(gpu_ctx, form):
+    import lisreg
+    from lisreg import synth
+    tc, ts, wall, thick = _clouds(1)
+    tc2, ts2, _, _ = _clouds(2)
+    empty = synth.to_pcl(np.zeros((0, 3), np.float32), np.zeros(0, np.uint16))
+    tiny = synth.to_pcl(np.array([[0, 0, 0], [0.1, 0, 0], [5, 5, 1], [5, 5.01, 1], [-3, 2, 0]], np.float32), np.zeros(5, np.uint16))
+    targets = [(tc, ts), (tc2, wall), (tiny, thick), (empty, ts2)]
+    for s, (a, b) in enumerate(targets):
+        gpu_ctx.set_target(a, b, slot=s)
+    sc = synth.make_scan(16, 300, 77)
+    items = [dict(src_corner=sc["corner"], src_surf=sc["surf"], target=s) for s in range(len(targets))]
+    p = lisreg.default_params(1); p.fixed_iters = 2
+    gpu_ctx.set_option("index_build", form); gpu_ctx.set_option("rebuild_targets_each_run", 1)
+    try:
+        gpu_ctx.align_batch(items, np.tile(sc["T_true"].astype(np.float32), (len(targets), 1)), p)
+        assert gpu_ctx.get_option("index_build_now") == form
+        for s, (a, b) in enumerate(targets):
+            _check(gpu_ctx, s, 0, a)
+            _check(gpu_ctx, s, 1, b)
+    finally:
+        gpu_ctx.set_option("index_build", 2); gpu_ctx.set_option("rebuild_targets_each_run", 0)
+
+
+@pytest.mark.gpu
+def test_single_target_build_matches_too(gpu_ctx):
+    tc, ts, wall, thick = _clouds(3)
+    gpu_ctx.set_target(tc, thick, slot=0)
+    _check(gpu_ctx, 0, 0, tc)
+    _check(gpu_ctx, 0, 1, thick)
