@@ -188,9 +188,13 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * certificate, 3 k-NN graph scan with the walk as its fall-back, 4 auto [default]: 3 when the prepared batch asks at
  * least "graph_min_ratio" query-iterations per target point, else 1 — all return the same neighbours),
  * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
+ * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
+ * point, 1 strip form — LDS histograms, one workgroup per strip of cells; an error if a grid does not fit its LDS tables —,
+ * 2 [default] strip form whenever the grids fit; both produce the same index bit for bit), "index_strip_cells", "index_strip_cap",
  * "graph_min_ratio", "graph_radius_mm", "cert_slack_mm", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
-/* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved). */
+/* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
+ * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form. */
 int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
 
 /* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):

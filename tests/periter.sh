@@ -4,7 +4,7 @@ cd $R
 python - <<'PY'
 import csv,glob,collections
 f=glob.glob('gpurun_out/periter/**/*kernel_trace.csv',recursive=True)[0]
-rows=[r for r in csv.DictReader(open(f)) if 'k_assoc_walk' in r['Kernel_Name']]
+rows=[r for r in csv.DictReader(open(f)) if 'k_assoc_' in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 d=collections.defaultdict(list)
 for i,r in enumerate(rows): d[i%10].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)

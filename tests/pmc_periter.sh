@@ -9,7 +9,7 @@ import csv,glob,collections
 rows=collections.defaultdict(dict)
 for fn in glob.glob('gpurun_out/pmc_periter/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(fn)):
-        if 'k_assoc_walk' in r['Kernel_Name']:
+        if 'k_assoc_' in r['Kernel_Name']:
             rows[int(r['Dispatch_Id'])][r['Counter_Name']]=float(r['Counter_Value'])
 ids=sorted(rows)
 per=collections.defaultdict(lambda: collections.defaultdict(list))
