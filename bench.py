@@ -8,7 +8,7 @@ already resident in HBM: target index build (the reference rebuilds both kd-tree
 odomEstimationNode.cpp:602-603; here once per batch because the submap is shared), 10 x {correspondence +
 normal-equation kernel, solve kernel}, finalize.
 
-  python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg4|cfg5]
+  python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg4|cfg5|odom]
 
 Multi-GPU: one process per GPU, independent batches per rank (weak scaling), one RCCL all-gather of the result
 blocks per step.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this script under
@@ -50,6 +50,9 @@ WORKLOADS = {
     "cfg3": (64, 1800, 0, 1, 0, False,
              "configs[2] synthetic stand-in: sequential replay of a synthetic drive (previous pose as the guess, semantic "
              "split -> per-class voxel grid -> label-weighted registration against the sliding local map, early exit)"),
+    "odom": (64, 1800, 0, 1, 0, False,
+             "configs[0] as a sequence: scan-to-map odometry on raw unlabelled 64x1800 sweeps of a synthetic drive (range image + "
+             "LOAM features -> voxel grids -> copy #1 registration against the <= 19 newest keyframes, early exit)"),
     "cfg4": (64, 1800, 200_000, 256, 10, True,
              "configs[3] shape on one GPU: 256 independent registrations, each against its OWN 200k-pt target "
              "(index built per item inside the step), 10 fixed GN iterations"),
@@ -122,9 +125,10 @@ def main():
         assert dist.get_world_size() == args.gpus
     n_gpus = world
 
-    if args.workload == "cfg3":
+    if args.workload in ("cfg3", "odom"):
         from lisreg import replay
-        out = replay.bench_sequence(dev_index, steps=args.steps, warmup=args.warmup) if rank == 0 else None
+        fn = replay.bench_sequence if args.workload == "cfg3" else replay.bench_odometry
+        out = fn(dev_index, steps=args.steps, warmup=args.warmup) if rank == 0 else None
         if use_dist:
             dist.barrier(); dist.destroy_process_group()
         if out is not None:

@@ -374,6 +374,21 @@ int  lisreg_localmap_extract(lisreg_ctx* ctx, int map_id, const float cur_pose[6
 /* Copy one cloud out as 16-byte records (host or device destination): cls 0-4 = the class clouds, 5 / 6 = the corner / surf
  * target of the last extract.  *n_out is always set; LISREG_ERR_ARG if capacity is too small. */
 int  lisreg_localmap_get(lisreg_ctx* ctx, int map_id, int cls, void* out, int capacity, int* n_out);
+/* The odometry node's target (odomEstimationNode.cpp, USING_MULTI_FRAME_TARGET), device-resident:
+ *   _push   = saveKeyFrames (:421-468): the frame's FULL corner / surf feature clouds (host PCL structs or LISREG_FMT_DEVICE records,
+ *             sensor frame) are transformPointCloud'ed by `pose` into the map frame and kept; the oldest frames are dropped until at
+ *             most max_keep remain (the reference keeps fewer than 20: max_keep = 19);
+ *   _target = laserCloudInfoHandler (:185-207) + the two kd-tree builds (:602-603): the kept frames concatenated NEWEST FIRST, voxel
+ *             grids with the two leaf sizes (mappingCornerLeafSize 0.2, mappingSurfLeafSize 0.4), installed as target `target_slot`
+ *             (-1: assembled only).  The target clouds live in the ring until the next _target / _reset of that ring. */
+typedef struct lisreg_keyframes_info {
+    int n_keyframes;                      /* frames kept now                                                 */
+    int n_target_corner, n_target_surf;   /* laserCloud{Corner,Surf}FromMapDS sizes of the last _target call */
+} lisreg_keyframes_info;
+int  lisreg_keyframes_reset(lisreg_ctx* ctx, int ring_id);
+int  lisreg_keyframes_push(lisreg_ctx* ctx, int ring_id, const void* corner, int n_corner, const void* surf, int n_surf, int stride_bytes,
+                           int fmt, const float pose[6], int max_keep, lisreg_keyframes_info* info);
+int  lisreg_keyframes_target(lisreg_ctx* ctx, int ring_id, float corner_leaf, float surf_leaf, int target_slot, lisreg_keyframes_info* info);
 /* updateInitialGuess with neither IMU nor odometry (odomEstimationNode.cpp:351-392; subMapOptmizationNode.cpp:984-1020): the
  * constant-velocity guess T_cur * (T_last^-1 * T_cur). */
 void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6]);

@@ -10,6 +10,7 @@
 //   extract: cur_bbx moved by the current pose (transform_bbx) -> intersection with the map bound + 2 m -> in-place voxel
 //            grids 0.1 / 0.05 / 0.4 / 0.2 / 0.6 -> bbx_filter of every class -> corner target = pole,
 //            surf target = ground + building + dynamic (:1408-1419) -> both target indexes built.
+// Also here: the key-frame ring of the odometry node (lisreg_keyframes_*), the same idea for odomEstimationNode's target.
 // No CPU fallback: without a HIP device these fail with LISREG_ERR_HIP.
 #include "lisreg_ctx.hpp"
 
@@ -257,6 +258,109 @@ int lisreg_localmap_get(lisreg_ctx* c, int map_id, int cls, void* out, int capac
 // updateInitialGuess without IMU / odometry input (odomEstimationNode.cpp:351-392, subMapOptmizationNode.cpp:984-1020): the last
 // frame-to-frame increment applied once more, T_guess = T_cur * (T_last^-1 * T_cur), in Eigen's float arithmetic
 // (pcl::getTransformation, Affine3f::inverse, getTranslationAndEulerAngles).
+// ---- the key-frame target of the odometry node (odomEstimationNode.cpp, USING_MULTI_FRAME_TARGET) ---------------------------
+// saveKeyFrames (:421-468): the frame's full corner / surf feature clouds, transformPointCloud'ed into the map frame, appended;
+// fewer than 20 are kept.  laserCloudInfoHandler (:185-207): target = the kept frames concatenated NEWEST FIRST, voxel grids
+// mappingCornerLeafSize / mappingSurfLeafSize, then both kd-trees (scan2SubMapOptimization :602-603).  Here the frames stay in
+// HBM as 16-byte records; per call the host sees counts only.
+int lisreg_keyframes_reset(lisreg_ctx* c, int ring_id)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (ring_id < 0 || ring_id > 1023) return bad(c, "keyframes_reset: bad ring id");
+    if ((size_t)ring_id >= c->keyrings.size()) c->keyrings.resize((size_t)ring_id + 1);
+    KeyframeRing& r = c->keyrings[(size_t)ring_id];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& f : r.frames) { f.cloud[0].release(); f.cloud[1].release(); }
+    r.frames.clear();
+    r.n_tgt[0] = r.n_tgt[1] = 0;
+    r.valid = true;
+    return LISREG_OK;
+}
+
+int lisreg_keyframes_push(lisreg_ctx* c, int ring_id, const void* corner, int n_corner, const void* surf, int n_surf, int stride, int fmt,
+                          const float pose[6], int max_keep, lisreg_keyframes_info* info)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!pose || n_corner < 0 || n_surf < 0 || (n_corner > 0 && !corner) || (n_surf > 0 && !surf) || max_keep < 1) return bad(c, "keyframes_push: bad argument");
+    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return bad(c, "keyframes_push: unknown fmt");
+    if (fmt != LISREG_FMT_DEVICE && stride < 12) return bad(c, "keyframes_push: bad stride");
+    if (ring_id < 0 || (size_t)ring_id >= c->keyrings.size() || !c->keyrings[(size_t)ring_id].valid) {
+        int rc = lisreg_keyframes_reset(c, ring_id);
+        if (rc) return rc;
+    }
+    KeyframeRing& r = c->keyrings[(size_t)ring_id];
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    KeyframeRing::Frame f;
+    const void* src_h[2] = { corner, surf };
+    const int n[2] = { n_corner, n_surf };
+    for (int k = 0; k < 2; ++k) {
+        f.n[k] = n[k];
+        HIPCHK(c, f.cloud[k].ensure(sizeof(float4) * (size_t)std::max(n[k], 1)));
+        if (n[k] == 0) continue;
+        const float4* src = nullptr;
+        if (fmt == LISREG_FMT_DEVICE) src = static_cast<const float4*>(src_h[k]);
+        else {
+            const size_t bytes = (size_t)n[k] * (size_t)stride;
+            HIPCHK(c, c->raw_upload.ensure(bytes + 32));
+            HIPCHK(c, c->lm_in.ensure(sizeof(float4) * (size_t)n[k]));
+            HIPCHK(c, hipMemcpyAsync(c->raw_upload.p, src_h[k], bytes, hipMemcpyHostToDevice, st));
+            launch_pack_cloud(c->raw_upload.p, (size_t)n[k], stride, fmt == LISREG_FMT_XYZIL, c->lm_in.as<float4>(), st);
+            HIPCHK(c, hipStreamSynchronize(st));     // pageable sources are free to change after the call
+            src = c->lm_in.as<float4>();
+        }
+        int rc = lisreg_transform_cloud(c, src, n[k], 16, LISREG_FMT_DEVICE, pose, f.cloud[k].p);      // transformPointCloud(.., &thisPose6D)
+        if (rc) return rc;
+    }
+    r.frames.push_back(f);
+    while ((int)r.frames.size() > max_keep) {         // while (size() >= 20) erase(begin())  with max_keep = 19
+        HIPCHK(c, hipStreamSynchronize(st));
+        r.frames.front().cloud[0].release(); r.frames.front().cloud[1].release();
+        r.frames.erase(r.frames.begin());
+    }
+    if (info) { info->n_keyframes = (int)r.frames.size(); info->n_target_corner = r.n_tgt[0]; info->n_target_surf = r.n_tgt[1]; }
+    return LISREG_OK;
+}
+
+int lisreg_keyframes_target(lisreg_ctx* c, int ring_id, float corner_leaf, float surf_leaf, int target_slot, lisreg_keyframes_info* info)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (ring_id < 0 || (size_t)ring_id >= c->keyrings.size() || !c->keyrings[(size_t)ring_id].valid)
+        return ctx_fail(c, LISREG_ERR_NO_TARGET, "keyframes_target: no such key-frame ring");
+    KeyframeRing& r = c->keyrings[(size_t)ring_id];
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const float leaf[2] = { corner_leaf, surf_leaf };
+    for (int k = 0; k < 2; ++k) {
+        size_t total = 0;
+        for (const auto& f : r.frames) total += (size_t)f.n[k];
+        HIPCHK(c, r.cat[k].ensure(sizeof(float4) * std::max<size_t>(total, 1)));
+        HIPCHK(c, r.tgt[k].ensure(sizeof(float4) * std::max<size_t>(total, 1)));
+        size_t off = 0;
+        for (size_t i = r.frames.size(); i-- > 0;) {                 // newest first (:191-194)
+            const auto& f = r.frames[i];
+            if (f.n[k] > 0) HIPCHK(c, hipMemcpyAsync(r.cat[k].as<float4>() + off, f.cloud[k].p, sizeof(float4) * (size_t)f.n[k], hipMemcpyDeviceToDevice, st));
+            off += (size_t)f.n[k];
+        }
+        int nv = 0;
+        if (total > 0) {
+            int rc = lisreg_voxel_downsample(c, r.cat[k].p, (int)total, 16, LISREG_FMT_DEVICE, leaf[k], r.tgt[k].p, (int)total, &nv);
+            if (rc == LISREG_LEAF_TOO_SMALL) {               // PCL warns and hands the input through
+                HIPCHK(c, hipMemcpyAsync(r.tgt[k].p, r.cat[k].p, sizeof(float4) * total, hipMemcpyDeviceToDevice, st));
+                nv = (int)total;
+            } else if (rc) return rc;
+        }
+        r.n_tgt[k] = nv;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (target_slot >= 0) {
+        int rc = lisreg_set_target_slot(c, target_slot, r.tgt[0].p, r.n_tgt[0], r.tgt[1].p, r.n_tgt[1], 16, LISREG_FMT_DEVICE);
+        if (rc) return rc;
+    }
+    if (info) { info->n_keyframes = (int)r.frames.size(); info->n_target_corner = r.n_tgt[0]; info->n_target_surf = r.n_tgt[1]; }
+    return LISREG_OK;
+}
+
 void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6])
 {
     float A[12], B[12];

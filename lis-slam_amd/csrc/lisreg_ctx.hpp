@@ -56,6 +56,15 @@ struct LocalMap {
     double bound[6] = { 0, 0, 0, 0, 0, 0 };
 };
 
+// the <= 19 newest key frames of the odometry node in the map frame (lisreg_api_localmap.hip: lisreg_keyframes_*)
+struct KeyframeRing {
+    bool valid = false;
+    struct Frame { DevBuf cloud[2]; int n[2] = { 0, 0 }; };     // corner, surf
+    std::vector<Frame> frames;      // oldest first
+    DevBuf cat[2], tgt[2];
+    int    n_tgt[2] = { 0, 0 };
+};
+
 struct RcclApi {
     void* handle = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
@@ -82,6 +91,7 @@ struct lisreg_ctx {
            ft_lists, ft_counts, ft_rings, ft_gather, ft_cat, ft_bounds, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
     std::vector<lisreg::MapIndex> maps;
     std::vector<lisreg::LocalMap> localmaps;
+    std::vector<lisreg::KeyframeRing> keyrings;
     lisreg::DevBuf lm_in, lm_tmp, lm_bbox;
     lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur;
     int*      done_host = nullptr;          // pinned

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
@@ -111,6 +111,10 @@ class LocalMapParams(C.Structure):
     _fields_ = [("max_num_pts", C.c_int), ("dynamic_removal_on", C.c_int), ("dynamic_removal_center_radius", C.c_float),
                 ("dynamic_dist_thre_min", C.c_float), ("dynamic_dist_thre_max", C.c_float), ("near_dist_thre", C.c_float),
                 ("leaf", C.c_float * 5), ("crop_box", C.c_float * 6), ("crop_pad", C.c_float)]
+
+
+class KeyframesInfo(C.Structure):
+    _fields_ = [("n_keyframes", C.c_int), ("n_target_corner", C.c_int), ("n_target_surf", C.c_int)]
 
 
 class LocalMapInfo(C.Structure):
@@ -214,6 +218,9 @@ def lib():
         L.lisreg_cloud_bounds.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dp]
         L.lisreg_localmap_default_params.argtypes = [C.POINTER(LocalMapParams)]
         L.lisreg_localmap_reset.argtypes = [vp, C.c_int]
+        L.lisreg_keyframes_reset.argtypes = [vp, C.c_int]
+        L.lisreg_keyframes_push.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(KeyframesInfo)]
+        L.lisreg_keyframes_target.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(KeyframesInfo)]
         L.lisreg_localmap_insert.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, fp,
                                              C.POINTER(LocalMapParams), C.POINTER(LocalMapInfo)]
         L.lisreg_localmap_extract.argtypes = [vp, C.c_int, fp, C.POINTER(LocalMapParams), C.c_int, C.POINTER(LocalMapInfo)]
@@ -539,6 +546,23 @@ class Context:
         m = (C.c_uint32 * 32)(*using_label) if using_label is not None else None
         self._chk(self._L.lisreg_semantic_split(self._h, _vp(cloud), len(cloud), cloud.dtype.itemsize, FMT_XYZIL, m, C.byref(so)))
         return [bufs[k][: so.n[k]] for k in range(5)]
+
+    # -- the odometry node's key-frame target, device-resident ------------------------------------------------
+    def keyframes_reset(self, ring_id: int = 0):
+        self._chk(self._L.lisreg_keyframes_reset(self._h, ring_id))
+
+    def keyframes_push(self, ring_id: int, corner: np.ndarray, surf: np.ndarray, pose, max_keep: int = 19) -> dict:
+        corner = np.ascontiguousarray(corner); surf = np.ascontiguousarray(surf)
+        T = np.ascontiguousarray(pose, np.float32)
+        info = KeyframesInfo()
+        self._chk(self._L.lisreg_keyframes_push(self._h, ring_id, _vp(corner), len(corner), _vp(surf), len(surf), corner.dtype.itemsize,
+                                                _fmt_of(corner), T.ctypes.data_as(C.POINTER(C.c_float)), max_keep, C.byref(info)))
+        return dict(n_keyframes=info.n_keyframes)
+
+    def keyframes_target(self, ring_id: int, corner_leaf: float, surf_leaf: float, target_slot: int = 0) -> dict:
+        info = KeyframesInfo()
+        self._chk(self._L.lisreg_keyframes_target(self._h, ring_id, corner_leaf, surf_leaf, target_slot, C.byref(info)))
+        return dict(n_keyframes=info.n_keyframes, n_target_corner=info.n_target_corner, n_target_surf=info.n_target_surf)
 
     # -- §8 f-3: device-resident sliding local map -----------------------------------------------------------
     def localmap_reset(self, map_id: int = 0):

@@ -6,9 +6,20 @@
               target indexes) -> label-weighted registration, copy #2 (:1509-1541) -> lisreg_localmap_insert
               (SubMapManager::insert_local_map, subMap.h:979-1059)
 
-The local map lives in HBM from the first frame to the last.  Also here: the synthetic drive used when no dataset is mounted,
-the KITTI / SemanticKITTI readers, and the trajectory writer in the reference's format (transformFusion, :5079-5179).
-This module is host-side driver code (the reference's ROS node, minus ROS); it computes nothing itself."""
+The local map lives in HBM from the first frame to the last.
+
+Second loop (BASELINE.json configs[0], no labels needed): the scan-to-map odometry of odomEstimationNode
+(/root/reference/src/node/odomEstimationNode.cpp:164-232) on raw sweeps:
+
+  per frame   range-image projection + LOAM features (LaserProcessing, laserProcessing.cpp:467-713 -> lisreg_extract_features)
+              -> pose guess (updateInitialGuess :298-419) -> target = the <= 19 newest keyframes, newest first, voxel grids 0.2 / 0.4 m
+              (:185-207) -> source voxel grids (currentCloudInit :260-281) -> registration, copy #1 (:596-626)
+              -> keyframe gate and saveKeyFrames (:213-226, 421-468: transformPointCloud into the map frame, keep < 20)
+
+Also here: the synthetic drives used when no dataset is mounted, the KITTI / SemanticKITTI readers (incl. the ring assignment of
+laserPretreatmentNode.cpp:60-140, which KITTI's .bin files need), and the trajectory writer in the reference's format
+(transformFusion, :5079-5179).  This module is host-side driver code (the reference's ROS nodes, minus ROS): every cloud
+operation is a liblisreg call; what it computes itself is bookkeeping on 6-vectors and the reader's per-point ring number."""
 from __future__ import annotations
 
 import os
@@ -87,6 +98,154 @@ def write_trajectory(path: str, poses):
                 H0 = np.linalg.inv(H)
             R = H0 @ H
             f.write(" ".join(f"{R[i, j]:.6e}" for i in range(3) for j in range(4)) + "\n")
+
+
+# ---- raw sweeps (no labels): pretreatment + drive -----------------------------------------------------------------------
+def kitti_rings(raw: np.ndarray, n_scan: int = 64, min_range: float = 0.0, max_range: float = 70.0) -> np.ndarray:
+    """laserPretreatmentNode.cpp:60-140 for an HDL-64 sweep without a ring channel (KITTI velodyne/*.bin: x y z remission):
+    NaN and range filter (removeClosedPointCloud, laserPretreatment.h:26-54), ring from the elevation angle with the reference's
+    two-slope table, rings > 50 and angles outside [-24.33, 2] dropped.  Returns a PointXYZIRT struct array (time 0: no de-skewing
+    without IMU), points in input order."""
+    assert n_scan == 64, "the reference's table for KITTI is the N_SCAN == 64 branch"
+    raw = np.asarray(raw, np.float32).reshape(-1, 4)
+    x, y, z = raw[:, 0], raw[:, 1], raw[:, 2]
+    ok = np.isfinite(x) & np.isfinite(y) & np.isfinite(z)
+    r2 = x * x + y * y + z * z
+    ok &= ~(r2 < np.float32(min_range) * np.float32(min_range)) & ~(r2 > np.float32(max_range) * np.float32(max_range))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        angle = (np.arctan(z / np.sqrt(x * x + y * y)) * np.float32(180.0) / np.float32(np.pi)).astype(np.float32)
+    upper = angle >= np.float32(-8.83)
+    with np.errstate(invalid="ignore"):
+        ring = np.where(upper, ((np.float32(2) - angle) * np.float32(3.0) + np.float32(0.5)).astype(np.int64),
+                        n_scan // 2 + ((np.float32(-8.83) - angle) * np.float32(2.0) + np.float32(0.5)).astype(np.int64))
+    ok &= ~((angle > 2) | (angle < np.float32(-24.33)) | (ring > 50) | (ring < 0)) & np.isfinite(angle)
+    out = np.zeros(int(ok.sum()), synth.XYZIRT_DTYPE)
+    out["x"], out["y"], out["z"], out["intensity"] = x[ok], y[ok], z[ok], raw[ok, 3]
+    out["ring"] = ring[ok].astype(np.uint16)
+    return out
+
+
+def kitti_raw_sequence(root: str, seq: str, max_frames: int | None = None):
+    """Yields the pretreated sweeps (PointXYZIRT) of <root>/sequences/<seq>/velodyne in order."""
+    d = os.path.join(root, "sequences", seq, "velodyne")
+    names = sorted(f for f in os.listdir(d) if f.endswith(".bin"))
+    for i, nm in enumerate(names):
+        if max_frames is not None and i >= max_frames:
+            return
+        yield kitti_rings(np.fromfile(os.path.join(d, nm), np.float32).reshape(-1, 4)), None
+
+
+def synthetic_raw_drive(n_frames: int, h: int = 64, w: int = 1800, step: float = 0.45, seed: int = 11):
+    """Unlabelled sweeps (PointXYZIRT, ring-major as a spinning lidar delivers them) along the path of synthetic_drive."""
+    x0, y0 = -14.0, -6.0
+    for k in range(n_frames):
+        yaw = 0.35 * np.sin(0.08 * k)
+        x = x0 + step * k * np.cos(0.12)
+        y = y0 + step * k * np.sin(0.12) + 1.5 * np.sin(0.05 * k)
+        T_world = np.array([0.0, 0.0, yaw, x, y, synth.SENSOR_Z])
+        sc = synth.make_scan(h, w, seed * 1000 + k, T_true=T_world)
+        both = synth.concat_clouds([sc["corner"], sc["surf"]])
+        xyz = synth.pcl_xyz(both)
+        el = np.degrees(np.arctan2(xyz[:, 2], np.hypot(xyz[:, 0], xyz[:, 1])))
+        ring = np.clip(np.rint((el + 24.8) / (26.8 / (h - 1))), 0, h - 1).astype(np.uint16)
+        order = np.lexsort((np.arctan2(xyz[:, 1], xyz[:, 0]), ring))
+        out = np.zeros(len(xyz), synth.XYZIRT_DTYPE)
+        out["x"], out["y"], out["z"] = xyz[order, 0], xyz[order, 1], xyz[order, 2]
+        out["ring"] = ring[order]
+        yield out, np.array([0.0, 0.0, yaw, x - x0, y - y0, 0.0])
+
+
+def xyzi_of(cloud) -> np.ndarray:
+    """pcl::fromROSMsg(cloud_info.cloud_corner, PointCloud<PointXYZI>): keep x, y, z, intensity (odomEstimationNode.cpp:266-267)."""
+    xyz = np.stack([cloud["x"], cloud["y"], cloud["z"]], 1).astype(np.float32)
+    return synth.to_pcl(xyz, None, np.asarray(cloud["intensity"], np.float32))
+
+
+ODOM = dict(corner_leaf=0.2, surf_leaf=0.4, key_dist=1.4, key_yaw=0.5, max_keyframes=19)      # params.yaml:132-141
+
+
+def increment(T_from, T_to) -> np.ndarray:
+    """calculateTranslation (odomEstimationNode.cpp:284-295): transBack^-1 * transTobe as (roll, pitch, yaw, x, y, z)."""
+    A, B = synth.pose_matrix(np.asarray(T_from, np.float64)), synth.pose_matrix(np.asarray(T_to, np.float64))
+    F = np.linalg.inv(A) @ B
+    return np.array([np.arctan2(F[2, 1], F[2, 2]), np.arcsin(-F[2, 0]), np.arctan2(F[1, 0], F[0, 0]), F[0, 3], F[1, 3], F[2, 3]])
+
+
+class OdomReplayer:
+    """laserCloudInfoHandler's state (odomEstimationNode.cpp:164-232): transformTobeMapped, the previous pose, the keyframe
+    clouds in the map frame (<= 19), transformPriFrame, keyFrameId.  Everything that touches a cloud runs in liblisreg."""
+
+    def __init__(self, ctx, feature_params=None, target_slot: int = 0, ring_id: int = 0):
+        import lisreg
+        self.ctx, self.slot = ctx, target_slot
+        self.params = lisreg.default_params(1)
+        self.fp = feature_params or lisreg.default_feature_params()
+        self.T = np.zeros(6, np.float32)
+        self.T_last = None
+        self.calls = 0
+        self.ring = ring_id
+        ctx.keyframes_reset(ring_id)
+        self.T_pri = np.zeros(6, np.float32)
+        self.key_id = 0
+        self.k = 0
+
+    def _guess(self):
+        """updateInitialGuess without IMU / odometry input (:298-384): call 1 initialises, call 2 records, then constant velocity."""
+        import lisreg
+        self.calls += 1
+        if self.calls == 1:
+            return
+        if self.T_last is None:
+            self.T_last = self.T.copy()
+            return
+        g = lisreg.predict_pose(self.T_last, self.T)
+        self.T_last = self.T.copy()
+        self.T = g
+
+    def _save_keyframe(self, corner, surf):
+        """saveKeyFrames (:421-468): the frame's FULL feature clouds, transformed into the map frame; fewer than 20 are kept —
+        in HBM (lisreg_keyframes_push)."""
+        self.ctx.keyframes_push(self.ring, corner, surf, self.T, ODOM["max_keyframes"])
+        self.T_pri = self.T.copy()
+        self.key_id += 1
+
+    def step(self, sweep) -> dict:
+        t0 = time.perf_counter()
+        f = self.ctx.extract_features(sweep, self.fp)
+        corner, surf = xyzi_of(f["corner"]), xyzi_of(f["surface"])
+        self._guess()
+        rec = dict(frame=self.k, n_corner=len(corner), n_surf=len(surf), guess=self.T.copy(), stats=None, keyframe=False)
+        if self.k == 0:                                             # FirstFlag branch (:178-186)
+            self._save_keyframe(corner, surf)
+            rec["keyframe"] = True
+        else:
+            # target = the kept key frames, newest first, voxel grids, both indexes (:185-207, 602-603) — assembled in HBM
+            info = self.ctx.keyframes_target(self.ring, ODOM["corner_leaf"], ODOM["surf_leaf"], self.slot)
+            sc = self.ctx.voxel_downsample(corner, ODOM["corner_leaf"])[1] if len(corner) else corner
+            ss = self.ctx.voxel_downsample(surf, ODOM["surf_leaf"])[1] if len(surf) else surf
+            T, st, _ = self.ctx.align(sc, ss, self.T, self.params)
+            self.T = T.astype(np.float32)
+            rec.update(stats=st, n_target_corner=info["n_target_corner"], n_target_surf=info["n_target_surf"],
+                       n_src_corner=len(sc), n_src_surf=len(ss))
+            if st["status"] == 0 and (st["deltaR"] < 0.005 or st["deltaT"] < 0.05):                       # :213-226
+                inc = increment(self.T_pri, self.T)
+                if self.key_id <= 5 or abs(inc[2]) >= ODOM["key_yaw"] or abs(inc[3]) >= ODOM["key_dist"] or abs(inc[4]) >= ODOM["key_dist"]:
+                    self._save_keyframe(corner, surf)
+                    rec["keyframe"] = True
+        rec.update(T=self.T.copy(), key_id=self.key_id, ms=1e3 * (time.perf_counter() - t0))
+        self.k += 1
+        return rec
+
+
+def replay_odom(ctx, sweeps, feature_params=None, on_frame=None):
+    r = OdomReplayer(ctx, feature_params)
+    out = []
+    for sw in sweeps:
+        rec = r.step(sw)
+        out.append(rec)
+        if on_frame:
+            on_frame(rec)
+    return out
 
 
 # ---- the frame loop -------------------------------------------------------------------------------------------------
@@ -172,4 +331,30 @@ def bench_sequence(device: int, steps: int = 20, warmup: int = 2) -> dict:
                                                         "device-resident sliding local map, copy #2 parameters, early exit"},
             "roofline": None, "cpu_baseline": None,
             "accuracy": {"max_xy_err_vs_truth_m": err, "frames": n,
+                         "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]}}
+
+
+def bench_odometry(device: int, steps: int = 20, warmup: int = 2) -> dict:
+    """bench.py --workload odom: frames/s of the raw-sweep odometry chain on the HIP path (host-inclusive: every sweep crosses
+    PCIe, features and keyframes come back to the host driver as in the reference's node graph)."""
+    import lisreg
+    n = max(steps, 2) + warmup
+    frames, truth = zip(*synthetic_raw_drive(n))
+    ctx = lisreg.Context(device)
+    r = OdomReplayer(ctx)
+    recs, t0 = [], None
+    for k, sw in enumerate(frames):
+        if k == warmup:
+            t0 = time.perf_counter()
+        recs.append(r.step(sw))
+    dt = time.perf_counter() - t0
+    err = max(float(np.abs(np.asarray(rec["T"], np.float64)[3:5] - truth[rec["frame"]][3:5]).max()) for rec in recs)
+    ctx.close()
+    return {"metric": "sequential scan-to-map odometry frames/sec (synthetic raw drive, no labels)",
+            "value": round((n - warmup) / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / (n - warmup), 3), "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": "configs[0] as a sequence: raw 64x1800 sweeps in, range image + LOAM features, "
+                                                        "voxel grids, copy #1 registration against <= 19 keyframes, early exit"},
+            "roofline": None, "cpu_baseline": None,
+            "accuracy": {"max_xy_err_vs_truth_m": err, "frames": n, "keyframes": int(sum(rec["keyframe"] for rec in recs)),
                          "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]}}

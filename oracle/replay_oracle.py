@@ -136,3 +136,77 @@ def replay(frames, n_threads=8, params=None, on_frame=None):
         if on_frame:
             on_frame(rec)
     return out
+
+
+# ---- the odometry loop of odomEstimationNode (copy #1) on raw sweeps -----------------------------------------------------
+ODOM = dict(corner_leaf=0.2, surf_leaf=0.4, key_dist=1.4, key_yaw=0.5)          # /root/reference/config/params.yaml:132-141
+
+
+def _xyzi(cloud, idx):
+    """pcl::fromROSMsg into PointXYZI: x, y, z, intensity of the selected points (odomEstimationNode.cpp:266-267)."""
+    from lisreg import synth                                         # layout helper only (struct dtype)
+    c = cloud[idx]
+    xyz = np.stack([c["x"], c["y"], c["z"]], 1).astype(np.float32)
+    return synth.to_pcl(xyz, None, np.asarray(c["intensity"], np.float32))
+
+
+def _increment(T_from, T_to):
+    A = np.vstack([pose_matrix_f32(T_from), [[0, 0, 0, 1]]]).astype(np.float64)
+    B = np.vstack([pose_matrix_f32(T_to), [[0, 0, 0, 1]]]).astype(np.float64)
+    F = np.linalg.inv(A) @ B
+    return np.array([np.arctan2(F[2, 1], F[2, 2]), np.arcsin(-F[2, 0]), np.arctan2(F[1, 0], F[0, 0]), F[0, 3], F[1, 3], F[2, 3]])
+
+
+def replay_odom(sweeps, feature_params=None, n_threads=8, on_frame=None):
+    """laserCloudInfoHandler (odomEstimationNode.cpp:164-232) on PointXYZIRT sweeps, every step through the C restatement:
+    orc_extract_features, orc_voxel_grid, orc_transform_cloud, orc_align (variant 1).  Returns per-frame dicts like replay()."""
+    fp = feature_params or oc.default_feature_params()
+    p = oc.default_params(1)
+    T = np.zeros(6, np.float32)
+    T_last, calls = None, 0
+    key_c, key_s = [], []
+    T_pri = np.zeros(6, np.float32)
+    key_id = 0
+    out = []
+    for k, sw in enumerate(sweeps):
+        f = oc.extract_features(sw, fp)
+        corner, surf = _xyzi(sw, f["corner"]), _xyzi(sw, f["surface"])
+        calls += 1                                                  # updateInitialGuess (:298-384), no IMU / odometry input
+        if calls > 1:
+            if T_last is None:
+                T_last = T.copy()
+            else:
+                g = predict_pose(T_last, T)
+                T_last = T.copy()
+                T = g
+        rec = dict(frame=k, n_corner=len(corner), n_surf=len(surf), guess=T.copy(), stats=None, keyframe=False)
+
+        def save():
+            nonlocal T_pri, key_id
+            key_c.append(oc.transform_cloud(corner, T, fmt=1) if len(corner) else corner)
+            key_s.append(oc.transform_cloud(surf, T, fmt=1) if len(surf) else surf)
+            while len(key_s) >= 20:
+                key_s.pop(0); key_c.pop(0)
+            T_pri = T.copy(); key_id += 1
+            rec["keyframe"] = True
+
+        if k == 0:
+            save()
+        else:
+            tc, ts = cat(key_c[::-1]), cat(key_s[::-1])
+            tc = oc.voxel_grid(tc, ODOM["corner_leaf"], fmt=1)[1] if len(tc) else tc
+            ts = oc.voxel_grid(ts, ODOM["surf_leaf"], fmt=1)[1] if len(ts) else ts
+            sc = oc.voxel_grid(corner, ODOM["corner_leaf"], fmt=1)[1] if len(corner) else corner
+            ss = oc.voxel_grid(surf, ODOM["surf_leaf"], fmt=1)[1] if len(surf) else surf
+            Tn, st, _ = oc.align(tc, ts, sc, ss, T, p, n_threads=n_threads, max_trace=1)
+            T = Tn.astype(np.float32)
+            rec.update(stats=st, n_target_corner=len(tc), n_target_surf=len(ts), n_src_corner=len(sc), n_src_surf=len(ss))
+            if st["status"] == 0 and (st["deltaR"] < 0.005 or st["deltaT"] < 0.05):
+                inc = _increment(T_pri, T)
+                if key_id <= 5 or abs(inc[2]) >= ODOM["key_yaw"] or abs(inc[3]) >= ODOM["key_dist"] or abs(inc[4]) >= ODOM["key_dist"]:
+                    save()
+        rec.update(T=T.copy(), key_id=key_id)
+        out.append(rec)
+        if on_frame:
+            on_frame(rec)
+    return out

@@ -1,4 +1,5 @@
-"""BASELINE configs[2] (sequential replay, semantic mask on) on the synthetic drive, and the device-resident sliding local map.
+"""BASELINE configs[2] (sequential replay, semantic mask on) and configs[0] (scan-to-map odometry on raw, unlabelled sweeps) on
+synthetic drives, and the device-resident sliding local map.
 
 CPU (-m "not gpu"): the oracle chain (oracle/replay_oracle.py: the reference's frame loop restated over the C restatement's
 primitives) tracks the known trajectory of a short drive; its pose-guess helper agrees with the library's host helper.
@@ -184,3 +185,126 @@ def test_kitti_tool_end_to_end_on_a_synthesised_sequence(tmp_path):
     rows = np.loadtxt(out)
     assert rows.shape == (6, 12) and np.allclose(rows[0].reshape(3, 4), np.eye(4)[:3])
     assert abs(rows[-1, 3] - truth[-1][3]) < 0.05 and abs(rows[-1, 7] - truth[-1][4]) < 0.05
+
+
+# ---- the odometry loop on raw sweeps (odomEstimationNode, copy #1; BASELINE configs[0]) -------------------------------------
+def test_kitti_ring_assignment():
+    """laserPretreatmentNode.cpp:95-117: the two-slope HDL-64 table, the angle / ring limits, the range filter, NaN removal."""
+    from lisreg import replay
+    ang = np.array([1.9, 0.0, -8.0, -8.83, -9.0, -20.0, -24.3, -24.4, 2.1, -3.0], np.float64)
+    r = 10.0
+    raw = np.zeros((len(ang) + 3, 4), np.float32)
+    raw[:len(ang), 0] = r * np.cos(np.radians(ang)); raw[:len(ang), 2] = r * np.sin(np.radians(ang))
+    raw[len(ang)] = (80.0, 0, 0, 0)                       # beyond lidarMaxRange
+    raw[len(ang) + 1] = (np.nan, 0, 0, 0)
+    raw[len(ang) + 2] = (5.0, 5.0, -1.0, 0.5)
+    out = replay.kitti_rings(raw)
+    a32 = np.degrees(np.arctan(raw[:len(ang), 2] / raw[:len(ang), 0])).astype(np.float32)
+    want = [int((2 - a) * 3.0 + 0.5) if a >= np.float32(-8.83) else 32 + int((np.float32(-8.83) - a) * 2.0 + 0.5) for a in a32]
+    keep = [(a <= 2) and (a >= np.float32(-24.33)) and 0 <= w <= 50 for a, w in zip(a32, want)]
+    assert list(out["ring"][: sum(keep)]) == [w for w, k in zip(want, keep) if k]
+    assert len(out) == sum(keep) + 1 and out["intensity"][-1] == np.float32(0.5)        # the far and the NaN point are gone
+    assert not keep[7] and not keep[8]                                                   # -24.4 deg and 2.1 deg are outside
+
+
+def test_oracle_odometry_chain_tracks_the_raw_drive(oracle):
+    import replay_oracle as ro
+    from lisreg import replay
+    h, w = 32, 900
+    frames, truth = zip(*replay.synthetic_raw_drive(8, h=h, w=w))
+    recs = ro.replay_odom(frames, oracle.FeatureParams(h, w, 1, 0.0, 70.0, 1.0, 0.1), n_threads=8)
+    assert recs[0]["keyframe"] and recs[0]["stats"] is None
+    for rec, t in zip(recs[1:], truth[1:]):
+        assert rec["stats"]["status"] == 0 and rec["stats"]["degenerate"] == 0
+        assert np.abs(rec["T"][3:5] - t[3:5]).max() < 0.06 and abs(rec["T"][2] - t[2]) < 0.01, (rec["frame"], rec["T"], t)
+    assert not all(r["keyframe"] for r in recs)             # the keyframe gate closed at least once (key_id > 5, < 1.4 m travelled)
+    assert recs[-1]["n_target_surf"] > recs[1]["n_target_surf"]        # the target is the union of the keyframes
+
+
+@pytest.mark.gpu
+def test_odometry_replay_matches_oracle_frame_by_frame(oracle):
+    """configs[0] stand-in at full sweep size: 64x1800 raw sweeps -> projection + features -> voxel grids -> copy #1 registration
+    against the <= 19 newest keyframes -> keyframe gate; HIP chain vs oracle chain."""
+    import lisreg
+    import replay_oracle as ro
+    from lisreg import replay
+    n = 9
+    frames, truth = zip(*replay.synthetic_raw_drive(n))
+    ref = ro.replay_odom(frames, n_threads=16)
+    ctx = lisreg.Context(0)
+    got = replay.replay_odom(ctx, frames)
+    ctx.close()
+    worst = 0.0
+    for g, r, t in zip(got, ref, truth):
+        assert (g["n_corner"], g["n_surf"]) == (r["n_corner"], r["n_surf"])             # feature extraction is exact
+        assert g["keyframe"] == r["keyframe"] and g["key_id"] == r["key_id"]
+        if r["stats"] is None:
+            assert g["stats"] is None
+            continue
+        assert g["stats"]["status"] == r["stats"]["status"] == 0
+        assert abs(g["stats"]["iters"] - r["stats"]["iters"]) <= 1, (g["frame"], g["stats"], r["stats"])
+        e = max(pose_err(g["T"], r["T"]))
+        worst = max(worst, e)
+        assert e <= 1e-3, (g["frame"], e, g["T"], r["T"])
+        assert abs(g["n_target_surf"] - r["n_target_surf"]) <= max(3, 0.002 * r["n_target_surf"])
+        assert g["n_src_surf"] == r["n_src_surf"] and g["n_src_corner"] == r["n_src_corner"]   # same input, same voxel grid
+        assert np.abs(np.asarray(g["T"], np.float64)[3:5] - t[3:5]).max() < 0.06
+    print(f"odometry replay: worst pose difference HIP vs oracle over {n} frames: {worst:.2e}; iterations "
+          f"{[g['stats']['iters'] for g in got[1:]]}; keyframes {[int(g['keyframe']) for g in got]}")
+
+
+@pytest.mark.gpu
+def test_kitti_tool_odometry_mode_on_a_synthesised_sequence(tmp_path):
+    """tools/kitti_replay.py --mode odom on velodyne/*.bin files only (no labels): ring assignment -> features -> keyframe
+    odometry; must agree with the CPU restatement of the same loop and write the trajectory in the reference's format."""
+    import json
+    import subprocess
+    import sys
+    from lisreg import replay
+    frames, truth = zip(*replay.synthetic_raw_drive(6))
+    vd = tmp_path / "sequences" / "00" / "velodyne"
+    os.makedirs(vd)
+    for k, sw in enumerate(frames):
+        raw = np.stack([sw["x"], sw["y"], sw["z"], sw["intensity"]], 1).astype(np.float32)
+        raw.tofile(str(vd / f"{k:06d}.bin"))
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "kitti_replay.py")
+    out = tmp_path / "traj.txt"
+    res = subprocess.run([sys.executable, tool, "--root", str(tmp_path), "--seq", "00", "--mode", "odom", "--out", str(out),
+                          "--check-oracle", "6"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    summary = json.loads(res.stdout.strip().split("\n")[-1])
+    assert summary["frames"] == 6 and summary["mode"] == "odom"
+    assert summary["oracle_check"]["max_trans_diff_m"] <= 1e-3 and summary["oracle_check"]["max_rot_diff_rad"] <= 1e-3
+    rows = np.loadtxt(out)
+    assert rows.shape == (6, 12) and np.allclose(rows[0].reshape(3, 4), np.eye(4)[:3])
+    assert abs(rows[-1, 3] - truth[-1][3]) < 0.08 and abs(rows[-1, 7] - truth[-1][4]) < 0.08
+
+
+@pytest.mark.gpu
+def test_keyframe_ring_target_equals_oracle_bitwise(oracle, gpu_ctx):
+    """lisreg_keyframes_push / _target (the odometry node's target, kept in HBM) against the host restatement of
+    saveKeyFrames + laserCloudInfoHandler: transformPointCloud, newest-first concatenation, the two voxel grids; and the ring
+    drops its oldest frames beyond max_keep."""
+    import replay_oracle as ro
+    from lisreg import replay, synth
+    frames, truth = zip(*replay.synthetic_raw_drive(5, h=32, w=900))
+    fp = oracle.FeatureParams(32, 900, 1, 0.0, 70.0, 1.0, 0.1)
+    gpu_ctx.keyframes_reset(2)
+    kc, ks = [], []
+    for k, (sw, T) in enumerate(zip(frames, truth)):
+        f = oracle.extract_features(sw, fp)
+        corner, surf = ro._xyzi(sw, f["corner"]), ro._xyzi(sw, f["surface"])
+        T = T.astype(np.float32)
+        info = gpu_ctx.keyframes_push(2, corner, surf, T, max_keep=3)
+        kc.append(oracle.transform_cloud(corner, T)); ks.append(oracle.transform_cloud(surf, T))
+        kc, ks = kc[-3:], ks[-3:]
+        assert info["n_keyframes"] == len(kc)
+        tinfo = gpu_ctx.keyframes_target(2, 0.2, 0.4, target_slot=0)
+        want_c = oracle.voxel_grid(ro.cat(kc[::-1]), 0.2)[1]
+        want_s = oracle.voxel_grid(ro.cat(ks[::-1]), 0.4)[1]
+        assert (tinfo["n_target_corner"], tinfo["n_target_surf"]) == (len(want_c), len(want_s))
+        for kind, want in ((0, want_c), (1, want_s)):
+            idx = gpu_ctx.target_index(0, kind)
+            got = np.zeros((idx["n"], 3), np.float32)
+            got[idx["sorted"][:, 3].view(np.int32)] = idx["sorted"][:, :3]          # back to the target cloud's own order
+            assert np.array_equal(got, synth.pcl_xyz(want)), (k, kind)

@@ -2,6 +2,7 @@
 """Sequential replay of a KITTI odometry / SemanticKITTI sequence on the HIP path (BASELINE.json configs[0] / configs[2]).
 
     python tools/kitti_replay.py --root $KITTI_ROOT --seq 05 [--frames 200] [--out traj_05.txt] [--check-oracle 5]
+    python tools/kitti_replay.py --root $KITTI_ROOT --seq 00 --mode odom ...        (no labels needed)
 
 Expects the standard layout <root>/sequences/<seq>/velodyne/*.bin (float32 x y z remission) and, for the semantic mask,
 <root>/sequences/<seq>/labels/*.label (SemanticKITTI; mapped to the 20 RangeNet++ classes through the reference's
@@ -12,6 +13,10 @@ map -> label-weighted registration (copy #2) with early exit -> map insert.  The
 format (transformFusion, :5079-5179: 12 numbers per pose, relative to the first, scientific notation) so that it can be scored
 with the KITTI devkit exactly like the reference's result file.  --check-oracle N additionally runs the CPU restatement of
 the same loop on the first N frames and reports the pose differences (the parity bar is 1e-3 m / 1e-3 rad).
+
+--mode odom runs the scan-to-map odometry of odomEstimationNode instead (/root/reference/src/node/odomEstimationNode.cpp:164-232,
+BASELINE configs[0]): ring assignment of laserPretreatmentNode -> range image + LOAM features -> voxel grids -> registration
+(copy #1) against the <= 19 newest keyframes -> keyframe gate (lisreg.replay.OdomReplayer); it needs velodyne/*.bin only.
 
 No dataset ships with this repository and none is reachable from the build environment; tests/test_replay.py exercises this
 tool on a KITTI-format directory it synthesises.  Exit code 2 when the sequence directory does not exist."""
@@ -33,6 +38,8 @@ def main(argv=None):
     ap.add_argument("--out", default="")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--variant", type=int, default=2, help="parameter set: 2 = subMapOptimization (default), 3 = loop-closure copy")
+    ap.add_argument("--mode", choices=("submap", "odom"), default="submap",
+                    help="submap: labelled sweeps through the sliding local map (copy #2); odom: raw sweeps, keyframe odometry (copy #1)")
     ap.add_argument("--check-oracle", type=int, default=0, metavar="N", help="also run the CPU restatement on the first N frames")
     args = ap.parse_args(argv)
     seq_dir = os.path.join(args.root, "sequences", args.seq, "velodyne")
@@ -42,9 +49,10 @@ def main(argv=None):
     import numpy as np
     import lisreg
     from lisreg import replay
-    frames = replay.kitti_sequence(args.root, args.seq, args.frames or None)
+    odom = args.mode == "odom"
+    frames = (replay.kitti_raw_sequence if odom else replay.kitti_sequence)(args.root, args.seq, args.frames or None)
     ctx = lisreg.Context(args.device)
-    r = replay.Replayer(ctx, args.variant)
+    r = replay.OdomReplayer(ctx) if odom else replay.Replayer(ctx, args.variant)
     recs, kept = [], []
     t0 = time.perf_counter()
     for cloud, _ in frames:
@@ -58,13 +66,13 @@ def main(argv=None):
     ctx.close()
     if args.out:
         replay.write_trajectory(args.out, [rec["T"] for rec in recs])
-    summary = dict(sequence=args.seq, frames=len(recs), seconds=round(dt, 3), frames_per_s=round(len(recs) / max(dt, 1e-9), 2),
+    summary = dict(sequence=args.seq, mode=args.mode, frames=len(recs), seconds=round(dt, 3), frames_per_s=round(len(recs) / max(dt, 1e-9), 2),
                    mean_iters=float(np.mean([rec["stats"]["iters"] for rec in recs if rec["stats"]] or [0])),
                    final_pose=[float(v) for v in recs[-1]["T"]] if recs else None, trajectory=args.out or None)
     if args.check_oracle > 0 and kept:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import replay_oracle as ro                       # checker only
-        ref = ro.replay(kept, n_threads=min(16, os.cpu_count() or 1))
+        ref = (ro.replay_odom if odom else ro.replay)(kept, n_threads=min(16, os.cpu_count() or 1))
         d = [np.abs(np.asarray(a["T"], np.float64) - np.asarray(b["T"], np.float64)) for a, b in zip(recs, ref)]
         summary["oracle_check"] = dict(frames=len(ref), max_rot_diff_rad=float(max(x[:3].max() for x in d)),
                                        max_trans_diff_m=float(max(x[3:].max() for x in d)))
