@@ -293,6 +293,9 @@ void lisreg_destroy(lisreg_ctx* c)
     if (c->stage_host) (void)hipHostFree(c->stage_host);
     if (c->fetch_host) (void)hipHostFree(c->fetch_host);
     if (c->stage_done) (void)hipEventDestroy(c->stage_done);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -693,6 +696,14 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
             sl.cnt = c->strip_tab.as<int>(); sl.fill = sl.cnt + (c->t_strips + 1); sl.start = sl.fill + (c->t_strips + 1);
             sl.scan_tmp = sl.start + (c->t_strips + 2);
             sl.tmp_pts = c->tmp_pts.as<float4>(); sl.slot_idx = c->elem_bucket.as<uint32_t>(); sl.slot_pos = c->elem_sub.as<uint32_t>();
+            if (!c->side_stream) {                    // created once; failure just means the two variants run back to back
+                if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+                if (c->side_stream && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                                       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+                    (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr;
+                }
+            }
+            sl.side = c->side_stream; sl.ev_fork = c->ev_fork; sl.ev_join = c->ev_join;
             if (launch_build_targets_strips(c->tchunk_dev.as<BlockDesc>(), (int)c->h_tchunks.size(), c->tseg_dev.as<TargetSeg>(),
                                             (int)c->h_tsegs.size(), c->t_strips, c->t_max_units, c->t_max_ucells, c->strip_cap, sl, st))
                 return fail(c, LISREG_ERR_HIP, "strip index build: LDS configuration refused");

@@ -109,6 +109,8 @@ struct lisreg_ctx {
     int       index_build = 2;                          // 0 bucket sort, 1 strip form (error if a grid does not fit it), 2 strip form whenever it fits
     int       strip_cells = 2048, strip_cap = 2048;     // cells per strip aimed at; points per strip of the small-workgroup variant
     bool      strip_now = false;
+    hipStream_t side_stream = nullptr;                  // strip build: the big-strip kernel runs here, forked from / joined to `stream`
+    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
     bool      dump_neighbors = false;   // tests: keep the five neighbour ids of every query of the last iteration run

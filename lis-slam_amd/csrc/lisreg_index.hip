@@ -937,8 +937,15 @@ int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const Tar
     exclusive_scan(sb.cnt, sb.start, sb.scan_tmp, n_strips, st);
     if (n_chunks > 0) k_strip_partition<true><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, nullptr, sb.start, sb.fill, sb.tmp_pts);
     const dim3 grid((unsigned)std::max(max_units, 1), (unsigned)n_tsegs);
+    // the two variants work on disjoint strips: the few big strips (one workgroup per CU each) run on a side stream underneath
+    // the many small ones instead of after them
+    // (worth the two event hops only for big batches: measured +20 us on a single 200 k target, -200 us on 128 of them)
+    const bool fork = n_chunks >= 512 && sb.side && sb.ev_fork && sb.ev_join && hipEventRecord(sb.ev_fork, st) == hipSuccess &&
+                      hipStreamWaitEvent(sb.side, sb.ev_fork, 0) == hipSuccess;
+    k_strip_build<true><<<grid, 1024, lds_large, fork ? sb.side : st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
+    if (fork) (void)hipEventRecord(sb.ev_join, sb.side);
     k_strip_build<false><<<grid, 256, lds_small, st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
-    k_strip_build<true><<<grid, 1024, lds_large, st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
+    if (fork) (void)hipStreamWaitEvent(st, sb.ev_join, 0);
     return 0;
 }
 

@@ -139,6 +139,8 @@ struct StripBuffers {
     float4*   tmp_pts;         // [n_elems] records by strip
     uint32_t* slot_idx;        // [n_elems] } slot tables of strips too big for LDS
     uint32_t* slot_pos;        // [n_elems] }
+    hipStream_t side;          // optional: stream + events for running the big-strip variant underneath the small-strip one
+    hipEvent_t  ev_fork, ev_join;
 };
 int  launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const TargetSeg* tsegs, int n_tsegs, int n_strips, int max_units,
                                  int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st);
