@@ -130,6 +130,17 @@ int main()
         ok = ok && inf.feature_point_num == (int)(mapSurf.size() + mapCorner.size()) && ex.n_target_corner > 0 && ex.n_target_surf > 0 &&
              ex.n_target_surf <= (int)mapSurf.size();
     }
+    // the odometry node's key-frame target (saveKeyFrames + the target assembly of laserCloudInfoHandler), kept in HBM
+    {
+        KeyframeTarget<PointType> keyframes(reg.handle(), 0, 2);
+        const float p0[6] = { 0, 0, 0, 0, 0, 0 }, p1[6] = { 0, 0, 0.02f, 0.5f, 0.1f, 0 }, p2[6] = { 0, 0, 0.04f, 1.0f, 0.2f, 0 };
+        keyframes.saveKeyFrame(mapCorner, mapSurf, p0);
+        keyframes.saveKeyFrame(mapCorner, mapSurf, p1);
+        const int kept = keyframes.saveKeyFrame(mapCorner, mapSurf, p2);             // max_keep = 2: the oldest frame is dropped
+        lisreg_keyframes_info ti = keyframes.extractTarget(0.2f, 0.4f, 0);
+        std::printf("KeyframeTarget: %d frames kept; target corner %d, surf %d\n", kept, ti.n_target_corner, ti.n_target_surf);
+        ok = ok && kept == 2 && ti.n_keyframes == 2 && ti.n_target_surf > 0 && ti.n_target_surf <= 2 * (int)mapSurf.size();
+    }
     std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
     return ok ? 0 : 1;
 }

@@ -409,6 +409,39 @@ private:
     int id_;
 };
 
+// The odometry node's multi-frame target (odomEstimationNode.cpp, USING_MULTI_FRAME_TARGET), device-resident: replaces
+// laserCloud{Corner,Surf}Vec + the concatenation loop + the two VoxelGrid filters of laserCloudInfoHandler (:185-207) and the
+// transformPointCloud / push_back / erase of saveKeyFrames (:452-467).  The frame loop becomes
+//     keyframes.extractTarget(mappingCornerLeafSize, mappingSurfLeafSize);  reg.scan2SubMapOptimization(...);
+//     if (key frame) keyframes.saveKeyFrame(*laserCloudCornerLast, *laserCloudSurfLast, reg.transformTobeMapped);
+template <class PointT = PointType>
+class KeyframeTarget {
+public:
+    explicit KeyframeTarget(lisreg_ctx* ctx, int ring_id = 0, int max_keep = 19) : ctx_(ctx), id_(ring_id), keep_(max_keep) {
+        int rc = lisreg_keyframes_reset(ctx_, id_);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+    }
+    // saveKeyFrames(): the frame's FULL feature clouds (sensor frame) + thisPose6D
+    int saveKeyFrame(const PointCloud<PointT>& cornerLast, const PointCloud<PointT>& surfLast, const float pose[6]) {
+        lisreg_keyframes_info info{};
+        int rc = lisreg_keyframes_push(ctx_, id_, cornerLast.points.data(), (int)cornerLast.size(), surfLast.points.data(), (int)surfLast.size(),
+                                       (int)sizeof(PointT), fmt(), pose, keep_, &info);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        return info.n_keyframes;
+    }
+    // laserCloud{Corner,Surf}FromMapDS + both kd-tree setInputCloud calls: the target lands in `target_slot`
+    lisreg_keyframes_info extractTarget(float cornerLeaf, float surfLeaf, int target_slot = 0) {
+        lisreg_keyframes_info info{};
+        int rc = lisreg_keyframes_target(ctx_, id_, cornerLeaf, surfLeaf, target_slot, &info);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        return info;
+    }
+private:
+    static constexpr int fmt() { return std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI; }
+    lisreg_ctx* ctx_;
+    int id_, keep_;
+};
+
 // updateInitialGuess with neither IMU nor odometry (odomEstimationNode.cpp:351-392): constant-velocity pose guess
 inline void updateInitialGuess(const float lastTransformTobeMapped[6], float transformTobeMapped[6]) {
     float g[6];
