@@ -605,6 +605,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             ts.grid_id = slot * 2 + k;
             ts.strip_base = tstrip;
             ts.ystrip = std::max(1, std::min(ts.ny, (c->strip_cells + ts.nz / 2) / std::max(ts.nz, 1)));
+            // wide grids: fewer, longer strips so that nx * nstrips stays inside the partition histogram (kMaxStrips bins)
+            if (ts.nx > 0 && ts.nx <= kMaxStrips) {
+                const int max_nstrips = std::max(1, kMaxStrips / ts.nx);
+                ts.ystrip = std::max(ts.ystrip, (ts.ny + max_nstrips - 1) / max_nstrips);
+            }
             ts.nstrips = (ts.ny + ts.ystrip - 1) / ts.ystrip;
             const int id = (int)c->h_tsegs.size();
             c->h_tsegs.push_back(ts);

@@ -78,3 +78,28 @@ def test_single_target_build_matches_too(gpu_ctx):
     gpu_ctx.set_target(tc, thick, slot=0)
     _check(gpu_ctx, 0, 0, tc)
     _check(gpu_ctx, 0, 1, thick)
+
+
+@pytest.mark.gpu
+def test_wide_sparse_map_still_takes_the_strip_form(gpu_ctx):
+    """A 700 m x 700 m map: its grid has far more (ix, iy-run) strips than the partition histogram holds at the default strip
+    length, so the strips are made longer; still the strip form, still exact."""
+    import lisreg
+    from lisreg import synth
+    rng = np.random.default_rng(5)
+    xyz = np.concatenate([rng.uniform(-350, 350, (120000, 2)), rng.uniform(-2, 8, (120000, 1))], 1).astype(np.float32)
+    big = synth.to_pcl(xyz, np.zeros(len(xyz), np.uint16))
+    tc, ts, _, _ = _clouds(4)
+    gpu_ctx.set_target(tc, big, slot=0)
+    sc = synth.make_scan(16, 300, 78)
+    p = lisreg.default_params(1); p.fixed_iters = 1
+    gpu_ctx.set_option("index_build", 1); gpu_ctx.set_option("rebuild_targets_each_run", 1)
+    try:
+        gpu_ctx.align_batch([dict(src_corner=sc["corner"], src_surf=sc["surf"], target=0)], sc["T_true"].astype(np.float32)[None], p)
+        assert gpu_ctx.get_option("index_build_now") == 1
+        idx = gpu_ctx.target_index(0, 1)
+        assert idx["nx"] * idx["ny"] > 8192 * 16                  # the default 2048-cell strips would not have fitted
+        _check(gpu_ctx, 0, 1, big)
+        _check(gpu_ctx, 0, 0, tc)
+    finally:
+        gpu_ctx.set_option("index_build", 2); gpu_ctx.set_option("rebuild_targets_each_run", 0)
