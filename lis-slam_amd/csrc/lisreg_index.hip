@@ -925,7 +925,10 @@ int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const Tar
     if (hist_bytes + 6 * 1024 > kStripLdsLarge || lds_small > kStripLdsLarge) return 2;
     const int cap_large = (int)std::min<size_t>((kStripLdsLarge - hist_bytes) / 6, 65535);
     const size_t lds_large = hist_bytes + (size_t)cap_large * 6;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = { false };       // the attribute is per device; contexts of several devices may share the process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& attr_set = attr_set_dev[dev & 63];
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_build<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsLarge);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_build<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsLarge);
