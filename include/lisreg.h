@@ -47,6 +47,9 @@ extern "C" {
 #define LISREG_FMT_XYZI    0   /* pcl::PointXYZI   : floats x@0 y@4 z@8, intensity@16                        */
 #define LISREG_FMT_XYZIL   1   /* PointXYZIL       : as XYZI + uint16 label@20   (common.h:25-35)            */
 #define LISREG_FMT_DEVICE  2   /* pointer is a DEVICE pointer to lisreg_dpoint[n] (stride ignored)           */
+#define LISREG_FMT_DEVICE_XYZI 4 /* the same, but the 32-bit payload is a float intensity, not a label: only where a function says so
+                                  * (lisreg_voxel_downsample averages it like PCL's PointXYZI centroid instead of taking a label vote;
+                                  * lisreg_keyframes_push remembers it for the ring's voxel grids)                                      */
 
 typedef struct lisreg_dpoint {   /* 16-B device record (SURVEY.md §8d "Device record")                        */
     float    x, y, z;

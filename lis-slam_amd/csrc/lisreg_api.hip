@@ -1024,13 +1024,13 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
 {
     if (!c) return LISREG_ERR_ARG;
     if (!n_out || n < 0 || !(leaf > 0.f) || (n > 0 && (!in || !out))) return fail(c, LISREG_ERR_ARG, "voxel_downsample: bad arguments");
-    if (fmt != LISREG_FMT_DEVICE && (stride < 12 || (fmt == LISREG_FMT_XYZIL && stride < 22)))
+    const bool dev = fmt == LISREG_FMT_DEVICE || fmt == LISREG_FMT_DEVICE_XYZI;
+    if (!dev && (stride < 12 || (fmt == LISREG_FMT_XYZIL && stride < 22)))
         return fail(c, LISREG_ERR_ARG, "voxel_downsample: bad stride");
     *n_out = 0;
     if (n == 0) return LISREG_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const bool dev = fmt == LISREG_FMT_DEVICE;
     const bool has_intensity = !dev && stride >= 20;
     // ---- stage the input as float4 (x,y,z, intensity | payload) [+ labels] ---------------------------------------
     const float4* pts = nullptr;
@@ -1110,7 +1110,7 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
     if (!dev) { HIPCHK(c, c->vox_out.ensure(sizeof(float4) * (size_t)n_vox)); out_pts = c->vox_out.as<float4>(); }
     uint32_t* out_lab = nullptr;
     if (fmt == LISREG_FMT_XYZIL) { HIPCHK(c, c->vox_outlab.ensure(sizeof(uint32_t) * (size_t)n_vox)); out_lab = c->vox_outlab.as<uint32_t>(); }
-    launch_voxel_centroids(n, n_vox, pts, labels, dev ? 1 : 0, c->vox_order.as<int>(), c->vox_head.as<int>(),
+    launch_voxel_centroids(n, n_vox, pts, labels, fmt == LISREG_FMT_DEVICE ? 1 : 0 /* label vote on the payload, else .w averaged */, c->vox_order.as<int>(), c->vox_head.as<int>(),
                            c->vox_slot.as<int>(), c->vox_start.as<int>(), out_pts, out_lab, st);
     HIPCHK(c, hipGetLastError());
     if (!dev) {

@@ -282,8 +282,9 @@ int lisreg_keyframes_push(lisreg_ctx* c, int ring_id, const void* corner, int n_
 {
     if (!c) return LISREG_ERR_ARG;
     if (!pose || n_corner < 0 || n_surf < 0 || (n_corner > 0 && !corner) || (n_surf > 0 && !surf) || max_keep < 1) return bad(c, "keyframes_push: bad argument");
-    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return bad(c, "keyframes_push: unknown fmt");
-    if (fmt != LISREG_FMT_DEVICE && stride < 12) return bad(c, "keyframes_push: bad stride");
+    const bool devfmt = fmt == LISREG_FMT_DEVICE || fmt == LISREG_FMT_DEVICE_XYZI;
+    if (!devfmt && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return bad(c, "keyframes_push: unknown fmt");
+    if (!devfmt && stride < 12) return bad(c, "keyframes_push: bad stride");
     if (ring_id < 0 || (size_t)ring_id >= c->keyrings.size() || !c->keyrings[(size_t)ring_id].valid) {
         int rc = lisreg_keyframes_reset(c, ring_id);
         if (rc) return rc;
@@ -299,7 +300,7 @@ int lisreg_keyframes_push(lisreg_ctx* c, int ring_id, const void* corner, int n_
         HIPCHK(c, f.cloud[k].ensure(sizeof(float4) * (size_t)std::max(n[k], 1)));
         if (n[k] == 0) continue;
         const float4* src = nullptr;
-        if (fmt == LISREG_FMT_DEVICE) src = static_cast<const float4*>(src_h[k]);
+        if (devfmt) src = static_cast<const float4*>(src_h[k]);
         else {
             const size_t bytes = (size_t)n[k] * (size_t)stride;
             HIPCHK(c, c->raw_upload.ensure(bytes + 32));
@@ -313,6 +314,7 @@ int lisreg_keyframes_push(lisreg_ctx* c, int ring_id, const void* corner, int n_
         if (rc) return rc;
     }
     r.frames.push_back(f);
+    r.payload_is_label = fmt == LISREG_FMT_DEVICE || fmt == LISREG_FMT_XYZIL;       // what the ring's voxel grids do with the fourth channel
     while ((int)r.frames.size() > max_keep) {         // while (size() >= 20) erase(begin())  with max_keep = 19
         HIPCHK(c, hipStreamSynchronize(st));
         r.frames.front().cloud[0].release(); r.frames.front().cloud[1].release();
@@ -344,7 +346,7 @@ int lisreg_keyframes_target(lisreg_ctx* c, int ring_id, float corner_leaf, float
         }
         int nv = 0;
         if (total > 0) {
-            int rc = lisreg_voxel_downsample(c, r.cat[k].p, (int)total, 16, LISREG_FMT_DEVICE, leaf[k], r.tgt[k].p, (int)total, &nv);
+            int rc = lisreg_voxel_downsample(c, r.cat[k].p, (int)total, 16, r.payload_is_label ? LISREG_FMT_DEVICE : LISREG_FMT_DEVICE_XYZI, leaf[k], r.tgt[k].p, (int)total, &nv);
             if (rc == LISREG_LEAF_TOO_SMALL) {               // PCL warns and hands the input through
                 HIPCHK(c, hipMemcpyAsync(r.tgt[k].p, r.cat[k].p, sizeof(float4) * total, hipMemcpyDeviceToDevice, st));
                 nv = (int)total;

@@ -59,6 +59,7 @@ struct LocalMap {
 // the <= 19 newest key frames of the odometry node in the map frame (lisreg_api_localmap.hip: lisreg_keyframes_*)
 struct KeyframeRing {
     bool valid = false;
+    bool payload_is_label = false;  // fourth channel of the kept records: label (vote) or intensity (average) in the voxel grids
     struct Frame { DevBuf cloud[2]; int n[2] = { 0, 0 }; };     // corner, surf
     std::vector<Frame> frames;      // oldest first
     DevBuf cat[2], tgt[2];

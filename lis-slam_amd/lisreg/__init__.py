@@ -19,7 +19,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES, LEAF_TOO_SMALL = 0, 1, 2, 3
 ERR_ARG, ERR_HIP, ERR_NO_TARGET, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5
-FMT_XYZI, FMT_XYZIL, FMT_DEVICE, FMT_XYZIRT = 0, 1, 2, 3
+FMT_XYZI, FMT_XYZIL, FMT_DEVICE, FMT_XYZIRT, FMT_DEVICE_XYZI = 0, 1, 2, 3, 4
 VARIANT_ODOM, VARIANT_KEYFRAME, VARIANT_SUBMAP = 1, 2, 3
 TRACE_STRIDE = 56
 RESULT_SIZE = 12
@@ -480,9 +480,11 @@ class Context:
         self._chk(rc, allow=(OK, LEAF_TOO_SMALL))
         return rc, out[: n_out.value]
 
-    def voxel_downsample_device(self, in_ptr: int, n: int, leaf: float, out_ptr: int, capacity: int):
+    def voxel_downsample_device(self, in_ptr: int, n: int, leaf: float, out_ptr: int, capacity: int, intensity: bool = False):
+        """Device records in, device records out.  intensity=True: the payload is a float (PointXYZI clouds) and is averaged;
+        otherwise it is a label and the voxel takes the majority."""
         n_out = C.c_int(0)
-        rc = self._L.lisreg_voxel_downsample(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, leaf, C.c_void_p(out_ptr),
+        rc = self._L.lisreg_voxel_downsample(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE_XYZI if intensity else FMT_DEVICE, leaf, C.c_void_p(out_ptr),
                                              capacity, C.byref(n_out))
         self._chk(rc, allow=(OK, LEAF_TOO_SMALL))
         return rc, n_out.value
@@ -535,6 +537,29 @@ class Context:
         self._chk(self._L.lisreg_extract_features_batch(self._h, S, ptrs, ns, C.byref(params), fos))
         return [{k: getattr(fos[s], "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")} for s in range(S)]
 
+    def semantic_split_device(self, in_ptr: int, n: int, out_ptrs, cap: int, using_label=None) -> list:
+        """categoryMapping on device records (label in the payload): out_ptrs = five device buffers of `cap` records
+        (dynamic, ground, building, pole, outlier).  Returns the five counts."""
+        so = SemanticOut()
+        for k in range(5):
+            so.cloud[k] = int(out_ptrs[k]); so.cap[k] = cap
+        m = (C.c_uint32 * 32)(*using_label) if using_label is not None else None
+        self._chk(self._L.lisreg_semantic_split(self._h, C.c_void_p(in_ptr), n, 16, FMT_DEVICE, m, C.byref(so)))
+        return [int(so.n[k]) for k in range(5)]
+
+    def align_device(self, corner_ptr: int, n_corner: int, surf_ptr: int, n_surf: int, T_init, params: Params, imu: Imu | None = None):
+        """lisreg_align on device-resident source records.  Returns (T, stats dict)."""
+        T = np.array(T_init, np.float32).copy()
+        st = Stats()
+        rc = self._L.lisreg_align(self._h, C.c_void_p(corner_ptr) if n_corner else None, n_corner, C.c_void_p(surf_ptr) if n_surf else None,
+                                  n_surf, 16, FMT_DEVICE, C.byref(params), C.byref(imu) if imu is not None else None,
+                                  T.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
+        self._chk(rc, allow=(OK, NOT_ENOUGH_FEATURES, TOO_FEW_CORRESPONDENCES))
+        d = stats_dict(st)
+        if rc == NOT_ENOUGH_FEATURES:
+            d["status"] = NOT_ENOUGH_FEATURES
+        return T, d
+
     def semantic_split(self, cloud: np.ndarray, using_label=None) -> list:
         """categoryMapping replacement: [dynamic, ground, building, pole, outlier] from a PointXYZIL struct array."""
         cloud = np.ascontiguousarray(cloud)
@@ -557,6 +582,15 @@ class Context:
         info = KeyframesInfo()
         self._chk(self._L.lisreg_keyframes_push(self._h, ring_id, _vp(corner), len(corner), _vp(surf), len(surf), corner.dtype.itemsize,
                                                 _fmt_of(corner), T.ctypes.data_as(C.POINTER(C.c_float)), max_keep, C.byref(info)))
+        return dict(n_keyframes=info.n_keyframes)
+
+    def keyframes_push_device(self, ring_id: int, corner_ptr: int, n_corner: int, surf_ptr: int, n_surf: int, pose, max_keep: int = 19,
+                              label_payload: bool = False) -> dict:
+        T = np.ascontiguousarray(pose, np.float32)
+        info = KeyframesInfo()
+        self._chk(self._L.lisreg_keyframes_push(self._h, ring_id, C.c_void_p(corner_ptr) if n_corner else None, n_corner,
+                                                C.c_void_p(surf_ptr) if n_surf else None, n_surf, 16, FMT_DEVICE if label_payload else FMT_DEVICE_XYZI,
+                                                T.ctypes.data_as(C.POINTER(C.c_float)), max_keep, C.byref(info)))
         return dict(n_keyframes=info.n_keyframes)
 
     def keyframes_target(self, ring_id: int, corner_leaf: float, surf_leaf: float, target_slot: int = 0) -> dict:
@@ -741,6 +775,24 @@ class DeviceArray:
         if self.nbytes and self._hip.hipMemcpy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p),
                                                C.c_size_t(self.nbytes), 1) != 0:
             raise RuntimeError("hipMemcpy H2D failed")
+
+    def upload(self, host: np.ndarray, offset_bytes: int = 0):
+        """H2D into this buffer (it must be large enough)."""
+        host = np.ascontiguousarray(host)
+        assert offset_bytes + host.nbytes <= max(self.nbytes, 16)
+        if host.nbytes and self._hip.hipMemcpy(C.c_void_p(self.ptr + offset_bytes), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def copy_from_device(self, src_ptr: int, nbytes: int, offset_bytes: int = 0):
+        assert offset_bytes + nbytes <= max(self.nbytes, 16)
+        if nbytes and self._hip.hipMemcpy(C.c_void_p(self.ptr + offset_bytes), C.c_void_p(src_ptr), C.c_size_t(nbytes), 3) != 0:
+            raise RuntimeError("hipMemcpy D2D failed")
+
+    def download(self, n_rows: int) -> np.ndarray:
+        out = np.zeros((n_rows,) + tuple(self.shape[1:]), np.float32)
+        if out.nbytes and self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return out
 
     def free(self):
         if getattr(self, "ptr", None):

@@ -237,8 +237,59 @@ class OdomReplayer:
         return rec
 
 
-def replay_odom(ctx, sweeps, feature_params=None, on_frame=None):
-    r = OdomReplayer(ctx, feature_params)
+class DeviceOdomReplayer(OdomReplayer):
+    """The odometry loop with the frame's clouds kept in HBM: the sweep goes up once as (x, y, z, ring) records, the feature
+    clouds, their voxel grids, the registration sources and the key frame never come back.  Same kernels, same order, same poses."""
+
+    def __init__(self, ctx, feature_params=None, target_slot: int = 0, ring_id: int = 0):
+        super().__init__(ctx, feature_params, target_slot, ring_id)
+        import lisreg
+        self.cap = self.fp.n_scan * self.fp.horizon_scan
+        z = np.zeros((self.cap, 4), np.float32)
+        self.raw = lisreg.DeviceArray(np.zeros((2 * self.cap, 4), np.float32))
+        self.names = ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")
+        self.feat = {k: lisreg.DeviceArray(z) for k in self.names}
+        self.ds_c, self.ds_s = lisreg.DeviceArray(z), lisreg.DeviceArray(z)
+
+    def _save_keyframe_device(self, n_c, n_s):
+        self.ctx.keyframes_push_device(self.ring, self.feat["corner"].ptr, n_c, self.feat["surface"].ptr, n_s, self.T, ODOM["max_keyframes"])
+        self.T_pri = self.T.copy()
+        self.key_id += 1
+
+    def step(self, sweep) -> dict:
+        t0 = time.perf_counter()
+        n = len(sweep)
+        assert n <= 2 * self.cap
+        rec4 = np.zeros((n, 4), np.float32)
+        rec4[:, 0], rec4[:, 1], rec4[:, 2] = sweep["x"], sweep["y"], sweep["z"]
+        rec4[:, 3] = sweep["ring"].astype(np.uint32).view(np.float32)
+        self.raw.upload(rec4)
+        cnt = self.ctx.extract_features_device(self.raw.ptr, n, self.fp, {k: v.ptr for k, v in self.feat.items()}, self.cap)
+        n_c, n_s = cnt["corner"], cnt["surface"]
+        self._guess()
+        rec = dict(frame=self.k, n_corner=n_c, n_surf=n_s, guess=self.T.copy(), stats=None, keyframe=False)
+        if self.k == 0:
+            self._save_keyframe_device(n_c, n_s)
+            rec["keyframe"] = True
+        else:
+            info = self.ctx.keyframes_target(self.ring, ODOM["corner_leaf"], ODOM["surf_leaf"], self.slot)
+            nsc = self.ctx.voxel_downsample_device(self.feat["corner"].ptr, n_c, ODOM["corner_leaf"], self.ds_c.ptr, self.cap, intensity=True)[1] if n_c else 0
+            nss = self.ctx.voxel_downsample_device(self.feat["surface"].ptr, n_s, ODOM["surf_leaf"], self.ds_s.ptr, self.cap, intensity=True)[1] if n_s else 0
+            T, st = self.ctx.align_device(self.ds_c.ptr, nsc, self.ds_s.ptr, nss, self.T, self.params)
+            self.T = T.astype(np.float32)
+            rec.update(stats=st, n_target_corner=info["n_target_corner"], n_target_surf=info["n_target_surf"], n_src_corner=nsc, n_src_surf=nss)
+            if st["status"] == 0 and (st["deltaR"] < 0.005 or st["deltaT"] < 0.05):
+                inc = increment(self.T_pri, self.T)
+                if self.key_id <= 5 or abs(inc[2]) >= ODOM["key_yaw"] or abs(inc[3]) >= ODOM["key_dist"] or abs(inc[4]) >= ODOM["key_dist"]:
+                    self._save_keyframe_device(n_c, n_s)
+                    rec["keyframe"] = True
+        rec.update(T=self.T.copy(), key_id=self.key_id, ms=1e3 * (time.perf_counter() - t0))
+        self.k += 1
+        return rec
+
+
+def replay_odom(ctx, sweeps, feature_params=None, on_frame=None, device_resident: bool = False):
+    r = DeviceOdomReplayer(ctx, feature_params) if device_resident else OdomReplayer(ctx, feature_params)
     out = []
     for sw in sweeps:
         rec = r.step(sw)
@@ -295,8 +346,62 @@ class Replayer:
         return rec
 
 
-def replay(ctx, frames, variant: int = 2, on_frame=None):
-    r = Replayer(ctx, variant)
+class DeviceReplayer(Replayer):
+    """The same loop with every cloud of the frame kept in HBM between the steps: the sweep goes up once as 16-byte records
+    (label in the payload), categoryMapping, the per-class voxel grids, the source assembly, the registration and the map insert
+    all take device pointers.  Only counts and the pose come back.  Same kernels in the same order as Replayer: the poses are
+    bit-identical (tests/test_replay.py)."""
+
+    def __init__(self, ctx, variant: int = 2, map_id: int = 0, target_slot: int = 0, capacity: int = 1 << 18):
+        super().__init__(ctx, variant, map_id, target_slot)
+        import lisreg
+        z = np.zeros((capacity, 4), np.float32)
+        self.cap = capacity
+        self.raw = lisreg.DeviceArray(z)
+        self.full = [lisreg.DeviceArray(z) for _ in range(5)]       # dynamic, ground, building, pole, outlier (categoryMapping order)
+        self.down = [lisreg.DeviceArray(z) for _ in range(5)]
+        self.src_s = lisreg.DeviceArray(z)
+
+    def step(self, cloud) -> dict:
+        import lisreg
+        t0 = time.perf_counter()
+        n = len(cloud)
+        assert n <= self.cap
+        self.raw.upload(lisreg.pack_device_records(cloud))
+        nf = self.ctx.semantic_split_device(self.raw.ptr, n, [b.ptr for b in self.full], self.cap)
+        order = ("dynamic", "ground", "building", "pole", "outlier")
+        leaf = [FRAME_LEAF[k] for k in order]
+        nd = [self.ctx.voxel_downsample_device(self.full[k].ptr, nf[k], leaf[k], self.down[k].ptr, self.cap)[1] if nf[k] else 0 for k in range(5)]
+        rec = dict(frame=self.k)
+        if self.k == 0:
+            rec.update(T=self.T.copy(), guess=self.T.copy(), stats=None)
+        else:
+            if self.T_last is None:
+                self.T_last = self.T.copy()
+                guess = self.T.copy()
+            else:
+                guess = lisreg.predict_pose(self.T_last, self.T)
+                self.T_last = self.T.copy()
+            info = self.ctx.localmap_extract(self.map_id, guess, self.lm_params, self.slot)
+            # currentCloudInit (:866-889): corner = pole; surf = dynamic + building + ground
+            off = 0
+            for k in (0, 2, 1):
+                self.src_s.copy_from_device(self.down[k].ptr, 16 * nd[k], 16 * off)
+                off += nd[k]
+            T, st = self.ctx.align_device(self.down[3].ptr, nd[3], self.src_s.ptr, off, guess, self.params)
+            self.T = T.astype(np.float32)
+            rec.update(T=self.T.copy(), guess=guess.copy(), stats=st, n_target_corner=info["n_target_corner"],
+                       n_target_surf=info["n_target_surf"], n_src_corner=nd[3], n_src_surf=off, crop=info["crop"])
+        # append_feature order of the map: dynamic, pole, ground, building, outlier
+        idx = (0, 3, 1, 2, 4)
+        info = self.ctx.localmap_insert_device(self.map_id, [self.full[k].ptr for k in idx], [nf[k] for k in idx], self.T, self.lm_params)
+        rec.update(n_map=info["n"], feature_point_num=info["feature_point_num"], bound=info["bound"], ms=1e3 * (time.perf_counter() - t0))
+        self.k += 1
+        return rec
+
+
+def replay(ctx, frames, variant: int = 2, on_frame=None, device_resident: bool = False):
+    r = DeviceReplayer(ctx, variant) if device_resident else Replayer(ctx, variant)
     out = []
     for cloud in frames:
         rec = r.step(cloud)
@@ -314,7 +419,7 @@ def bench_sequence(device: int, steps: int = 20, warmup: int = 2) -> dict:
     frames = [c for c, _ in synthetic_drive(n)]
     truth = [t for _, t in synthetic_drive(n)]
     ctx = lisreg.Context(device)
-    r = Replayer(ctx, 2)
+    r = DeviceReplayer(ctx, 2)
     recs = []
     t0 = None
     for k, cloud in enumerate(frames):
@@ -341,7 +446,7 @@ def bench_odometry(device: int, steps: int = 20, warmup: int = 2) -> dict:
     n = max(steps, 2) + warmup
     frames, truth = zip(*synthetic_raw_drive(n))
     ctx = lisreg.Context(device)
-    r = OdomReplayer(ctx)
+    r = DeviceOdomReplayer(ctx)
     recs, t0 = [], None
     for k, sw in enumerate(frames):
         if k == warmup:

@@ -308,3 +308,36 @@ def test_keyframe_ring_target_equals_oracle_bitwise(oracle, gpu_ctx):
             got = np.zeros((idx["n"], 3), np.float32)
             got[idx["sorted"][:, 3].view(np.int32)] = idx["sorted"][:, :3]          # back to the target cloud's own order
             assert np.array_equal(got, synth.pcl_xyz(want)), (k, kind)
+
+
+@pytest.mark.gpu
+def test_device_resident_frame_loop_equals_host_driven_loop_bitwise():
+    """DeviceReplayer (sweep uploaded once, every cloud of the frame stays in HBM) against Replayer (host clouds between the
+    steps): the same kernels in the same order, so poses, iteration counts and map sizes are identical."""
+    import lisreg
+    from lisreg import replay
+    frames, _ = zip(*replay.synthetic_drive(8, h=32, w=900))
+    ctx = lisreg.Context(0)
+    a = replay.replay(ctx, frames)
+    b = replay.replay(ctx, frames, device_resident=True)
+    ctx.close()
+    for x, y in zip(a, b):
+        assert np.array_equal(x["T"], y["T"]) and x["n_map"] == y["n_map"]
+        assert (x["stats"] is None) == (y["stats"] is None)
+        if x["stats"]:
+            assert x["stats"]["iters"] == y["stats"]["iters"] and x["n_src_surf"] == y["n_src_surf"]
+
+
+@pytest.mark.gpu
+def test_device_resident_odometry_loop_equals_host_driven_loop_bitwise():
+    import lisreg
+    from lisreg import replay
+    frames, _ = zip(*replay.synthetic_raw_drive(8))
+    ctx = lisreg.Context(0)
+    a = replay.replay_odom(ctx, frames)
+    b = replay.replay_odom(ctx, frames, device_resident=True)
+    ctx.close()
+    for x, y in zip(a, b):
+        assert np.array_equal(x["T"], y["T"]) and x["keyframe"] == y["keyframe"] and (x["n_corner"], x["n_surf"]) == (y["n_corner"], y["n_surf"])
+        if x["stats"]:
+            assert x["stats"]["iters"] == y["stats"]["iters"] and x["n_src_surf"] == y["n_src_surf"] and x["n_target_surf"] == y["n_target_surf"]
