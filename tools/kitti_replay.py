@@ -52,7 +52,8 @@ def main(argv=None):
     odom = args.mode == "odom"
     frames = (replay.kitti_raw_sequence if odom else replay.kitti_sequence)(args.root, args.seq, args.frames or None)
     ctx = lisreg.Context(args.device)
-    r = replay.OdomReplayer(ctx) if odom else replay.Replayer(ctx, args.variant)
+    # the device-resident drivers: the sweep goes up once, every cloud of the frame stays in HBM (bit-identical to the host-cloud drivers)
+    r = replay.DeviceOdomReplayer(ctx) if odom else replay.DeviceReplayer(ctx, args.variant)
     recs, kept = [], []
     t0 = time.perf_counter()
     for cloud, _ in frames:
