@@ -311,7 +311,7 @@ int lisreg_keyframes_push(lisreg_ctx* c, int ring_id, const void* corner, int n_
             src = c->lm_in.as<float4>();
         }
         int rc = lisreg_transform_cloud(c, src, n[k], 16, LISREG_FMT_DEVICE, pose, f.cloud[k].p);      // transformPointCloud(.., &thisPose6D)
-        if (rc) return rc;
+        if (rc) { f.cloud[0].release(); f.cloud[1].release(); return rc; }
     }
     r.frames.push_back(f);
     r.payload_is_label = fmt == LISREG_FMT_DEVICE || fmt == LISREG_FMT_XYZIL;       // what the ring's voxel grids do with the fourth channel
