@@ -174,8 +174,8 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
     float n0 = 0, n1 = 0, n2 = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) { n0 += a[i][0] * a[i][0]; n1 += a[i][1] * a[i][1]; n2 += a[i][2] * a[i][2]; }
-    const float maxn = sqrtf(fmaxf(n0, fmaxf(n1, n2)));
-    const float thr = (maxn * 1.1920929e-7f) * (maxn * 1.1920929e-7f) / 5.f;
+    const float maxn = __builtin_amdgcn_sqrtf(fmaxf(n0, fmaxf(n1, n2)));          // v_sqrt_f32 (1 ulp; the arguments are far from the denormal range)
+    const float thr = (maxn * 1.1920929e-7f) * (maxn * 1.1920929e-7f) * 0.2f;     // / rows (a rank threshold: <= 1 ulp from the division)
     int p0 = 0, p1 = 1, p2 = 2;        // perm: column k of the working matrix is original column p_k
     int rank = 3;
     float y[3] = { 0.f, 0.f, 0.f };
@@ -189,7 +189,7 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) tail_ += a[i_][k] * a[i_][k]; \
         float beta_, tau_, v_[5]; \
         if (tail_ <= 1.17549435e-38f) { tau_ = 0.f; beta_ = c0_; _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = 0.f; } \
-        else { beta_ = sqrtf(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
+        else { beta_ = __builtin_amdgcn_sqrtf(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
                const float invd_ = __builtin_amdgcn_rcpf(c0_ - beta_); \
                _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? a[i_][k] * invd_ : 0.f; \
                tau_ = (beta_ - c0_) * __builtin_amdgcn_rcpf(beta_); } \
@@ -255,7 +255,7 @@ __device__ __forceinline__ float4 surf_model(const float4 nb[5], const DevParams
     float X[3];
     lstsq5x3(nb, X);
     float pa = X[0], pb = X[1], pc = X[2], pd = 1.f;
-    const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+    const float ps = __builtin_amdgcn_sqrtf(pa * pa + pb * pb + pc * pc);
     const float ips = __builtin_amdgcn_rcpf(ps);          // 1-ulp reciprocal (the reference divides; <= 2 ulp apart)
     pa *= ips; pb *= ips; pc *= ips; pd = ips;
     bool valid = true;
@@ -270,7 +270,7 @@ __device__ __forceinline__ bool surf_eval(const float4 m, float x0, float y0, fl
 {
     const float pa = m.x, pb = m.y, pc = m.z, pd = m.w;
     const float pd2 = pa * x0 + pb * y0 + pc * z0 + pd;
-    const float rng = sqrtf(sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
+    const float rng = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
     const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)rng);
     const float ws = w * s;
     cf[0] = ws * pa; cf[1] = ws * pb; cf[2] = ws * pc; cf[3] = ws * pd2;
