@@ -35,8 +35,8 @@ __device__ __forceinline__ float hypot_f(float a, float b)
 {
     a = fabsf(a); b = fabsf(b);
     const float mx = fmaxf(a, b), mn = fminf(a, b);
-    const float r = mn / mx;
-    return mx > 0.f ? mx * sqrtf(1.f + r * r) : 0.f;
+    const float r = mn * __builtin_amdgcn_rcpf(mx);          // 1-ulp reciprocal and square root (v_rcp_f32, v_sqrt_f32): the Jacobi
+    return mx > 0.f ? mx * __builtin_amdgcn_sqrtf(1.f + r * r) : 0.f;      // sweeps absorb a last-bit difference per rotation
 }
 
 // one Jacobi rotation annihilating A[k][l] of a symmetric 3x3 held in registers (cv::eigen's rotation formulas)
@@ -57,8 +57,9 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
                 const float y = (w1 - w0) * 0.5f;
                 float t = fabsf(y) + hypot_f(p, y);
                 float s = hypot_f(p, t);
-                const float c = t / s;
-                s = p / s; t = (p / t) * p;
+                const float inv_s = __builtin_amdgcn_rcpf(s);
+                const float c = t * inv_s;
+                s = p * inv_s; t = (p * __builtin_amdgcn_rcpf(t)) * p;
                 if (y < 0.f) { s = -s; t = -t; }
                 a12 = 0.f; w0 -= t; w1 += t;
                 LISREG_ROT(a13, a23);
@@ -71,8 +72,9 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
                 const float y = (w2 - w0) * 0.5f;
                 float t = fabsf(y) + hypot_f(p, y);
                 float s = hypot_f(p, t);
-                const float c = t / s;
-                s = p / s; t = (p / t) * p;
+                const float inv_s = __builtin_amdgcn_rcpf(s);
+                const float c = t * inv_s;
+                s = p * inv_s; t = (p * __builtin_amdgcn_rcpf(t)) * p;
                 if (y < 0.f) { s = -s; t = -t; }
                 a13 = 0.f; w0 -= t; w2 += t;
                 LISREG_ROT(a12, a23);
@@ -85,8 +87,9 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
                 const float y = (w2 - w1) * 0.5f;
                 float t = fabsf(y) + hypot_f(p, y);
                 float s = hypot_f(p, t);
-                const float c = t / s;
-                s = p / s; t = (p / t) * p;
+                const float inv_s = __builtin_amdgcn_rcpf(s);
+                const float c = t * inv_s;
+                s = p * inv_s; t = (p * __builtin_amdgcn_rcpf(t)) * p;
                 if (y < 0.f) { s = -s; t = -t; }
                 a23 = 0.f; w1 -= t; w2 += t;
                 // rows 1,2 rotate: elements A[0][1], A[0][2]
@@ -143,8 +146,8 @@ __device__ __forceinline__ bool corner_eval(const float4 m0, const float4 m1, fl
     const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
     const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
     const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
-    const float a012 = sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
-    const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    const float a012 = __builtin_amdgcn_sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
+    const float l12 = __builtin_amdgcn_sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
     const float inv_al = __builtin_amdgcn_rcpf(a012 * l12);     // one 1-ulp reciprocal for the three `/ a012 / l12` (:713-723)
     const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) * inv_al;
     const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) * inv_al;
@@ -284,20 +287,20 @@ __device__ __forceinline__ bool surf_coeff(const float4 nb[5], float x0, float y
 }
 
 // LMOptimization row (odomEstimationNode.cpp:862-915); (ox,oy,oz) is the UNtransformed source point
-__device__ __forceinline__ void jacobian_row(const float* sc, float ox, float oy, float oz, const float cf[4],
+__device__ __forceinline__ void jacobian_row(const float* K /* ItemState::jk */, float ox, float oy, float oz, const float cf[4],
                                              float row[6], float& b)
 {
-    const float srx = sc[0], crx = sc[1], sry = sc[2], cry = sc[3], srz = sc[4], crz = sc[5];   // ItemState::sc
+    // the pose-only factors K come from write_pose_cache (lisreg_solve.hip), formed with the reference's association
     const float px = oy, py = oz, pz = ox;
     const float cx = cf[1], cy = cf[2], cz = cf[0];
-    const float arx = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cx +
-                      (-srx * srz * px - crz * srx * py - crx * pz) * cy +
-                      (crx * cry * srz * px + crx * cry * crz * py - cry * srx * pz) * cz;
-    const float ary = ((cry * srx * srz - crz * sry) * px + (sry * srz + cry * crz * srx) * py + crx * cry * pz) * cx +
-                      ((-cry * crz - srx * sry * srz) * px + (cry * srz - crz * srx * sry) * py - crx * sry * pz) * cz;
-    const float arz = ((crz * srx * sry - cry * srz) * px + (-cry * crz - srx * sry * srz) * py) * cx +
-                      (crx * crz * px - crx * srz * py) * cy +
-                      ((sry * srz + cry * crz * srx) * px + (crz * sry - cry * srx * srz) * py) * cz;
+    const float arx = (K[0] * px + K[1] * py - K[2] * pz) * cx +
+                      (K[3] * px - K[4] * py - K[5] * pz) * cy +
+                      (K[6] * px + K[7] * py - K[8] * pz) * cz;
+    const float ary = (K[9] * px + K[10] * py + K[11] * pz) * cx +
+                      (K[12] * px + K[13] * py - K[14] * pz) * cz;
+    const float arz = (K[15] * px + K[12] * py) * cx +
+                      (K[16] * px - K[17] * py) * cy +
+                      (K[10] * px + K[18] * py) * cz;
     row[0] = arz; row[1] = arx; row[2] = ary; row[3] = cz; row[4] = cx; row[5] = cy;
     b = -cf[3];
 }
@@ -355,7 +358,7 @@ __device__ __forceinline__ float label_weight(const DevParams& P, float payload)
 
 // Jacobian row + fixed-order fp64 reduction of the 28 normal-equation terms: wave halving butterfly -> LDS ->
 // one partial row per workgroup.  `ok` = this lane contributes a correspondence with coefficients cf.
-__device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* sc,
+__device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* jk,
                                                const DevParams& P, double (*s_acc)[kNumAcc], double* __restrict__ out);
 
 // Residual model shared by the search front-ends that re-fit every iteration.
@@ -383,7 +386,7 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
 
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
-                                                    const float* sc, const DevParams& P, int kind,
+                                                    const float* jk, const DevParams& P, int kind,
                                                     double (*s_acc)[kNumAcc], double* __restrict__ out, int* dbg_ok = nullptr)
 {
     float cf[4];
@@ -398,17 +401,17 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
 #ifdef LISREG_ABL_RED2
     { float cf2[4] = { cf[0], cf[1], cf[2], cf[3] }; asm volatile("" : "+v"(cf2[0]), "+v"(cf2[1]), "+v"(cf2[2]), "+v"(cf2[3]));
-      row_and_reduce(ok, cf2, q4, sc, P, s_acc, out); __syncthreads(); }
+      row_and_reduce(ok, cf2, q4, jk, P, s_acc, out); __syncthreads(); }
 #endif
-    row_and_reduce(ok, cf, q4, sc, P, s_acc, out);
+    row_and_reduce(ok, cf, q4, jk, P, s_acc, out);
 }
 
-__device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* sc,
+__device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* jk,
                                                const DevParams& P, double (*s_acc)[kNumAcc], double* __restrict__ out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
-    if (ok) { jacobian_row(sc, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
+    if (ok) { jacobian_row(jk, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
     // the 28 normal-equation terms of this row, produced on demand (float x float is exact in double):
     //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
     auto term = [&](int k) -> double {
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
         }
     }
 
-    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out);
+    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_acc, out);
 }
 
 // sorted top-5 insertion (ascending); `id` must not already be in the list
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
     if (kQ == 1) {
-        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->sc, P, sg.kind, s_acc, out,
+        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_acc, out,
                             dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
     } else {
         // kQ lanes per query: the coefficients go to memory and k_rows_reduce builds the partial rows with the SAME 256-query
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __rest
         ok = coef_ok[qflat] != 0;
     }
     const float cf[4] = { c4.x, c4.y, c4.z, c4.w };
-    row_and_reduce(ok, cf, q4, it->sc, P, s_acc, out);
+    row_and_reduce(ok, cf, q4, it->jk, P, s_acc, out);
 }
 
 // walk with a FIXED coverage radius: every cell that can hold a point with d^2 < cov2 is visited, so after the
@@ -1200,7 +1203,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
         if (kind == 0) { if (m0.w == 1.f) ok = corner_eval(m0, m1, px, py, pz, w, P, cf); }
         else           { if (m0.w == m0.w) ok = surf_eval(m0, px, py, pz, w, P, cf); }
     }
-    row_and_reduce(ok, cf, q4, it->sc, P, s_acc, out);
+    row_and_reduce(ok, cf, q4, it->jk, P, s_acc, out);
 }
 
 }  // namespace

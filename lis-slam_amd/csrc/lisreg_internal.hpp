@@ -83,6 +83,7 @@ struct ItemState {
     float P[36];               // matP
     float M[12];               // trans2Affine3f(T) for the NEXT correspondence launch (uniform -> scalar loads)
     float sc[6];               // srx, crx, sry, cry, srz, crz of LMOptimization (:862-867) for the same T
+    float jk[21];              // the pose-only factors of LMOptimization's arx / ary / arz (:898-907), see jacobian_row
     int   iter;                // iterations started so far
     int   done;                // converged / exhausted: all later launches skip this item
     int   iters_out;           // iterCount as the reference reports it

@@ -195,6 +195,18 @@ __device__ void write_pose_cache(ItemState* it)
     it->sc[0] = D; it->sc[1] = C;      // srx = sin(pitch), crx = cos(pitch)
     it->sc[2] = B; it->sc[3] = A;      // sry = sin(yaw),   cry = cos(yaw)
     it->sc[4] = F; it->sc[5] = E;      // srz = sin(roll),  crz = cos(roll)
+    // LMOptimization :898-907: every coefficient of pointOri.{x,y,z} in arx / ary / arz depends on the pose only.  They are formed
+    // here once per registration and iteration with the reference's own association ((a*b)*c ...), so that the correspondence kernel
+    // multiplies each by the point coordinate exactly where the reference does — instead of 64 lanes redoing ~45 uniform products.
+    const float srx = D, crx = C, sry = B, cry = A, srz = F, crz = E;
+    float* K = it->jk;
+    K[0] = crx * sry * srz;  K[1] = crx * crz * sry;  K[2] = srx * sry;
+    K[3] = -srx * srz;       K[4] = crz * srx;        K[5] = crx;
+    K[6] = crx * cry * srz;  K[7] = crx * cry * crz;  K[8] = cry * srx;
+    K[9] = cry * srx * srz - crz * sry;    K[10] = sry * srz + cry * crz * srx;   K[11] = crx * cry;
+    K[12] = -cry * crz - srx * sry * srz;  K[13] = cry * srz - crz * srx * sry;   K[14] = crx * sry;
+    K[15] = crz * srx * sry - cry * srz;   K[16] = crx * crz;                      K[17] = crx * srz;
+    K[18] = crz * sry - cry * srx * srz;   K[19] = 0.f;                            K[20] = 0.f;
 }
 
 __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P,
