@@ -343,6 +343,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const v2f* gptr_f2;
 typedef __attribute__((address_space(1))) v4i*       gptr_i4w;
 
+// gather of record `i` (16-byte records) from a wave-uniform base: a 32-bit unsigned byte offset lets the compiler use the
+// scalar-base + vector-offset form of global_load (no 64-bit address arithmetic per lane).  i * 16 < 2^32: targets up to 268 M points.
+typedef __attribute__((address_space(1))) const char* gptr_c;
+#define LISREG_LD3(base, i) (*(gptr_f3)((gptr_c)(base) + ((unsigned)(i) << 4)))
+#define LISREG_LD4(base, i) (*(gptr_f4)((gptr_c)(base) + ((unsigned)(i) << 4)))
+
 __device__ __forceinline__ int grid_coord(float v, float origin, float inv_cell)
 {
     return (int)floorf((v - origin) * inv_cell);
@@ -373,7 +379,7 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
     if (found) {
         float4 nb[5];
         const gptr_f4 gp = (gptr_f4)g.pts;
-        const v4f n0 = gp[i0], n1 = gp[i1], n2 = gp[i2], n3 = gp[i3], n4 = gp[i4];
+        const v4f n0 = LISREG_LD4(gp, i0), n1 = LISREG_LD4(gp, i1), n2 = LISREG_LD4(gp, i2), n3 = LISREG_LD4(gp, i3), n4 = LISREG_LD4(gp, i4);
         nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
         nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
         nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
@@ -706,7 +712,7 @@ constexpr int kWalkCap = 8;
 // build).  Candidates are tested against the running five best; the scan stops once the list has moved past c5 + d_a.
 #define LISREG_GRAPH_GROUP(IDV, TRYM) do { \
         const int k0_ = (IDV).x, k1_ = (IDV).y < 0 ? a_ : (IDV).y, k2_ = (IDV).z < 0 ? a_ : (IDV).z, k3_ = (IDV).w < 0 ? a_ : (IDV).w; \
-        const v3f c0_ = *(gptr_f3)(pts + k0_), c1_ = *(gptr_f3)(pts + k1_), c2_ = *(gptr_f3)(pts + k2_), c3_ = *(gptr_f3)(pts + k3_); \
+        const v3f c0_ = LISREG_LD3(pts, k0_), c1_ = LISREG_LD3(pts, k1_), c2_ = LISREG_LD3(pts, k2_), c3_ = LISREG_LD3(pts, k3_); \
         const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
         const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
         const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
@@ -746,7 +752,7 @@ constexpr int kWalkCap = 8;
             float thr2_; \
             if (hop_ == 0 && cnt_ >= 4) { \
                 /* anchor + the first four entries: all distinct, nothing in the list yet -> sort the five and take what is inside tau */ \
-                const v3f c0_ = *(gptr_f3)(pts + id0_.x), c1_ = *(gptr_f3)(pts + id0_.y), c2_ = *(gptr_f3)(pts + id0_.z), c3_ = *(gptr_f3)(pts + id0_.w); \
+                const v3f c0_ = LISREG_LD3(pts, id0_.x), c1_ = LISREG_LD3(pts, id0_.y), c2_ = LISREG_LD3(pts, id0_.z), c3_ = LISREG_LD3(pts, id0_.w); \
                 float sd[5]; int sid[5] = { a_, id0_.x, id0_.y, id0_.z, id0_.w }; \
                 sd[0] = da2_; \
                 { const float x_ = qx - c0_.x, y_ = qy - c0_.y, z_ = qz - c0_.z; sd[1] = x_ * x_ + y_ * y_ + z_ * z_; } \
