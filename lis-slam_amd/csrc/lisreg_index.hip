@@ -642,7 +642,7 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
     __builtin_amdgcn_wave_barrier();
 
     constexpr unsigned long long kEmpty = ((unsigned long long)0x7f800000u << 32) | 0xffffffffull;      // (+inf, id -1)
-    unsigned long long top = kEmpty;                        // running 32 best in lanes 0..31, ascending
+    unsigned long long top = kEmpty;                        // running kGraphK best in lanes 0..kGraphK-1, ascending
 #pragma unroll 1
     for (int c0 = 0; c0 < total; c0 += 64) {
         const int t = c0 + lane;
@@ -658,19 +658,27 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
             if (j != s && d2 < 3.0e38f) k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;   // NaN / Inf points are never neighbours
         }
         k = sort64(k, lane);
-        // lanes 32..63 <- the chunk's 32 smallest, reversed; lanes 0..31 keep the running best: one bitonic sequence, merged
-        // by the half-cleaners alone
-        const unsigned rlo = (unsigned)__shfl((int)(unsigned)k, 63 - lane), rhi = (unsigned)__shfl((int)(unsigned)(k >> 32), 63 - lane);
-        unsigned long long m = lane < 32 ? top : (((unsigned long long)rhi << 32) | rlo);
-        top = half_cleaners<32>(m, lane);
+        if constexpr (kGraphK == 32) {
+            // lanes 32..63 <- the chunk's 32 smallest, reversed; lanes 0..31 keep the running best: one bitonic sequence, merged
+            // by the half-cleaners alone
+            const unsigned rlo = (unsigned)__shfl((int)(unsigned)k, 63 - lane), rhi = (unsigned)__shfl((int)(unsigned)(k >> 32), 63 - lane);
+            unsigned long long m = lane < 32 ? top : (((unsigned long long)rhi << 32) | rlo);
+            top = half_cleaners<32>(m, lane);
+        } else {
+            // running 64 best in all lanes: the lane-wise minimum of the running list and the reversed chunk is the 64 smallest of
+            // both as one bitonic sequence; the half-cleaners sort it
+            const unsigned rlo = (unsigned)__shfl((int)(unsigned)k, 63 - lane), rhi = (unsigned)__shfl((int)(unsigned)(k >> 32), 63 - lane);
+            const unsigned long long r = ((unsigned long long)rhi << 32) | rlo;
+            top = half_cleaners<32>(r < top ? r : top, lane);
+        }
     }
     const float tk = __uint_as_float((unsigned)(top >> 32));
     const int ti = (int)(unsigned)top;
-    const float d32 = __shfl(tk, 31);
-    const float rho2 = fminf(rc * rc, d32);
-    const bool keep = lane < 32 && ti >= 0 && tk <= rho2;
+    const float dK = __shfl(tk, kGraphK - 1);
+    const float rho2 = fminf(rc * rc, dK);
+    const bool keep = lane < kGraphK && ti >= 0 && tk <= rho2;
     const int cnt = __popcll(__ballot(keep));
-    if (lane < 32) const_cast<int*>(g.nbr)[(size_t)s * kGraphK + lane] = keep ? ti : -1;
+    if (lane < kGraphK) const_cast<int*>(g.nbr)[(size_t)s * kGraphK + lane] = keep ? ti : -1;
     if (lane == 0) const_cast<float2*>(g.nbr_meta)[s] = make_float2(rho2, __int_as_float(cnt));
 }
 

@@ -12,7 +12,7 @@ constexpr int kStageCap   = 1024;  // target points staged in LDS per chunk (16 
 constexpr int kNumAcc     = 28;    // 21 upper-tri AtA + 6 AtB + 1 count
 constexpr int kResultSize = 12;    // floats per item in the result block
 constexpr int kTraceStride = LISREG_TRACE_STRIDE;
-constexpr int kGraphK     = 32;    // neighbour-list length of the target's k-NN graph (search_mode 3)
+constexpr int kGraphK     = 64;    // neighbour-list length of the target's k-NN graph (search_mode 3)
 
 // Uniform-grid index over one target cloud (replaces one pcl::KdTreeFLANN, odomEstimationNode.cpp:602-603).
 // Points are bucket-sorted by cell; linear cell id = (ix*ny + iy)*nz + iz (z fastest), so a z-range of one
