@@ -194,10 +194,14 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
  * point, 1 strip form — LDS histograms, one workgroup per strip of cells; an error if a grid does not fit its LDS tables —,
  * 2 [default] strip form whenever the grids fit; both produce the same index bit for bit), "index_strip_cells", "index_strip_cap",
+ * "xcd_order" (dispatch order of the correspondence workgroups of a graph-front-end batch: 0 block order, 1 by target sector so that
+ * each of the 8 XCDs — each with its own L2 — works on one eighth of the target, 2 auto [default]: 1 for batches of >= 32 registrations;
+ * results do not depend on it, bit for bit),
  * "graph_min_ratio", "graph_radius_mm", "cert_slack_mm", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
- * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form. */
+ * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the
+ * sector dispatch order. */
 int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
 
 /* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):

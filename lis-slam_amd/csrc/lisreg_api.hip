@@ -262,6 +262,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_WIDE_UNTIL")) c->graph_wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_HOPS")) c->graph_hops = atoi(m);
+    if (const char* m = getenv("LISREG_XCD_ORDER")) c->xcd_order = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_MIN_RATIO")) c->graph_min_ratio = atoi(m);
     if (const char* m = getenv("LISREG_WIDE_FROM")) c->wide_from = atoi(m);
     *out = c;
@@ -277,7 +278,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->xcd_tab, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
@@ -725,6 +726,15 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
+    // XCD-aware dispatch order (lisreg_assoc.hip, launch_xcd_order): two small launches per run, at the initial poses.  Auto: the graph
+    // front-end with >= 32 registrations (measured: +2.5 % at 64 scans, +4.9 % at 256; with 8 big scans the sectors are unevenly loaded
+    // and it costs 2 %; the walk front-end gains nothing)
+    c->xcd_now = c->mode_now == 3 && c->lanes_q != 8 && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32));
+    if (c->xcd_now) {
+        HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
+        launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
+                         c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, st);
+    }
     const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk != 0;
     // how often the host looks at the "registrations finished" counter: a skipped launch of a big batch still dispatches tens of
     // thousands of workgroups (check every 3 iterations), a skipped launch of a single frame costs ~2 us (check every 6: one
@@ -739,7 +749,8 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                      it >= c->wide_from && it <= (c->mode_now == 3 ? c->graph_wide_until : c->wide_until), c->graph_hops,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
                      c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, c->lanes_q,
-                     c->blocks_q.as<BlockDesc>(), (int)c->h_blocks_q.size(), c->coef.as<float4>(), c->coef_ok.as<int>(), st);
+                     c->blocks_q.as<BlockDesc>(), (int)c->h_blocks_q.size(), c->coef.as<float4>(), c->coef_ok.as<int>(),
+                     c->xcd_now ? c->xcd_tab.as<int>() + c->n_blocks : nullptr, st);
         prof_mark(c, 1);
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
@@ -811,6 +822,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "graph_radius_mm")) { c->graph_radius = 1e-3f * (float)value; for (auto& t : c->targets) t.graph_valid[0] = t.graph_valid[1] = false; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
+    if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; return LISREG_OK; }
     if (!strcmp(name, "index_build")) {
         if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "index_build: 0 bucket sort, 1 strip form, 2 auto");
         c->index_build = value; c->prepared = false;
@@ -843,6 +855,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "sorted_now")) { *value = c->sort_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { *value = c->graph_min_ratio; return LISREG_OK; }
+    if (!strcmp(name, "xcd_order")) { *value = c->xcd_order; return LISREG_OK; }
+    if (!strcmp(name, "xcd_order_now")) { *value = c->xcd_now ? 1 : 0; return LISREG_OK; }
     return LISREG_ERR_ARG;
 }
 

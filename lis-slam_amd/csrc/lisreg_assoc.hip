@@ -800,19 +800,27 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
                                                         int* __restrict__ nn_, int n_elems, float first_pass_r2,
                                                         int graph_hops, unsigned long long* __restrict__ counters,
                                                         int* __restrict__ dbg_nn, float4* __restrict__ coef, int* __restrict__ coef_ok,
-                                                        double* __restrict__ partials)
+                                                        double* __restrict__ partials, const int* __restrict__ xcd_order)
 {
     __shared__ double s_acc[4][kNumAcc];
     __shared__ int2   s_runs[kWalkCap][kBlockQ];          // per-lane list of candidate runs for the flattened walk
     constexpr float kEps = 1e-3f;
 
     const int tid = threadIdx.x;
-    const BlockDesc bd = blocks[blockIdx.x];
+    // XCD-aware dispatch order (launch_xcd_order below): workgroup p runs on XCD p % 8; the table (blocks ranked by sector) hands it a
+    // block of "its" eighth of the ranking.  Partial rows stay addressed by the block id, so the sums do not depend on the order.
+    int bid = blockIdx.x;
+    if (xcd_order) {
+        // XCD x owns dispatch positions x, x + 8, ... (m + 1 of them for x < t, else m) and the ranks [x * m + min(x, t), ...) of the sector order
+        const int m = gridDim.x >> 3, t = gridDim.x & 7, x = blockIdx.x & 7;
+        bid = xcd_order[x * m + min(x, t) + (int)(blockIdx.x >> 3)];
+    }
+    const BlockDesc bd = blocks[bid];
     const ItemState* it = &items[bd.item];
     if (it->done) return;
     const Segment sg = segs[bd.seg];
     const GridIndex g = grids[sg.target];
-    double* out = partials + (size_t)blockIdx.x * kNumAcc;
+    double* out = partials + (size_t)bid * kNumAcc;
     if (g.n < 5) {
         if (kQ == 1 && tid < kNumAcc) out[tid] = 0.0;      // kQ > 1: k_rows_reduce owns the partial rows
         return;
@@ -1212,22 +1220,107 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __res
     row_and_reduce(ok, cf, q4, it->jk, P, s_acc, out);
 }
 
+
+// ---- XCD-aware dispatch order for shared-target batches (search_mode 3) ----------------------------------------------------------
+// MI355X hands workgroup p of a launch to XCD p % 8, and every XCD has its own 4 MB L2.  In dispatch order = block order, each
+// XCD sees queries from everywhere in the target, i.e. the whole graph (rows + points: 30-60 MB for a 200 k-point submap) streams
+// through every L2.  Here the blocks are ranked by the azimuth of their middle query around the target's centre (map frame, initial
+// pose) and dealt so that XCD x gets the x-th eighth of that ranking, in ascending order: each L2 serves one sector, and at any moment
+// a narrow wedge of it (L2 hit rate of the correspondence launches 73 % -> 88 %).  Sectors rather than slabs:
+// they are statistically alike, so the eight XCDs finish together (x- or y-slabs measured 5 % SLOWER: the outer slabs hold the
+// expensive far-field blocks).  Keys by one thread per block, then one workgroup: 1024-bin counting sort in LDS; the order inside a bin is arbitrary and does not
+// matter (results are addressed by block id).
+constexpr int kSectorBins = 1024;
+__global__ __launch_bounds__(256) void k_xcd_keys(const BlockDesc* __restrict__ blocks, int n_blocks, const Segment* __restrict__ segs,
+                                                  const GridIndex* __restrict__ grids, const ItemState* __restrict__ items,
+                                                  const float4* __restrict__ sorted_all, int* __restrict__ keys)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc bd = blocks[b];
+    const Segment sg = segs[bd.seg];
+    const GridIndex g = grids[sg.target];
+    const float* M = items[bd.item].M;
+    const int e = bd.start + bd.count / 2;
+    const float4 q = sorted_all ? sorted_all[sg.flat_base + e] : sg.src[e];
+    const float x = M[0] * q.x + M[1] * q.y + M[2] * q.z + M[3] - (g.ox + 0.5f * (float)g.nx * g.cell);
+    const float y = M[4] * q.x + M[5] * q.y + M[6] * q.z + M[7] - (g.oy + 0.5f * (float)g.ny * g.cell);
+    const float a = atan2f(y, x) * (0.5f * (float)kSectorBins / 3.14159265f) + 0.5f * (float)kSectorBins;
+    const int k = (a == a) ? (int)a : 0;                     // NaN poses / points: bin 0
+    keys[b] = min(max(k, 0), kSectorBins - 1);
+}
+
+__global__ __launch_bounds__(1024) void k_xcd_order(int n_blocks, const int* __restrict__ keys, int* __restrict__ order)
+{
+    __shared__ int s_cnt[kSectorBins], s_tmp[kSectorBins];
+    const int tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    __syncthreads();
+    // kU independent key loads in flight per thread: a single workgroup is bound by the round trips, not by bandwidth
+    constexpr int kU = 32;
+    for (int base = 0; base < n_blocks; base += kU * 1024) {
+        int k[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int b = base + u * 1024 + tid; k[u] = b < n_blocks ? keys[b] : -1; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (k[u] >= 0) atomicAdd(&s_cnt[k[u]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins: shuffles inside each of the 16 waves, the 16 wave totals through LDS (two barriers, not twenty)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int mine = s_cnt[tid];
+    int v = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+    if (lane == 63) s_tmp[wave] = v;
+    __syncthreads();
+    if (tid < 16) {
+        int w = s_tmp[tid];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(w, d); if (tid >= d) w += o; }
+        s_tmp[16 + tid] = w - s_tmp[tid];                    // exclusive offset of wave `tid`
+    }
+    __syncthreads();
+    v += s_tmp[16 + wave];
+    s_cnt[tid] = v - mine;                                   // cursor = first rank of the bin
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += kU * 1024) {
+        int k[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int b = base + u * 1024 + tid; k[u] = b < n_blocks ? keys[b] : -1; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (k[u] < 0) continue;
+            const int r = atomicAdd(&s_cnt[k[u]], 1);
+            order[r] = base + u * 1024 + tid;                // ranks of a wave's equal keys are consecutive: near-coalesced stores
+        }
+    }
+}
+
 }  // namespace
+
+void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,
+                      const float4* sorted_all, int* keys, int* order, hipStream_t st)
+{
+    if (n_blocks <= 0) return;
+    k_xcd_keys<<<(n_blocks + 255) / 256, 256, 0, st>>>(blocks, n_blocks, segs, grids, items, sorted_all, keys);
+    k_xcd_order<<<1, 1024, 0, st>>>(n_blocks, keys, order);
+}
 
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
                   float slack, bool wide, int graph_hops, unsigned long long* counters, int* dbg_nn, int lanes_q,
-                  const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, hipStream_t st)
+                  const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st)
 {
     if (n_blocks <= 0) return;
     if (mode == 1 && lanes_q == 8) {
         if (wide)
             k_assoc_walk<true, false, 8><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                         first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+                                                                         first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
             k_assoc_walk<false, false, 8><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                          first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+                                                                          first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         k_rows_reduce<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, coef, coef_ok, partials);
         return;
     }
@@ -1236,17 +1329,17 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
     else if (mode == 1)
         if (wide)
             k_assoc_walk<true, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
             k_assoc_walk<false, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
     else if (mode == 3)
         if (wide)
             k_assoc_walk<true, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                      first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+                                                                      first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
         else
             k_assoc_walk<false, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials);
+                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
     else
         k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
                                                      model1, n_elems, first_pass_r2, slack, counters, partials);

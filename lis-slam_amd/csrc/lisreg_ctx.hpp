@@ -86,7 +86,7 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
-    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, tchunk_dev, strip_tab, done_dev,
+    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, tchunk_dev, strip_tab, done_dev, xcd_tab,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_cat, ft_bounds, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
@@ -121,6 +121,8 @@ struct lisreg_ctx {
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
     bool      lanes_per_query_auto = true;
     int       graph_min_ratio = 100;     // auto: query-iterations per target point from which the graph build pays (measured break-even ~75)
+    int       xcd_order = 2;             // XCD-aware dispatch order of the correspondence launches: 0 off, 1 on (graph front-end), 2 auto (graph front-end, >= 32 registrations, >= 2048 blocks)
+    bool      xcd_now = false;           // what the last run used
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
     float     graph_radius = 1.5f;       // coverage radius of a short neighbour list (search_mode 3)

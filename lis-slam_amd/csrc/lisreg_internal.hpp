@@ -164,7 +164,11 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
                   int* dbg_nn /* may be null; modes 1 and 3: [6][n_elems] original indices of each query's neighbours + accept flag */,
                   int lanes_q /* mode 1: 1, or 8 lanes per query (small batches) */,
                   const BlockDesc* blocks_q, int n_blocks_q /* lanes_q = 8: descriptors of kBlockQ / 8 queries for the search */,
-                  float4* coef, int* coef_ok /* lanes_q = 8: per-query coefficients handed to k_rows_reduce */, hipStream_t st);
+                  float4* coef, int* coef_ok /* lanes_q = 8: per-query coefficients handed to k_rows_reduce */,
+                  const int* xcd_order /* mode 3: dispatch position -> block id (launch_xcd_order), or null */, hipStream_t st);
+// XCD-aware dispatch order of a shared-target batch: blocks ranked by the azimuth of their middle query around the target centre
+void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,
+                      const float4* sorted_all, int* keys, int* order, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);

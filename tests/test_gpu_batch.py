@@ -135,6 +135,26 @@ def test_graph_scan_equals_cell_walk_bitwise(gpu_ctx, variant, labelled, seed, m
     assert np.array_equal(tr1, tr3)
 
 
+def test_xcd_dispatch_order_does_not_change_results(gpu_ctx):
+    """The sector dispatch order of the graph front-end (option "xcd_order": correspondence workgroups dealt to the 8 XCDs by
+    target sector) only changes WHICH workgroup slot processes a block; partial rows are addressed by block id, so poses and
+    stats are bit-identical with it on and off.  Also checks the option really engaged (xcd_order_now)."""
+    import lisreg
+    tc, ts, cases = _cases(9)
+    p = lisreg.default_params(1)
+    T0 = np.array([c["T_init"] for c in cases])
+    out = {}
+    for xo in (0, 1):
+        c2 = lisreg.Context(0)
+        c2.set_option("search_mode", 3); c2.set_option("xcd_order", xo)
+        c2.set_target(tc, ts)
+        out[xo] = c2.align_batch(cases, T0, p)
+        assert c2.get_option("xcd_order_now") == xo
+        c2.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
+
+
 def test_edge_cases(oracle, gpu_ctx):
     import lisreg
     from lisreg import synth
