@@ -143,16 +143,17 @@ def test_xcd_dispatch_order_does_not_change_results(gpu_ctx):
     tc, ts, cases = _cases(9)
     p = lisreg.default_params(1)
     T0 = np.array([c["T_init"] for c in cases])
-    out = {}
-    for xo in (0, 1):
-        c2 = lisreg.Context(0)
-        c2.set_option("search_mode", 3); c2.set_option("xcd_order", xo)
-        c2.set_target(tc, ts)
-        out[xo] = c2.align_batch(cases, T0, p)
-        assert c2.get_option("xcd_order_now") == xo
-        c2.close()
-    assert np.array_equal(out[0][0], out[1][0])
-    assert out[0][1] == out[1][1]
+    for sort in (0, 1):                                    # caller-order sources and the tile-sorted copy
+        out = {}
+        for xo in (0, 1):
+            c2 = lisreg.Context(0)
+            c2.set_option("search_mode", 3); c2.set_option("xcd_order", xo); c2.set_option("sort_sources", sort)
+            c2.set_target(tc, ts)
+            out[xo] = c2.align_batch(cases, T0, p)
+            assert c2.get_option("xcd_order_now") == xo
+            c2.close()
+        assert np.array_equal(out[0][0], out[1][0])
+        assert out[0][1] == out[1][1]
 
 
 def test_edge_cases(oracle, gpu_ctx):
