@@ -168,9 +168,9 @@ int build_target_kind(lisreg_ctx* c, Target& t, int k)
 int ensure_graph(lisreg_ctx* c, Target& t, int k, bool launch)
 {
     const size_t n = (size_t)std::max(t.n[k], 1);
-    HIPCHK(c, t.nbr[k].ensure(sizeof(int) * kGraphK * n));
+    HIPCHK(c, t.nbr[k].ensure(sizeof(float4) * kGraphK * n));
     HIPCHK(c, t.nbr_meta[k].ensure(sizeof(float2) * n));
-    t.g[k].nbr = t.nbr[k].as<int>();
+    t.g[k].nbr = t.nbr[k].as<float4>();
     t.g[k].nbr_meta = t.nbr_meta[k].as<float2>();
     if (launch && !t.graph_valid[k]) {
         launch_build_graph_one(t.g[k], c->graph_radius, c->stream);

@@ -708,24 +708,24 @@ constexpr int kWalkCap = 8;
 // insertion without the duplicate test: inside ONE neighbour list (plus its anchor) every id occurs once
 #define LISREG_TRY_ND(d2_, j_) do { if ((d2_) < b4) LISREG_INSERT((d2_), (j_)); } while (0)
 
-// one group of four list entries: ids IDV (padded with -1), list distance LMAX of the group's last entry (squared, from the
-// build).  Candidates are tested against the running five best; the scan stops once the list has moved past c5 + d_a.
-#define LISREG_GRAPH_GROUP(IDV, TRYM) do { \
-        const int k0_ = (IDV).x, k1_ = (IDV).y < 0 ? a_ : (IDV).y, k2_ = (IDV).z < 0 ? a_ : (IDV).z, k3_ = (IDV).w < 0 ? a_ : (IDV).w; \
-        const v3f c0_ = LISREG_LD3(pts, k0_), c1_ = LISREG_LD3(pts, k1_), c2_ = LISREG_LD3(pts, k2_), c3_ = LISREG_LD3(pts, k3_); \
-        const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
-        const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
-        const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
-        const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
+// one group of four list entries E0..E3 = (x, y, z, id bits) straight from the anchor's row — no id -> point gather: the row carries the
+// neighbours' coordinates (padded entries: the anchor's own coordinates, id -1).  Candidates are tested against the running five best;
+// the scan stops once the list has moved past c5 + d_a.
+#define LISREG_GRAPH_GROUP(E0, E1, E2, E3, TRYM) do { \
+        const int k0_ = __float_as_int((E0).w), k1_ = __float_as_int((E1).w), k2_ = __float_as_int((E2).w), k3_ = __float_as_int((E3).w); \
+        const float ax_ = qx - (E0).x, ay_ = qy - (E0).y, az_ = qz - (E0).z; \
+        const float bx_ = qx - (E1).x, by_ = qy - (E1).y, bz_ = qz - (E1).z; \
+        const float gx_ = qx - (E2).x, gy_ = qy - (E2).y, gz_ = qz - (E2).z; \
+        const float hx_ = qx - (E3).x, hy_ = qy - (E3).y, hz_ = qz - (E3).z; \
         const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_; \
-        const float e1_ = (IDV).y < 0 ? 3.0e38f : bx_ * bx_ + by_ * by_ + bz_ * bz_; \
-        const float e2_ = (IDV).z < 0 ? 3.0e38f : gx_ * gx_ + gy_ * gy_ + gz_ * gz_; \
-        const float e3_ = (IDV).w < 0 ? 3.0e38f : hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
+        const float e1_ = k1_ < 0 ? 3.0e38f : bx_ * bx_ + by_ * by_ + bz_ * bz_; \
+        const float e2_ = k2_ < 0 ? 3.0e38f : gx_ * gx_ + gy_ * gy_ + gz_ * gz_; \
+        const float e3_ = k3_ < 0 ? 3.0e38f : hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
         /* list distance of the group's entries (the list ascends; padded entries alias the anchor: 0) */ \
-        const float px_ = ap_.x - c0_.x, py_ = ap_.y - c0_.y, pz_ = ap_.z - c0_.z; \
-        const float rx_ = ap_.x - c1_.x, ry_ = ap_.y - c1_.y, rz_ = ap_.z - c1_.z; \
-        const float sx_ = ap_.x - c2_.x, sy_ = ap_.y - c2_.y, sz_ = ap_.z - c2_.z; \
-        const float tx_ = ap_.x - c3_.x, ty_ = ap_.y - c3_.y, tz_ = ap_.z - c3_.z; \
+        const float px_ = ap_.x - (E0).x, py_ = ap_.y - (E0).y, pz_ = ap_.z - (E0).z; \
+        const float rx_ = ap_.x - (E1).x, ry_ = ap_.y - (E1).y, rz_ = ap_.z - (E1).z; \
+        const float sx_ = ap_.x - (E2).x, sy_ = ap_.y - (E2).y, sz_ = ap_.z - (E2).z; \
+        const float tx_ = ap_.x - (E3).x, ty_ = ap_.y - (E3).y, tz_ = ap_.z - (E3).z; \
         const float l0_ = px_ * px_ + py_ * py_ + pz_ * pz_, l1_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_; \
         const float l2_ = sx_ * sx_ + sy_ * sy_ + sz_ * sz_, l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
         if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
@@ -734,13 +734,13 @@ constexpr int kWalkCap = 8;
         } \
         if (fmaxf(fmaxf(l0_, l1_), fmaxf(l2_, l3_)) > thr2_) stop_ = true; } while (0)
 
-// The first two id groups, the row's (rho^2, count) and the anchor point are fetched together; anchor + first four candidates
-// seed the five-best list through a 9-comparator network; later groups are streamed.
+// The first group, the row's (rho^2, count) and the anchor point are fetched together; anchor + first four candidates seed the
+// five-best list through a 9-comparator network; later groups stream out of the same row (consecutive 64-byte pieces).
 #define LISREG_GRAPH_SCAN() do { \
         int a_ = anchor; \
         _Pragma("unroll 1") for (int hop_ = 0; hop_ < graph_hops; ++hop_) { \
-            const gptr_i4 R4_ = (gptr_i4)(nbr + (size_t)a_ * kGraphK); \
-            const v4i id0_ = R4_[0], id1_ = R4_[1]; \
+            const gptr_f4 R_ = (gptr_f4)(nbr + (size_t)a_ * kGraphK); \
+            const v4f r0_ = R_[0], r1_ = R_[1], r2_ = R_[2], r3_ = R_[3]; \
             const v2f am_ = meta[a_]; \
             const v4f ap_ = pts[a_]; \
             const float rho2_ = am_.x; \
@@ -752,14 +752,13 @@ constexpr int kWalkCap = 8;
             float thr2_; \
             if (hop_ == 0 && cnt_ >= 4) { \
                 /* anchor + the first four entries: all distinct, nothing in the list yet -> sort the five and take what is inside tau */ \
-                const v3f c0_ = LISREG_LD3(pts, id0_.x), c1_ = LISREG_LD3(pts, id0_.y), c2_ = LISREG_LD3(pts, id0_.z), c3_ = LISREG_LD3(pts, id0_.w); \
-                float sd[5]; int sid[5] = { a_, id0_.x, id0_.y, id0_.z, id0_.w }; \
+                float sd[5]; int sid[5] = { a_, __float_as_int(r0_.w), __float_as_int(r1_.w), __float_as_int(r2_.w), __float_as_int(r3_.w) }; \
                 sd[0] = da2_; \
-                { const float x_ = qx - c0_.x, y_ = qy - c0_.y, z_ = qz - c0_.z; sd[1] = x_ * x_ + y_ * y_ + z_ * z_; } \
-                { const float x_ = qx - c1_.x, y_ = qy - c1_.y, z_ = qz - c1_.z; sd[2] = x_ * x_ + y_ * y_ + z_ * z_; } \
-                { const float x_ = qx - c2_.x, y_ = qy - c2_.y, z_ = qz - c2_.z; sd[3] = x_ * x_ + y_ * y_ + z_ * z_; } \
-                { const float x_ = qx - c3_.x, y_ = qy - c3_.y, z_ = qz - c3_.z; sd[4] = x_ * x_ + y_ * y_ + z_ * z_; } \
-                const float lx_ = ap_.x - c3_.x, ly_ = ap_.y - c3_.y, lz_ = ap_.z - c3_.z; \
+                { const float x_ = qx - r0_.x, y_ = qy - r0_.y, z_ = qz - r0_.z; sd[1] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - r1_.x, y_ = qy - r1_.y, z_ = qz - r1_.z; sd[2] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - r2_.x, y_ = qy - r2_.y, z_ = qz - r2_.z; sd[3] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - r3_.x, y_ = qy - r3_.y, z_ = qz - r3_.z; sd[4] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                const float lx_ = ap_.x - r3_.x, ly_ = ap_.y - r3_.y, lz_ = ap_.z - r3_.z; \
                 const float l3_ = lx_ * lx_ + ly_ * ly_ + lz_ * lz_; \
                 LISREG_CE5(0, 1); LISREG_CE5(3, 4); LISREG_CE5(2, 4); LISREG_CE5(2, 3); LISREG_CE5(0, 3); \
                 LISREG_CE5(0, 2); LISREG_CE5(1, 4); LISREG_CE5(1, 3); LISREG_CE5(1, 2); \
@@ -771,12 +770,11 @@ constexpr int kWalkCap = 8;
             } else { \
                 LISREG_TRY(da2_, a_); \
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
-                if (cnt_ > 0) LISREG_GRAPH_GROUP(id0_, LISREG_TRY); \
+                if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY); \
             } \
-            if (!stop_ && cnt_ > 4) { if (hop_ == 0) LISREG_GRAPH_GROUP(id1_, LISREG_TRY_ND); else LISREG_GRAPH_GROUP(id1_, LISREG_TRY); } \
-            _Pragma("unroll 1") for (int g_ = 2; !stop_ && 4 * g_ < cnt_; ++g_) { \
-                const v4i idg_ = R4_[g_]; \
-                if (hop_ == 0) LISREG_GRAPH_GROUP(idg_, LISREG_TRY_ND); else LISREG_GRAPH_GROUP(idg_, LISREG_TRY); \
+            _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
+                const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
+                if (hop_ == 0) LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); else LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY); \
             } \
             if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
             if (stop_) { certified = true; break; } \
@@ -854,7 +852,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (valid && it->iter > 0 && g.nbr) {
             const int anchor = nn[qflat];
             if (anchor >= 0) {
-                const gptr_i32 nbr = (gptr_i32)g.nbr;
+                const gptr_f4 nbr = (gptr_f4)g.nbr;
                 const gptr_f2 meta = (gptr_f2)g.nbr_meta;
                 bool certified = false;
                 LISREG_GRAPH_SCAN();

@@ -678,7 +678,13 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
     const float rho2 = fminf(rc * rc, dK);
     const bool keep = lane < kGraphK && ti >= 0 && tk <= rho2;
     const int cnt = __popcll(__ballot(keep));
-    if (lane < kGraphK) const_cast<int*>(g.nbr)[(size_t)s * kGraphK + lane] = keep ? ti : -1;
+    if (lane < kGraphK) {
+        // the row carries the neighbour's coordinates next to its id (one coalesced 1-KB store per point): the correspondence
+        // kernel then scans a row without an id -> point gather.  Entries that are not kept alias the point itself.
+        float4 e = make_float4(q.x, q.y, q.z, __int_as_float(-1));
+        if (keep) { const float4 c = g.pts[ti]; e = make_float4(c.x, c.y, c.z, __int_as_float(ti)); }
+        const_cast<float4*>(g.nbr)[(size_t)s * kGraphK + lane] = e;
+    }
     if (lane == 0) const_cast<float2*>(g.nbr_meta)[s] = make_float2(rho2, __int_as_float(cnt));
 }
 

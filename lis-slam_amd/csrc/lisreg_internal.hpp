@@ -24,10 +24,11 @@ struct GridIndex {
     float ox, oy, oz;          // grid origin (min corner)
     float cell, inv_cell;
     int   nx, ny, nz;
-    // k-NN graph over the sorted points (search_mode 3; null otherwise): nbr[s * kGraphK + j] = sorted position of the j-th
-    // nearest other point of sorted point s (ascending by distance, -1 padded); nbr_meta[s] = (rho^2, count bits) where
-    // every point closer to s than rho is in the list.
-    const int*    nbr;
+    // k-NN graph over the sorted points (search_mode 3; null otherwise): nbr[s * kGraphK + j] = (x, y, z, sorted position as int
+    // bits) of the j-th nearest other point of sorted point s, ascending by distance — the row carries the neighbours' COORDINATES,
+    // so a scan reads consecutive bytes of one row instead of gathering a point per id; padded entries = (s's own coordinates, -1).
+    // nbr_meta[s] = (rho^2, count bits) where every point closer to s than rho is in the list.
+    const float4* nbr;
     const float2* nbr_meta;
 };
 
