@@ -721,18 +721,15 @@ constexpr int kWalkCap = 8;
         const float e1_ = k1_ < 0 ? 3.0e38f : bx_ * bx_ + by_ * by_ + bz_ * bz_; \
         const float e2_ = k2_ < 0 ? 3.0e38f : gx_ * gx_ + gy_ * gy_ + gz_ * gz_; \
         const float e3_ = k3_ < 0 ? 3.0e38f : hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
-        /* list distance of the group's entries (the list ascends; padded entries alias the anchor: 0) */ \
-        const float px_ = ap_.x - (E0).x, py_ = ap_.y - (E0).y, pz_ = ap_.z - (E0).z; \
-        const float rx_ = ap_.x - (E1).x, ry_ = ap_.y - (E1).y, rz_ = ap_.z - (E1).z; \
-        const float sx_ = ap_.x - (E2).x, sy_ = ap_.y - (E2).y, sz_ = ap_.z - (E2).z; \
+        /* list distance of the group's LAST entry: the list ascends (the build computed these very values, same expression), so it \
+           is the group's largest; a padded last entry aliases the anchor (0) and then the list ends here: rho decides */ \
         const float tx_ = ap_.x - (E3).x, ty_ = ap_.y - (E3).y, tz_ = ap_.z - (E3).z; \
-        const float l0_ = px_ * px_ + py_ * py_ + pz_ * pz_, l1_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_; \
-        const float l2_ = sx_ * sx_ + sy_ * sy_ + sz_ * sz_, l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
+        const float l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
         if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
             TRYM(e0_, k0_); TRYM(e1_, k1_); TRYM(e2_, k2_); TRYM(e3_, k3_); \
             const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
         } \
-        if (fmaxf(fmaxf(l0_, l1_), fmaxf(l2_, l3_)) > thr2_) stop_ = true; } while (0)
+        if (l3_ > thr2_) stop_ = true; } while (0)
 
 // The first group, the row's (rho^2, count) and the anchor point are fetched together; anchor + first four candidates seed the
 // five-best list through a 9-comparator network; later groups stream out of the same row (consecutive 64-byte pieces).
