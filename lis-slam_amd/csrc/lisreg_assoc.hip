@@ -769,9 +769,18 @@ constexpr int kWalkCap = 8;
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY); \
             } \
-            _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
-                const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
-                if (hop_ == 0) LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); else LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY); \
+            /* two loops, not one loop with the hop test inside: the five-best list then has ONE home per loop (with the test inside, \
+               the compiler kept a second copy of the list for the other variant: 22 moves per group) */ \
+            if (hop_ == 0) { \
+                _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
+                    const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
+                    LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); \
+                } \
+            } else { \
+                _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
+                    const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
+                    LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY); \
+                } \
             } \
             if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
             if (stop_) { certified = true; break; } \
