@@ -274,7 +274,14 @@ __device__ __forceinline__ bool surf_eval(const float4 m, float x0, float y0, fl
     const float pa = m.x, pb = m.y, pc = m.z, pd = m.w;
     const float pd2 = pa * x0 + pb * y0 + pc * z0 + pd;
     const float rng = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
-    const float s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)rng);
+    // s = 1 - 0.9 * fabs(pd2) / sqrt(sqrt(...)) is a DOUBLE expression in the reference (:806, 0.9 is a double literal).  The quotient
+    // through a reciprocal refined twice from the 1-ulp float seed (relative error ~2^-52, against a ~20-instruction IEEE double
+    // division with its quarter-rate v_rcp_f64): the float s differs from the divided one about once in 10^8 evaluations, by one ulp.
+    const double rd = (double)rng;
+    double ir = (double)__builtin_amdgcn_rcpf(rng);
+    ir = ir * (2.0 - rd * ir);
+    ir = ir * (2.0 - rd * ir);
+    const float s = (float)(1.0 - (0.9 * (double)fabsf(pd2)) * ir);
     const float ws = w * s;
     cf[0] = ws * pa; cf[1] = ws * pb; cf[2] = ws * pc; cf[3] = ws * pd2;
     return (pd == pd) && (s > P.accept_s);
