@@ -766,9 +766,13 @@ constexpr int kWalkCap = 8;
                 const float l3_ = lx_ * lx_ + ly_ * ly_ + lz_ * lz_; \
                 LISREG_CE5(0, 1); LISREG_CE5(3, 4); LISREG_CE5(2, 4); LISREG_CE5(2, 3); LISREG_CE5(0, 3); \
                 LISREG_CE5(0, 2); LISREG_CE5(1, 4); LISREG_CE5(1, 3); LISREG_CE5(1, 2); \
-                b0 = fminf(sd[0], P.tau); b1 = fminf(sd[1], P.tau); b2 = fminf(sd[2], P.tau); b3 = fminf(sd[3], P.tau); b4 = fminf(sd[4], P.tau); \
-                i0 = sd[0] < P.tau ? sid[0] : -1; i1 = sd[1] < P.tau ? sid[1] : -1; i2 = sd[2] < P.tau ? sid[2] : -1; \
-                i3 = sd[3] < P.tau ? sid[3] : -1; i4 = sd[4] < P.tau ? sid[4] : -1; \
+                if (__builtin_amdgcn_ballot_w64(!(sd[4] < P.tau)) == 0) {           /* the usual case: all five inside tau in every lane */ \
+                    b0 = sd[0]; b1 = sd[1]; b2 = sd[2]; b3 = sd[3]; b4 = sd[4]; i0 = sid[0]; i1 = sid[1]; i2 = sid[2]; i3 = sid[3]; i4 = sid[4]; \
+                } else { \
+                    b0 = fminf(sd[0], P.tau); b1 = fminf(sd[1], P.tau); b2 = fminf(sd[2], P.tau); b3 = fminf(sd[3], P.tau); b4 = fminf(sd[4], P.tau); \
+                    i0 = sd[0] < P.tau ? sid[0] : -1; i1 = sd[1] < P.tau ? sid[1] : -1; i2 = sd[2] < P.tau ? sid[2] : -1; \
+                    i3 = sd[3] < P.tau ? sid[3] : -1; i4 = sd[4] < P.tau ? sid[4] : -1; \
+                } \
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (l3_ > thr2_) stop_ = true; \
             } else { \
