@@ -188,8 +188,9 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * build inside every lisreg_batch_run, as the reference rebuilds both kd-trees per registration, :602-603),
  * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (the exact 5-NN front-end
  * that stands in for pcl::KdTreeFLANN::nearestKSearch: 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion
- * certificate, 3 k-NN graph scan with the walk as its fall-back, 4 auto [default]: 3 when the prepared batch asks at
- * least "graph_min_ratio" query-iterations per target point, else 1 — all return the same neighbours),
+ * certificate, 3 k-NN graph scan with the walk as its fall-back — costs 1 KB of device memory per target point for the
+ * neighbour rows —, 4 auto [default]: 3 when the prepared batch asks at least "graph_min_ratio" query-iterations per target
+ * point, else 1 — all return the same neighbours),
  * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
  * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
  * point, 1 strip form — LDS histograms, one workgroup per strip of cells; an error if a grid does not fit its LDS tables —,
