@@ -738,11 +738,10 @@ constexpr int kWalkCap = 8;
         } \
         if (l3_ > thr2_) stop_ = true; } while (0)
 
-// The first group, the row's (rho^2, count) and the anchor point are fetched together; anchor + first four candidates seed the
-// five-best list through a 9-comparator network; later groups stream out of the same row (consecutive 64-byte pieces).
-#define LISREG_GRAPH_SCAN() do { \
-        int a_ = anchor; \
-        _Pragma("unroll 1") for (int hop_ = 0; hop_ < graph_hops; ++hop_) { \
+// One list: the first group, the row's (rho^2, count) and the anchor point are fetched together; on the FIRST list of a query, anchor
+// + first four candidates seed the five-best list through a 9-comparator network and the inserts need no duplicate test; later groups
+// stream out of the same row (consecutive 64-byte pieces).  Leaves stop_ = "the five kept are certified".
+#define LISREG_GRAPH_HOP(FIRST) \
             const gptr_f4 R_ = (gptr_f4)(nbr + (size_t)a_ * kGraphK); \
             const v4f r0_ = R_[0], r1_ = R_[1], r2_ = R_[2], r3_ = R_[3]; \
             const v2f am_ = meta[a_]; \
@@ -752,9 +751,9 @@ constexpr int kWalkCap = 8;
             const float ux_ = qx - ap_.x, uy_ = qy - ap_.y, uz_ = qz - ap_.z; \
             const float da2_ = ux_ * ux_ + uy_ * uy_ + uz_ * uz_; \
             const float da_ = __builtin_amdgcn_sqrtf(da2_) * 1.0001f + kEps; \
-            bool stop_ = false; \
+            stop_ = false; \
             float thr2_; \
-            if (hop_ == 0 && cnt_ >= 4) { \
+            if ((FIRST) && cnt_ >= 4) { \
                 /* anchor + the first four entries: all distinct, nothing in the list yet -> sort the five and take what is inside tau */ \
                 float sd[5]; int sid[5] = { a_, __float_as_int(r0_.w), __float_as_int(r1_.w), __float_as_int(r2_.w), __float_as_int(r3_.w) }; \
                 sd[0] = da2_; \
@@ -780,9 +779,7 @@ constexpr int kWalkCap = 8;
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY); \
             } \
-            /* two loops, not one loop with the hop test inside: the five-best list then has ONE home per loop (with the test inside, \
-               the compiler kept a second copy of the list for the other variant: 22 moves per group) */ \
-            if (hop_ == 0) { \
+            if (FIRST) { \
                 _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
                     const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
                     LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); \
@@ -793,10 +790,23 @@ constexpr int kWalkCap = 8;
                     LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY); \
                 } \
             } \
-            if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
-            if (stop_) { certified = true; break; } \
-            if (i0 == a_ || i0 < 0) break;                     /* nowhere better to hop to */ \
-            a_ = i0; \
+            if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */
+
+// The first list is straight-line code (in the steady state it is the only one); the hops after it — taken only without a certificate —
+// are a loop of their own, so that the five-best list is not a loop-carried value of the common path (the compiler kept it in a
+// second register set and copied 11 registers per pass, plus three rounds of initialisation).
+#define LISREG_GRAPH_SCAN() do { \
+        int a_ = anchor; \
+        bool stop_; \
+        { LISREG_GRAPH_HOP(true) } \
+        if (stop_) certified = true; \
+        else { \
+            _Pragma("unroll 1") for (int hop_ = 1; hop_ < graph_hops; ++hop_) { \
+                if (i0 == a_ || i0 < 0) break;                 /* nowhere better to hop to */ \
+                a_ = i0; \
+                { LISREG_GRAPH_HOP(false) } \
+                if (stop_) { certified = true; break; } \
+            } \
         } } while (0)
 
 #define LISREG_CE5(a, b) do { const bool sw_ = sd[b] < sd[a]; const float ta_ = sd[a]; const int ia_ = sid[a]; \
