@@ -775,6 +775,7 @@ constexpr int kWalkCap = 8;
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (l3_ > thr2_) stop_ = true; \
             } else { \
+                if (FIRST) LISREG_LIST_INIT(); \
                 LISREG_TRY(da2_, a_); \
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY); \
@@ -871,21 +872,26 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         qz = M[8] * q0.x + M[9] * q0.y + M[10] * q0.z + M[11];
     }
 
-    float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau;
-    int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
+    // the five-best list (ascending).  Not initialised here: the common path (graph scan, first list with >= 4 entries) overwrites all
+    // ten registers, and an initialisation up front is executed by every wavefront (the compiler even emitted it twice)
+    float b0, b1, b2, b3, b4;
+    int   i0, i1, i2, i3, i4;
+#define LISREG_LIST_INIT() do { b0 = b1 = b2 = b3 = b4 = P.tau; i0 = i1 = i2 = i3 = i4 = -1; } while (0)
     if (kGraph) {
         // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
-        bool need_walk = valid;
+        bool need_walk = valid, scanned = false;
         if (valid && it->iter > 0 && g.nbr) {
             const int anchor = nn[qflat];
             if (anchor >= 0) {
                 const gptr_f4 nbr = (gptr_f4)g.nbr;
                 const gptr_f2 meta = (gptr_f2)g.nbr_meta;
                 bool certified = false;
+                scanned = true;
                 LISREG_GRAPH_SCAN();
                 need_walk = !certified;
             }
         }
+        if (!scanned) LISREG_LIST_INIT();
         if (counters && it->iter > 0 && it->iter < 32) {       // diagnostics: lanes that fell back to the cell walk
             const int nw = __popcll(__ballot(need_walk)), nv = __popcll(__ballot(valid));
             if ((tid & 63) == 0) {
@@ -904,7 +910,10 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
             (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
         }
         if (valid) nn[qflat] = i0;                             // next iteration's anchor: the nearest neighbour (-1: none)
-    } else if (valid) {
+    } else if (!valid) {
+        LISREG_LIST_INIT();
+    } else {
+        LISREG_LIST_INIT();
         bool seeded = false;
         if (it->iter > 0) {
             // seeds: last iteration's neighbours bound the new 5th-nearest distance (any 5 points do), so the walk
