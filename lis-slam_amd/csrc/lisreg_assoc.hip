@@ -312,6 +312,8 @@ __device__ __forceinline__ void jacobian_row(const float* K /* ItemState::jk */,
     b = -cf[3];
 }
 
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+#ifdef LISREG_REDUCE_FP64
 __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -322,7 +324,6 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 // gfx950 lane swaps (V_PERMLANE32_SWAP / V_PERMLANE16_SWAP): exchange the upper 32 lanes (odd 16-lane rows) of `a` with the
 // lower 32 lanes (even rows) of `b`.  After the swap a + b is the halving-butterfly step with no select and no LDS traffic:
 // lanes of the lower half hold a(l) + a(partner), lanes of the upper half hold b(partner) + b(l).
-typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double swap_add32(double a, double b)
 {
     const v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
@@ -335,6 +336,7 @@ __device__ __forceinline__ double swap_add16(double a, double b)
     const v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
     return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
 }
+#endif
 
 // The index arrays are reached through pointers stored in device structs, which the compiler can only treat as
 // generic (flat_load).  They are always global memory: say so, and get global_load with a scalar base.
@@ -425,6 +427,7 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
     if (ok) { jacobian_row(jk, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
+#ifdef LISREG_REDUCE_FP64
     // the 28 normal-equation terms of this row, produced on demand (float x float is exact in double):
     //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
     auto term = [&](int k) -> double {
@@ -465,6 +468,62 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
         const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         if ((lane & 1) == 0 && idx < kNumAcc) s_acc[wave][idx] = v1;
     }
+#else
+    // the 28 normal-equation terms of this row, produced on demand:
+    //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
+    // ---- fixed-order reduction of a wavefront's 64 rows: fp32 halving butterfly, then fp64 from the wave sums on ------------------
+    // The kernel is bound by vector instructions and fp64 ones cost double: 28 fp64 products + a 32-step fp64 butterfly were 17 % of
+    // a steady-state launch.  Here the products and the 64-term tree are fp32 (relative error of a wave sum <= ~2e-7 of the sum of
+    // magnitudes — the reference's own matAtA is a float cv::gemm, and the step is solved in float); everything above a wave (four
+    // waves of a workgroup, workgroups of a registration) stays fp64 in a fixed order.  -DLISREG_REDUCE_FP64 builds the all-fp64
+    // form for comparison.  Each step exchanges HALF of the values with a partner lane in the other half of the
+    // group (xor 32 and 16 by V_PERMLANE32/16_SWAP; 15, 7, 3, 1 — row mirror, half-row mirror, quad mirror, neighbour — as DPP
+    // operands of the add), so 32 values need 16 + 8 + 4 + 2 + 1 (+ 1) adds; lane l ends with the sum of value index bits(l)[5:1].
+    auto term = [&](int k) -> float {
+        constexpr int R[21] = { 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5 };
+        constexpr int C[21] = { 0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5 };
+        if (k < 21) return row[R[k]] * row[C[k]];
+        if (k < 27) return row[k - 21] * rb;
+        if (k == 27) return one;
+        return 0.f;
+    };
+    auto swap32 = [](float a, float b) -> float {
+        const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float(r.x) + __uint_as_float(r.y);
+    };
+    auto swap16 = [](float a, float b) -> float {
+        const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float(r.x) + __uint_as_float(r.y);
+    };
+    float v16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v16[i] = swap32(term(i), term(i + 16));           // lanes 0-31: term i, lanes 32-63: term i + 16
+    float v8[8], v4[4], v2[2], v1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = swap16(v16[i], v16[i + 8]);                // even rows: v16[i], odd rows: v16[i + 8]
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v4[i] = (up ? v8[i + 4] : v8[i]) + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(up ? v8[i] : v8[i + 4]), 0x140, 0xF, 0xF, true));   // row_mirror: lane ^ 15
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            v2[i] = (up ? v4[i + 2] : v4[i]) + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(up ? v4[i] : v4[i + 2]), 0x141, 0xF, 0xF, true));   // row_half_mirror: lane ^ 7
+    }
+    {
+        const bool up = (lane & 2) != 0;
+        v1 = (up ? v2[1] : v2[0]) + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(up ? v2[0] : v2[1]), 0x1B, 0xF, 0xF, true));                  // quad_perm [3,2,1,0]: lane ^ 3
+    }
+    v1 += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v1), 0xB1, 0xF, 0xF, true));                                                              // quad_perm [1,0,3,2]: lane ^ 1
+    {
+        // value index held by this lane: bit5 -> +16, bit4 -> +8, bit3 -> +4, bit2 -> +2, bit1 -> +1
+        const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        if ((lane & 1) == 0 && idx < kNumAcc) s_acc[wave][idx] = (double)v1;
+    }
+#endif
     __syncthreads();
     if (tid < kNumAcc) {
         double v = s_acc[0][tid];
