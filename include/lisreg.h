@@ -190,7 +190,8 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * that stands in for pcl::KdTreeFLANN::nearestKSearch: 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion
  * certificate, 3 k-NN graph scan with the walk as its fall-back — costs 1 KB of device memory per target point for the
  * neighbour rows —, 4 auto [default]: 3 when the prepared batch asks at least "graph_min_ratio" query-iterations per target
- * point, else 1 — all return the same neighbours),
+ * point, else 1 — all return the same neighbours; the one exception is two candidates at exactly equal float distance from a query
+ * competing for the fifth place: the first one met wins, and the front-ends meet them in different orders),
  * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
  * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
  * point, 1 strip form — LDS histograms, one workgroup per strip of cells; an error if a grid does not fit its LDS tables —,
@@ -224,6 +225,12 @@ int  lisreg_get_neighbors(lisreg_ctx* ctx, int* out, int n_elems);
  * Any output pointer may be NULL. */
 int  lisreg_get_target_index(lisreg_ctx* ctx, int slot, int kind, int* dims, float* geom,
                              float* sorted_out, int sorted_capacity, int* cell_start_out, int cell_capacity);
+
+/* Diagnostics: the k-NN graph of a target's search index (search front-end 3; built now if it was not yet).  *k = entries per
+ * row; rows_out[p * k + j] = (x, y, z, sorted position as int bits) of the j-th nearest other point of sorted point p, ascending
+ * by distance, padded with (p's own coordinates, -1); meta_out[p] = (rho^2, count as int bits): every point closer to p than rho
+ * is in its row.  Either output may be NULL.  capacity_points >= the target's point count. */
+int  lisreg_get_target_graph(lisreg_ctx* ctx, int slot, int kind, int* k, float* rows_out, float* meta_out, int capacity_points);
 
 /* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
 int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);

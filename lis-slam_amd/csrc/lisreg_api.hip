@@ -1008,6 +1008,27 @@ int lisreg_get_target_index(lisreg_ctx* c, int slot, int kind, int* dims /* n, n
     return LISREG_OK;
 }
 
+int lisreg_get_target_graph(lisreg_ctx* c, int slot, int kind, int* k_out, float* rows_out, float* meta_out, int capacity_points)
+{
+    if (!c || slot < 0 || (size_t)slot >= c->targets.size() || kind < 0 || kind > 1 || !c->targets[(size_t)slot].valid)
+        return fail(c, LISREG_ERR_ARG, "get_target_graph: no such target");
+    Target& t = c->targets[(size_t)slot];
+    if (k_out) *k_out = kGraphK;
+    if (!rows_out && !meta_out) return LISREG_OK;
+    if (capacity_points < t.n[kind]) return fail(c, LISREG_ERR_ARG, "get_target_graph: capacity_points too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!t.graph_valid[kind] || !t.g[kind].nbr) {            // build it now (it is built on demand otherwise)
+        int rc = ensure_graph(c, t, kind, true);
+        if (rc) return rc;
+        c->grids_dirty = true;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)t.n[kind];
+    if (rows_out && n) HIPCHK(c, hipMemcpy(rows_out, t.nbr[kind].p, sizeof(float4) * kGraphK * n, hipMemcpyDeviceToHost));
+    if (meta_out && n) HIPCHK(c, hipMemcpy(meta_out, t.nbr_meta[kind].p, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    return LISREG_OK;
+}
+
 int lisreg_get_neighbors(lisreg_ctx* c, int* out, int n_elems)
 {
     if (!c || !out || n_elems < 0) return LISREG_ERR_ARG;

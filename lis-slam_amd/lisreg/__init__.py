@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
@@ -187,6 +187,7 @@ def lib():
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
         L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.lisreg_get_target_graph.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.lisreg_get_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
         L.lisreg_set_profiling.argtypes = [vp, C.c_int]
@@ -456,6 +457,18 @@ class Context:
         self._chk(self._L.lisreg_get_target_index(self._h, slot, kind, dims, geom, pts.ctypes.data, n, cs.ctypes.data, nc + 1))
         return dict(n=n, nx=nx, ny=ny, nz=nz, n_cells=nc, origin=np.array(geom[:3], np.float32), cell=float(geom[3]),
                     sorted=pts[:n], cell_start=cs)
+
+    def target_graph(self, slot: int = 0, kind: int = 1) -> dict:
+        """Diagnostics: the k-NN graph of a target (see lisreg_get_target_graph): ids [n, k] (sorted positions, -1 padded),
+        xyz [n, k, 3], rho2 [n], count [n]."""
+        n = self.target_index(slot, kind)["n"]
+        k = C.c_int()
+        self._chk(self._L.lisreg_get_target_graph(self._h, slot, kind, C.byref(k), None, None, 0))
+        rows = np.zeros((max(n, 1), k.value, 4), np.float32); meta = np.zeros((max(n, 1), 2), np.float32)
+        self._chk(self._L.lisreg_get_target_graph(self._h, slot, kind, C.byref(k), rows.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  meta.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return dict(k=k.value, ids=rows[:n, :, 3].copy().view(np.int32), xyz=rows[:n, :, :3], rho2=meta[:n, 0],
+                    count=meta[:n, 1].copy().view(np.int32))
 
     def raw_counters(self):
         out = (C.c_ulonglong * 128)()

@@ -103,3 +103,40 @@ def test_wide_sparse_map_still_takes_the_strip_form(gpu_ctx):
         _check(gpu_ctx, 0, 0, tc)
     finally:
         gpu_ctx.set_option("index_build", 2); gpu_ctx.set_option("rebuild_targets_each_run", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m_points,kind", [(60000, 1), (8000, 1), (60000, 0)])
+def test_graph_rows_cover_their_radius(gpu_ctx, m_points, kind):
+    """The k-NN graph behind search front-end 3 (lisreg_get_target_graph): for every row, (1) the entries are other points, each once,
+    in ascending distance from the row's point, (2) the coordinates stored in the row are the listed points' own, bit for bit (the
+    scan never gathers them), (3) EVERY target point closer than rho is listed — the guarantee the 5-NN certificate rests on —
+    checked against a float64 kd-tree, (4) padded entries carry the point's own coordinates and id -1."""
+    from scipy.spatial import cKDTree
+    from lisreg import synth
+    tc, ts = synth.make_submap(m_points, 77)
+    gpu_ctx.set_target(tc, ts)
+    idx = gpu_ctx.target_index(0, kind); g = gpu_ctx.target_graph(0, kind)
+    n, k = idx["n"], g["k"]
+    pts32 = idx["sorted"][:, :3]; pts = pts32.astype(np.float64)
+    assert g["ids"].shape == (n, k) and (g["count"] >= 0).all() and (g["count"] <= k).all()
+    col = np.arange(k)[None, :]
+    listed = col < g["count"][:, None]
+    assert ((g["ids"] >= 0) == listed).all()                                   # a prefix of real entries, then padding
+    own = np.broadcast_to(pts32[:, None, :], g["xyz"].shape)
+    assert np.array_equal(g["xyz"][~listed], own[~listed])                     # (4)
+    safe = np.where(listed, g["ids"], 0)
+    assert np.array_equal(g["xyz"][listed], pts32[safe][listed])               # (2)
+    assert (g["ids"][listed] != np.broadcast_to(np.arange(n)[:, None], (n, k))[listed]).all()
+    d = np.linalg.norm(g["xyz"].astype(np.float64) - pts[:, None, :], axis=2)
+    dd = np.where(listed, d, np.inf)
+    assert (np.diff(dd, axis=1)[listed[:, 1:]] >= -1e-6).all()                 # (1) ascending
+    assert (dd[listed] <= np.sqrt(g["rho2"].astype(np.float64))[:, None].repeat(k, 1)[listed] * (1 + 1e-6)).all()
+    tree = cKDTree(pts)
+    rng = np.random.default_rng(1)
+    for s in rng.choice(n, min(n, 4000), replace=False):
+        rho = float(np.sqrt(g["rho2"][s]))
+        want = set(tree.query_ball_point(pts[s], rho * (1 - 1e-5))) - {int(s)}
+        have = set(g["ids"][s][:g["count"][s]].tolist())
+        assert len(have) == g["count"][s]                                      # each once
+        assert want <= have, (s, rho, sorted(want - have)[:4])                 # (3)
