@@ -199,7 +199,7 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * "xcd_order" (dispatch order of the correspondence workgroups of a graph-front-end batch: 0 block order, 1 by target sector so that
  * each of the 8 XCDs — each with its own L2 — works on one eighth of the target, 2 auto [default]: 1 for batches of >= 32 registrations;
  * results do not depend on it, bit for bit),
- * "graph_min_ratio", "graph_radius_mm", "cert_slack_mm", "first_pass_mm", "count_searches", "early_stop_chunk". */
+ * "graph_min_ratio", "cert_slack_mm", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
  * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the

@@ -173,7 +173,7 @@ int ensure_graph(lisreg_ctx* c, Target& t, int k, bool launch)
     t.g[k].nbr = t.nbr[k].as<float4>();
     t.g[k].nbr_meta = t.nbr_meta[k].as<float2>();
     if (launch && !t.graph_valid[k]) {
-        launch_build_graph_one(t.g[k], c->graph_radius, c->stream);
+        launch_build_graph_one(t.g[k], c->stream);
         HIPCHK(c, hipGetLastError());
         t.graph_valid[k] = true;
     }
@@ -258,7 +258,6 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
     if (const char* m = getenv("LISREG_CERT_SLACK_MM")) c->cert_slack = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
-    if (const char* m = getenv("LISREG_GRAPH_RADIUS_MM")) c->graph_radius = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_WIDE_UNTIL")) c->graph_wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_HOPS")) c->graph_hops = atoi(m);
@@ -672,9 +671,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->sort_now = c->sort_sources == 1;
     if (c->sort_sources == 2 && c->n_elems >= 65536) {
         launch_count_jumps(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), 1.5f, c->done_dev.as<int>(), c->stream);
-        HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int jumps_stack = 0;
+        int* jumps = c->done_host ? c->done_host : &jumps_stack;       // lisreg_create tolerates a failed pinned allocation
+        HIPCHK(c, hipMemcpyAsync(jumps, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->sort_now = (double)*c->done_host > 0.25 * (double)c->n_elems;
+        c->sort_now = (double)*jumps > 0.25 * (double)c->n_elems;
     }
     // scratch of the bucket sorts: the target rebuild (if the batch does that) and the source sort (only if it will run)
     {
@@ -718,7 +719,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                                          (int)c->h_tsegs.size(), c->t_elems, c->t_buckets, sort_buffers(c), st);
         if (c->mode_now == 3)
             launch_build_graph(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
-                               c->grids_dev.as<GridIndex>(), c->graph_radius, st);
+                               c->grids_dev.as<GridIndex>(), st);
         prof_mark(c, -1);
     }
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
@@ -820,7 +821,6 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
     if (!strcmp(name, "search_mode")) { c->search_mode = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
-    if (!strcmp(name, "graph_radius_mm")) { c->graph_radius = 1e-3f * (float)value; for (auto& t : c->targets) t.graph_valid[0] = t.graph_valid[1] = false; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; return LISREG_OK; }
     if (!strcmp(name, "index_build")) {
@@ -913,11 +913,12 @@ int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, con
     static const bool host_prof = getenv("LISREG_HOST_PROF") != nullptr;      // where a synchronous call spends its host time
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t0 = now();
+    // a failure after uploads have been enqueued must not return while the DMA still reads the caller's (possibly pinned) buffers
     int rc = lisreg_batch_prepare(c, n_items, dev_items.data(), params, T);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     const auto t1 = now();
     rc = run_impl(c, true);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     const auto t2 = now();
     rc = lisreg_batch_fetch(c, T, stats);
     if (host_prof) {
@@ -1371,7 +1372,9 @@ int lisreg_extract_features_batch(lisreg_ctx* c, int n_sweeps, const void* const
     HIPCHK(c, c->ft_counts.ensure(sizeof(int) * 8));
     HIPCHK(c, c->ft_cat.ensure(sizeof(float4) * (size_t)std::max(N, 1)));
     HIPCHK(c, c->ft_rings.ensure(sizeof(uint32_t) * (size_t)std::max(N, 1)));
-    HIPCHK(c, c->ft_bounds.ensure(sizeof(int) * 5 * ((size_t)n_sweeps + 1) + 16 * 5 * (size_t)n_sweeps));
+    // layout: (S + 1) x 5 list boundaries, then — at the next 16-byte boundary — the 5 x S gather jobs (16 bytes each)
+    const size_t jobs_off = (sizeof(int) * 5 * ((size_t)n_sweeps + 1) + 15) & ~(size_t)15;
+    HIPCHK(c, c->ft_bounds.ensure(jobs_off + 16 * 5 * (size_t)n_sweeps));
     FeatureBuffers fb;
     fb.owner = c->ft_owner.as<int>(); fb.flag = c->ft_flag.as<int>(); fb.pos = c->ft_pos.as<int>(); fb.scan_tmp = c->ft_scan.as<int>();
     fb.col = c->ft_col.as<int>(); fb.range = c->ft_range.as<float>(); fb.src = c->ft_src.as<int>(); fb.curv = c->ft_curv.as<float>();
@@ -1409,8 +1412,8 @@ int lisreg_extract_features_batch(lisreg_ctx* c, int n_sweeps, const void* const
             if (bufs[k]) max_count[k] = std::max(max_count[k], cnt[k]);
         }
     }
-    Job* jobs_dev = reinterpret_cast<Job*>(Bdev + 5 * ((size_t)n_sweeps + 1) + 3) ;     // 16-byte slots behind the bounds
-    jobs_dev = reinterpret_cast<Job*>(((uintptr_t)jobs_dev + 15) & ~(uintptr_t)15);
+    static_assert(sizeof(Job) == 16, "gather job = one 16-byte slot");
+    Job* jobs_dev = reinterpret_cast<Job*>(reinterpret_cast<unsigned char*>(Bdev) + jobs_off);     // hipMalloc'ed base is 256-byte aligned
     HIPCHK(c, hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
     const int* idx[5] = { fb.src, fb.lists + 0 * L, fb.lists + 1 * L, fb.lists + 2 * L, fb.lists + 3 * L };
     for (int k = 0; k < 5; ++k)

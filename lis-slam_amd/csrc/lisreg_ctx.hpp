@@ -125,7 +125,6 @@ struct lisreg_ctx {
     bool      xcd_now = false;           // what the last run used
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
-    float     graph_radius = 1.5f;       // coverage radius of a short neighbour list (search_mode 3)
     float     cert_slack = 0.10f;
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch

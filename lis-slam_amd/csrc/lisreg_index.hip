@@ -966,18 +966,16 @@ int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const Tar
     return 0;
 }
 
-void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, float radius,
+void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids,
                         hipStream_t st)
 {
     if (n_blocks <= 0) return;
-    (void)radius;
     k_graph_build_batched<<<n_blocks * (kBlockQ / (4 * kGraphPPW)), 256, 0, st>>>(blocks, tsegs, grids);
 }
 
-void launch_build_graph_one(GridIndex g, float radius, hipStream_t st)
+void launch_build_graph_one(GridIndex g, hipStream_t st)
 {
     if (g.n <= 0 || !g.nbr) return;
-    (void)radius;
     k_graph_build_one<<<(g.n + 4 * kGraphPPW - 1) / (4 * kGraphPPW), 256, 0, st>>>(g);
 }
 

@@ -147,9 +147,8 @@ struct StripBuffers {
 int  launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const TargetSeg* tsegs, int n_tsegs, int n_strips, int max_units,
                                  int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st);
 // k-NN graph of every target in `tsegs` (grids[t.grid_id] must describe the finished index and carry nbr / nbr_meta)
-void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, float radius,
-                        hipStream_t st);
-void launch_build_graph_one(GridIndex g, float radius, hipStream_t st);
+void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, hipStream_t st);
+void launch_build_graph_one(GridIndex g, hipStream_t st);
 // sources of a whole batch: tile-sort every segment under its item's initial pose
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
