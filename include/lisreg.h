@@ -187,8 +187,8 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
 /* Options outside the reference's parameter surface: "rebuild_targets_each_run" (0/1: re-run the target index
  * build inside every lisreg_batch_run, as the reference rebuilds both kd-trees per registration, :602-603),
  * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (the exact 5-NN front-end
- * that stands in for pcl::KdTreeFLANN::nearestKSearch: 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion
- * certificate, 3 k-NN graph scan with the walk as its fall-back — costs 1 KB of device memory per target point for the
+ * that stands in for pcl::KdTreeFLANN::nearestKSearch: 0 LDS-staged workgroup box, 1 per-lane grid walk,
+ * 3 k-NN graph scan with the walk as its fall-back — costs 1 KB of device memory per target point for the
  * neighbour rows —, 4 auto [default]: 3 when the prepared batch asks at least "graph_min_ratio" query-iterations per target
  * point, else 1 — all return the same neighbours; the one exception is two candidates at exactly equal float distance from a query
  * competing for the fifth place: the first one met wins, and the front-ends meet them in different orders),
@@ -199,7 +199,12 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * "xcd_order" (dispatch order of the correspondence workgroups of a graph-front-end batch: 0 block order, 1 by target sector so that
  * each of the 8 XCDs — each with its own L2 — works on one eighth of the target, 2 auto [default]: 1 for batches of >= 32 registrations;
  * results do not depend on it, bit for bit),
- * "graph_min_ratio", "cert_slack_mm", "first_pass_mm", "count_searches", "early_stop_chunk". */
+ * "exact_arithmetic" (0 [default] the production arithmetic of the correspondence kernel: FMA contraction, 1-ulp hardware reciprocal /
+ * square root in the line and plane fits, fp32 sums inside a wavefront — poses within 1e-3 of the reference, a handful of
+ * threshold-straddling correspondences per thousand may differ; 1 the reference's arithmetic operation for operation — IEEE division
+ * and sqrt, cv::eigen's pivoted Jacobi, fp64 sums, no contraction, correctly rounded sin / cos: accept flags, correspondence counts
+ * and iteration counts EQUAL the CPU restatement's (tests/test_exact.py), at roughly 0.6x the throughput),
+ * "graph_min_ratio", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
  * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the

@@ -256,7 +256,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
     if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
-    if (const char* m = getenv("LISREG_CERT_SLACK_MM")) c->cert_slack = 1e-3f * (float)atoi(m);
+    if (const char* m = getenv("LISREG_EXACT")) c->exact = atoi(m) != 0;
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_WIDE_UNTIL")) c->graph_wide_until = atoi(m);
@@ -277,7 +277,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
-                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->cert, &c->model0, &c->model1, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->xcd_tab, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
+                       &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->xcd_tab, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
                        &c->vox_head, &c->vox_slot, &c->vox_start, &c->vox_out, &c->vox_outlab, &c->vox_M,
                        &c->ft_owner, &c->ft_flag, &c->ft_pos, &c->ft_scan, &c->ft_col, &c->ft_range, &c->ft_src, &c->ft_curv,
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
@@ -468,6 +468,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->prepared = false;
     c->params = *params;
     c->prm = make_dev_params(*params);
+    c->prm.exact = c->exact ? 1 : 0;
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
@@ -574,9 +575,6 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         HIPCHK(c, c->dbg_nn.ensure(sizeof(int) * 6 * (size_t)std::max(flat, 1)));
         HIPCHK(c, hipMemsetAsync(c->dbg_nn.p, 0xff, sizeof(int) * 6 * (size_t)std::max(flat, 1), c->stream));
     }
-    HIPCHK(c, c->cert.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
-    HIPCHK(c, c->model0.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
-    HIPCHK(c, c->model1.ensure(sizeof(float4) * (size_t)std::max(flat, 1)));
     HIPCHK(c, c->partials.ensure(sizeof(double) * kNumAcc * (size_t)std::max(c->n_blocks, 1)));
     HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * (size_t)std::max(n_items, 1)));
     if (c->trace_cap > 0) HIPCHK(c, c->trace.ensure(sizeof(float) * kTraceStride * (size_t)c->trace_cap * (size_t)std::max(n_items, 1)));
@@ -743,10 +741,10 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     const int chunk = c->early_stop_chunk > 0 ? c->early_stop_chunk : (c->n_blocks <= 1024 ? 6 : 3);
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
-        launch_assoc(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
+        (c->exact ? launch_assoc_exact : launch_assoc)(
+                     c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
                      c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>(),
-                     c->mode_now, c->nn.as<int>(), c->cert.as<float4>(), c->model0.as<float4>(), c->model1.as<float4>(),
-                     c->n_elems, c->first_pass_r * c->first_pass_r, c->cert_slack,
+                     c->mode_now, c->nn.as<int>(), c->n_elems, c->first_pass_r * c->first_pass_r,
                      it >= c->wide_from && it <= (c->mode_now == 3 ? c->graph_wide_until : c->wide_until), c->graph_hops,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
                      c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, c->lanes_q,
@@ -819,7 +817,10 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         return LISREG_OK;
     }
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
-    if (!strcmp(name, "search_mode")) { c->search_mode = value; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "search_mode")) {
+        if (value < 0 || value > 4 || value == 2) return fail(c, LISREG_ERR_ARG, "search_mode: 0 LDS-staged box, 1 cell walk, 3 k-NN graph scan, 4 auto");
+        c->search_mode = value; c->prepared = false; return LISREG_OK;
+    }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; return LISREG_OK; }
@@ -837,7 +838,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     }
     if (!strcmp(name, "lanes_per_query")) { c->lanes_per_query_auto = value != 1; c->prepared = false; return LISREG_OK; }   // 1 forces one lane per query, anything else = auto
     if (!strcmp(name, "dump_neighbors")) { c->dump_neighbors = value != 0; c->prepared = false; return LISREG_OK; }
-    if (!strcmp(name, "cert_slack_mm")) { c->cert_slack = 1e-3f * (float)value; return LISREG_OK; }
+    if (!strcmp(name, "exact_arithmetic")) { c->exact = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
@@ -847,6 +848,7 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
 {
     if (!c || !name || !value) return LISREG_ERR_ARG;
     if (!strcmp(name, "search_mode")) { *value = c->search_mode; return LISREG_OK; }
+    if (!strcmp(name, "exact_arithmetic")) { *value = c->exact ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "index_build")) { *value = c->index_build; return LISREG_OK; }
     if (!strcmp(name, "index_build_now")) { *value = c->strip_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }

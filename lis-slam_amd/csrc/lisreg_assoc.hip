@@ -6,34 +6,65 @@
 //   :829-850 (compaction — fused away: accepted rows go straight into the reduction), :862-920 (J rows, AtA, AtB)
 // and the label-weighted copies src/node/subMapOptmizationNode.cpp:1557-1917, 4556-4916.
 //
-// gfx950 mapping (three search front-ends share one residual / reduction tail; `search_mode` selects)
+// gfx950 mapping (search front-ends share one residual / reduction tail; `search_mode` selects)
 //   * a workgroup = 256 consecutive queries of one (item, stage), kept in caller order (scan / voxel order is
 //     spatially coherent, which is what the cell walk's L1 hit rate needs);
 //   * pcl::KdTreeFLANN::nearestKSearch(k=5) + `sqDist[4] < tau` is replaced by an exact fixed-radius 5-NN over the
 //     uniform grid of lisreg_index.hip, with a sorted top-5 in registers initialised at tau:
-//       k_assoc_walk   (default) every lane walks only the cells that can hold a point closer than its current
+//       k_assoc_walk<.., kGraph = false>  every lane walks only the cells that can hold a point closer than its current
 //                      5th-best distance, seeded with last iteration's neighbours (any five points bound the radius);
 //                      candidates are 16-B records read through L1/L2, four loads in flight per lane;
-//       k_assoc_cached (experimental) the same walk, run only for queries that fail a triangle-inequality motion
-//                      certificate, compacted through LDS; line/plane model cached per neighbour set;
+//       k_assoc_walk<.., kGraph = true>   certified scan of the k-NN graph row of last iteration's nearest neighbour, the cell walk
+//                      only without a certificate (big shared-target batches);
 //       k_assoc_staged (first version, kept for cross-checks) workgroup bounding box + sqrt(tau), covered cell runs
 //                      staged through LDS, all lanes scan via LDS broadcast;
-//     all three return the same neighbour SETS (tests require identical correspondence counts);
+//     all return the same neighbour SETS (tests require identical correspondence counts);
 //   * the 5 neighbours are gathered once (5 x 16 B), the 3x3 eigen / 5x3 QR fit, weights and the Jacobian row stay in
-//     registers, and the 28 normal-equation scalars (exact fp64 products of floats) are reduced by a wave-level
-//     halving butterfly -> LDS -> one partial row per workgroup (fixed order, no float atomics: reproducible).
+//     registers, and the 28 normal-equation scalars are reduced by a wave-level halving butterfly -> LDS -> one partial row
+//     per workgroup (fixed order, no float atomics: reproducible).
 // No dense contraction exists here (K = n_corr, M = N = 6), so MFMA is not used.  Measured: the
 // submap is L2 / Infinity-Cache resident, HBM traffic is below the algorithmic bytes, and the kernel is bound by VALU
-// issue, per-lane gather address processing and dependent-load latency at 8 waves/SIMD (63 VGPRs).
+// issue at 8 waves/SIMD (<= 64 VGPRs).
 #include "lisreg_internal.hpp"
+
+// Two translation units are built from this source (csrc/Makefile):
+//   lisreg_assoc.o        the production arithmetic: FMA contraction where the source says a*b+c, 1-ulp hardware reciprocal / square
+//                         root in the line and plane fits, `* 0.2f` for `/ 5`, fp32 sums inside a wavefront;
+//   lisreg_assoc_exact.o  (-DLISREG_EXACT=1 -ffp-contract=off) the reference's arithmetic operation for operation: no contraction,
+//                         IEEE division and square root wherever the reference divides or calls sqrt, cv::eigen's pivoted Jacobi,
+//                         fp64 sums throughout.  Selected at run time with lisreg_set_option("exact_arithmetic", 1); it is the parity
+//                         anchor (tests require its integer outputs — accept flags, n_corr, iteration counts — to EQUAL the oracle's)
+//                         and runs the same search front-ends, so the production build's deviations can be attributed against it.
+#ifndef LISREG_EXACT
+#define LISREG_EXACT 0
+#endif
+#if LISREG_EXACT
+#define LISREG_ASSOC_NS exact_arith
+#define LISREG_LAUNCH_ASSOC launch_assoc_exact
+#else
+#define LISREG_ASSOC_NS fast_arith
+#define LISREG_LAUNCH_ASSOC launch_assoc
+#endif
 
 namespace lisreg {
 
 namespace {
+namespace LISREG_ASSOC_NS {
+
+constexpr bool kExactArith = LISREG_EXACT != 0;
+// the reference's `/` and sqrt(): IEEE in the exact build, one v_rcp_f32 / v_sqrt_f32 (1 ulp) in the production build
+__device__ __forceinline__ float fdiv(float a, float b) { return kExactArith ? a / b : a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fsqrt(float x) { return kExactArith ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fdiv5(float a) { return kExactArith ? a / 5.f : a * 0.2f; }
 
 __device__ __forceinline__ float hypot_f(float a, float b)
 {
     a = fabsf(a); b = fabsf(b);
+    if (kExactArith) {                         // cv::eigen's hypot (JacobiImpl_), division and sqrt as written
+        if (a > b) { b /= a; return a * sqrtf(1.f + b * b); }
+        if (b > 0.f) { a /= b; return b * sqrtf(1.f + a * a); }
+        return 0.f;
+    }
     const float mx = fmaxf(a, b), mn = fminf(a, b);
     const float r = mn * __builtin_amdgcn_rcpf(mx);          // 1-ulp reciprocal and square root (v_rcp_f32, v_sqrt_f32): the Jacobi
     return mx > 0.f ? mx * __builtin_amdgcn_sqrtf(1.f + r * r) : 0.f;      // sweeps absorb a last-bit difference per rotation
@@ -41,13 +72,79 @@ __device__ __forceinline__ float hypot_f(float a, float b)
 
 // one Jacobi rotation annihilating A[k][l] of a symmetric 3x3 held in registers (cv::eigen's rotation formulas)
 #define LISREG_ROT(v0, v1) do { const float a0_ = (v0), b0_ = (v1); (v0) = a0_ * c - b0_ * s; (v1) = a0_ * s + b0_ * c; } while (0)
+// rotation parameters for the pivot p = A[k][l], y = (w_l - w_k) / 2: leaves c, s, t (the eigenvalue shift)
+#define LISREG_JACOBI_CST(p, y) \
+        float t = fabsf(y) + hypot_f((p), (y)); \
+        float s = hypot_f((p), t); \
+        const float c = fdiv(t, s); \
+        s = fdiv((p), s); t = fdiv((p), t) * (p); \
+        if ((y) < 0.f) { s = -s; t = -t; }
 
-// Largest eigenvector and the two largest eigenvalues of the symmetric 3x3 {a11..a33} by cyclic Jacobi.
+// Largest eigenvector and the two largest eigenvalues of the symmetric 3x3 {a11..a33}.
+//   production build: cyclic Jacobi, at most six sweeps (same eigen-system to a few ulp, no pivot search);
+//   exact build: cv::eigen as OpenCV 3.2 runs it on CV_32F (JacobiImpl_): the pivot is the largest off-diagonal element found through
+//     the per-row / per-column maximum tables indR / indC, which are refreshed only for the two rotated indices — the stale
+//     entries are part of the algorithm and are carried here (for n = 3: indR[0] in {1, 2} and indC[2] in {0, 1}; indR[1] = 2 and
+//     indC[1] = 0 always) — at most n * n * 30 rotations, stop at |pivot| <= FLT_EPSILON.
 __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, float a22, float a23, float a33,
                                            float& l0, float& l1, float v0[3])
 {
     float w0 = a11, w1 = a22, w2 = a33;
     float v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;   // rows = vectors
+    if (kExactArith) {
+        int indR0 = fabsf(a12) < fabsf(a13) ? 2 : 1;
+        int indC2 = fabsf(a13) < fabsf(a23) ? 1 : 0;
+#pragma unroll 1
+        for (int it = 0; it < 270; ++it) {
+            // pivot search in cv::eigen's order: rows 0, 1 through indR, then columns 1, 2 through indC; strict '<' keeps the first maximum
+            int k = 0, l = indR0;
+            float mv = fabsf(indR0 == 1 ? a12 : a13);
+            { const float v = fabsf(a23); if (mv < v) { mv = v; k = 1; l = 2; } }
+            { const float v = fabsf(a12); if (mv < v) { mv = v; k = 0; l = 1; } }
+            { const float v = fabsf(indC2 == 0 ? a13 : a23); if (mv < v) { mv = v; k = indC2; l = 2; } }
+            if (k == 0 && l == 1) {
+                const float p = a12;
+                if (fabsf(p) <= 1.1920929e-7f) break;
+                const float y = (w1 - w0) * 0.5f;
+                LISREG_JACOBI_CST(p, y)
+                a12 = 0.f; w0 -= t; w1 += t;
+                LISREG_ROT(a13, a23);
+                LISREG_ROT(v00, v10); LISREG_ROT(v01, v11); LISREG_ROT(v02, v12);
+                indR0 = fabsf(a12) < fabsf(a13) ? 2 : 1;          // idx = k = 0: indR[0]; idx = l = 1: indR[1] = 2, indC[1] = 0
+            } else if (k == 0) {
+                const float p = a13;
+                if (fabsf(p) <= 1.1920929e-7f) break;
+                const float y = (w2 - w0) * 0.5f;
+                LISREG_JACOBI_CST(p, y)
+                a13 = 0.f; w0 -= t; w2 += t;
+                LISREG_ROT(a12, a23);
+                LISREG_ROT(v00, v20); LISREG_ROT(v01, v21); LISREG_ROT(v02, v22);
+                indR0 = fabsf(a12) < fabsf(a13) ? 2 : 1;          // idx = 0: indR[0]; idx = 2: indC[2]
+                indC2 = fabsf(a13) < fabsf(a23) ? 1 : 0;
+            } else {
+                const float p = a23;
+                if (fabsf(p) <= 1.1920929e-7f) break;
+                const float y = (w2 - w1) * 0.5f;
+                LISREG_JACOBI_CST(p, y)
+                a23 = 0.f; w1 -= t; w2 += t;
+                LISREG_ROT(a12, a13);
+                LISREG_ROT(v10, v20); LISREG_ROT(v11, v21); LISREG_ROT(v12, v22);
+                indC2 = fabsf(a13) < fabsf(a23) ? 1 : 0;          // idx = 1: indR[1] = 2, indC[1] = 0; idx = 2: indC[2]; indR[0] goes stale
+            }
+        }
+        // descending selection sort with row swaps (:280-287 of the restatement): only D[0], D[1] and V row 0 are read (:692-702)
+        float e0 = w0, e1 = w1, e2 = w2, x = v00, y = v01, z = v02;
+        {   // k = 0: m = first index of the maximum under strict '<'
+            int m = 0; float wm = e0;
+            if (wm < e1) { m = 1; wm = e1; }
+            if (wm < e2) { m = 2; wm = e2; }
+            if (m == 1) { const float tw = e0; e0 = e1; e1 = tw; x = v10; y = v11; z = v12; }
+            else if (m == 2) { const float tw = e0; e0 = e2; e2 = tw; x = v20; y = v21; z = v22; }
+        }
+        l0 = e0; l1 = (e1 < e2) ? e2 : e1;
+        v0[0] = x; v0[1] = y; v0[2] = z;
+        return;
+    }
 #pragma unroll 1
     for (int sweep = 0; sweep < 6; ++sweep) {
         if (fabsf(a12) + fabsf(a13) + fabsf(a23) <= 1e-30f) break;
@@ -55,12 +152,7 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
             const float p = a12;
             if (fabsf(p) > 0.f) {
                 const float y = (w1 - w0) * 0.5f;
-                float t = fabsf(y) + hypot_f(p, y);
-                float s = hypot_f(p, t);
-                const float inv_s = __builtin_amdgcn_rcpf(s);
-                const float c = t * inv_s;
-                s = p * inv_s; t = (p * __builtin_amdgcn_rcpf(t)) * p;
-                if (y < 0.f) { s = -s; t = -t; }
+                LISREG_JACOBI_CST(p, y)
                 a12 = 0.f; w0 -= t; w1 += t;
                 LISREG_ROT(a13, a23);
                 LISREG_ROT(v00, v10); LISREG_ROT(v01, v11); LISREG_ROT(v02, v12);
@@ -70,12 +162,7 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
             const float p = a13;
             if (fabsf(p) > 0.f) {
                 const float y = (w2 - w0) * 0.5f;
-                float t = fabsf(y) + hypot_f(p, y);
-                float s = hypot_f(p, t);
-                const float inv_s = __builtin_amdgcn_rcpf(s);
-                const float c = t * inv_s;
-                s = p * inv_s; t = (p * __builtin_amdgcn_rcpf(t)) * p;
-                if (y < 0.f) { s = -s; t = -t; }
+                LISREG_JACOBI_CST(p, y)
                 a13 = 0.f; w0 -= t; w2 += t;
                 LISREG_ROT(a12, a23);
                 LISREG_ROT(v00, v20); LISREG_ROT(v01, v21); LISREG_ROT(v02, v22);
@@ -85,12 +172,7 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
             const float p = a23;
             if (fabsf(p) > 0.f) {
                 const float y = (w2 - w1) * 0.5f;
-                float t = fabsf(y) + hypot_f(p, y);
-                float s = hypot_f(p, t);
-                const float inv_s = __builtin_amdgcn_rcpf(s);
-                const float c = t * inv_s;
-                s = p * inv_s; t = (p * __builtin_amdgcn_rcpf(t)) * p;
-                if (y < 0.f) { s = -s; t = -t; }
+                LISREG_JACOBI_CST(p, y)
                 a23 = 0.f; w1 -= t; w2 += t;
                 // rows 1,2 rotate: elements A[0][1], A[0][2]
                 LISREG_ROT(a12, a13);
@@ -108,8 +190,7 @@ __device__ __forceinline__ void eigen_sym3(float a11, float a12, float a13, floa
 }
 
 // cornerOptimization body for one point (odomEstimationNode.cpp:658-742), split in two:
-//   corner_model : depends only on the five neighbours (centroid, principal direction, lambda0 > 3*lambda1 test) —
-//                  what k_assoc_cached keeps across iterations while the neighbour set is provably unchanged;
+//   corner_model : depends only on the five neighbours (centroid, principal direction, lambda0 > 3*lambda1 test);
 //   corner_eval  : depends on the transformed query point (line residual, robust weight, accept test).
 // m0 = (cx, cy, cz, valid ? 1 : NaN), m1 = (vx, vy, vz, 0).
 __device__ __forceinline__ void corner_model(const float4 nb[5], const DevParams& P, float4& m0, float4& m1)
@@ -117,14 +198,14 @@ __device__ __forceinline__ void corner_model(const float4 nb[5], const DevParams
     float cx = 0, cy = 0, cz = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) { cx += nb[j].x; cy += nb[j].y; cz += nb[j].z; }
-    cx *= 0.2f; cy *= 0.2f; cz *= 0.2f;          // /5 (reciprocal multiply: <= 1 ulp from the reference's division)
+    cx = fdiv5(cx); cy = fdiv5(cy); cz = fdiv5(cz);          // /5 (:664; production: reciprocal multiply, <= 1 ulp from the division)
     float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const float ax = nb[j].x - cx, ay = nb[j].y - cy, az = nb[j].z - cz;
         a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
     }
-    a11 *= 0.2f; a12 *= 0.2f; a13 *= 0.2f; a22 *= 0.2f; a23 *= 0.2f; a33 *= 0.2f;
+    a11 = fdiv5(a11); a12 = fdiv5(a12); a13 = fdiv5(a13); a22 = fdiv5(a22); a23 = fdiv5(a23); a33 = fdiv5(a33);
     float l0, l1, v[3];
     eigen_sym3(a11, a12, a13, a22, a23, a33, l0, l1, v);
     const bool ok = l0 > P.line_ratio * l1;                               // :692
@@ -146,16 +227,23 @@ __device__ __forceinline__ bool corner_eval(const float4 m0, const float4 m1, fl
     const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
     const float m22 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
     const float m33 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
-    const float a012 = __builtin_amdgcn_sqrtf(m11 * m11 + m22 * m22 + m33 * m33);
-    const float l12 = __builtin_amdgcn_sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
-    const float inv_al = __builtin_amdgcn_rcpf(a012 * l12);     // one 1-ulp reciprocal for the three `/ a012 / l12` (:713-723)
-    const float la = ((y1 - y2) * m11 + (z1 - z2) * m22) * inv_al;
-    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m33) * inv_al;
-    const float lc = -((x1 - x2) * m22 + (y1 - y2) * m33) * inv_al;
+    const float a012 = fsqrt(m11 * m11 + m22 * m22 + m33 * m33);
+    const float l12 = fsqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    float la, lb, lc;
+    if (kExactArith) {                                                    // :713-723 `/ a012 / l12`
+        la = ((y1 - y2) * m11 + (z1 - z2) * m22) / a012 / l12;
+        lb = -((x1 - x2) * m11 - (z1 - z2) * m33) / a012 / l12;
+        lc = -((x1 - x2) * m22 + (y1 - y2) * m33) / a012 / l12;
+    } else {
+        const float inv_al = __builtin_amdgcn_rcpf(a012 * l12);           // one 1-ulp reciprocal for the three `/ a012 / l12`
+        la = ((y1 - y2) * m11 + (z1 - z2) * m22) * inv_al;
+        lb = -((x1 - x2) * m11 - (z1 - z2) * m33) * inv_al;
+        lc = -((x1 - x2) * m22 + (y1 - y2) * m33) * inv_al;
+    }
     const float ld2 = a012 / l12;
     const float s = (float)(1.0 - 0.9 * (double)fabsf(ld2));
-    const float ws = w * s;
-    cf[0] = ws * la; cf[1] = ws * lb; cf[2] = ws * lc; cf[3] = ws * ld2;
+    if (kExactArith) { cf[0] = w * s * la; cf[1] = w * s * lb; cf[2] = w * s * lc; cf[3] = w * s * ld2; }      // :729-732 (w * s) * la
+    else { const float ws = w * s; cf[0] = ws * la; cf[1] = ws * lb; cf[2] = ws * lc; cf[3] = ws * ld2; }
     return (m0.w == 1.f) && (s > P.accept_s);                             // :734 (uses s, not w*s)
 }
 
@@ -177,8 +265,8 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
     float n0 = 0, n1 = 0, n2 = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) { n0 += a[i][0] * a[i][0]; n1 += a[i][1] * a[i][1]; n2 += a[i][2] * a[i][2]; }
-    const float maxn = __builtin_amdgcn_sqrtf(fmaxf(n0, fmaxf(n1, n2)));          // v_sqrt_f32 (1 ulp; the arguments are far from the denormal range)
-    const float thr = (maxn * 1.1920929e-7f) * (maxn * 1.1920929e-7f) * 0.2f;     // / rows (a rank threshold: <= 1 ulp from the division)
+    const float maxn = fsqrt(fmaxf(n0, fmaxf(n1, n2)));          // production: v_sqrt_f32 (1 ulp; the arguments are far from the denormal range)
+    const float thr = fdiv5((maxn * 1.1920929e-7f) * (maxn * 1.1920929e-7f));     // / rows (a rank threshold)
     int p0 = 0, p1 = 1, p2 = 2;        // perm: column k of the working matrix is original column p_k
     int rank = 3;
     float y[3] = { 0.f, 0.f, 0.f };
@@ -192,10 +280,9 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         _Pragma("unroll") for (int i_ = k + 1; i_ < 5; ++i_) tail_ += a[i_][k] * a[i_][k]; \
         float beta_, tau_, v_[5]; \
         if (tail_ <= 1.17549435e-38f) { tau_ = 0.f; beta_ = c0_; _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = 0.f; } \
-        else { beta_ = __builtin_amdgcn_sqrtf(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
-               const float invd_ = __builtin_amdgcn_rcpf(c0_ - beta_); \
-               _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? a[i_][k] * invd_ : 0.f; \
-               tau_ = (beta_ - c0_) * __builtin_amdgcn_rcpf(beta_); } \
+        else { beta_ = fsqrt(c0_ * c0_ + tail_); if (c0_ >= 0.f) beta_ = -beta_; \
+               _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) v_[i_] = (i_ > k) ? fdiv(a[i_][k], c0_ - beta_) : 0.f; \
+               tau_ = fdiv(beta_ - c0_, beta_); } \
         a[k][k] = beta_; \
         _Pragma("unroll") for (int j_ = k + 1; j_ < 3; ++j_) { \
             float dot_ = a[k][j_]; \
@@ -232,9 +319,9 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         else LISREG_HOUSEHOLDER(2);
     }
     if (rank == 3) {
-        y[2] = c[2] * __builtin_amdgcn_rcpf(a[2][2]);
-        y[1] = (c[1] - a[1][2] * y[2]) * __builtin_amdgcn_rcpf(a[1][1]);
-        y[0] = (c[0] - a[0][1] * y[1] - a[0][2] * y[2]) * __builtin_amdgcn_rcpf(a[0][0]);
+        y[2] = fdiv(c[2], a[2][2]);
+        y[1] = fdiv(c[1] - a[1][2] * y[2], a[1][1]);
+        y[0] = fdiv(c[0] - a[0][1] * y[1] - a[0][2] * y[2], a[0][0]);
     } else if (rank == 2) {
         y[1] = c[1] / a[1][1];
         y[0] = (c[0] - a[0][1] * y[1]) / a[0][0];
@@ -258,9 +345,9 @@ __device__ __forceinline__ float4 surf_model(const float4 nb[5], const DevParams
     float X[3];
     lstsq5x3(nb, X);
     float pa = X[0], pb = X[1], pc = X[2], pd = 1.f;
-    const float ps = __builtin_amdgcn_sqrtf(pa * pa + pb * pb + pc * pc);
-    const float ips = __builtin_amdgcn_rcpf(ps);          // 1-ulp reciprocal (the reference divides; <= 2 ulp apart)
-    pa *= ips; pb *= ips; pc *= ips; pd = ips;
+    const float ps = fsqrt(pa * pa + pb * pb + pc * pc);
+    if (kExactArith) { pa /= ps; pb /= ps; pc /= ps; pd /= ps; }          // :790-791
+    else { const float ips = __builtin_amdgcn_rcpf(ps); pa *= ips; pb *= ips; pc *= ips; pd = ips; }   // 1-ulp reciprocal (<= 2 ulp from the divisions)
     bool valid = true;
 #pragma unroll
     for (int j = 0; j < 5; ++j)
@@ -273,17 +360,22 @@ __device__ __forceinline__ bool surf_eval(const float4 m, float x0, float y0, fl
 {
     const float pa = m.x, pb = m.y, pc = m.z, pd = m.w;
     const float pd2 = pa * x0 + pb * y0 + pc * z0 + pd;
-    const float rng = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
-    // s = 1 - 0.9 * fabs(pd2) / sqrt(sqrt(...)) is a DOUBLE expression in the reference (:806, 0.9 is a double literal).  The quotient
-    // through a reciprocal refined twice from the 1-ulp float seed (relative error ~2^-52, against a ~20-instruction IEEE double
-    // division with its quarter-rate v_rcp_f64): the float s differs from the divided one about once in 10^8 evaluations, by one ulp.
-    const double rd = (double)rng;
-    double ir = (double)__builtin_amdgcn_rcpf(rng);
-    ir = ir * (2.0 - rd * ir);
-    ir = ir * (2.0 - rd * ir);
-    const float s = (float)(1.0 - (0.9 * (double)fabsf(pd2)) * ir);
-    const float ws = w * s;
-    cf[0] = ws * pa; cf[1] = ws * pb; cf[2] = ws * pc; cf[3] = ws * pd2;
+    const float rng = fsqrt(fsqrt(x0 * x0 + y0 * y0 + z0 * z0));
+    // s = 1 - 0.9 * fabs(pd2) / sqrt(sqrt(...)) is a DOUBLE expression in the reference (:806, 0.9 is a double literal).
+    float s;
+    if (kExactArith) {
+        s = (float)(1.0 - 0.9 * (double)fabsf(pd2) / (double)rng);
+    } else {
+        // the quotient through a reciprocal refined twice from the 1-ulp float seed (relative error ~2^-52, against a ~20-instruction IEEE
+        // double division with its quarter-rate v_rcp_f64): the float s differs from the divided one about once in 10^8 evaluations, by one ulp
+        const double rd = (double)rng;
+        double ir = (double)__builtin_amdgcn_rcpf(rng);
+        ir = ir * (2.0 - rd * ir);
+        ir = ir * (2.0 - rd * ir);
+        s = (float)(1.0 - (0.9 * (double)fabsf(pd2)) * ir);
+    }
+    if (kExactArith) { cf[0] = w * s * pa; cf[1] = w * s * pb; cf[2] = w * s * pc; cf[3] = w * s * pd2; }      // :808-811
+    else { const float ws = w * s; cf[0] = ws * pa; cf[1] = ws * pb; cf[2] = ws * pc; cf[3] = ws * pd2; }
     return (pd == pd) && (s > P.accept_s);
 }
 
@@ -313,7 +405,7 @@ __device__ __forceinline__ void jacobian_row(const float* K /* ItemState::jk */,
 }
 
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-#ifdef LISREG_REDUCE_FP64
+#if LISREG_EXACT
 __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -406,18 +498,7 @@ __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, 
 {
     float cf[4];
     const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
-    // ablation builds (-DLISREG_ABL_FIT2 / -DLISREG_ABL_RED2, tests/pmc_periter.sh): the model fit resp. the row + reduction run
-    // twice with identical results, so the difference in VALU instructions and time per launch is that stage's cost
-#ifdef LISREG_ABL_FIT2
-    { float cf2[4]; float qx2 = qx; int j0 = i0; asm volatile("" : "+v"(qx2), "+v"(j0));
-      const bool ok2 = residual_coeffs(valid, j0, i1, i2, i3, i4, g, q4, qx2, qy, qz, P, kind, cf2);
-      if (ok2 && cf2[0] == 12345.f && cf2[3] == 54321.f) cf[0] += 1.f; }
-#endif
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
-#ifdef LISREG_ABL_RED2
-    { float cf2[4] = { cf[0], cf[1], cf[2], cf[3] }; asm volatile("" : "+v"(cf2[0]), "+v"(cf2[1]), "+v"(cf2[2]), "+v"(cf2[3]));
-      row_and_reduce(ok, cf2, q4, jk, P, s_acc, out); __syncthreads(); }
-#endif
     row_and_reduce(ok, cf, q4, jk, P, s_acc, out);
 }
 
@@ -427,7 +508,7 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
     if (ok) { jacobian_row(jk, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
-#ifdef LISREG_REDUCE_FP64
+#if LISREG_EXACT
     // the 28 normal-equation terms of this row, produced on demand (float x float is exact in double):
     //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
     auto term = [&](int k) -> double {
@@ -475,8 +556,8 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
     // The kernel is bound by vector instructions and fp64 ones cost double: 28 fp64 products + a 32-step fp64 butterfly were 17 % of
     // a steady-state launch.  Here the products and the 64-term tree are fp32 (relative error of a wave sum <= ~2e-7 of the sum of
     // magnitudes — the reference's own matAtA is a float cv::gemm, and the step is solved in float); everything above a wave (four
-    // waves of a workgroup, workgroups of a registration) stays fp64 in a fixed order.  -DLISREG_REDUCE_FP64 builds the all-fp64
-    // form for comparison.  Each step exchanges HALF of the values with a partner lane in the other half of the
+    // waves of a workgroup, workgroups of a registration) stays fp64 in a fixed order.  The exact build (LISREG_EXACT) runs the all-fp64
+    // form above.  Each step exchanges HALF of the values with a partner lane in the other half of the
     // group (xor 32 and 16 by V_PERMLANE32/16_SWAP; 15, 7, 3, 1 — row mirror, half-row mirror, quad mirror, neighbour — as DPP
     // operands of the add), so 32 values need 16 + 8 + 4 + 2 + 1 (+ 1) adds; lane l ends with the sum of value index bits(l)[5:1].
     auto term = [&](int k) -> float {
@@ -1105,215 +1186,9 @@ __global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __rest
     row_and_reduce(ok, cf, q4, it->jk, P, s_acc, out);
 }
 
-// walk with a FIXED coverage radius: every cell that can hold a point with d^2 < cov2 is visited, so after the
-// walk any point that was not seen is at least sqrt(cov2) away.  Tracks b5 = smallest squared distance among the
-// visited points that did not end up in the top-5 (needed for the motion certificate of k_assoc_cached).
-#define LISREG_TEST6(c_, j_) do { \
-        const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
-        const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_; \
-        if (d2_ < b4) { \
-            const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
-            if (!dup_) { b5 = fminf(b5, b4); LISREG_INSERT(d2_, (j_)); } \
-        } else if ((j_) != i4) b5 = fminf(b5, d2_); } while (0)
+}  // namespace LISREG_ASSOC_NS
 
-#define LISREG_WALK_COV(cov2_expr) do { \
-        const float lim_ = (cov2_expr); \
-        const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps; \
-        const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
-        const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
-        const int cz0_ = max(grid_coord(qz - rad_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rad_, g.oz, g.inv_cell), g.nz - 1); \
-        if (cz0_ <= cz1_) \
-        for (int ix_ = cx0_; ix_ <= cx1_; ++ix_) { \
-            const float xl_ = g.ox + (float)ix_ * g.cell; \
-            const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
-            const float dx2_ = dx_ * dx_; \
-            if (dx2_ >= lim_) continue; \
-            for (int iy_ = cy0_; iy_ <= cy1_; ++iy_) { \
-                const float yl_ = g.oy + (float)iy_ * g.cell; \
-                const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
-                if (dx2_ + dy_ * dy_ >= lim_) continue; \
-                const int base_ = (ix_ * g.ny + iy_) * g.nz; \
-                const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
-                for (int j_ = js_; j_ < je_; j_ += 4) { \
-                    const int l_ = je_ - 1; \
-                    const v4f c0_ = pts[j_], c1_ = pts[min(j_ + 1, l_)], c2_ = pts[min(j_ + 2, l_)], c3_ = pts[min(j_ + 3, l_)]; \
-                    LISREG_TEST6(c0_, j_); \
-                    if (j_ + 1 <= l_) LISREG_TEST6(c1_, j_ + 1); \
-                    if (j_ + 2 <= l_) LISREG_TEST6(c2_, j_ + 2); \
-                    if (j_ + 3 <= l_) LISREG_TEST6(c3_, j_ + 3); \
-                } \
-            } \
-        } } while (0)
-
-// k_assoc_cached — the default front-end.  Same exact neighbour sets and the same residual arithmetic as
-// k_assoc_walk, but the search and the line/plane fit are only redone for queries whose neighbour set might have
-// changed since it was last computed:
-//
-//   motion certificate.  When a query is searched at position q_ref we record d5 (5th-nearest distance) and a lower
-//   bound d6 on the distance of every OTHER target point (smallest rejected distance seen, capped by the walk's
-//   coverage radius d5 + slack).  Later, at position q with delta = |q - q_ref|, every top-5 point is within
-//   d5 + delta and every other point is at least d6 - delta away (triangle inequality), so if
-//   delta < min((d6 - d5)/2, sqrt(tau) - d5) the five nearest neighbours inside radius sqrt(tau) are the same SET and
-//   the cached line / plane model (a function of the set only, kept in the order it was fitted) is reused.  Gauss-Newton
-//   steps shrink geometrically, so from the third iteration on most queries pass.
-//
-//   compaction.  Queries that fail the certificate are compacted through LDS into the first lanes of the workgroup
-//   ("jobs"), so the expensive search + fit runs on densely populated waves instead of on every wave that happens
-//   to contain one failing lane; results go back to the owning lanes through LDS.
-//
-// Per passing query the kernel touches 48 B (point, certificate, model), all coalesced.
-__global__ __launch_bounds__(kBlockQ) void k_assoc_cached(const BlockDesc* __restrict__ blocks,
-                                                          const Segment* __restrict__ segs,
-                                                          const GridIndex* __restrict__ grids,
-                                                          const ItemState* __restrict__ items, const DevParams P,
-                                                          const float4* __restrict__ sorted_all,
-                                                          int* __restrict__ nn_, float4* __restrict__ cert,
-                                                          float4* __restrict__ model0, float4* __restrict__ model1,
-                                                          int n_elems, float first_pass_r2, float slack,
-                                                          unsigned long long* __restrict__ counters,
-                                                          double* __restrict__ partials)
-{
-    __shared__ double s_acc[4][kNumAcc];
-    __shared__ int    s_cnt[4];
-    __shared__ float4 s_job_in[kBlockQ];          // qx, qy, qz, owner tid
-    __shared__ float4 s_job_m0[kBlockQ], s_job_m1[kBlockQ];
-    constexpr float kEps = 1e-3f;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const BlockDesc bd = blocks[blockIdx.x];
-    const ItemState* it = &items[bd.item];
-    if (it->done) return;
-    const Segment sg = segs[bd.seg];
-    const GridIndex g = grids[sg.target];
-    double* out = partials + (size_t)blockIdx.x * kNumAcc;
-    if (g.n < 5) {
-        if (tid < kNumAcc) out[tid] = 0.0;
-        return;
-    }
-    const gptr_f4 pts = (gptr_f4)g.pts;
-    const gptr_i32 cells = (gptr_i32)g.cell_start;
-    const gptr_i32w nn = (gptr_i32w)nn_;
-    const float* M = it->M;
-    const int iter = it->iter;
-    const int kind = sg.kind;
-
-    const bool valid = tid < bd.count;
-    const int qbase = sg.flat_base + bd.start;
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) q4 = sorted_all ? sorted_all[qbase + tid] : sg.src[bd.start + tid];
-    const float px = M[0] * q4.x + M[1] * q4.y + M[2] * q4.z + M[3];
-    const float py = M[4] * q4.x + M[5] * q4.y + M[6] * q4.z + M[7];
-    const float pz = M[8] * q4.x + M[9] * q4.y + M[10] * q4.z + M[11];
-
-    // ---- motion certificate ---------------------------------------------------------------------------------------
-    float4 m0 = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000)), m1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool pass = false;
-    if (valid && iter > 0) {
-        const float4 c = cert[qbase + tid];
-        const float ex = px - c.x, ey = py - c.y, ez = pz - c.z;
-        pass = (c.w > 0.f) && (ex * ex + ey * ey + ez * ez < c.w * c.w);
-        if (pass) {
-            m0 = model0[qbase + tid];
-            if (kind == 0) m1 = model1[qbase + tid];
-        }
-    }
-    const bool need = valid && !pass;
-
-    // ---- compact the failing queries into jobs -----------------------------------------------------------------------
-    const unsigned long long ballot = __ballot(need);
-    if (lane == 0) s_cnt[wave] = __popcll(ballot);
-    __syncthreads();
-    int jbase = 0, njobs = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = s_cnt[w]; if (w < wave) jbase += c; njobs += c; }
-    const int slot = jbase + __popcll(ballot & ((1ull << lane) - 1ull));
-    if (counters && tid == 0 && iter < 32) {            // diagnostics: searched vs total queries per GN iteration
-        atomicAdd(&counters[2 * iter], (unsigned long long)njobs);
-        atomicAdd(&counters[2 * iter + 1], (unsigned long long)bd.count);
-    }
-    if (need) s_job_in[slot] = make_float4(px, py, pz, __int_as_float(tid));
-    __syncthreads();
-
-    if (tid < njobs) {
-        const float4 jin = s_job_in[tid];
-        const float qx = jin.x, qy = jin.y, qz = jin.z;
-        const int qflat = qbase + __float_as_int(jin.w);
-        float b0 = P.tau, b1 = P.tau, b2 = P.tau, b3 = P.tau, b4 = P.tau, b5 = 3.0e38f;
-        int   i0 = -1, i1 = -1, i2 = -1, i3 = -1, i4 = -1;
-        bool seeded = false;
-        if (iter > 0) {
-            const int s4 = nn[4 * (size_t)n_elems + qflat];
-            if (s4 >= 0) {
-                int sid[5];
-                sid[4] = s4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sid[k] = nn[(size_t)k * n_elems + qflat];
-                v4f sp[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) sp[k] = pts[sid[k]];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const float ex = qx - sp[k].x, ey = qy - sp[k].y, ez = qz - sp[k].z;
-                    const float d2 = ex * ex + ey * ey + ez * ez;
-                    if (d2 < b4) LISREG_INSERT(d2, sid[k]);       // seeds beyond tau are simply dropped
-                }
-                seeded = true;
-            }
-        }
-        float cov2;
-        if (!seeded || i4 < 0) {
-            cov2 = first_pass_r2;                          // tight first pass establishes a bound cheaply
-            LISREG_WALK_COV(cov2);
-            if (!(b4 <= first_pass_r2)) {
-                const float r = __builtin_amdgcn_sqrtf(b4) + slack;
-                cov2 = (i4 >= 0) ? r * r : P.tau;         // nothing beyond tau matters while five are not found
-                cov2 = fmaxf(cov2, first_pass_r2);
-                LISREG_WALK_COV(cov2);
-            }
-        } else {
-            const float r = __builtin_amdgcn_sqrtf(b4) + slack;
-            cov2 = r * r;
-            LISREG_WALK_COV(cov2);
-        }
-        nn[0 * (size_t)n_elems + qflat] = i0; nn[1 * (size_t)n_elems + qflat] = i1;
-        nn[2 * (size_t)n_elems + qflat] = i2; nn[3 * (size_t)n_elems + qflat] = i3;
-        nn[4 * (size_t)n_elems + qflat] = i4;
-
-        float4 jm0 = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000)), jm1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float r_safe = -1.f;
-        if (i4 >= 0) {
-            float4 nb[5];
-            const v4f n0 = pts[i0], n1 = pts[i1], n2 = pts[i2], n3 = pts[i3], n4 = pts[i4];
-            nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
-            nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
-            nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
-            if (kind == 0) corner_model(nb, P, jm0, jm1); else jm0 = surf_model(nb, P);
-            // certificate radius: all of the top five stay inside tau and ahead of every other point while the query
-            // moves less than r_safe (2e-4 m covers fp32 rounding of the distances involved)
-            const float d5 = sqrtf(b4), d6 = sqrtf(fminf(b5, cov2));
-            r_safe = fminf(0.5f * (d6 - d5), sqrtf(P.tau) - d5) - 2e-4f;
-        }
-        cert[qflat] = make_float4(qx, qy, qz, r_safe);
-        model0[qflat] = jm0;
-        if (kind == 0) model1[qflat] = jm1;
-        s_job_m0[tid] = jm0; s_job_m1[tid] = jm1;
-    }
-    __syncthreads();
-    if (need) { m0 = s_job_m0[slot]; m1 = s_job_m1[slot]; }
-
-    // ---- residual from the (cached or fresh) model ---------------------------------------------------------------------
-    float cf[4] = { 0.f, 0.f, 0.f, 0.f };
-    bool ok = false;
-    if (valid) {
-        float w = 1.f;
-        if (P.use_label) w = label_weight(P, q4.w);
-        if (kind == 0) { if (m0.w == 1.f) ok = corner_eval(m0, m1, px, py, pz, w, P, cf); }
-        else           { if (m0.w == m0.w) ok = surf_eval(m0, px, py, pz, w, P, cf); }
-    }
-    row_and_reduce(ok, cf, q4, it->jk, P, s_acc, out);
-}
-
-
+#if !LISREG_EXACT
 // ---- XCD-aware dispatch order for shared-target batches (search_mode 3) ----------------------------------------------------------
 // MI355X hands workgroup p of a launch to XCD p % 8, and every XCD has its own 4 MB L2.  In dispatch order = block order, each
 // XCD sees queries from everywhere in the target, i.e. the whole graph (rows + points: 30-60 MB for a 200 k-point submap) streams
@@ -1390,8 +1265,11 @@ __global__ __launch_bounds__(1024) void k_xcd_order(int n_blocks, const int* __r
     }
 }
 
+#endif
+
 }  // namespace
 
+#if !LISREG_EXACT
 void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,
                       const float4* sorted_all, int* keys, int* order, hipStream_t st)
 {
@@ -1399,13 +1277,16 @@ void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs
     k_xcd_keys<<<(n_blocks + 255) / 256, 256, 0, st>>>(blocks, n_blocks, segs, grids, items, sorted_all, keys);
     k_xcd_order<<<1, 1024, 0, st>>>(n_blocks, keys, order);
 }
+#endif
 
-void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
-                  const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                  int mode, int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, bool wide, int graph_hops, unsigned long long* counters, int* dbg_nn, int lanes_q,
-                  const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st)
+// launch_assoc (production arithmetic) / launch_assoc_exact (the reference's arithmetic): same arguments, same front-ends
+void LISREG_LAUNCH_ASSOC(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
+                         const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
+                         int mode, int* nn, int n_elems, float first_pass_r2, bool wide, int graph_hops,
+                         unsigned long long* counters, int* dbg_nn, int lanes_q,
+                         const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st)
 {
+    using namespace LISREG_ASSOC_NS;
     if (n_blocks <= 0) return;
     if (mode == 1 && lanes_q == 8) {
         if (wide)
@@ -1419,23 +1300,21 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
     }
     if (mode == 0)
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
-    else if (mode == 1)
+    else if (mode == 1) {
         if (wide)
             k_assoc_walk<true, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
             k_assoc_walk<false, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                         first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
-    else if (mode == 3)
+    } else {
         if (wide)
             k_assoc_walk<true, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
         else
             k_assoc_walk<false, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
-    else
-        k_assoc_cached<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, cert, model0,
-                                                     model1, n_elems, first_pass_r2, slack, counters, partials);
+    }
 }
 
 }  // namespace lisreg

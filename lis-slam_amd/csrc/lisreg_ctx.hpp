@@ -86,7 +86,7 @@ struct lisreg_ctx {
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
-    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, cert, model0, model1, counters, tseg_dev, tblk_dev, tchunk_dev, strip_tab, done_dev, xcd_tab,
+    lisreg::DevBuf blocks, segs, items, sorted_all, order_all, partials, results, trace, src_upload, raw_upload, dbg_nn, blocks_q, coef, coef_ok, nn, counters, tseg_dev, tblk_dev, tchunk_dev, strip_tab, done_dev, xcd_tab,
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_cat, ft_bounds, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
@@ -115,7 +115,7 @@ struct lisreg_ctx {
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
     bool      dump_neighbors = false;   // tests: keep the five neighbour ids of every query of the last iteration run
-    int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 2 walk + motion certificate, 3 k-NN graph scan,
+    int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 3 k-NN graph scan,
                                          // 4 auto: 3 when the prepared batch asks enough queries per target point to pay for the graph, else 1
     int       mode_now = 1;              // front-end of the prepared batch
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
@@ -125,7 +125,7 @@ struct lisreg_ctx {
     bool      xcd_now = false;           // what the last run used
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
-    float     cert_slack = 0.10f;
+    bool      exact = false;             // "exact_arithmetic": the correspondence launches and the pose cache run the reference's arithmetic (lisreg_assoc.hip)
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch
     float     first_pass_r = 0.45f;

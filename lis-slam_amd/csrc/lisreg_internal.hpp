@@ -74,6 +74,7 @@ struct DevParams {
     float tau, line_ratio, plane_tol, accept_s, conv_deg, conv_cm, eig_thresh;
     int   min_corr, use_label, emulate_shadow, skip_empty, fixed_iters, bound, edge_min, surf_min, use_imu;
     float imu_w, rot_tol, z_tol;
+    int   exact;               // "exact_arithmetic": pose cache with correctly rounded sin / cos (the launches pick launch_assoc_exact)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
 };
 
@@ -156,9 +157,9 @@ void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* s
 void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st);
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                  int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 2 walk + motion certificate */,
-                  int* nn, float4* cert, float4* model0, float4* model1, int n_elems, float first_pass_r2,
-                  float slack, bool wide /* mode 1: centre-first walk for the early iterations whose seeds are stale */,
+                  int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 3 k-NN graph scan (walk without a certificate) */,
+                  int* nn, int n_elems, float first_pass_r2,
+                  bool wide /* centre-first walk for the early iterations whose seeds / anchors are stale */,
                   int graph_hops /* mode 3: neighbour lists scanned per query before the cell walk takes over */,
                   unsigned long long* counters /* may be null */,
                   int* dbg_nn /* may be null; modes 1 and 3: [6][n_elems] original indices of each query's neighbours + accept flag */,
@@ -166,6 +167,12 @@ void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, co
                   const BlockDesc* blocks_q, int n_blocks_q /* lanes_q = 8: descriptors of kBlockQ / 8 queries for the search */,
                   float4* coef, int* coef_ok /* lanes_q = 8: per-query coefficients handed to k_rows_reduce */,
                   const int* xcd_order /* mode 3: dispatch position -> block id (launch_xcd_order), or null */, hipStream_t st);
+// the same launch with the reference's arithmetic (lisreg_assoc.hip built with -DLISREG_EXACT=1 -ffp-contract=off): the parity anchor
+void launch_assoc_exact(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
+                        const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
+                        int mode, int* nn, int n_elems, float first_pass_r2, bool wide, int graph_hops,
+                        unsigned long long* counters, int* dbg_nn, int lanes_q, const BlockDesc* blocks_q, int n_blocks_q,
+                        float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st);
 // XCD-aware dispatch order of a shared-target batch: blocks ranked by the azimuth of their middle query around the target centre
 void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,
                       const float4* sorted_all, int* keys, int* order, hipStream_t st);

@@ -183,10 +183,18 @@ __device__ void inv6_lu(float* A, float* B)
 
 // pcl::getTransformation via trans2Affine3f (common.cpp:54-57) and LMOptimization's sin/cos (:862-867), computed
 // once per registration per iteration here instead of once per thread in the correspondence kernel.
-__device__ void write_pose_cache(ItemState* it)
+__device__ void write_pose_cache(ItemState* it, bool exact)
 {
     const float* T = it->T;
-    const float A = cosf(T[2]), B = sinf(T[2]), C = cosf(T[1]), D = sinf(T[1]), E = cosf(T[0]), F = sinf(T[0]);
+    float A, B, C, D, E, F;
+    if (exact) {
+        // the reference's host libm returns the correctly rounded float sine / cosine (glibc computes them in double); the device's
+        // sinf / cosf are 1-2 ulp routines, so the exact build takes the double functions and rounds once
+        A = (float)cos((double)T[2]); B = (float)sin((double)T[2]); C = (float)cos((double)T[1]);
+        D = (float)sin((double)T[1]); E = (float)cos((double)T[0]); F = (float)sin((double)T[0]);
+    } else {
+        A = cosf(T[2]); B = sinf(T[2]); C = cosf(T[1]); D = sinf(T[1]); E = cosf(T[0]); F = sinf(T[0]);
+    }
     const float DE = D * E, DF = D * F;
     float* M = it->M;
     M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ item
     it->degenerate = it->degenerate_in;
     it->n_corr = 0;
     it->any_solved = 0;
-    write_pose_cache(it);
+    write_pose_cache(it, P.exact != 0);
 }
 
 constexpr int kSolveThreads = 512;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
             }
         }
         for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];          // :955-960
-        write_pose_cache(it);
+        write_pose_cache(it, P.exact != 0);
         const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
         const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
         const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
