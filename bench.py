@@ -323,6 +323,10 @@ def main():
         cnt = ctx.counters()
         print("searched fraction per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in cnt[:ITERS]], file=sys.stderr)
         print("wavefronts with a walking lane per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in ctx.wave_counters()[:ITERS]], file=sys.stderr)
+        if os.environ.get("LISREG_COUNT") == "3":
+            print("raw counters 96..127:", ctx.raw_counters()[96:128], file=sys.stderr)
+        if os.environ.get("LISREG_COUNT") == "3":
+            print("raw counters 96..127:", ctx.raw_counters()[96:128], file=sys.stderr)
         if os.environ.get("LISREG_COUNT") == "2":
             raw = ctx.raw_counters()[96:96 + ITERS]
             print("queries with an unchanged ordered neighbour set / wavefronts where all are unchanged:", [(int(r >> 32), int(r & 0xffffffff)) for r in raw], file=sys.stderr)
