@@ -180,6 +180,16 @@ int  lisreg_batch_prepare(lisreg_ctx* ctx, int n_items, const lisreg_item* items
                           const lisreg_params* params, const float* T_init);
 int  lisreg_batch_run(lisreg_ctx* ctx);
 int  lisreg_batch_fetch(lisreg_ctx* ctx, float* T, lisreg_stats* stats);
+/* Host feeder for streams of batches (lisreg_api_feed.hip).  Packs the HOST clouds of `items` (the reference's PCL structs) to 16-byte
+ * device records with "feeder_threads" host threads (option, default 8) into pinned staging and uploads them asynchronously, on a copy
+ * stream of the context, into one of two device buffers the context owns; items_out[i] is items[i] with device pointers and
+ * LISREG_FMT_DEVICE.  The caller's clouds are not referenced after the call returns.  The next lisreg_batch_prepare waits for the
+ * uploads ON THE DEVICE.  Buffers alternate between calls, so the loop
+ *     stage(k+1); fetch(k); prepare(k+1); run(k+1);          (or: prepare(k); run(k); stage(k+1); fetch(k); ...)
+ * uploads batch k+1 underneath the kernels of batch k — the reference has no counterpart (its clouds never leave the host);
+ * lisreg_align_batch uses it internally for batches of >= 262144 source points. */
+int  lisreg_stage_host_items(lisreg_ctx* ctx, int n_items, const lisreg_item* items, lisreg_item* items_out);
+
 /* Device pointer to the prepared batch's result block: n_items x 12 floats
  * {T[6], iters, deltaR, deltaT, degenerate, n_corr_last, status} — what a multi-GPU host all-gathers. */
 void* lisreg_batch_result_device(const lisreg_ctx* ctx);

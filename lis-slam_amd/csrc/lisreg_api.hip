@@ -274,6 +274,7 @@ void lisreg_destroy(lisreg_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     lisreg_comm_destroy(c);
+    feeder_destroy(c);
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
@@ -560,6 +561,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->n_elems = flat;
     c->n_buckets = std::max(bucket, 1);
     int rc = LISREG_OK;
+    if (c->pack_pending) {                        // sources staged by lisreg_stage_host_items: the device waits for the uploads, the host does not
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->pack_pending, 0));
+        c->pack_pending = nullptr;
+        c->pack_in_use = c->pack_last;
+    }
     HIPCHK(c, c->blocks.ensure(sizeof(BlockDesc) * (size_t)std::max(c->n_blocks, 1)));
     HIPCHK(c, c->segs.ensure(sizeof(Segment) * (size_t)std::max(c->n_segs, 1)));
     HIPCHK(c, c->items.ensure(sizeof(ItemState) * (size_t)std::max(n_items, 1)));
@@ -762,6 +768,8 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     }
     launch_finalize(c->items.as<ItemState>(), c->n_items, c->prm, c->results.as<float>(), st);
     HIPCHK(c, hipGetLastError());
+    if (c->pack_in_use >= 0 && c->pack_free[c->pack_in_use])      // the staged source buffer may be overwritten once this run is through
+        HIPCHK(c, hipEventRecord(c->pack_free[c->pack_in_use], st));
     return LISREG_OK;
 }
 
@@ -841,6 +849,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "exact_arithmetic")) { c->exact = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "feeder_threads")) { c->feeder_threads = std::min(std::max(value, 0), 64); return LISREG_OK; }
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
 
@@ -880,9 +889,20 @@ int lisreg_align_batch(lisreg_ctx* c, int n_items, const lisreg_item* items, con
             total += (size_t)in.n_corner + (size_t)in.n_surf;
         }
     }
-    // Host clouds cross PCIe as they are (the caller's structs, asynchronously on the context's stream — at full link rate
-    // when the caller's memory is pinned) and are packed to 16-byte records on the device; nothing is repacked on the CPU.
     std::vector<lisreg_item> dev_items((size_t)n_items);
+    // Big host batches go through the feeder (lisreg_api_feed.hip): a few host threads pack the structs to 16-byte records in pinned
+    // staging and the chunks are uploaded as they complete — half the bytes on the link, a few big copies instead of one per cloud.
+    if (total >= 262144 && c->feeder_threads > 0) {
+        int rc = lisreg_stage_host_items(c, n_items, items, dev_items.data());
+        if (rc) return rc;
+        rc = lisreg_batch_prepare(c, n_items, dev_items.data(), params, T);
+        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        rc = run_impl(c, true);
+        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        return lisreg_batch_fetch(c, T, stats);
+    }
+    // Small ones (a single odometry frame) cross PCIe as they are — the caller's structs, asynchronously on the context's stream —
+    // and are packed to 16-byte records on the device: no thread is woken, nothing is repacked on the CPU.
     HIPCHK(c, c->src_upload.ensure(sizeof(lisreg_dpoint) * std::max<size_t>(total, 1)));
     size_t raw_bytes = 0;
     for (int i = 0; i < n_items; ++i)

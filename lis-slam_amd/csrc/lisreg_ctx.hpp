@@ -2,6 +2,7 @@
 #pragma once
 #include "lisreg_internal.hpp"
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,9 @@ struct KeyframeRing {
     int    n_tgt[2] = { 0, 0 };
 };
 
+struct PackPool;           // host feeder threads (lisreg_api_feed.hip)
+struct PackChunk { const unsigned char* src; lisreg_dpoint* dst; int n, stride, fmt; };      // <= 64 k points of one host cloud
+
 struct RcclApi {
     void* handle = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
@@ -90,6 +94,19 @@ struct lisreg_ctx {
            vox_in, vox_lab, vox_order, vox_sidx, vox_head, vox_slot, vox_start, vox_out, vox_outlab, vox_M,
            ft_owner, ft_flag, ft_pos, ft_scan, ft_col, ft_range, ft_src, ft_curv, ft_picked, ft_label, ft_rlists, ft_rcounts,
            ft_lists, ft_counts, ft_rings, ft_gather, ft_cat, ft_bounds, ft_dsk_tab, ft_dsk_pts, ft_dsk_misc, ft_dsk_time;
+    // host feeder (lisreg_api_feed.hip): clouds packed to 16-byte records by a few threads into pinned staging, uploaded on a copy stream
+    lisreg::PackPool* pack_pool = nullptr;
+    int          feeder_threads = 8;
+    unsigned char* pack_host[2] = { nullptr, nullptr };
+    size_t       pack_cap[2] = { 0, 0 };
+    lisreg::DevBuf pack_dev[2];
+    hipEvent_t   pack_copied[2] = { nullptr, nullptr };   // the uploads into device buffer b are done (recorded on copy_stream)
+    hipEvent_t   pack_free[2] = { nullptr, nullptr };     // the batch reading device buffer b has run (recorded on stream)
+    hipEvent_t   pack_pending = nullptr;                  // uploads the next prepared batch has to wait for
+    int          pack_flip = 0, pack_last = -1, pack_in_use = -1;
+    hipStream_t  copy_stream = nullptr;
+    std::vector<lisreg::PackChunk> pack_chunks;
+    std::vector<std::atomic<int>> pack_done;
     std::vector<lisreg::MapIndex> maps;
     std::vector<lisreg::LocalMap> localmaps;
     std::vector<lisreg::KeyframeRing> keyrings;
@@ -158,6 +175,7 @@ struct lisreg_ctx {
 };
 
 namespace lisreg {
+void feeder_destroy(lisreg_ctx* c);
 int  ctx_fail(lisreg_ctx* c, int code, const std::string& msg);
 // pack PCL structs (stride/format of common.h:9,25-35) into 16-B device records
 void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* out);

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_transform_cloud",
@@ -179,6 +179,7 @@ def lib():
                                    C.POINTER(Imu), fp, C.POINTER(Stats)]
         L.lisreg_align_batch.argtypes = [vp, C.c_int, C.POINTER(Item), C.POINTER(Params), fp, C.POINTER(Stats)]
         L.lisreg_batch_prepare.argtypes = [vp, C.c_int, C.POINTER(Item), C.POINTER(Params), fp]
+        L.lisreg_stage_host_items.argtypes = [vp, C.c_int, C.POINTER(Item), C.POINTER(Item)]
         L.lisreg_batch_run.argtypes = [vp]
         L.lisreg_batch_fetch.argtypes = [vp, fp, C.POINTER(Stats)]
         L.lisreg_batch_result_device.argtypes = [vp]

@@ -341,3 +341,58 @@ def test_non_finite_inputs_are_contained(gpu_ctx):
     raw = synth.make_raw_scan(16, 450, 1701); raw["x"][5] = np.nan; raw["y"][6] = np.inf; raw["z"][100] = -np.inf
     f = gpu_ctx.extract_features(raw, lisreg.FeatureParams(16, 450, 1, 0.0, 70.0, 1.0, 0.1))
     assert len(f["deskewed"]) > 5000
+
+
+@pytest.mark.parametrize("labelled", [False, True])
+def test_staged_host_items_equal_align_batch(labelled):
+    """lisreg_stage_host_items (feeder threads pack the PCL structs to 16-byte records, asynchronous upload on the copy stream) followed
+    by prepare / run / fetch gives the bits of lisreg_align_batch; two batches staged back to back land in different device buffers, so
+    batch k + 1 can be staged while batch k is still queued — both come out right.  Big enough (>= 262144 points) that the thread pool
+    really runs, and lisreg_align_batch itself takes the feeder path."""
+    import ctypes as C
+    import lisreg
+    from lisreg import synth
+    variant = 2 if labelled else 1
+    cases = [synth.make_case(h=64, w=900, m_points=40000, scan_seed=3300 + i, labelled=labelled) for i in range(6)]
+    p = lisreg.default_params(variant)
+    p.fixed_iters = 4
+    ctx = lisreg.Context(0)
+    ctx.set_target(cases[0]["tgt_corner"], cases[0]["tgt_surf"])
+    n = len(cases)
+    assert sum(len(c["src_corner"]) + len(c["src_surf"]) for c in cases) >= 262144
+    T0 = np.stack([c["T_init"] for c in cases]).astype(np.float32)
+    T_ref, st_ref = ctx.align_batch([dict(src_corner=c["src_corner"], src_surf=c["src_surf"]) for c in cases], T0, p)
+    ctx.set_option("feeder_threads", 0)                       # the plain path: structs uploaded as they are, packed on the device
+    T_plain, st_plain = ctx.align_batch([dict(src_corner=c["src_corner"], src_surf=c["src_surf"]) for c in cases], T0, p)
+    ctx.set_option("feeder_threads", 8)
+    assert np.array_equal(T_ref, T_plain) and st_ref == st_plain
+
+    def items_of(order):
+        arr = (lisreg.Item * n)()
+        keep = []
+        for i, k in enumerate(order):
+            sc = np.ascontiguousarray(cases[k]["src_corner"]); ss = np.ascontiguousarray(cases[k]["src_surf"])
+            keep += [sc, ss]
+            arr[i].src_corner = sc.ctypes.data_as(C.c_void_p); arr[i].n_corner = len(sc)
+            arr[i].src_surf = ss.ctypes.data_as(C.c_void_p); arr[i].n_surf = len(ss)
+            arr[i].stride_bytes = sc.dtype.itemsize; arr[i].fmt = lisreg.FMT_XYZIL if labelled else lisreg.FMT_XYZI
+        return arr, keep
+    L = ctx._L
+    fwd, rev = list(range(n)), list(range(n))[::-1]
+    (arr_a, keep_a), (arr_b, keep_b) = items_of(fwd), items_of(rev)
+    st_a, st_b = (lisreg.Item * n)(), (lisreg.Item * n)()
+    assert L.lisreg_stage_host_items(ctx._h, n, arr_a, st_a) == 0
+    assert L.lisreg_stage_host_items(ctx._h, n, arr_b, st_b) == 0          # second buffer, while the first has not been consumed yet
+    del keep_a, keep_b                                                      # the caller's clouds are not referenced after the call
+    assert st_a[0].src_surf != st_b[0].src_surf and st_a[0].fmt == lisreg.FMT_DEVICE
+    out = []
+    for staged, order in ((st_a, fwd), (st_b, rev)):
+        Tin = np.ascontiguousarray(T0[order])
+        assert L.lisreg_batch_prepare(ctx._h, n, staged, C.byref(p), Tin.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        assert L.lisreg_batch_run(ctx._h) == 0
+        ctx._n_items = n
+        out.append(ctx.batch_fetch())
+    ctx.close()
+    (Ta, sa), (Tb, sb) = out
+    assert np.array_equal(Ta, T_ref) and sa == st_ref
+    assert np.array_equal(Tb, T_ref[::-1]) and sb == st_ref[::-1]
