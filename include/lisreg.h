@@ -214,6 +214,12 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * threshold-straddling correspondences per thousand may differ; 1 the reference's arithmetic operation for operation — IEEE division
  * and sqrt, cv::eigen's pivoted Jacobi, fp64 sums, no contraction, correctly rounded sin / cos: accept flags, correspondence counts
  * and iteration counts EQUAL the CPU restatement's (tests/test_exact.py), at roughly 0.6x the throughput),
+ * "canonical_ties" (0 [default]: of two target points at EXACTLY equal float distance from a query the first one met is kept, and
+ * the search front-ends meet them in different orders — about one query in 10^5-10^6 on scan data, like FLANN's own traversal order;
+ * 1: such ties are noted during the search and resolved by (distance, original index), so the five neighbours, their order and every
+ * bit computed from them are the same in every front-end and batch shape — a frame registers identically alone and inside any batch —
+ * at +7 % per correspondence launch; implied by "exact_arithmetic"),
+ * "feeder_threads" (host threads of lisreg_stage_host_items, default 8; 0 = structs uploaded as they are and packed on the device),
  * "graph_min_ratio", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or

@@ -257,6 +257,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
     if (const char* m = getenv("LISREG_EXACT")) c->exact = atoi(m) != 0;
+    if (const char* m = getenv("LISREG_CANONICAL_TIES")) c->canonical_ties = atoi(m) != 0;
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_WIDE_UNTIL")) c->graph_wide_until = atoi(m);
@@ -470,6 +471,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->params = *params;
     c->prm = make_dev_params(*params);
     c->prm.exact = c->exact ? 1 : 0;
+    c->prm.ties = (c->canonical_ties || c->exact) ? 1 : 0;
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
@@ -847,6 +849,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "lanes_per_query")) { c->lanes_per_query_auto = value != 1; c->prepared = false; return LISREG_OK; }   // 1 forces one lane per query, anything else = auto
     if (!strcmp(name, "dump_neighbors")) { c->dump_neighbors = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "exact_arithmetic")) { c->exact = value != 0; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "canonical_ties")) { c->canonical_ties = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "feeder_threads")) { c->feeder_threads = std::min(std::max(value, 0), 64); return LISREG_OK; }
@@ -858,6 +861,7 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!c || !name || !value) return LISREG_ERR_ARG;
     if (!strcmp(name, "search_mode")) { *value = c->search_mode; return LISREG_OK; }
     if (!strcmp(name, "exact_arithmetic")) { *value = c->exact ? 1 : 0; return LISREG_OK; }
+    if (!strcmp(name, "canonical_ties")) { *value = (c->canonical_ties || c->exact) ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "index_build")) { *value = c->index_build; return LISREG_OK; }
     if (!strcmp(name, "index_build_now")) { *value = c->strip_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }

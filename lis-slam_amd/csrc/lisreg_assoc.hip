@@ -767,6 +767,28 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
             const bool dup_ = (j_) == i0 || (j_) == i1 || (j_) == i2 || (j_) == i3 || (j_) == i4; \
             if (!dup_) LISREG_INSERT((d2_), (j_)); } } while (0)
 
+// Equal distances (kTies instantiations; option "canonical_ties", always on in the exact build).  "First met wins" makes the five kept —
+// and their order, hence the float sums of the fit — depend on the order in which a front-end meets its candidates (cell walk, graph
+// scan, eight lanes per query all differ) when two target points are equidistant from the query to the last bit (about one query in
+// 10^5-10^6 on scan data; every query of a map that holds a point twice).  With kTies the search NOTES a tie that can matter (`tie`, a
+// lane mask) and a noted lane re-selects its five among the points inside its final radius by (distance, ORIGINAL index) —
+// LISREG_CANONICAL_FIVE below — so every front-end returns the same five in the same order, always.  Where it is noted: once per
+// candidate GROUP, after its insertions: (1) a candidate of the group at exactly the new 5th-best distance that is not the new fifth
+// itself — it competes with it whichever was met first; (2) two equal distances next to each other in the list.  That is complete: a tie
+// can only enter the list through an insertion (caught by (2) at the end of that group), an entry can only be DROPPED tied with the fifth
+// that stays if the two were neighbours in the list at the start of the group (caught by (2) at the end of the group before, or by the
+// check after the seeds / the sorting network), and a candidate equal to an older entry is inserted BEHIND it (strict '<'), so it is the
+// candidate that falls first.  Cost (measured): ~170 vector instructions per wavefront, +7 % on a steady-state launch.
+#define LISREG_GROUP_TIES(e0_, k0_, e1_, k1_, e2_, k2_, e3_, k3_) do { if (kTies) { \
+        /* bitwise, not short-circuit: a dozen compares into lane masks and scalar ors, no branches */ \
+        const bool t_ = (int)(b0 == b1) | (int)(b1 == b2) | (int)(b2 == b3) | (int)(b3 == b4) | \
+                        ((int)((e0_) == b4) & (int)((k0_) != i4)) | ((int)((e1_) == b4) & (int)((k1_) != i4)) | \
+                        ((int)((e2_) == b4) & (int)((k2_) != i4)) | ((int)((e3_) == b4) & (int)((k3_) != i4)); \
+        tie = (int)tie | ((int)t_ & (int)(i4 >= 0)); } } while (0)
+#define LISREG_LIST_TIES() do { if (kTies) tie = (int)tie | ((int)(i4 >= 0) & ((int)(b0 == b1) | (int)(b1 == b2) | (int)(b2 == b3) | (int)(b3 == b4))); } while (0)
+// the "nothing closer" gate of a group: with kTies a candidate AT the bound has to be looked at too
+#define LISREG_GATE(m_) (kTies ? (m_) <= b4 : (m_) < b4)
+
 // Flattened walk.  Nested (x, y, run) loops — the first version of this kernel — cost, per wave, the SUM over columns of the
 // longest run any lane has in that column (16.7 candidate groups in the steady state of configs[1]), although
 // the busiest lane needs 11 and the average lane 7.  Here every lane first collects the non-empty cell runs of its columns
@@ -824,8 +846,9 @@ constexpr int kWalkCap = 8;
                 const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
                 const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
                 const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
-                if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
+                if (LISREG_GATE(fminf(fminf(e0_, e1_), fminf(e2_, e3_)))) { \
                     LISREG_TRY(e0_, j_); LISREG_TRY(e1_, j1_); LISREG_TRY(e2_, j2_); LISREG_TRY(e3_, j3_); \
+                    LISREG_GROUP_TIES(e0_, j_, e1_, j1_, e2_, j2_, e3_, j3_); \
                 } \
                 j_ += 4; \
             } \
@@ -840,6 +863,7 @@ constexpr int kWalkCap = 8;
                 const float p0_ = __shfl_xor(b0, d_), p1_ = __shfl_xor(b1, d_), p2_ = __shfl_xor(b2, d_), p3_ = __shfl_xor(b3, d_), p4_ = __shfl_xor(b4, d_); \
                 const int   j0_ = __shfl_xor(i0, d_), j1_ = __shfl_xor(i1, d_), j2_ = __shfl_xor(i2, d_), j3_ = __shfl_xor(i3, d_), j4_ = __shfl_xor(i4, d_); \
                 LISREG_TRY(p0_, j0_); LISREG_TRY(p1_, j1_); LISREG_TRY(p2_, j2_); LISREG_TRY(p3_, j3_); LISREG_TRY(p4_, j4_); \
+                LISREG_GROUP_TIES(p0_, j0_, p1_, j1_, p2_, j2_, p3_, j3_); if (kTies && i4 >= 0 && p4_ == b4 && j4_ != i4) tie = true; \
             } } } while (0)
 
 // Graph scan (search_mode 3, GN iterations >= 1).  The target carries a k-NN graph (lisreg_index.hip: kGraphK nearest other
@@ -872,8 +896,9 @@ constexpr int kWalkCap = 8;
            is the group's largest; a padded last entry aliases the anchor (0) and then the list ends here: rho decides */ \
         const float tx_ = ap_.x - (E3).x, ty_ = ap_.y - (E3).y, tz_ = ap_.z - (E3).z; \
         const float l3_ = tx_ * tx_ + ty_ * ty_ + tz_ * tz_; \
-        if (fminf(fminf(e0_, e1_), fminf(e2_, e3_)) < b4) { \
+        if (LISREG_GATE(fminf(fminf(e0_, e1_), fminf(e2_, e3_)))) { \
             TRYM(e0_, k0_); TRYM(e1_, k1_); TRYM(e2_, k2_); TRYM(e3_, k3_); \
+            LISREG_GROUP_TIES(e0_, k0_, e1_, k1_, e2_, k2_, e3_, k3_); \
             const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
         } \
         if (l3_ > thr2_) stop_ = true; } while (0)
@@ -912,10 +937,12 @@ constexpr int kWalkCap = 8;
                     i0 = sd[0] < P.tau ? sid[0] : -1; i1 = sd[1] < P.tau ? sid[1] : -1; i2 = sd[2] < P.tau ? sid[2] : -1; \
                     i3 = sd[3] < P.tau ? sid[3] : -1; i4 = sd[4] < P.tau ? sid[4] : -1; \
                 } \
+                LISREG_LIST_TIES(); \
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (l3_ > thr2_) stop_ = true; \
             } else { \
                 if (FIRST) LISREG_LIST_INIT(); \
+                if (kTies && i4 >= 0 && da2_ == b4 && a_ != i4) tie = true; \
                 LISREG_TRY(da2_, a_); \
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY); \
@@ -953,11 +980,50 @@ constexpr int kWalkCap = 8;
 #define LISREG_CE5(a, b) do { const bool sw_ = sd[b] < sd[a]; const float ta_ = sd[a]; const int ia_ = sid[a]; \
                               sd[a] = sw_ ? sd[b] : ta_; sd[b] = sw_ ? ta_ : sd[b]; sid[a] = sw_ ? sid[b] : ia_; sid[b] = sw_ ? ia_ : sid[b]; } while (0)
 
+// Canonical five of a lane that noted a tie: every point with d^2 <= the final 5th-best distance (there are five or a few more), ordered
+// by (d^2, original index of the point in the caller's cloud), the first five kept.  Plain loops over the cells the ball touches; the
+// squared distance is formed by the same expression as in the search, so it has the same bits.  With kQ lanes per query every lane of
+// the group runs it (the note is shared first), and all arrive at the same list.
+#define LISREG_CANON_INSERT(d2_, o_, j_) do { \
+        const bool c3_ = (d2_) < b3 || ((d2_) == b3 && (o_) < o3), c2_ = (d2_) < b2 || ((d2_) == b2 && (o_) < o2); \
+        const bool c1_ = (d2_) < b1 || ((d2_) == b1 && (o_) < o1), c0_ = (d2_) < b0 || ((d2_) == b0 && (o_) < o0); \
+        b4 = c3_ ? b3 : (d2_);               i4 = c3_ ? i3 : (j_);               o4 = c3_ ? o3 : (o_); \
+        b3 = c3_ ? (c2_ ? b2 : (d2_)) : b3;  i3 = c3_ ? (c2_ ? i2 : (j_)) : i3;  o3 = c3_ ? (c2_ ? o2 : (o_)) : o3; \
+        b2 = c2_ ? (c1_ ? b1 : (d2_)) : b2;  i2 = c2_ ? (c1_ ? i1 : (j_)) : i2;  o2 = c2_ ? (c1_ ? o1 : (o_)) : o2; \
+        b1 = c1_ ? (c0_ ? b0 : (d2_)) : b1;  i1 = c1_ ? (c0_ ? i0 : (j_)) : i1;  o1 = c1_ ? (c0_ ? o0 : (o_)) : o1; \
+        b0 = c0_ ? (d2_) : b0;               i0 = c0_ ? (j_) : i0;               o0 = c0_ ? (o_) : o0; } while (0)
+#define LISREG_CANONICAL_FIVE() do { if (kTies) { \
+        if (kQ > 1) { _Pragma("unroll") for (int d_ = 1; d_ < kQ; d_ <<= 1) tie = tie || __shfl_xor((int)tie, d_) != 0; } \
+        LISREG_LIST_TIES(); \
+        if (tie && i4 >= 0) { \
+            const float lim_ = b4; \
+            const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps; \
+            const int cx0_ = max(grid_coord(qx - rad_, g.ox, g.inv_cell), 0), cx1_ = min(grid_coord(qx + rad_, g.ox, g.inv_cell), g.nx - 1); \
+            const int cy0_ = max(grid_coord(qy - rad_, g.oy, g.inv_cell), 0), cy1_ = min(grid_coord(qy + rad_, g.oy, g.inv_cell), g.ny - 1); \
+            const int cz0_ = max(grid_coord(qz - rad_, g.oz, g.inv_cell), 0), cz1_ = min(grid_coord(qz + rad_, g.oz, g.inv_cell), g.nz - 1); \
+            b0 = b1 = b2 = b3 = b4 = 3.0e38f; i0 = i1 = i2 = i3 = i4 = -1; \
+            int o0 = 0x7fffffff, o1 = 0x7fffffff, o2 = 0x7fffffff, o3 = 0x7fffffff, o4 = 0x7fffffff; \
+            if (cz0_ <= cz1_) \
+            _Pragma("unroll 1") for (int ix_ = cx0_; ix_ <= cx1_; ++ix_) \
+            _Pragma("unroll 1") for (int iy_ = cy0_; iy_ <= cy1_; ++iy_) { \
+                const int base_ = (ix_ * g.ny + iy_) * g.nz; \
+                const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
+                _Pragma("unroll 1") for (int j_ = js_; j_ < je_; ++j_) { \
+                    const v4f c_ = pts[j_]; \
+                    const float ax_ = qx - c_.x, ay_ = qy - c_.y, az_ = qz - c_.z; \
+                    const float e_ = ax_ * ax_ + ay_ * ay_ + az_ * az_; \
+                    const int o_ = __float_as_int(c_.w); \
+                    if (e_ <= lim_ && (e_ < b4 || (e_ == b4 && o_ < o4))) LISREG_CANON_INSERT(e_, o_, j_); \
+                } \
+            } \
+            (void)o4; \
+        } } } while (0)
+
 // kQ = lanes per query.  1 for big batches (every lane its own query: throughput).  A single odometry-sized registration is a
 // few hundred waves on a chip with 8192 wave slots, i.e. one wave per SIMD with nothing to hide its dependent cell -> candidate
 // loads behind: there kQ = 8 lanes share one query (columns dealt round-robin, five-best lists merged by butterfly), which cuts
 // the serial chain of the walk by the same factor.  The five neighbours, and everything computed from them, are identical.
-template <bool kWide, bool kGraph, int kQ>
+template <bool kWide, bool kGraph, int kQ, bool kTies>
 __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
@@ -1016,6 +1082,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // ten registers, and an initialisation up front is executed by every wavefront (the compiler even emitted it twice)
     float b0, b1, b2, b3, b4;
     int   i0, i1, i2, i3, i4;
+    bool  tie = false;                                     // kTies: an equal-distance pair that can matter was met
 #define LISREG_LIST_INIT() do { b0 = b1 = b2 = b3 = b4 = P.tau; i0 = i1 = i2 = i3 = i4 = -1; } while (0)
     if (kGraph) {
         // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
@@ -1049,6 +1116,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
             (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
         }
+        LISREG_CANONICAL_FIVE();
         if (valid) nn[qflat] = i0;                             // next iteration's anchor: the nearest neighbour (-1: none)
     } else if (!valid) {
         LISREG_LIST_INIT();
@@ -1087,6 +1155,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
                     for (int k = 0; k < 5; ++k) if (sd[k] < b4) LISREG_INSERT(sd[k], sid[k]);
                 }
                 seeded = true;
+                LISREG_LIST_TIES();
             }
         }
         int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;            // columns covered by an INNER pass (empty)
@@ -1110,6 +1179,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
         LISREG_GROUP_MERGE();
         (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
+        LISREG_CANONICAL_FIVE();
         // remember the neighbours for the next iteration (slot 4 = -1 marks "no valid set").  Skipping this store
         // while the set is unchanged was measured twice: keeping the five ids live costs an occupancy step (8 -> 7,
         // 4 % slower); a one-register XOR signature keeps 8 waves but gains nothing — the kernel is not HBM-bound.
@@ -1279,22 +1349,23 @@ void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs
 }
 #endif
 
-// launch_assoc (production arithmetic) / launch_assoc_exact (the reference's arithmetic): same arguments, same front-ends
-void LISREG_LAUNCH_ASSOC(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
-                         const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
-                         int mode, int* nn, int n_elems, float first_pass_r2, bool wide, int graph_hops,
-                         unsigned long long* counters, int* dbg_nn, int lanes_q,
-                         const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st)
+// launch_assoc (production arithmetic) / launch_assoc_exact (the reference's arithmetic, equal distances always resolved canonically):
+// same arguments, same front-ends
+template <bool kTies>
+static void launch_assoc_impl(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
+                              const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
+                              int mode, int* nn, int n_elems, float first_pass_r2, bool wide, int graph_hops,
+                              unsigned long long* counters, int* dbg_nn, int lanes_q,
+                              const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st)
 {
     using namespace LISREG_ASSOC_NS;
-    if (n_blocks <= 0) return;
     if (mode == 1 && lanes_q == 8) {
         if (wide)
-            k_assoc_walk<true, false, 8><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                         first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+            k_assoc_walk<true, false, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                                first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
-            k_assoc_walk<false, false, 8><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                          first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+            k_assoc_walk<false, false, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                                 first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         k_rows_reduce<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, coef, coef_ok, partials);
         return;
     }
@@ -1302,19 +1373,39 @@ void LISREG_LAUNCH_ASSOC(const BlockDesc* blocks, int n_blocks, const Segment* s
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
     else if (mode == 1) {
         if (wide)
-            k_assoc_walk<true, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+            k_assoc_walk<true, false, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                              first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
-            k_assoc_walk<false, false, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+            k_assoc_walk<false, false, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                               first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
     } else {
         if (wide)
-            k_assoc_walk<true, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                      first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
+            k_assoc_walk<true, true, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                             first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
         else
-            k_assoc_walk<false, true, 1><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
+            k_assoc_walk<false, true, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                              first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
     }
+}
+
+void LISREG_LAUNCH_ASSOC(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
+                         const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
+                         int mode, int* nn, int n_elems, float first_pass_r2, bool wide, int graph_hops,
+                         unsigned long long* counters, int* dbg_nn, int lanes_q,
+                         const BlockDesc* blocks_q, int n_blocks_q, float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st)
+{
+    if (n_blocks <= 0) return;
+#if LISREG_EXACT
+    launch_assoc_impl<true>(blocks, n_blocks, segs, grids, items, prm, sorted_all, partials, mode, nn, n_elems, first_pass_r2, wide, graph_hops,
+                            counters, dbg_nn, lanes_q, blocks_q, n_blocks_q, coef, coef_ok, xcd_order, st);
+#else
+    if (prm.ties)
+        launch_assoc_impl<true>(blocks, n_blocks, segs, grids, items, prm, sorted_all, partials, mode, nn, n_elems, first_pass_r2, wide, graph_hops,
+                                counters, dbg_nn, lanes_q, blocks_q, n_blocks_q, coef, coef_ok, xcd_order, st);
+    else
+        launch_assoc_impl<false>(blocks, n_blocks, segs, grids, items, prm, sorted_all, partials, mode, nn, n_elems, first_pass_r2, wide, graph_hops,
+                                 counters, dbg_nn, lanes_q, blocks_q, n_blocks_q, coef, coef_ok, xcd_order, st);
+#endif
 }
 
 }  // namespace lisreg

@@ -142,6 +142,7 @@ struct lisreg_ctx {
     bool      xcd_now = false;           // what the last run used
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
+    bool      canonical_ties = false;    // "canonical_ties" (always on with exact_arithmetic)
     bool      exact = false;             // "exact_arithmetic": the correspondence launches and the pose cache run the reference's arithmetic (lisreg_assoc.hip)
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch

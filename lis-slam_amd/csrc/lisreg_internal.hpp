@@ -74,6 +74,7 @@ struct DevParams {
     float tau, line_ratio, plane_tol, accept_s, conv_deg, conv_cm, eig_thresh;
     int   min_corr, use_label, emulate_shadow, skip_empty, fixed_iters, bound, edge_min, surf_min, use_imu;
     float imu_w, rot_tol, z_tol;
+    int   ties;                // "canonical_ties": equal distances resolved by (distance, original index) in every front-end
     int   exact;               // "exact_arithmetic": pose cache with correctly rounded sin / cos (the launches pick launch_assoc_exact)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
 };

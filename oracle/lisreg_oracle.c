@@ -142,11 +142,17 @@ static inline float knn_worst(const knn_set* s) { return s->cnt < s->k ? FLT_MAX
 
 static inline void knn_add(knn_set* s, float d, int id)
 {
-    /* sorted insertion, ascending; equal distances keep first-come order */
+    /* sorted insertion, ascending by (distance, index).  FLANN keeps equal distances in traversal order, i.e. which of two exactly
+     * equidistant points is the fifth neighbour is an accident of the tree; the restatement fixes it to the smaller index so that
+     * the kd-tree search, the brute-force search and every GPU front-end agree on ties (about one query in 10^5) */
     int i;
     if (s->cnt < s->k) i = s->cnt++;
-    else { if (!(d < s->sqd[s->k - 1])) return; i = s->k - 1; }
-    while (i > 0 && s->sqd[i - 1] > d) { s->sqd[i] = s->sqd[i - 1]; s->idx[i] = s->idx[i - 1]; --i; }
+    else {
+        const float w = s->sqd[s->k - 1];
+        if (!(d < w || (d == w && id < s->idx[s->k - 1]))) return;
+        i = s->k - 1;
+    }
+    while (i > 0 && (s->sqd[i - 1] > d || (s->sqd[i - 1] == d && s->idx[i - 1] > id))) { s->sqd[i] = s->sqd[i - 1]; s->idx[i] = s->idx[i - 1]; --i; }
     s->sqd[i] = d; s->idx[i] = id;
 }
 
@@ -166,7 +172,7 @@ static void search_rec(const orc_kdtree* t, int id, const float q[3], float mind
     if (nd->left < 0) {
         for (int i = nd->lo; i < nd->hi; ++i) {
             float d = sqdist3(q, &t->pts[3 * i]);
-            if (d < knn_worst(s) || s->cnt < s->k) knn_add(s, d, t->perm[i]);
+            if (d <= knn_worst(s) || s->cnt < s->k) knn_add(s, d, t->perm[i]);
         }
         return;
     }
@@ -202,7 +208,7 @@ int orc_bruteforce_knn(const float* xyz, int n, const float q[3], int k, int* id
     knn_set s = { k, 0, idx, sqd };
     for (int i = 0; i < n; ++i) {
         float d = sqdist3(q, &xyz[3 * i]);
-        if (s.cnt < k || d < knn_worst(&s)) knn_add(&s, d, i);
+        if (s.cnt < k || d <= knn_worst(&s)) knn_add(&s, d, i);
     }
     return s.cnt;
 }

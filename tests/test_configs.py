@@ -62,6 +62,7 @@ def test_cfg1_batch_vs_oracle(oracle, gpu_ctx):
     gpu_ctx.set_target_device(tcd.ptr, len(tc), tsd.ptr, len(ts))
     items = [dict(corner_ptr=a.ptr, n_corner=a.shape[0], surf_ptr=b.ptr, n_surf=b.shape[0]) for a, b in recs]
     gpu_ctx.set_option("rebuild_targets_each_run", 1)
+    gpu_ctx.set_option("canonical_ties", 1)          # equal distances resolved by (distance, original index): bits independent of the front-end
     try:
         gpu_ctx.batch_prepare_device(items, T0, p)
         gpu_ctx.batch_run()
@@ -75,17 +76,18 @@ def test_cfg1_batch_vs_oracle(oracle, gpu_ctx):
         assert abs(st[i]["n_corr_last"] - so["n_corr_last"]) <= max(3, 0.001 * so["n_corr_last"])
         worst = max(worst, *pose_err(T[i], To))
     assert worst <= TOL, worst
-    # batch == single calls, bit for bit — with the SAME search front-end: the batch qualifies for the graph scan (auto), a single
-    # registration would take the walk, and the two may order two candidates at exactly equal float distance differently
-    fe = gpu_ctx.get_option("front_end")
-    gpu_ctx.set_option("search_mode", fe)
+    # batch == single calls, bit for bit, with the front-end left at auto: the batch qualifies for the graph scan, a single
+    # registration takes the eight-lanes-per-query cell walk — equal distances are resolved by (distance, original index) in all of
+    # them with the option "canonical_ties" (LISREG_CANONICAL_FIVE), so a frame's bits do not depend on the batch it sits in
+    assert gpu_ctx.get_option("front_end") == 3
     try:
         gpu_ctx.set_target(tc, ts)
         for i in (0, n - 1):
             Ts, ss, _ = gpu_ctx.align(scans[i]["corner"], scans[i]["surf"], T0[i], p)
+            assert gpu_ctx.get_option("front_end") == 1
             assert np.array_equal(Ts, T[i]) and ss == st[i]
     finally:
-        gpu_ctx.set_option("search_mode", 4)
+        gpu_ctx.set_option("canonical_ties", 0)
 
 
 def test_cfg3_own_targets_256(oracle, gpu_ctx):
@@ -152,6 +154,7 @@ def test_cfg4_dense_1m(oracle, gpu_ctx):
     for mode in (1, 3):
         ctx = lisreg.Context(0)
         ctx.set_option("search_mode", mode)
+        ctx.set_option("canonical_ties", 1)
         ctx.set_target_device(tcd.ptr, len(tc), tsd.ptr, len(ts))
         ctx.batch_prepare_device(items, T0, p)
         assert ctx.front_end() == mode
@@ -166,8 +169,7 @@ def test_cfg4_dense_1m(oracle, gpu_ctx):
             assert abs(tr[k, 0] - tro[k, 0]) <= max(3, 0.001 * tro[k, 0]), (mode, k, tr[k, 0], tro[k, 0])
         results[mode] = (T, st)
         ctx.close()
-    # same neighbours -> same bits, except where two candidates are equidistant in float32 (63 M query-iterations against a
-    # 1 M-point map meet a few such ties; either choice is a correct 5-NN, tests/test_neighbors.py bounds them): the
-    # front-ends must still agree far inside the parity bar
-    assert max(pose_err(results[1][0], results[3][0])) <= 2e-5
-    assert all(abs(a["n_corr_last"] - b["n_corr_last"]) <= 1 for a, b in zip(results[1][1], results[3][1]))
+    # same neighbours, same order -> same bits: 63 M query-iterations against a 1 M-point map do meet candidates at exactly equal
+    # float distance; with "canonical_ties" both front-ends resolve them by (distance, original index)
+    assert np.array_equal(results[1][0], results[3][0])
+    assert results[1][1] == results[3][1]

@@ -88,3 +88,59 @@ def test_neighbour_sets_are_exact(h, w, m_points, variant):
         assert differing <= a[2] + b[2] + 2, (iters, differing)
         if differing == 0:
             assert np.array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_equal_distances_resolve_by_original_index_in_every_front_end(oracle):
+    """Option "canonical_ties".  A target in which EVERY point exists twice (exact copies, far apart in the cloud) and a mirror-symmetric part: each query meets
+    exact distance ties inside its five neighbours and at the fifth / sixth place.  The cell walk with one and with eight lanes per
+    query, the graph scan, and the exact-arithmetic build must return the same five ORIGINAL indices in the same order — the smaller
+    index first among equals — and the registration must then agree bit for bit between them, and in its integer outputs with the
+    oracle (whose k-NN resolves equal distances the same way)."""
+    import lisreg
+    from lisreg import synth
+    from helpers import copy_params
+    case = synth.make_case(h=16, w=450, m_points=12000, scan_seed=4711, trans=0.2, rot_deg=1.0)
+
+    def doubled(cloud, seed):
+        rng = np.random.default_rng(seed)
+        both = synth.concat_clouds([cloud, cloud])
+        return both[rng.permutation(len(both))]
+    tc, ts = doubled(case["tgt_corner"], 1), doubled(case["tgt_surf"], 2)
+    p = lisreg.default_params(1)
+    p.fixed_iters = 3
+    n = len(case["src_corner"]) + len(case["src_surf"])
+    out = {}
+    for name, mode, lanes, exact in (("walk1", 1, 1, 0), ("walk8", 1, 0, 0), ("graph", 3, 1, 0), ("exact", 1, 1, 1)):
+        c = lisreg.Context(0)
+        c.set_option("search_mode", mode); c.set_option("lanes_per_query", lanes); c.set_option("exact_arithmetic", exact)
+        c.set_option("canonical_ties", 1)                      # (implied by exact_arithmetic)
+        c.set_option("dump_neighbors", 1)
+        c.set_target(tc, ts)
+        T, st, tr = c.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        out[name] = (T, st, tr, c.neighbors(n)[:5].copy())
+        c.close()
+    nb = out["walk1"][3]
+    found = nb[4] >= 0
+    assert found.sum() > 0.5 * n
+    # every query with five neighbours has ties: its neighbours come in exact pairs
+    txyz = {0: synth.pcl_xyz(tc), 1: synth.pcl_xyz(ts)}
+    nc = len(case["src_corner"])
+    for q in np.flatnonzero(found)[:200]:
+        xyz = txyz[0 if q < nc else 1][nb[:, q]]
+        pairs = sum(np.array_equal(xyz[k], xyz[k + 1]) for k in range(4))
+        assert pairs >= 2, (q, xyz)
+        for k in range(4):
+            if np.array_equal(xyz[k], xyz[k + 1]):
+                assert nb[k, q] < nb[k + 1, q]                              # the smaller original index first among equals
+    for name in ("walk8", "graph"):
+        # (queries with fewer than five neighbours inside tau contribute nothing; the partial lists they keep are not canonicalised)
+        assert np.array_equal(out[name][3][4] >= 0, found), name
+        bad = np.flatnonzero((out[name][3][:, found] != nb[:, found]).any(0))
+        assert len(bad) == 0, (name, len(bad), out[name][3][:, found][:, bad[:3]], nb[:, found][:, bad[:3]])
+        assert np.array_equal(out[name][0], out["walk1"][0]) and np.array_equal(out[name][2], out["walk1"][2]), name
+    assert np.array_equal(out["exact"][3][:, found], nb[:, found])
+    p_o = copy_params(p, oracle.Params)
+    To, so, tro = oracle.align(tc, ts, case["src_corner"], case["src_surf"], case["T_init"], p_o)
+    assert np.array_equal(out["exact"][2][:, 0], tro[:, 0])
+    assert max(np.abs(out["exact"][0] - To).max(), 0) <= 2e-6
