@@ -410,6 +410,43 @@ int  lisreg_localmap_extract(lisreg_ctx* ctx, int map_id, const float cur_pose[6
 /* Copy one cloud out as 16-byte records (host or device destination): cls 0-4 = the class clouds, 5 / 6 = the corner / surf
  * target of the last extract.  *n_out is always set; LISREG_ERR_ARG if capacity is too small. */
 int  lisreg_localmap_get(lisreg_ctx* ctx, int map_id, int cls, void* out, int capacity, int* n_out);
+/* Copy #3's side of the same row: submap_t + SubMapManager::insert_submap (src/include/subMap.h:835-978) and
+ * SubMapOptmizationNode::extractSubMapCloud (src/node/subMapOptmizationNode.cpp:3976-4081), device-resident.  Submaps share the id space and
+ * the storage of the local maps (lisreg_localmap_reset / _get work on them: classes 0-4, 5 / 6 = the clouds of the last extract).
+ *   _insert  = insert_submap: the key frame's DOWN-sampled class clouds (semantic_*_down, all FIVE — the outlier class is appended here,
+ *              :882) are transformPointCloud'ed by the frame's relative_pose into the submap's own frame, the dynamic class goes through
+ *              the map-based removal once feature_point_num > max_num_pts / 5 (:887-892), append_feature, feature_point_num, local_bound
+ *              over all classes (:961-963) and bound = transform_bbx(local_bound, local_cp, submap_pose_6D_optimized) (:968-969);
+ *              relative_pose = NULL is fisrt_submap (:785-830): the first key frame of a submap, appended as it is;
+ *   _extract = extractSubMapCloud for (previous submap, current submap): bound boxes under the two poses, their intersection padded by
+ *              `pad` (10 m, :3995); TARGET = previous submap's pole | ground + building + dynamic transformed into the map frame by pre_pose
+ *              and cropped (:3997-4020), installed as registration target `target_slot` (-1: assembled only); SOURCES = current submap's
+ *              pole | dynamic + ground + building in the submap's own frame, cropped by the intersection box moved into that frame
+ *              (tran_map.inverse(), :4056-4061) and voxel-downsampled (0.2 / 0.5, :4066-4067): device records owned by the context, valid
+ *              until the next call on that submap — hand them to lisreg_align (LISREG_FMT_DEVICE, LISREG_VARIANT_SUBMAP) with cur_pose as
+ *              the guess = subMap2SubMapOptimization (:4485-4540);
+ *   _crop_boxes = the host arithmetic of the two boxes alone (double boxes, float matrices, Eigen's cofactor Affine3f::inverse). */
+typedef struct lisreg_submap_info {
+    int    n[5];                          /* points per class now (dynamic, pole, ground, building, outlier)       */
+    int    feature_point_num;
+    double local_bound[6];                /* local_bound: {min x, y, z, max x, y, z} in the submap's own frame       */
+    double bound[6];                      /* bound: local_bound moved by submap_pose (transform_bbx)                 */
+} lisreg_submap_info;
+typedef struct lisreg_submap_extract_out {
+    double isect[6];                      /* bbx_intersection in the map frame                                       */
+    double isect_local[6];                /* the same box moved into the current submap's frame                      */
+    int    n_target_corner, n_target_surf;/* laserCloud{Corner,Surf}FromSubMap                                       */
+    const void* src_corner; int n_src_corner;     /* laserCloudCornerLastDS (device records)                         */
+    const void* src_surf;   int n_src_surf;       /* laserCloudSurfLastDS                                            */
+} lisreg_submap_extract_out;
+int  lisreg_submap_insert(lisreg_ctx* ctx, int map_id, const void* const clouds[5], const int n[5], int stride_bytes, int fmt,
+                          const float relative_pose[6], const float submap_pose[6], const lisreg_localmap_params* params,
+                          lisreg_submap_info* info);
+int  lisreg_submap_extract(lisreg_ctx* ctx, int pre_id, int cur_id, const float pre_pose[6], const float cur_pose[6], float pad,
+                           float corner_leaf, float surf_leaf, int target_slot, lisreg_submap_extract_out* out);
+void lisreg_submap_crop_boxes(const double pre_local_bound[6], const float pre_pose[6], const double cur_local_bound[6],
+                              const float cur_pose[6], float pad, double isect[6], double isect_local[6]);
+
 /* The odometry node's target (odomEstimationNode.cpp, USING_MULTI_FRAME_TARGET), device-resident:
  *   _push   = saveKeyFrames (:421-468): the frame's FULL corner / surf feature clouds (host PCL structs or LISREG_FMT_DEVICE records,
  *             sensor frame) are transformPointCloud'ed by `pose` into the map frame and kept; the oldest frames are dropped until at

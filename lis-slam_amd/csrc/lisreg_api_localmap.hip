@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <string>
 
 using namespace lisreg;
 
@@ -115,24 +116,18 @@ int lisreg_localmap_reset(lisreg_ctx* c, int map_id)
     return LISREG_OK;
 }
 
-int lisreg_localmap_insert(lisreg_ctx* c, int map_id, const void* const clouds[5], const int n[5], int stride, int fmt,
-                           const float pose[6], const lisreg_localmap_params* P, lisreg_localmap_info* info)
+// insert_local_map (n_classes = 4: the outlier transform is commented out there, subMap.h:1003) and insert_submap (n_classes = 5,
+// subMap.h:878-882) share everything up to the bound
+static int insert_classes(lisreg_ctx* c, LocalMap* m, int map_id, const void* const clouds[5], const int n[5], int stride, int fmt,
+                          const float pose[6], const lisreg_localmap_params* P, int n_classes)
 {
-    if (!c) return LISREG_ERR_ARG;
-    if (!clouds || !n || !pose || !P) return bad(c, "localmap_insert: NULL argument");
-    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return bad(c, "localmap_insert: unknown fmt");
-    if (fmt != LISREG_FMT_DEVICE && (stride < 12 || (fmt == LISREG_FMT_XYZIL && stride < 22))) return bad(c, "localmap_insert: bad stride");
-    for (int k = 0; k < 5; ++k) if (n[k] < 0 || (n[k] > 0 && !clouds[k])) return bad(c, "localmap_insert: NULL cloud with n > 0");
-    LocalMap* m = get_map(c, map_id, true);
-    if (!m) return bad(c, "localmap_insert: bad map id");
-    if (!m->valid) { int rc = lisreg_localmap_reset(c, map_id); if (rc) return rc; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    // the reference widens the band first (subMap.h:1006): max(dynamic_dist_thre_max, (float)(dynamic_dist_thre_min + 0.1))
+    // the reference widens the band first (subMap.h:884 / :1006): max(dynamic_dist_thre_max, (float)(dynamic_dist_thre_min + 0.1))
     const float thre_max = std::max(P->dynamic_dist_thre_max, (float)((double)P->dynamic_dist_thre_min + 0.1));
-    for (int k = 0; k < 4; ++k) {                    // dynamic, pole, ground, building (outlier: not inserted, :1003)
+    for (int k = 0; k < n_classes; ++k) {            // dynamic, pole, ground, building (, outlier)
         if (n[k] == 0) continue;
-        // stage the frame's class cloud as device records, then transformPointCloud(.., &optimized_pose) into lm_tmp
+        // stage the frame's class cloud as device records, then transformPointCloud(.., &pose) into lm_tmp
         const float4* src = nullptr;
         if (fmt == LISREG_FMT_DEVICE) src = static_cast<const float4*>(clouds[k]);
         else {
@@ -145,11 +140,13 @@ int lisreg_localmap_insert(lisreg_ctx* c, int map_id, const void* const clouds[5
             src = c->lm_in.as<float4>();
         }
         HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)n[k]));
-        int rc = lisreg_transform_cloud(c, src, n[k], 16, LISREG_FMT_DEVICE, pose, c->lm_tmp.p);
+        int rc = LISREG_OK;
+        if (pose) rc = lisreg_transform_cloud(c, src, n[k], 16, LISREG_FMT_DEVICE, pose, c->lm_tmp.p);
+        else HIPCHK(c, hipMemcpyAsync(c->lm_tmp.p, src, sizeof(float4) * (size_t)n[k], hipMemcpyDeviceToDevice, st));     // fisrt_submap: as it is
         if (rc) return rc;
         int n_add = n[k];
-        if (k == 0 && P->dynamic_removal_on && m->feature_point_num > P->max_num_pts / 5) {
-            // tree_dynamic->setInputCloud(submap_dynamic) + map_scan_feature_pts_distance_removal (:1008-1012)
+        if (pose && k == 0 && P->dynamic_removal_on && m->feature_point_num > P->max_num_pts / 5) {
+            // tree_dynamic->setInputCloud(submap_dynamic) + map_scan_feature_pts_distance_removal (:889-892 / :1008-1012)
             rc = lisreg_map_index_set(c, kMapSlotBase + map_id, m->cls[0].p, m->n[0], 16, LISREG_FMT_DEVICE);
             if (rc) return rc;
             rc = lisreg_dynamic_filter(c, kMapSlotBase + map_id, c->lm_tmp.p, n[k], 16, LISREG_FMT_DEVICE,
@@ -166,9 +163,168 @@ int lisreg_localmap_insert(lisreg_ctx* c, int map_id, const void* const clouds[5
     }
     HIPCHK(c, hipStreamSynchronize(st));
     m->feature_point_num = m->n[0] + m->n[1] + m->n[2] + m->n[3] + m->n[4];
-    int rc = update_bound(c, *m);
+    return update_bound(c, *m);
+}
+
+static int check_insert_args(lisreg_ctx* c, const char* who, const void* const clouds[5], const int n[5], int stride, int fmt)
+{
+    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return bad(c, (std::string(who) + ": unknown fmt").c_str());
+    if (fmt != LISREG_FMT_DEVICE && (stride < 12 || (fmt == LISREG_FMT_XYZIL && stride < 22))) return bad(c, (std::string(who) + ": bad stride").c_str());
+    for (int k = 0; k < 5; ++k) if (n[k] < 0 || (n[k] > 0 && !clouds[k])) return bad(c, (std::string(who) + ": NULL cloud with n > 0").c_str());
+    return LISREG_OK;
+}
+
+int lisreg_localmap_insert(lisreg_ctx* c, int map_id, const void* const clouds[5], const int n[5], int stride, int fmt,
+                           const float pose[6], const lisreg_localmap_params* P, lisreg_localmap_info* info)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!clouds || !n || !pose || !P) return bad(c, "localmap_insert: NULL argument");
+    int rc = check_insert_args(c, "localmap_insert", clouds, n, stride, fmt);
+    if (rc) return rc;
+    LocalMap* m = get_map(c, map_id, true);
+    if (!m) return bad(c, "localmap_insert: bad map id");
+    if (!m->valid) { rc = lisreg_localmap_reset(c, map_id); if (rc) return rc; }
+    rc = insert_classes(c, m, map_id, clouds, n, stride, fmt, pose, P, 4);
     if (rc) return rc;
     fill_info(*m, info);
+    return LISREG_OK;
+}
+
+// ---- copy #3's side of SURVEY.md section 8 f-3: submap_t + SubMapManager::insert_submap + SubMapOptmizationNode::extractSubMapCloud ----------
+// transform_bbx (subMap.h:214-228): the centre goes through the float matrix in double arithmetic, the box keeps its extents
+static void transform_bbx(const double in[6], const float M[12], double out[6])
+{
+    double cp[3], cpo[3];
+    for (int d = 0; d < 3; ++d) cp[d] = 0.5 * (in[d] + in[3 + d]);                       // local_cp = get_bound_cpt(local_bound)
+    for (int r = 0; r < 3; ++r) cpo[r] = M[4 * r + 0] * cp[0] + M[4 * r + 1] * cp[1] + M[4 * r + 2] * cp[2] + M[4 * r + 3];
+    for (int d = 0; d < 3; ++d) { out[3 + d] = in[3 + d] - cp[d] + cpo[d]; out[d] = in[d] - cp[d] + cpo[d]; }
+}
+
+// Eigen::Affine3f::inverse() of a pose matrix: linear part by the cofactor 3x3 inverse, t' = -L^-1 t (float)
+static void affine_inverse(const float A[12], float Ai[12])
+{
+    const float a = A[0], b = A[1], cc = A[2], d = A[4], e = A[5], f = A[6], g = A[8], h = A[9], i = A[10];
+    const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const float det = a * c00 + b * c01 + cc * c02, id = 1.f / det;
+    const float L[9] = { c00 * id, (cc * h - b * i) * id, (b * f - cc * e) * id,
+                         c01 * id, (a * i - cc * g) * id, (cc * d - a * f) * id,
+                         c02 * id, (b * g - a * h) * id, (a * e - b * d) * id };
+    for (int r = 0; r < 3; ++r) {
+        Ai[4 * r] = L[3 * r]; Ai[4 * r + 1] = L[3 * r + 1]; Ai[4 * r + 2] = L[3 * r + 2];
+        Ai[4 * r + 3] = -(L[3 * r] * A[3] + L[3 * r + 1] * A[7] + L[3 * r + 2] * A[11]);
+    }
+}
+
+void lisreg_submap_crop_boxes(const double pre_local_bound[6], const float pre_pose[6], const double cur_local_bound[6],
+                              const float cur_pose[6], float pad, double isect[6], double isect_local[6])
+{
+    float Mp[12], Mc[12], Mi[12];
+    lisreg_pose_to_matrix(pre_pose, Mp);             // pclPointToAffine3f(preSubMap->submap_pose_6D_optimized) (:3988)
+    lisreg_pose_to_matrix(cur_pose, Mc);             // trans2Affine3f(transformTobeMapped) (:3991)
+    double pre[6], cur[6];
+    transform_bbx(pre_local_bound, Mp, pre);
+    transform_bbx(cur_local_bound, Mc, cur);
+    for (int d = 0; d < 3; ++d) {                    // get_intersection_bbx(cur->bound, pre->bound, .., 10.0) (:3995)
+        isect[d] = std::max(cur[d], pre[d]) - (double)pad;
+        isect[3 + d] = std::min(cur[3 + d], pre[3 + d]) + (double)pad;
+    }
+    affine_inverse(Mc, Mi);                          // tran_map.inverse() (:4057), then transform_bbx of the intersection box (:4058)
+    transform_bbx(isect, Mi, isect_local);
+}
+
+int lisreg_submap_insert(lisreg_ctx* c, int map_id, const void* const clouds[5], const int n[5], int stride, int fmt,
+                         const float relative_pose[6], const float submap_pose[6], const lisreg_localmap_params* P, lisreg_submap_info* info)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!clouds || !n || !submap_pose || !P) return bad(c, "submap_insert: NULL argument");
+    int rc = check_insert_args(c, "submap_insert", clouds, n, stride, fmt);
+    if (rc) return rc;
+    LocalMap* m = get_map(c, map_id, true);
+    if (!m) return bad(c, "submap_insert: bad map id");
+    if (!m->valid) { rc = lisreg_localmap_reset(c, map_id); if (rc) return rc; }
+    rc = insert_classes(c, m, map_id, clouds, n, stride, fmt, relative_pose, P, 5);
+    if (rc) return rc;
+    if (info) {
+        for (int k = 0; k < 5; ++k) info->n[k] = m->n[k];
+        info->feature_point_num = m->feature_point_num;
+        for (int d = 0; d < 6; ++d) info->local_bound[d] = m->bound[d];
+        float M[12];
+        lisreg_pose_to_matrix(submap_pose, M);       // pclPointToAffine3f(local_map->submap_pose_6D_optimized) (:968)
+        transform_bbx(m->bound, M, info->bound);     // this->transform_bbx(local_bound, local_cp, bound, cp, tran_map) (:969)
+    }
+    return LISREG_OK;
+}
+
+int lisreg_submap_extract(lisreg_ctx* c, int pre_id, int cur_id, const float pre_pose[6], const float cur_pose[6], float pad,
+                          float corner_leaf, float surf_leaf, int target_slot, lisreg_submap_extract_out* out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (!pre_pose || !cur_pose || !out) return bad(c, "submap_extract: NULL argument");
+    LocalMap* pre = get_map(c, pre_id, false);
+    LocalMap* cur = get_map(c, cur_id, false);
+    if (!pre || !pre->valid || !cur || !cur->valid || pre == cur) return ctx_fail(c, LISREG_ERR_NO_TARGET, "submap_extract: no such submap pair");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    memset(out, 0, sizeof *out);
+    lisreg_submap_crop_boxes(pre->bound, pre_pose, cur->bound, cur_pose, pad, out->isect, out->isect_local);
+    // ---- target: the previous submap in the map frame, cropped (:3997-4020) ------------------------------------------------------
+    // corner = pole; surf = ground + building + dynamic; transformPointCloud by submap_pose_6D_optimized is point-wise, so every
+    // class is transformed straight into its place of the concatenation
+    const int tn[2] = { pre->n[1], pre->n[2] + pre->n[3] + pre->n[0] };
+    HIPCHK(c, pre->tgt[0].ensure(sizeof(float4) * (size_t)std::max(tn[0], 1)));
+    HIPCHK(c, pre->tgt[1].ensure(sizeof(float4) * (size_t)std::max(tn[1], 1)));
+    int rc;
+    if (pre->n[1] > 0) { rc = lisreg_transform_cloud(c, pre->cls[1].p, pre->n[1], 16, LISREG_FMT_DEVICE, pre_pose, pre->tgt[0].p); if (rc) return rc; }
+    {
+        size_t off = 0;
+        const int order[3] = { 2, 3, 0 };
+        for (int j = 0; j < 3; ++j) {
+            const int k = order[j];
+            if (pre->n[k] > 0) { rc = lisreg_transform_cloud(c, pre->cls[k].p, pre->n[k], 16, LISREG_FMT_DEVICE, pre_pose, pre->tgt[1].as<float4>() + off); if (rc) return rc; }
+            off += (size_t)pre->n[k];
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        pre->n_tgt[k] = tn[k];
+        if (tn[k] > 0) { rc = lisreg_bbx_filter(c, pre->tgt[k].p, tn[k], 16, LISREG_FMT_DEVICE, out->isect, 0, pre->tgt[k].p, &pre->n_tgt[k]); if (rc) return rc; }
+    }
+    // ---- sources: the current submap in its own frame, cropped by the box moved into that frame, voxel grids 0.2 / 0.5 (:4030-4067) -----
+    // corner = pole; surf = dynamic + ground + building
+    const int sn[2] = { cur->n[1], cur->n[0] + cur->n[2] + cur->n[3] };
+    HIPCHK(c, cur->tgt[0].ensure(sizeof(float4) * (size_t)std::max(sn[0], 1)));
+    HIPCHK(c, cur->tgt[1].ensure(sizeof(float4) * (size_t)std::max(sn[1], 1)));
+    if (cur->n[1] > 0) HIPCHK(c, hipMemcpyAsync(cur->tgt[0].p, cur->cls[1].p, sizeof(float4) * (size_t)cur->n[1], hipMemcpyDeviceToDevice, st));
+    {
+        size_t off = 0;
+        const int order[3] = { 0, 2, 3 };
+        for (int j = 0; j < 3; ++j) {
+            const int k = order[j];
+            if (cur->n[k] > 0) HIPCHK(c, hipMemcpyAsync(cur->tgt[1].as<float4>() + off, cur->cls[k].p, sizeof(float4) * (size_t)cur->n[k], hipMemcpyDeviceToDevice, st));
+            off += (size_t)cur->n[k];
+        }
+    }
+    const float leaf[2] = { corner_leaf, surf_leaf };
+    for (int k = 0; k < 2; ++k) {
+        int nk = sn[k];
+        if (nk > 0) { rc = lisreg_bbx_filter(c, cur->tgt[k].p, nk, 16, LISREG_FMT_DEVICE, out->isect_local, 0, cur->tgt[k].p, &nk); if (rc) return rc; }
+        if (nk > 0) {                                  // voxel_downsample_pcl(Last, LastDS, leaf): an empty cloud returns false and stays empty
+            HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)nk));
+            int nv = 0;
+            rc = lisreg_voxel_downsample(c, cur->tgt[k].p, nk, 16, LISREG_FMT_DEVICE, leaf[k], c->lm_tmp.p, nk, &nv);
+            if (rc != LISREG_OK && rc != LISREG_LEAF_TOO_SMALL) return rc;
+            HIPCHK(c, hipMemcpyAsync(cur->tgt[k].p, c->lm_tmp.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToDevice, st));
+            nk = nv;
+        }
+        cur->n_tgt[k] = nk;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (target_slot >= 0) {                            // kdtree{Corner,Surf}FromSubMap->setInputCloud (:4496-4497)
+        rc = lisreg_set_target_slot(c, target_slot, pre->tgt[0].p, pre->n_tgt[0], pre->tgt[1].p, pre->n_tgt[1], 16, LISREG_FMT_DEVICE);
+        if (rc) return rc;
+    }
+    out->n_target_corner = pre->n_tgt[0]; out->n_target_surf = pre->n_tgt[1];
+    out->src_corner = cur->tgt[0].p; out->n_src_corner = cur->n_tgt[0];
+    out->src_surf = cur->tgt[1].p; out->n_src_surf = cur->n_tgt[1];
     return LISREG_OK;
 }
 

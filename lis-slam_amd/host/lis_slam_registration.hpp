@@ -409,6 +409,50 @@ private:
     int id_;
 };
 
+// Copy #3's side: submap_t + SubMapManager::fisrt_submap / insert_submap (src/include/subMap.h:785-978) and
+// SubMapOptmizationNode::extractSubMapCloud (src/node/subMapOptmizationNode.cpp:3976-4081), kept in HBM.  subMapOptmizationThread becomes
+//     cur.fisrt_submap(down, pose); cur.insert_submap(down, relative_pose) ...;
+//     auto x = SubMap<>::extractSubMapCloud(ctx, pre, cur, transformTobeMapped);          // target installed, sources as device records
+//     reg.subMap2SubMapOptimization(x.src_corner, x.n_src_corner, x.src_surf, x.n_src_surf, LISREG_FMT_DEVICE, transformTobeMapped);
+template <class PointT = PointXYZIL>
+class SubMap {
+public:
+    lisreg_localmap_params params;          // max_num_pts, map_based_dynamic_removal_on, ... of makeSubMapThread (:603-612)
+    float submap_pose_6D_optimized[6] = { 0, 0, 0, 0, 0, 0 };
+    lisreg_submap_info info{};
+    SubMap(lisreg_ctx* ctx, int map_id) : ctx_(ctx), id_(map_id) {
+        lisreg_localmap_default_params(&params);
+        int rc = lisreg_localmap_reset(ctx_, id_);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+    }
+    int id() const { return id_; }
+    // this->fisrt_submap(currentSubMap, currentKeyFrame): the key frame's *_down class clouds as they are; the submap takes its optimized_pose
+    void fisrt_submap(const PointCloud<PointT> down[5], const float optimized_pose[6]) {
+        for (int k = 0; k < 6; ++k) submap_pose_6D_optimized[k] = optimized_pose[k];
+        insert(down, nullptr);
+    }
+    // this->insert_submap(currentSubMap, currentKeyFrame, ...): the *_down clouds moved by the frame's relative_pose, all five classes
+    void insert_submap(const PointCloud<PointT> down[5], const float relative_pose[6]) { insert(down, relative_pose); }
+    // extractSubMapCloud() for (preSubMap, curSubMapPtr) under the guess transformTobeMapped; bbx pad 10 m, voxel grids 0.2 / 0.5
+    static lisreg_submap_extract_out extractSubMapCloud(lisreg_ctx* ctx, const SubMap& pre, const SubMap& cur, const float transformTobeMapped[6],
+                                                        int target_slot = 0) {
+        lisreg_submap_extract_out out{};
+        int rc = lisreg_submap_extract(ctx, pre.id_, cur.id_, pre.submap_pose_6D_optimized, transformTobeMapped, 10.0f, 0.2f, 0.5f, target_slot, &out);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx));
+        return out;
+    }
+private:
+    void insert(const PointCloud<PointT> down[5], const float* rel) {
+        const void* ptr[5]; int n[5];
+        for (int k = 0; k < 5; ++k) { ptr[k] = down[k].points.data(); n[k] = (int)down[k].size(); }
+        int rc = lisreg_submap_insert(ctx_, id_, ptr, n, (int)sizeof(PointT), fmt(), rel, submap_pose_6D_optimized, &params, &info);
+        if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx_));
+    }
+    static constexpr int fmt() { return std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI; }
+    lisreg_ctx* ctx_;
+    int id_;
+};
+
 // The odometry node's multi-frame target (odomEstimationNode.cpp, USING_MULTI_FRAME_TARGET), device-resident: replaces
 // laserCloud{Corner,Surf}Vec + the concatenation loop + the two VoxelGrid filters of laserCloudInfoHandler (:185-207) and the
 // transformPointCloud / push_back / erase of saveKeyFrames (:452-467).  The frame loop becomes

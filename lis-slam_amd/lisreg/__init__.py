@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_extract_features_batch", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
-    "lisreg_localmap_get", "lisreg_predict_pose",
+    "lisreg_localmap_get", "lisreg_predict_pose", "lisreg_submap_insert", "lisreg_submap_extract", "lisreg_submap_crop_boxes",
     "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_gn_match",
 ]
 
@@ -120,6 +120,15 @@ class KeyframesInfo(C.Structure):
 class LocalMapInfo(C.Structure):
     _fields_ = [("n", C.c_int * 5), ("feature_point_num", C.c_int), ("bound", C.c_double * 6), ("crop", C.c_double * 6),
                 ("n_target_corner", C.c_int), ("n_target_surf", C.c_int)]
+
+
+class SubmapInfo(C.Structure):
+    _fields_ = [("n", C.c_int * 5), ("feature_point_num", C.c_int), ("local_bound", C.c_double * 6), ("bound", C.c_double * 6)]
+
+
+class SubmapExtractOut(C.Structure):
+    _fields_ = [("isect", C.c_double * 6), ("isect_local", C.c_double * 6), ("n_target_corner", C.c_int), ("n_target_surf", C.c_int),
+                ("src_corner", C.c_void_p), ("n_src_corner", C.c_int), ("src_surf", C.c_void_p), ("n_src_surf", C.c_int)]
 
 
 LOCALMAP_CLASSES = ("dynamic", "pole", "ground", "building", "outlier")      # class order of localMap_t (subMap.h:742-753)
@@ -227,6 +236,11 @@ def lib():
                                              C.POINTER(LocalMapParams), C.POINTER(LocalMapInfo)]
         L.lisreg_localmap_extract.argtypes = [vp, C.c_int, fp, C.POINTER(LocalMapParams), C.c_int, C.POINTER(LocalMapInfo)]
         L.lisreg_localmap_get.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
+        L.lisreg_submap_insert.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, fp, fp,
+                                           C.POINTER(LocalMapParams), C.POINTER(SubmapInfo)]
+        L.lisreg_submap_extract.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(SubmapExtractOut)]
+        L.lisreg_submap_crop_boxes.argtypes = [C.POINTER(C.c_double), fp, C.POINTER(C.c_double), fp, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.lisreg_submap_crop_boxes.restype = None
         L.lisreg_predict_pose.argtypes = [fp, fp, fp]
         L.lisreg_predict_pose.restype = None
         L.lisreg_icp_default_params.argtypes = [C.c_int, C.POINTER(IcpParams)]
@@ -642,6 +656,32 @@ class Context:
         self._chk(self._L.lisreg_localmap_extract(self._h, map_id, T.ctypes.data_as(C.POINTER(C.c_float)), C.byref(params),
                                                   target_slot, C.byref(info)))
         return _info_dict(info)
+
+    # -- copy #3: submap_t + insert_submap + extractSubMapCloud (device-resident) ------------------------------------
+    def submap_insert(self, map_id: int, clouds, relative_pose, submap_pose, params: LocalMapParams) -> dict:
+        """clouds: the key frame's five DOWN-sampled class clouds (LOCALMAP_CLASSES order); relative_pose None = fisrt_submap."""
+        arrs = [np.ascontiguousarray(a) for a in clouds]
+        ptrs = (C.c_void_p * 5)(*[a.ctypes.data if len(a) else None for a in arrs])
+        cnt = (C.c_int * 5)(*[len(a) for a in arrs])
+        Tr = None if relative_pose is None else np.ascontiguousarray(relative_pose, np.float32)
+        Ts = np.ascontiguousarray(submap_pose, np.float32)
+        info = SubmapInfo()
+        fp = C.POINTER(C.c_float)
+        self._chk(self._L.lisreg_submap_insert(self._h, map_id, ptrs, cnt, arrs[0].dtype.itemsize, _fmt_of(arrs[0]),
+                                               Tr.ctypes.data_as(fp) if Tr is not None else None, Ts.ctypes.data_as(fp), C.byref(params), C.byref(info)))
+        return dict(n=list(info.n), feature_point_num=info.feature_point_num, local_bound=np.array(info.local_bound[:], np.float64),
+                    bound=np.array(info.bound[:], np.float64))
+
+    def submap_extract(self, pre_id: int, cur_id: int, pre_pose, cur_pose, pad: float = 10.0, corner_leaf: float = 0.2,
+                       surf_leaf: float = 0.5, target_slot: int = 0) -> dict:
+        Tp = np.ascontiguousarray(pre_pose, np.float32); Tc = np.ascontiguousarray(cur_pose, np.float32)
+        out = SubmapExtractOut()
+        fp = C.POINTER(C.c_float)
+        self._chk(self._L.lisreg_submap_extract(self._h, pre_id, cur_id, Tp.ctypes.data_as(fp), Tc.ctypes.data_as(fp), pad, corner_leaf,
+                                                surf_leaf, target_slot, C.byref(out)))
+        return dict(isect=np.array(out.isect[:], np.float64), isect_local=np.array(out.isect_local[:], np.float64),
+                    n_target_corner=out.n_target_corner, n_target_surf=out.n_target_surf,
+                    src_corner_ptr=out.src_corner or 0, n_src_corner=out.n_src_corner, src_surf_ptr=out.src_surf or 0, n_src_surf=out.n_src_surf)
 
     def localmap_get(self, map_id: int, cls: int) -> np.ndarray:
         """[n, 4] float32 records (x, y, z, label bits) of class cls (0-4) or of the corner / surf target (5 / 6)."""

@@ -90,6 +90,78 @@ class LocalMapOracle:
         return self.cls[1].copy(), cat([self.cls[2], self.cls[3], self.cls[0]]), isect
 
 
+def _transform_bbx(b, M):
+    """subMap.h:214-228: the centre goes through the float matrix in double arithmetic, the box keeps its extents."""
+    M = M.astype(np.float64)
+    cp = 0.5 * (b[:3] + b[3:])
+    cpo = M[:, 0] * cp[0] + M[:, 1] * cp[1] + M[:, 2] * cp[2] + M[:, 3]
+    return np.concatenate([b[:3] - cp + cpo, b[3:] - cp + cpo])
+
+
+def _affine_inverse_f32(A):
+    """Eigen::Affine3f::inverse(): cofactor inverse of the linear part, t' = -L^-1 t, every operation in float."""
+    f = np.float32
+    a, b, c, d, e, ff, g, h, i = [f(v) for v in A[:, :3].ravel()]
+    c00, c01, c02 = f(f(e * i) - f(ff * h)), f(f(ff * g) - f(d * i)), f(f(d * h) - f(e * g))
+    det = f(f(f(a * c00) + f(b * c01)) + f(c * c02))
+    idet = f(f(1) / det)
+    L = np.array([[f(c00 * idet), f(f(f(c * h) - f(b * i)) * idet), f(f(f(b * ff) - f(c * e)) * idet)],
+                  [f(c01 * idet), f(f(f(a * i) - f(c * g)) * idet), f(f(f(c * d) - f(a * ff)) * idet)],
+                  [f(c02 * idet), f(f(f(b * g) - f(a * h)) * idet), f(f(f(a * e) - f(b * d)) * idet)]], np.float32)
+    t = A[:, 3].astype(np.float32)
+    ti = np.array([-f(f(f(L[r, 0] * t[0]) + f(L[r, 1] * t[1])) + f(L[r, 2] * t[2])) for r in range(3)], np.float32)
+    return np.concatenate([L, ti[:, None]], 1)
+
+
+def submap_crop_boxes(pre_local_bound, pre_pose, cur_local_bound, cur_pose, pad=10.0):
+    """extractSubMapCloud's two boxes (subMapOptmizationNode.cpp:3988-3995, 4055-4058)."""
+    Mp, Mc = pose_matrix_f32(pre_pose), pose_matrix_f32(cur_pose)
+    pre, cur = _transform_bbx(np.asarray(pre_local_bound, np.float64), Mp), _transform_bbx(np.asarray(cur_local_bound, np.float64), Mc)
+    isect = np.concatenate([np.maximum(cur[:3], pre[:3]) - np.float64(np.float32(pad)), np.minimum(cur[3:], pre[3:]) + np.float64(np.float32(pad))])
+    return isect, _transform_bbx(isect, _affine_inverse_f32(Mc))
+
+
+class SubMapOracle(LocalMapOracle):
+    """submap_t + fisrt_submap / insert_submap (subMap.h:785-978) on host struct arrays; `bound` is the LOCAL bound."""
+
+    def insert(self, clouds, relative_pose, max_num_pts=80000, dynamic_removal_on=True, center_radius=30.0, thre_min=0.3, thre_max=3.0,
+               near_thre=0.03):
+        """clouds: the key frame's five DOWN-sampled class clouds; relative_pose None = fisrt_submap (appended as they are)."""
+        thre_max = max(np.float32(thre_max), np.float32(np.float64(np.float32(thre_min)) + 0.1))           # :884
+        if relative_pose is None:
+            moved = list(clouds)
+        else:
+            moved = [oc.transform_cloud(c, relative_pose, fmt=1) if len(c) else c for c in clouds]         # all five (:878-882)
+            if dynamic_removal_on and self.feature_point_num > max_num_pts // 5 and len(self.cls[0]) > 0:
+                moved[0], _ = oc.dynamic_filter(self.cls[0], moved[0], center_radius, float(np.float32(thre_min)), float(thre_max),
+                                                float(np.float32(near_thre)))
+        for k in range(5):
+            self.cls[k] = cat([self.cls[k], moved[k]])
+        self.feature_point_num = sum(len(c) for c in self.cls)
+        self.bound = oc.cloud_bounds(cat(self.cls))
+
+    def global_bound(self, submap_pose):
+        return _transform_bbx(self.bound, pose_matrix_f32(submap_pose))
+
+
+def extract_submap_cloud(pre: "SubMapOracle", cur: "SubMapOracle", pre_pose, cur_pose, pad=10.0, corner_leaf=0.2, surf_leaf=0.5):
+    """extractSubMapCloud (subMapOptmizationNode.cpp:3976-4081): (target corner, target surf, source corner, source surf, isect, isect_local)."""
+    isect, isect_local = submap_crop_boxes(pre.bound, pre_pose, cur.bound, cur_pose, pad)
+    tc = pre.cls[1]
+    ts = cat([pre.cls[2], pre.cls[3], pre.cls[0]])
+    tc = oc.transform_cloud(tc, pre_pose, fmt=1) if len(tc) else tc
+    ts = oc.transform_cloud(ts, pre_pose, fmt=1) if len(ts) else ts
+    tc = oc.bbx_filter(tc, isect) if len(tc) else tc
+    ts = oc.bbx_filter(ts, isect) if len(ts) else ts
+    sc = cur.cls[1]
+    ss = cat([cur.cls[0], cur.cls[2], cur.cls[3]])
+    sc = oc.bbx_filter(sc, isect_local) if len(sc) else sc
+    ss = oc.bbx_filter(ss, isect_local) if len(ss) else ss
+    sc = oc.voxel_grid(sc, float(np.float32(corner_leaf)), fmt=1)[1] if len(sc) else sc
+    ss = oc.voxel_grid(ss, float(np.float32(surf_leaf)), fmt=1)[1] if len(ss) else ss
+    return tc, ts, sc, ss, isect, isect_local
+
+
 def split_and_downsample(labelled_cloud):
     """SemanticFusionNode::categoryMapping + keyframeInit's per-class voxel grids.  Returns (full, down) dicts keyed by class."""
     dyn, ground, building, pole, outlier = oc.semantic_split(labelled_cloud)

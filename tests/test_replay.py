@@ -341,3 +341,135 @@ def test_device_resident_odometry_loop_equals_host_driven_loop_bitwise():
         assert np.array_equal(x["T"], y["T"]) and x["keyframe"] == y["keyframe"] and (x["n_corner"], x["n_surf"]) == (y["n_corner"], y["n_surf"])
         if x["stats"]:
             assert x["stats"]["iters"] == y["stats"]["iters"] and x["n_src_surf"] == y["n_src_surf"] and x["n_target_surf"] == y["n_target_surf"]
+
+
+# ---- copy #3: submap_t + insert_submap + extractSubMapCloud + subMap2SubMapOptimization ---------------------------------------------
+def _submap_drive(n_submaps=3, per=3, h=32, w=900):
+    """Key frames of a synthetic labelled drive grouped into submaps of `per` frames: per frame the five DOWN-sampled class clouds
+    (keyframeInit's grids) and its true pose; a submap's pose = its first frame's."""
+    import replay_oracle as ro
+    from lisreg import replay
+    frames, truth = zip(*replay.synthetic_drive(n_submaps * per, h=h, w=w, step=0.9))
+    out = []
+    for s in range(n_submaps):
+        ks = list(range(s * per, (s + 1) * per))
+        downs = []
+        for k in ks:
+            f = frames[k].copy()
+            g = np.flatnonzero(f["label"] == 9)
+            f["label"][g[::7]] = 15                   # some "vegetation": the outlier class (label.yaml:177-196), which insert_submap keeps
+            _, down = ro.split_and_downsample(f)
+            downs.append([down[c] for c in ro.CLASSES])
+        out.append(dict(frames=downs, poses=[truth[k].astype(np.float32) for k in ks]))
+    return out
+
+
+def _relative(T_sub, T_frame):
+    """relative_pose of a key frame inside its submap: T_sub^-1 * T_frame (host float64 here; both sides are fed the same numbers)."""
+    from lisreg import synth
+    M = np.linalg.inv(synth.pose_matrix(T_sub)) @ synth.pose_matrix(T_frame)
+    return np.array([np.arctan2(M[2, 1], M[2, 2]), np.arcsin(-M[2, 0]), np.arctan2(M[1, 0], M[0, 0]), M[0, 3], M[1, 3], M[2, 3]], np.float32)
+
+
+def test_submap_crop_boxes_helper_matches_oracle():
+    import ctypes as C
+    import lisreg
+    import replay_oracle as ro
+    rng = np.random.default_rng(11)
+    L = lisreg.lib()
+    for _ in range(20):
+        pb = np.sort(rng.uniform(-40, 40, (2, 3)), 0).ravel(); cb = np.sort(rng.uniform(-40, 40, (2, 3)), 0).ravel()
+        Tp = np.concatenate([rng.uniform(-0.05, 0.05, 2), rng.uniform(-3, 3, 1), rng.uniform(-30, 30, 3)]).astype(np.float32)
+        Tc = (Tp + np.concatenate([rng.uniform(-0.02, 0.02, 3), rng.uniform(-5, 5, 3)])).astype(np.float32)
+        a, b = np.zeros(6), np.zeros(6)
+        dp = C.POINTER(C.c_double); fp = C.POINTER(C.c_float)
+        L.lisreg_submap_crop_boxes(pb.ctypes.data_as(dp), Tp.ctypes.data_as(fp), cb.ctypes.data_as(dp), Tc.ctypes.data_as(fp), 10.0,
+                                   a.ctypes.data_as(dp), b.ctypes.data_as(dp))
+        ia, ib = ro.submap_crop_boxes(pb, Tp, cb, Tc, 10.0)
+        assert np.array_equal(a, ia) and np.array_equal(b, ib), (a - ia, b - ib)
+
+
+@pytest.mark.gpu
+def test_submap_composite_equals_oracle_bitwise(oracle, gpu_ctx):
+    """fisrt_submap / insert_submap for three submaps and extractSubMapCloud for the two consecutive pairs, the SAME poses on both
+    sides: class clouds (all five, outlier included), feature_point_num, local and global bound, both crop boxes, both targets and
+    both down-sampled sources bit for bit."""
+    import lisreg
+    import replay_oracle as ro
+    subs = _submap_drive(3, 3)
+    P = lisreg.localmap_default_params()
+    P.max_num_pts = 20000                      # so that the map-based dynamic removal (feature_point_num > 4000) is exercised
+    oracles, removed = [], False
+    for s, sub in enumerate(subs):
+        mid = 20 + s
+        gpu_ctx.localmap_reset(mid)
+        so = ro.SubMapOracle(sub["frames"][0][0].dtype)
+        T_sub = sub["poses"][0]
+        for j, (clouds, T) in enumerate(zip(sub["frames"], sub["poses"])):
+            rel = None if j == 0 else _relative(T_sub, T)
+            n_dyn = len(so.cls[0])
+            so.insert(clouds, rel, max_num_pts=20000)
+            removed |= j > 0 and len(so.cls[0]) - n_dyn < len(clouds[0])
+            info = gpu_ctx.submap_insert(mid, clouds, rel, T_sub, P)
+            assert info["n"] == [len(c) for c in so.cls] and info["feature_point_num"] == so.feature_point_num
+            assert info["n"][4] > 0                                                    # the outlier class IS kept here
+            assert np.array_equal(info["local_bound"], so.bound) and np.array_equal(info["bound"], so.global_bound(T_sub))
+            for c in range(5):
+                assert np.array_equal(gpu_ctx.localmap_get(mid, c), _records(so.cls[c])), (s, j, c)
+        oracles.append((so, T_sub))
+    assert removed, "the drive never exercised the map-based dynamic removal"
+    for s in (1, 2):
+        (pre, Tp), (cur, Tc) = oracles[s - 1], oracles[s]
+        guess = (Tc + np.array([0.004, -0.003, 0.01, 0.15, -0.1, 0.02], np.float32)).astype(np.float32)
+        tc, ts, sc, ss, isect, isect_local = ro.extract_submap_cloud(pre, cur, Tp, guess)
+        out = gpu_ctx.submap_extract(20 + s - 1, 20 + s, Tp, guess, target_slot=1)
+        assert np.array_equal(out["isect"], isect) and np.array_equal(out["isect_local"], isect_local)
+        assert (out["n_target_corner"], out["n_target_surf"], out["n_src_corner"], out["n_src_surf"]) == (len(tc), len(ts), len(sc), len(ss))
+        assert len(ts) > 1000 and len(ss) > 500
+        assert np.array_equal(gpu_ctx.localmap_get(20 + s - 1, 5), _records(tc)) and np.array_equal(gpu_ctx.localmap_get(20 + s - 1, 6), _records(ts))
+        assert np.array_equal(gpu_ctx.localmap_get(20 + s, 5), _records(sc)) and np.array_equal(gpu_ctx.localmap_get(20 + s, 6), _records(ss))
+
+
+@pytest.mark.gpu
+def test_submap_to_submap_chain_matches_oracle(oracle):
+    """Variant 3 as a sequence (subMapOptmizationThread): for every new submap extractSubMapCloud against the previous one, then
+    subMap2SubMapOptimization (copy #3: label weights, 30 iterations at most, convergence 0.002 deg / 0.02 cm, corner stage skipped when
+    the target has no poles) from a perturbed guess — HIP chain (device-resident, sources handed over as device records) vs oracle
+    chain; the registered pose becomes the submap's pose for the next pair on both sides."""
+    import lisreg
+    import replay_oracle as ro
+    from helpers import copy_params
+    subs = _submap_drive(4, 3, h=64, w=900)
+    P = lisreg.localmap_default_params()
+    p_o = oracle.default_params(3)
+    p_g = copy_params(p_o, lisreg.Params)
+    ctx = lisreg.Context(0)
+    pose_o, pose_g, worst = None, None, 0.0
+    pre_o = None
+    for s, sub in enumerate(subs):
+        ctx.localmap_reset(s)
+        so = ro.SubMapOracle(sub["frames"][0][0].dtype)
+        T_true = sub["poses"][0]
+        for j, (clouds, T) in enumerate(zip(sub["frames"], sub["poses"])):
+            rel = None if j == 0 else _relative(T_true, T)
+            so.insert(clouds, rel)
+            ctx.submap_insert(s, clouds, rel, T_true, P)
+        if s == 0:
+            pose_o = pose_g = T_true.copy()
+        else:
+            guess = (T_true + np.array([0.003, -0.002, 0.008, 0.12, -0.08, 0.015], np.float32)).astype(np.float32)
+            tc, ts, sc, ss, _, _ = ro.extract_submap_cloud(pre_o, so, pose_o, guess)
+            To, st_o, _ = oracle.align(tc, ts, sc, ss, guess, p_o, n_threads=8, max_trace=1)
+            out = ctx.submap_extract(s - 1, s, pose_g, guess, target_slot=0)
+            Tg, st_g = ctx.align_device(out["src_corner_ptr"], out["n_src_corner"], out["src_surf_ptr"], out["n_src_surf"], guess, p_g)
+            assert st_g["status"] == st_o["status"] == 0, (s, st_g, st_o)
+            assert abs(st_g["iters"] - st_o["iters"]) <= 2, (s, st_g, st_o)
+            assert abs(out["n_target_surf"] - len(ts)) <= max(3, 0.002 * len(ts)) and abs(out["n_src_surf"] - len(ss)) <= max(3, 0.002 * len(ss))
+            e = max(pose_err(Tg, To))
+            worst = max(worst, e)
+            assert e <= 1e-3, (s, e, Tg, To)
+            assert np.abs(np.asarray(Tg, np.float64)[3:5] - T_true[3:5]).max() < 0.05 and abs(float(Tg[2]) - float(T_true[2])) < 0.01
+            pose_o, pose_g = To.astype(np.float32), Tg.astype(np.float32)
+        pre_o = so
+    ctx.close()
+    print(f"submap chain: worst pose difference HIP vs oracle over {len(subs) - 1} submap pairs: {worst:.2e}")
