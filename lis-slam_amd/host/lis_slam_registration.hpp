@@ -124,6 +124,17 @@ public:
     // subMap2SubMapOptimization() of SubMapOptmizationNode is the same call with Variant::SubMap (:4485-4540)
     int subMap2SubMapOptimization(const PointCloud<PointT>& c, const PointCloud<PointT>& s, const cloud_info& ci) { return scan2SubMapOptimization(c, s, ci); }
 
+    // the same with the sources already in HBM as 16-byte records (what SubMap<>::extractSubMapCloud and the device-resident maps hand over)
+    int subMap2SubMapOptimization(const lisreg_submap_extract_out& x, const cloud_info& cloudInfo) {
+        lisreg_imu imu{ cloudInfo.imuAvailable ? 1 : 0, cloudInfo.imuRollInit, cloudInfo.imuPitchInit };
+        lisreg_stats st{};
+        int rc = lisreg_align(ctx_, x.src_corner, x.n_src_corner, x.src_surf, x.n_src_surf, 16, LISREG_FMT_DEVICE, &params, &imu, transformTobeMapped, &st);
+        if (rc < 0) throw RegistrationError(rc, lisreg_last_error(ctx_));
+        iterCount = st.iters; laserCloudSelNum = st.n_corr_last;
+        if (rc != LISREG_NOT_ENOUGH_FEATURES) { isDegenerate = st.degenerate != 0; deltaR = st.deltaR; deltaT = st.deltaT; }
+        return rc;
+    }
+
     lisreg_ctx* handle() { return ctx_; }
 
 private:
@@ -413,7 +424,7 @@ private:
 // SubMapOptmizationNode::extractSubMapCloud (src/node/subMapOptmizationNode.cpp:3976-4081), kept in HBM.  subMapOptmizationThread becomes
 //     cur.fisrt_submap(down, pose); cur.insert_submap(down, relative_pose) ...;
 //     auto x = SubMap<>::extractSubMapCloud(ctx, pre, cur, transformTobeMapped);          // target installed, sources as device records
-//     reg.subMap2SubMapOptimization(x.src_corner, x.n_src_corner, x.src_surf, x.n_src_surf, LISREG_FMT_DEVICE, transformTobeMapped);
+//     reg.subMap2SubMapOptimization(x, cloudInfo);                                        // copy #3 on the device records
 template <class PointT = PointXYZIL>
 class SubMap {
 public:
