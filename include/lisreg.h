@@ -273,6 +273,12 @@ int  lisreg_get_timing(lisreg_ctx* ctx, double out[5]);
  * Returns LISREG_LEAF_TOO_SMALL (and copies the input, as PCL does) when the voxel index would overflow int32. */
 int  lisreg_voxel_downsample(lisreg_ctx* ctx, const void* in, int n, int stride_bytes, int fmt, float leaf,
                              void* out, int out_capacity, int* n_out);
+/* The same for K clouds of device records (LISREG_FMT_DEVICE: label vote, or LISREG_FMT_DEVICE_XYZI: intensity average) in ONE launch
+ * sequence with three host round trips in all (the K bounding boxes, the K counts, completion) — the five class grids of a key frame or of the local
+ * map are bound by their ~12 launches and 3 round trips apiece, not by bandwidth.  Results equal K single calls bit for bit; clouds
+ * that do not fit the joint sort (a leaf too small for its cloud, > 8 clouds) are done one by one. */
+int  lisreg_voxel_downsample_multi(lisreg_ctx* ctx, int k, const void* const* in, const int* n, const float* leaf, int fmt,
+                                   void* const* out, const int* out_capacity, int* n_out);
 /* Replaces transformPointCloud(cloud, &pose6D) (src/core/common.cpp:112-173 and the PointXYZIL overload; callers
  * odomEstimationNode.cpp:457-458, 574-575): p' = R(T) p + t with T = {roll,pitch,yaw,x,y,z}; other fields copied.
  * Same formats as above; in == out is allowed. */

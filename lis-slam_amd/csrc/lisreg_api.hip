@@ -1193,6 +1193,120 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
     return LISREG_OK;
 }
 
+// K device clouds through ONE launch sequence (one sort keyed by (cloud, voxel index), one centroid launch) with three host round trips
+// in all — the K bounding boxes, the K voxel counts — instead of ~12 launches and three round trips per cloud: the five class grids of a
+// key frame (subMapOptmizationNode.cpp:806-811) or of extractSlidingCloud (:1385-1389) are launch-bound, not bandwidth-bound.
+// Results are those of K lisreg_voxel_downsample calls, bit for bit (same sort order inside every cloud, same sequential sums).
+int lisreg_voxel_downsample_multi(lisreg_ctx* c, int k, const void* const* in, const int* n, const float* leaf, int fmt,
+                                  void* const* out, const int* out_capacity, int* n_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (k < 0 || (k > 0 && (!in || !n || !leaf || !out || !out_capacity || !n_out))) return fail(c, LISREG_ERR_ARG, "voxel_downsample_multi: bad arguments");
+    if (fmt != LISREG_FMT_DEVICE && fmt != LISREG_FMT_DEVICE_XYZI) return fail(c, LISREG_ERR_ARG, "voxel_downsample_multi: device records only (LISREG_FMT_DEVICE / _DEVICE_XYZI)");
+    for (int s = 0; s < k; ++s) {
+        if (n[s] < 0 || !(leaf[s] > 0.f) || (n[s] > 0 && (!in[s] || !out[s]))) return fail(c, LISREG_ERR_ARG, "voxel_downsample_multi: bad cloud");
+        n_out[s] = 0;
+    }
+    auto one_by_one = [&]() -> int {
+        for (int s = 0; s < k; ++s) {
+            int rc = lisreg_voxel_downsample(c, in[s], n[s], 16, fmt, leaf[s], out[s], out_capacity[s], &n_out[s]);
+            if (rc != LISREG_OK && rc != LISREG_LEAF_TOO_SMALL) return rc;
+        }
+        return LISREG_OK;
+    };
+    long long total_n = 0;
+    int live = 0;
+    for (int s = 0; s < k; ++s) { total_n += n[s]; live += n[s] > 0; }
+    if (live <= 1 || k > kVoxelMultiMax || total_n > 2000000000LL) return one_by_one();
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int N = (int)total_n;
+    // ---- concatenate, K bounding boxes, one round trip ---------------------------------------------------------------------------
+    HIPCHK(c, c->vox_in.ensure(sizeof(float4) * (size_t)N));
+    HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 6 * kVoxelMultiMax));
+    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256 * kVoxelMultiMax));
+    VoxelMulti m;
+    memset(&m, 0, sizeof m);
+    m.k = k;
+    float4* cat = c->vox_in.as<float4>();
+    for (int s = 0, o = 0; s < k; ++s) {
+        m.off[s] = o;
+        if (n[s] > 0) {
+            HIPCHK(c, hipMemcpyAsync(cat + o, in[s], sizeof(float4) * (size_t)n[s], hipMemcpyDeviceToDevice, st));
+            launch_bbox(cat + o, n[s], c->bbox_dev.as<float>() + 6 * s, c->bbox_scratch.as<float>() + 6 * 256 * s, st);
+        }
+        o += n[s];
+        m.off[s + 1] = o;
+    }
+    float bb[6 * kVoxelMultiMax];
+    HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof(float) * 6 * (size_t)k, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // ---- per-cloud geometry (voxel_grid.hpp), one common bucket span ----------------------------------------------------------
+    long long totals[kVoxelMultiMax] = { 0 }, sum_total = 0;
+    for (int s = 0; s < k; ++s) {
+        if (n[s] == 0) continue;
+        const float* b = bb + 6 * s;
+        for (int q = 0; q < 6; ++q) if (!std::isfinite(b[q])) return fail(c, LISREG_ERR_ARG, "voxel_downsample_multi: a cloud has infinite coordinates");
+        const float inv = 1.0f / leaf[s];
+        const long long dx = (long long)((b[3] - b[0]) * inv) + 1, dy = (long long)((b[4] - b[1]) * inv) + 1, dz = (long long)((b[5] - b[2]) * inv) + 1;
+        if (dx * dy * dz > 2147483647LL) return one_by_one();          // "leaf size too small" for one of them: the single-cloud path knows what to do
+        const int min_b[3] = { (int)floorf(b[0] * inv), (int)floorf(b[1] * inv), (int)floorf(b[2] * inv) };
+        const int max_b[3] = { (int)floorf(b[3] * inv), (int)floorf(b[4] * inv), (int)floorf(b[5] * inv) };
+        int div_b[3];
+        for (int q = 0; q < 3; ++q) div_b[q] = max_b[q] - min_b[q] + 1;
+        VoxelDesc& d = m.d[s];
+        d.inv_leaf = inv; d.min_b0 = min_b[0]; d.min_b1 = min_b[1]; d.min_b2 = min_b[2];
+        d.mul1 = div_b[0]; d.mul2 = div_b[0] * div_b[1];
+        totals[s] = (long long)div_b[0] * div_b[1] * div_b[2];
+        sum_total += totals[s];
+    }
+    if (sum_total >= (1LL << 32)) return one_by_one();                 // the joint voxel index has to fit 32 bits
+    // every cloud its own bucket span (a cloud with a tiny leaf must not coarsen the others' buckets: the rank pass is quadratic inside
+    // a bucket), at most 2^22 buckets in all
+    const long long max_buckets = (1LL << 22) / k;
+    long long nb = 0, ib = 0;
+    for (int s = 0; s < k; ++s) {
+        const uint32_t span = (uint32_t)std::max(1LL, (totals[s] + max_buckets - 1) / max_buckets);
+        m.d[s].span = span;
+        m.bucket_base[s] = (int)nb;
+        m.idx_base[s] = (uint32_t)ib;
+        nb += (totals[s] + span - 1) / span;
+        ib += totals[s];
+    }
+    m.bucket_base[k] = (int)nb;
+    m.idx_base[k] = (uint32_t)ib;
+    const int n_buckets = (int)std::max(nb, 1LL);
+    // ---- one sort, the K voxel counts in one round trip -------------------------------------------------------------------------
+    int rc = ensure_sort_scratch(c, (size_t)N, (size_t)std::max(n_buckets, N) + 1);
+    if (rc) return rc;
+    HIPCHK(c, c->vox_order.ensure(sizeof(int) * (size_t)N));
+    HIPCHK(c, c->vox_sidx.ensure(sizeof(uint32_t) * (size_t)N));
+    HIPCHK(c, c->vox_head.ensure(sizeof(int) * ((size_t)N + 1)));
+    HIPCHK(c, c->vox_slot.ensure(sizeof(int) * ((size_t)N + 2)));
+    launch_voxel_sort_multi(cat, N, m, n_buckets, sort_buffers(c), c->vox_order.as<int>(), c->vox_sidx.as<uint32_t>(),
+                            c->vox_head.as<int>(), c->vox_slot.as<int>(), st);
+    int vo[kVoxelMultiMax + 1];
+    for (int s = 0; s <= k; ++s)          // the sorted sequence is cloud by cloud: cloud s starts at sorted position off[s]
+        HIPCHK(c, hipMemcpyAsync(&vo[s], c->vox_slot.as<int>() + m.off[s], sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int n_vox = vo[k];
+    for (int s = 0; s < k; ++s) {
+        n_out[s] = vo[s + 1] - vo[s];
+        if (n_out[s] > out_capacity[s]) return fail(c, LISREG_ERR_ARG, "voxel_downsample_multi: out_capacity too small (see n_out)");
+    }
+    // ---- one centroid launch, the slices handed out ------------------------------------------------------------------------------
+    HIPCHK(c, c->vox_start.ensure(sizeof(int) * ((size_t)n_vox + 2)));
+    HIPCHK(c, c->vox_out.ensure(sizeof(float4) * (size_t)std::max(n_vox, 1)));
+    launch_voxel_centroids(N, n_vox, cat, nullptr, fmt == LISREG_FMT_DEVICE ? 1 : 0, c->vox_order.as<int>(), c->vox_head.as<int>(),
+                           c->vox_slot.as<int>(), c->vox_start.as<int>(), c->vox_out.as<float4>(), nullptr, st);
+    HIPCHK(c, hipGetLastError());
+    for (int s = 0; s < k; ++s)
+        if (n_out[s] > 0)
+            HIPCHK(c, hipMemcpyAsync(out[s], c->vox_out.as<float4>() + vo[s], sizeof(float4) * (size_t)n_out[s], hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));           // like the single-cloud call: the outputs are complete on return
+    return LISREG_OK;
+}
+
 int lisreg_transform_cloud(lisreg_ctx* c, const void* in, int n, int stride, int fmt, const float T[6], void* out)
 {
     if (!c) return LISREG_ERR_ARG;

@@ -352,17 +352,14 @@ int lisreg_localmap_extract(lisreg_ctx* c, int map_id, const float cur_pose[6], 
         isect[d] = std::max(cur[d], m->bound[d]) - (double)P->crop_pad;
         isect[3 + d] = std::min(cur[3 + d], m->bound[3 + d]) + (double)P->crop_pad;
     }
-    // voxel_downsample_pcl(cls, cls, leaf) in place (:1385-1389; an empty class returns false and stays empty), then bbx_filter
-    for (int k = 0; k < 5; ++k) {
-        if (m->n[k] > 0) {
-            HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)m->n[k]));
-            int nv = 0;
-            int rc = lisreg_voxel_downsample(c, m->cls[k].p, m->n[k], 16, LISREG_FMT_DEVICE, P->leaf[k], c->lm_tmp.p, m->n[k], &nv);
-            if (rc != LISREG_OK && rc != LISREG_LEAF_TOO_SMALL) return rc;
-            HIPCHK(c, hipMemcpyAsync(m->cls[k].p, c->lm_tmp.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToDevice, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            m->n[k] = nv;
-        }
+    // voxel_downsample_pcl(cls, cls, leaf) in place (:1385-1389; an empty class returns false and stays empty): the five grids as ONE
+    // launch sequence (lisreg_voxel_downsample_multi), then bbx_filter
+    {
+        const void* vin[5]; void* vout[5]; int vn[5], vcap[5], vno[5];
+        for (int k = 0; k < 5; ++k) { vin[k] = m->cls[k].p; vout[k] = m->cls[k].p; vn[k] = m->n[k]; vcap[k] = m->n[k]; vno[k] = 0; }
+        int rc = lisreg_voxel_downsample_multi(c, 5, vin, vn, P->leaf, LISREG_FMT_DEVICE, vout, vcap, vno);
+        if (rc) return rc;
+        for (int k = 0; k < 5; ++k) m->n[k] = vno[k];
     }
     for (int k = 0; k < 5; ++k) {
         if (m->n[k] > 0) {

@@ -759,6 +759,30 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
     atomicAdd(&hist[b], 1);
 }
 
+// K clouds in one sort (lisreg_voxel_downsample_multi): the clouds are concatenated, every cloud keeps its own grid geometry, and its
+// buckets follow the previous cloud's — the sorted sequence is cloud by cloud, each "ascending idx, ties by input index" as above.
+__global__ __launch_bounds__(256) void k_voxel_keys_multi(const float4* __restrict__ pts, int n, VoxelMulti m,
+                                                          uint32_t* __restrict__ elem_bucket, uint32_t* __restrict__ elem_sub,
+                                                          int* __restrict__ hist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < kVoxelMultiMax; ++k) if (k < m.k && i >= m.off[k]) s = k;
+    const VoxelDesc d = m.d[s];
+    const float4 p = pts[i];
+    const int i0 = (int)(floorf(p.x * d.inv_leaf) - (float)d.min_b0);
+    const int i1 = (int)(floorf(p.y * d.inv_leaf) - (float)d.min_b1);
+    const int i2 = (int)(floorf(p.z * d.inv_leaf) - (float)d.min_b2);
+    const uint32_t idx = (uint32_t)(i0 + i1 * d.mul1 + i2 * d.mul2);
+    const uint32_t lb = idx / d.span;
+    const uint32_t b = (uint32_t)m.bucket_base[s] + lb;
+    elem_bucket[i] = b;
+    elem_sub[i] = idx - lb * d.span;
+    atomicAdd(&hist[b], 1);
+}
+
 __global__ __launch_bounds__(256) void k_voxel_rank(int n, uint32_t span, const uint32_t* __restrict__ tmp_bucket,
                                                     const uint32_t* __restrict__ tmp_sub, const int* __restrict__ tmp_idx,
                                                     const int* __restrict__ bucket_start, int* __restrict__ order,
@@ -770,6 +794,24 @@ __global__ __launch_bounds__(256) void k_voxel_rank(int n, uint32_t span, const 
     const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
     order[dst] = e;
     sidx[dst] = tmp_bucket[p] * span + tmp_sub[p];
+}
+
+__global__ __launch_bounds__(256) void k_voxel_rank_multi(int n, VoxelMulti m, const uint32_t* __restrict__ tmp_bucket,
+                                                          const uint32_t* __restrict__ tmp_sub, const int* __restrict__ tmp_idx,
+                                                          const int* __restrict__ bucket_start, int* __restrict__ order,
+                                                          uint32_t* __restrict__ sidx)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int e;
+    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
+    order[dst] = e;
+    const uint32_t b = tmp_bucket[p];
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < kVoxelMultiMax; ++k) if (k < m.k && b >= (uint32_t)m.bucket_base[k]) s = k;
+    // joint voxel index: ascends through the sorted sequence and changes exactly where the voxel (or the cloud) changes
+    sidx[dst] = m.idx_base[s] + (b - (uint32_t)m.bucket_base[s]) * m.d[s].span + tmp_sub[p];
 }
 
 __global__ __launch_bounds__(256) void k_voxel_heads(int n, const uint32_t* __restrict__ sidx, int* __restrict__ head)
@@ -788,6 +830,7 @@ __global__ __launch_bounds__(256) void k_voxel_starts(int n, const int* __restri
     if (p == n - 1) vstart[slot[p] + head[p]] = n;
 }
 
+constexpr int kVoteBig = 48;            // voxels with more points take their label vote in k_voxel_vote_big
 // CentroidPoint (common/impl/accumulators.hpp): xyz and intensity = sequential float sums / n, label = most frequent
 // (smallest on ties).  One thread per output voxel; voxels hold a handful of points.
 // w_mode 0: .w is an intensity (averaged), labels (if any) in `labels`; w_mode 1: .w is a lisreg_dpoint payload whose
@@ -808,7 +851,7 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4
     }
     const float cnt = (float)(b - a);
     uint32_t best = 0u;
-    if (w_mode == 1 || labels) {
+    if ((w_mode == 1 || labels) && b - a <= kVoteBig) {          // bigger voxels: k_voxel_vote_big, one wavefront each
         // AccumulatorLabel: most frequent label, smallest on ties.  Voxels next to the sensor can hold thousands of
         // points, so count through up to 8 distinct (label, count) slots held in registers (compile-time indices);
         // only a voxel with more distinct labels than that falls back to the quadratic count.
@@ -849,6 +892,46 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4
     }
     out_pts[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, w_mode == 1 ? __uint_as_float(best) : sw / cnt);
     if (out_labels) out_labels[v] = best;
+}
+
+// AccumulatorLabel for the voxels k_voxel_centroids left out (more than kVoteBig points: the cells next to the sensor hold thousands, and
+// one lane counting them through eight label slots was 90 % of a grid's time).  One wavefront per voxel, one pass per DISTINCT label in
+// ascending order: every pass counts the current label and finds the next larger one (lanes stride over the points, wave reductions), so
+// the most frequent label — the smallest among equals, as the serial vote keeps it — falls out without any table.
+__global__ __launch_bounds__(64) void k_voxel_vote_big(int n_vox, const float4* __restrict__ pts, const uint32_t* __restrict__ labels, int w_mode,
+                                                       const int* __restrict__ order, const int* __restrict__ vstart,
+                                                       float4* __restrict__ out_pts, uint32_t* __restrict__ out_labels)
+{
+    const int v = blockIdx.x;
+    if (v >= n_vox) return;
+    const int a = vstart[v], b = vstart[v + 1];
+    if (b - a <= kVoteBig) return;
+    const int lane = threadIdx.x;
+    unsigned cur = 0xffffffffu;
+    for (int p = a + lane; p < b; p += 64) {
+        const int e = order[p];
+        cur = min(cur, (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cur = min(cur, (unsigned)__shfl_xor((int)cur, d));
+    unsigned best = 0u; int bestc = 0;
+    while (cur != 0xffffffffu) {
+        int c = 0; unsigned nxt = 0xffffffffu;
+        for (int p = a + lane; p < b; p += 64) {
+            const int e = order[p];
+            const unsigned lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
+            c += lp == cur ? 1 : 0;
+            if (lp > cur) nxt = min(nxt, lp);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d); nxt = min(nxt, (unsigned)__shfl_xor((int)nxt, d)); }
+        if (c > bestc) { bestc = c; best = cur; }              // ascending labels: a later equal count does not replace
+        cur = nxt;
+    }
+    if (lane == 0) {
+        if (w_mode == 1) out_pts[v].w = __uint_as_float(best);
+        if (out_labels) out_labels[v] = best;
+    }
 }
 
 // PCL point structs as they arrive over PCIe (stride-byte records: x, y, z at 0/4/8, uint16 label at 20 for PointXYZIL,
@@ -1010,12 +1093,26 @@ void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, Sor
     exclusive_scan(head, slot, sb.scan_tmp, n, st);
 }
 
+void launch_voxel_sort_multi(const float4* pts, int n, const VoxelMulti& m, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
+                             int* head, int* slot, hipStream_t st)
+{
+    (void)hipMemsetAsync(sb.hist, 0, sizeof(int) * (size_t)n_buckets, st);
+    k_voxel_keys_multi<<<(n + 255) / 256, 256, 0, st>>>(pts, n, m, sb.elem_bucket, sb.elem_sub, sb.hist);
+    exclusive_scan(sb.hist, sb.bucket_start, sb.scan_tmp, n_buckets, st);
+    k_scatter<<<(n + 255) / 256, 256, 0, st>>>(sb.elem_bucket, sb.elem_sub, n, sb.bucket_start, sb.hist, sb.tmp_bucket,
+                                               sb.tmp_sub, sb.tmp_idx);
+    k_voxel_rank_multi<<<(n + 255) / 256, 256, 0, st>>>(n, m, sb.tmp_bucket, sb.tmp_sub, sb.tmp_idx, sb.bucket_start, order, sidx);
+    k_voxel_heads<<<(n + 255) / 256, 256, 0, st>>>(n, sidx, head);
+    exclusive_scan(head, slot, sb.scan_tmp, n, st);
+}
+
 void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t* labels, int w_mode, const int* order,
                             const int* head, const int* slot, int* vstart, float4* out_pts, uint32_t* out_labels,
                             hipStream_t st)
 {
     k_voxel_starts<<<(n + 255) / 256, 256, 0, st>>>(n, head, slot, vstart);
     k_voxel_centroids<<<(n_vox + 255) / 256, 256, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
+    if (n_vox > 0 && (w_mode == 1 || labels)) k_voxel_vote_big<<<n_vox, 64, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
 }
 
 void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st)

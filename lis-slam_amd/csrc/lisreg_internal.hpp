@@ -109,6 +109,16 @@ struct VoxelDesc {
     uint32_t span;                 // consecutive voxel indices per sort bucket
 };
 
+// K clouds voxel-gridded by one sort (lisreg_voxel_downsample_multi): point i of the concatenation belongs to cloud s with off[s] <= i
+constexpr int kVoxelMultiMax = 8;
+struct VoxelMulti {
+    int       k;
+    int       off[kVoxelMultiMax + 1];
+    int       bucket_base[kVoxelMultiMax + 1];
+    uint32_t  idx_base[kVoxelMultiMax + 1];    // first joint voxel index of cloud s (the clouds' index spaces laid end to end, < 2^32 in all)
+    VoxelDesc d[kVoxelMultiMax];               // own geometry and own bucket span per cloud
+};
+
 // ---- launchers (lisreg_kernels.hip); all enqueue on `st`, none synchronise --------------------------------
 struct SortBuffers {           // scratch for one deterministic bucket sort
     int*      hist;            // [n_buckets] counts (consumed by the scatter)
@@ -184,6 +194,8 @@ void launch_finalize(ItemState* items, int n_items, DevParams prm, float* result
 // §8 f-1 (lisreg_index.hip)
 void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
                        int* head, int* slot /* [n+1], slot[n] = number of voxels */, hipStream_t st);
+void launch_voxel_sort_multi(const float4* pts, int n, const VoxelMulti& m, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
+                             int* head, int* slot, hipStream_t st);
 void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t* labels, int w_mode, const int* order,
                             const int* head, const int* slot, int* vstart /* [n_vox+1] */, float4* out_pts,
                             uint32_t* out_labels /* may be null */, hipStream_t st);

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
-    "lisreg_voxel_downsample", "lisreg_transform_cloud",
+    "lisreg_voxel_downsample", "lisreg_voxel_downsample_multi", "lisreg_transform_cloud",
     "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_extract_features_batch", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
@@ -211,6 +211,8 @@ def lib():
         L.lisreg_gather_results.argtypes = [vp, vp, C.c_int, vp]
         L.lisreg_comm_destroy.argtypes = [vp]
         L.lisreg_comm_destroy.restype = None
+        L.lisreg_voxel_downsample_multi.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
+                                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.lisreg_voxel_downsample.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, ip]
         L.lisreg_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, vp]
         L.lisreg_extract_features.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(FeatureParams), C.POINTER(FeatureOut)]
@@ -516,6 +518,16 @@ class Context:
                                              capacity, C.byref(n_out))
         self._chk(rc, allow=(OK, LEAF_TOO_SMALL))
         return rc, n_out.value
+
+    def voxel_downsample_multi_device(self, in_ptrs, counts, leafs, out_ptrs, capacities, intensity: bool = False):
+        """K device clouds through ONE launch sequence (lisreg_voxel_downsample_multi); returns the K output counts."""
+        k = len(in_ptrs)
+        ins = (C.c_void_p * k)(*[C.c_void_p(int(p)) if c else None for p, c in zip(in_ptrs, counts)])
+        outs = (C.c_void_p * k)(*[C.c_void_p(int(p)) if c else None for p, c in zip(out_ptrs, counts)])
+        cnt = (C.c_int * k)(*[int(x) for x in counts]); cap = (C.c_int * k)(*[int(x) for x in capacities])
+        lf = (C.c_float * k)(*[float(x) for x in leafs]); no = (C.c_int * k)()
+        self._chk(self._L.lisreg_voxel_downsample_multi(self._h, k, ins, cnt, lf, FMT_DEVICE_XYZI if intensity else FMT_DEVICE, outs, cap, no))
+        return [int(x) for x in no]
 
     def transform_cloud(self, cloud: np.ndarray, T):
         cloud = np.ascontiguousarray(cloud)

@@ -273,8 +273,9 @@ class DeviceOdomReplayer(OdomReplayer):
             rec["keyframe"] = True
         else:
             info = self.ctx.keyframes_target(self.ring, ODOM["corner_leaf"], ODOM["surf_leaf"], self.slot)
-            nsc = self.ctx.voxel_downsample_device(self.feat["corner"].ptr, n_c, ODOM["corner_leaf"], self.ds_c.ptr, self.cap, intensity=True)[1] if n_c else 0
-            nss = self.ctx.voxel_downsample_device(self.feat["surface"].ptr, n_s, ODOM["surf_leaf"], self.ds_s.ptr, self.cap, intensity=True)[1] if n_s else 0
+            nsc, nss = self.ctx.voxel_downsample_multi_device([self.feat["corner"].ptr, self.feat["surface"].ptr], [n_c, n_s],
+                                                              [ODOM["corner_leaf"], ODOM["surf_leaf"]], [self.ds_c.ptr, self.ds_s.ptr],
+                                                              [self.cap, self.cap], intensity=True)
             T, st = self.ctx.align_device(self.ds_c.ptr, nsc, self.ds_s.ptr, nss, self.T, self.params)
             self.T = T.astype(np.float32)
             rec.update(stats=st, n_target_corner=info["n_target_corner"], n_target_surf=info["n_target_surf"], n_src_corner=nsc, n_src_surf=nss)
@@ -371,7 +372,7 @@ class DeviceReplayer(Replayer):
         nf = self.ctx.semantic_split_device(self.raw.ptr, n, [b.ptr for b in self.full], self.cap)
         order = ("dynamic", "ground", "building", "pole", "outlier")
         leaf = [FRAME_LEAF[k] for k in order]
-        nd = [self.ctx.voxel_downsample_device(self.full[k].ptr, nf[k], leaf[k], self.down[k].ptr, self.cap)[1] if nf[k] else 0 for k in range(5)]
+        nd = self.ctx.voxel_downsample_multi_device([self.full[k].ptr for k in range(5)], nf, leaf, [self.down[k].ptr for k in range(5)], [self.cap] * 5)
         rec = dict(frame=self.k)
         if self.k == 0:
             rec.update(T=self.T.copy(), guess=self.T.copy(), stats=None)

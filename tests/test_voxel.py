@@ -158,3 +158,46 @@ def test_downsample_then_register_pipeline(oracle, gpu_ctx):
     Tg, sg, _ = gpu_ctx.align(out_g["src_corner"], out_g["src_surf"], case["T_init"], lisreg.default_params(1))
     assert sg["status"] == so["status"] == 0
     assert max(pose_err(Tg, To)) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_multi_cloud_grid_equals_single_calls_bitwise(gpu_ctx):
+    """lisreg_voxel_downsample_multi: K device clouds through one sort and one centroid launch — every cloud's output (membership, order,
+    centroids, label votes / intensity averages) identical to its own lisreg_voxel_downsample call; empty clouds, a single live cloud,
+    a cloud whose leaf is too small for it (falls back to single calls) and in-place use."""
+    import lisreg
+    from lisreg import synth
+    rng = np.random.default_rng(5)
+    tc, ts = synth.make_submap(120000, 77, labelled=True)
+    clouds = [ts[:50000], tc, ts[50000:90000], ts[:0], ts[90000:]]
+    leafs = [0.4, 0.05, 0.2, 0.3, 0.6]
+    recs = [lisreg.pack_device_records(c) for c in clouds]
+    for intensity in (False, True):
+        bufs_in = [lisreg.DeviceArray(r if len(r) else np.zeros((1, 4), np.float32)) for r in recs]
+        singles = []
+        for b, r, lf in zip(bufs_in, recs, leafs):
+            o = lisreg.DeviceArray(np.zeros((max(len(r), 1), 4), np.float32))
+            n = gpu_ctx.voxel_downsample_device(b.ptr, len(r), lf, o.ptr, max(len(r), 1), intensity=intensity)[1] if len(r) else 0
+            singles.append(o.download(n))
+            o.free()
+        outs = [lisreg.DeviceArray(np.zeros((max(len(r), 1), 4), np.float32)) for r in recs]
+        counts = gpu_ctx.voxel_downsample_multi_device([b.ptr for b in bufs_in], [len(r) for r in recs], leafs, [o.ptr for o in outs],
+                                                       [max(len(r), 1) for r in recs], intensity=intensity)
+        assert counts == [len(s) for s in singles] and counts[3] == 0
+        for o, s, cnt in zip(outs, singles, counts):
+            assert np.array_equal(o.download(cnt).view(np.uint32), s.view(np.uint32))
+        # in place (the local map's five grids), and one live cloud only
+        counts2 = gpu_ctx.voxel_downsample_multi_device([b.ptr for b in bufs_in], [len(r) for r in recs], leafs, [b.ptr for b in bufs_in],
+                                                        [max(len(r), 1) for r in recs], intensity=intensity)
+        assert counts2 == counts
+        for b, s, cnt in zip(bufs_in, singles, counts):
+            assert np.array_equal(b.download(cnt).view(np.uint32), s.view(np.uint32))
+        for b in bufs_in + outs:
+            b.free()
+    # a leaf far too small for its cloud ("Leaf size is too small for the input dataset": output = input) -> per-cloud path, same results
+    a = lisreg.DeviceArray(recs[0]); b = lisreg.DeviceArray(recs[1])
+    oa = lisreg.DeviceArray(np.zeros_like(recs[0])); ob = lisreg.DeviceArray(np.zeros_like(recs[1]))
+    cnt = gpu_ctx.voxel_downsample_multi_device([a.ptr, b.ptr], [len(recs[0]), len(recs[1])], [1e-4, 0.05], [oa.ptr, ob.ptr], [len(recs[0]), len(recs[1])])
+    assert cnt[0] == len(recs[0]) and np.array_equal(oa.download(cnt[0]), recs[0])
+    for x in (a, b, oa, ob):
+        x.free()
