@@ -124,6 +124,16 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     n_gpus = world
+    # self-check for the scaling record: what the process group says, and the device every rank is bound to
+    rank_devices = None
+    if use_dist:
+        props = torch.cuda.get_device_properties(dev_index)
+        mine = dict(rank=rank, local_rank=local_rank, device_index=dev_index, name=props.name,
+                    pci_bus_id=getattr(props, "pci_bus_id", None), uuid=str(getattr(props, "uuid", "")))
+        gathered_dev = [None] * world
+        dist.all_gather_object(gathered_dev, mine)
+        rank_devices = gathered_dev
+        print(f"[bench rank {rank}/{dist.get_world_size()}] backend {dist.get_backend()} device cuda:{dev_index} ({props.name})", file=sys.stderr)
 
     if args.workload in ("cfg3", "odom"):
         from lisreg import replay
@@ -339,7 +349,9 @@ def main():
             "step_loop_repeats": repeats, "timed_region_s": round(elapsed, 3),
             "config": {"workload": wl_desc,
                        "batch_per_gpu": batch, "scan": [H, W], "submap_points": M_SUBMAP, "gn_iters": ITERS,
-                       "source_points_per_batch": int(n_src), "parallelism": f"independent batches x{n_gpus} + RCCL all-gather of results"},
+                       "source_points_per_batch": int(n_src), "parallelism": f"independent batches x{n_gpus} + RCCL all-gather of results",
+                       "process_group": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                                   "ranks": rank_devices}},
             "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "accuracy": {"max_rot_err_vs_truth_rad": float(err_truth[:, :3].max()),
                          "max_trans_err_vs_truth_m": float(err_truth[:, 3:].max()),
