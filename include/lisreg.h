@@ -175,7 +175,13 @@ int  lisreg_align_batch(lisreg_ctx* ctx, int n_items, const lisreg_item* items,
  * eager launches, no host synchronisation, registrations that have converged make their workgroups exit at once — so
  * it can be timed with events on lisreg_get_stream().  T_init is copied at prepare time and re-applied on the device at
  * the start of every run.  (The synchronous entry points lisreg_align / lisreg_align_batch additionally read a 4-byte
- * finished-counter every few iterations and stop launching once every item is done.) */
+ * finished-counter every few iterations and stop launching once every item is done.)
+ * Life time of a target's search structures: the grid index of a target slot is built by lisreg_set_target* and stays valid until that
+ * slot is set again; its k-NN graph (front-end 3) is built on first use — at lisreg_set_target when "search_mode" is 3, else at the first
+ * lisreg_batch_prepare whose auto choice falls on the graph — and is then REUSED by every later prepare / run against that slot: a node
+ * that registers many batches against one submap pays for index and graph once.  Only with "rebuild_targets_each_run" = 1 (bench.py: the
+ * reference rebuilds both kd-trees inside every scan2SubMapOptimization, :602-603) does every lisreg_batch_run rebuild the indexes, and
+ * the graphs with them, of all targets of the prepared batch. */
 int  lisreg_batch_prepare(lisreg_ctx* ctx, int n_items, const lisreg_item* items,
                           const lisreg_params* params, const float* T_init);
 int  lisreg_batch_run(lisreg_ctx* ctx);
