@@ -198,3 +198,26 @@ def test_exact_build_equals_oracle_at_full_size(oracle):
         worst = max(max(pose_err(trg[k, 49:55], tro[k, 49:55])) for k in range(10))
         print(f"[exact] 64x1800 vs {m_points}: n_corr per iteration equal ({int(tro[0, 0])} .. {int(tro[-1, 0])}), worst pose difference {worst:.2e}")
         assert worst <= 2e-6
+
+
+def test_exact_build_equals_oracle_on_the_dense_config(oracle):
+    """BASELINE configs[4] shape: a 128x2048 scan against the 1 M-point submap, 30 fixed iterations (graph front-end forced): 262 k queries
+    per iteration, 7.9 M query-iterations — correspondence counts of all 30 iterations equal, poses to a few ulp."""
+    import lisreg
+    from lisreg import synth
+    tc, ts = synth.make_submap(1_000_000, 42)
+    scan = synth.make_scan(128, 2048, 5000)
+    T0 = synth.perturb_pose(scan["T_true"], np.random.default_rng(31)).astype(np.float32)
+    p_o = oracle.default_params(1)
+    p_o.fixed_iters = 30
+    To, so, tro = oracle.align(tc, ts, scan["corner"], scan["surf"], T0, p_o, n_threads=16, max_trace=30)
+    c = lisreg.Context(0)
+    c.set_option("exact_arithmetic", 1); c.set_option("search_mode", 3)
+    c.set_target(tc, ts)
+    Tg, sg, trg = c.align(scan["corner"], scan["surf"], T0, copy_params(p_o, lisreg.Params))
+    c.close()
+    assert sg["iters"] == so["iters"] == 30 and sg["status"] == so["status"] == 0
+    assert np.array_equal(trg[:, 0], tro[:, 0]), (trg[:, 0] - tro[:, 0])
+    worst = max(max(pose_err(trg[k, 49:55], tro[k, 49:55])) for k in range(30))
+    print(f"[exact] 128x2048 vs 1 M: n_corr of all 30 iterations equal ({int(tro[0, 0])} .. {int(tro[-1, 0])}), worst pose difference {worst:.2e}")
+    assert worst <= 2e-6
