@@ -218,8 +218,10 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * "exact_arithmetic" (0 [default] the production arithmetic of the correspondence kernel: FMA contraction, 1-ulp hardware reciprocal /
  * square root in the line and plane fits, fp32 sums inside a wavefront — poses within 1e-3 of the reference, a handful of
  * threshold-straddling correspondences per thousand may differ; 1 the reference's arithmetic operation for operation — IEEE division
- * and sqrt, cv::eigen's pivoted Jacobi, fp64 sums, no contraction, correctly rounded sin / cos: accept flags, correspondence counts
- * and iteration counts EQUAL the CPU restatement's (tests/test_exact.py), at roughly 0.6x the throughput),
+ * and sqrt, cv::eigen's pivoted Jacobi, fp64 sums, no contraction, the pose's sines / cosines from the host's libm (one small
+ * synchronous round trip per iteration: a run of this build blocks the caller and cannot be stream-captured): accept flags,
+ * correspondence counts, iteration counts and — bit for bit on the 100-configuration sweep — poses EQUAL the CPU restatement's
+ * (tests/test_exact.py, tests/exact_sweep.py), at roughly 0.5x the throughput),
  * "canonical_ties" (0 [default]: of two target points at EXACTLY equal float distance from a query the first one met is kept, and
  * the search front-ends meet them in different orders — about one query in 10^5-10^6 on scan data, like FLANN's own traversal order;
  * 1: such ties are noted during the search and resolved by (distance, original index), so the five neighbours, their order and every

@@ -288,7 +288,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
     for (auto& m : c->localmaps) { for (auto& b : m.cls) b.release(); m.tgt[0].release(); m.tgt[1].release(); }
     for (auto& r : c->keyrings) { for (auto& f : r.frames) { f.cloud[0].release(); f.cloud[1].release(); } r.cat[0].release(); r.cat[1].release(); r.tgt[0].release(); r.tgt[1].release(); }
-    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
+    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->exact_trig, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
     for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);
@@ -694,6 +694,30 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     return LISREG_OK;
 }
 
+// exact_arithmetic: the sine and cosine of the three pose angles are taken by the HOST's libm — the library the reference's
+// pcl::getTransformation and LMOptimization call (cosf / sinf on x86-64) — because no device routine returns its last bit in every case
+// (1 configuration in 100 showed a 1-ulp matrix entry, which swapped two candidates 8e-7 apart in squared distance).  One 24-byte-per-item
+// round trip per Gauss-Newton iteration; only this build pays it.
+static int exact_pose_caches(lisreg_ctx* c)
+{
+    const size_t n = (size_t)c->n_items;
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, c->exact_trig.ensure(sizeof(float) * 6 * n));
+    std::vector<float> T(6 * n), trig(6 * n);
+    launch_pose_gather(c->items.as<ItemState>(), c->n_items, c->exact_trig.as<float>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(T.data(), c->exact_trig.p, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; ++i) {
+        const float* t = &T[6 * i];
+        float* g = &trig[6 * i];
+        g[0] = cosf(t[2]); g[1] = sinf(t[2]); g[2] = cosf(t[1]); g[3] = sinf(t[1]); g[4] = cosf(t[0]); g[5] = sinf(t[0]);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->exact_trig.p, trig.data(), sizeof(float) * 6 * n, hipMemcpyHostToDevice, c->stream));
+    launch_pose_cache_from_trig(c->items.as<ItemState>(), c->n_items, c->exact_trig.as<float>(), c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // `trig` is a local
+    return LISREG_OK;
+}
+
 // Enqueue one full pass.  early_stop (synchronous entry points only): after every few iterations the host reads a
 // 4-byte "registrations finished" counter and stops launching once every item has converged — the reference's
 // `break` at :617 — instead of launching no-op kernels up to max_iters.  Results are identical either way.
@@ -729,6 +753,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         prof_mark(c, -1);
     }
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
+    if (c->exact) { int rc = exact_pose_caches(c); if (rc) return rc; }
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
@@ -762,6 +787,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
         prof_mark(c, -1);
+        if (c->exact && it + 1 < c->prm.bound) { int rc = exact_pose_caches(c); if (rc) return rc; }
         if (can_stop && (it + 1) % chunk == 0 && it + 1 < c->prm.bound) {
             HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));

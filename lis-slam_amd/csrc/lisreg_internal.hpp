@@ -75,7 +75,7 @@ struct DevParams {
     int   min_corr, use_label, emulate_shadow, skip_empty, fixed_iters, bound, edge_min, surf_min, use_imu;
     float imu_w, rot_tol, z_tol;
     int   ties;                // "canonical_ties": equal distances resolved by (distance, original index) in every front-end
-    int   exact;               // "exact_arithmetic": pose cache with correctly rounded sin / cos (the launches pick launch_assoc_exact)
+    int   exact;               // "exact_arithmetic" (the launches pick launch_assoc_exact; the host supplies the pose caches' sin / cos)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
 };
 
@@ -187,6 +187,9 @@ void launch_assoc_exact(const BlockDesc* blocks, int n_blocks, const Segment* se
 // XCD-aware dispatch order of a shared-target batch: blocks ranked by the azimuth of their middle query around the target centre
 void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,
                       const float4* sorted_all, int* keys, int* order, hipStream_t st);
+// exact build: poses to a dense [n][6] array / pose caches (M, sin-cos, Jacobian factors) rebuilt from host-computed trig values [n][6]
+void launch_pose_gather(const ItemState* items, int n_items, float* T_out, hipStream_t st);
+void launch_pose_cache_from_trig(ItemState* items, int n_items, const float* trig, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
 void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);

@@ -183,18 +183,14 @@ __device__ void inv6_lu(float* A, float* B)
 
 // pcl::getTransformation via trans2Affine3f (common.cpp:54-57) and LMOptimization's sin/cos (:862-867), computed
 // once per registration per iteration here instead of once per thread in the correspondence kernel.
-__device__ void write_pose_cache(ItemState* it, bool exact)
+// trig = {cos yaw, sin yaw, cos pitch, sin pitch, cos roll, sin roll} computed elsewhere (exact build: by the HOST's libm, see
+// launch_pose_cache_host_trig), or null: the device's own cosf / sinf
+__device__ void write_pose_cache(ItemState* it, const float* trig = nullptr)
 {
     const float* T = it->T;
     float A, B, C, D, E, F;
-    if (exact) {
-        // the reference's host libm returns the correctly rounded float sine / cosine (glibc computes them in double); the device's
-        // sinf / cosf are 1-2 ulp routines, so the exact build takes the double functions and rounds once
-        A = (float)cos((double)T[2]); B = (float)sin((double)T[2]); C = (float)cos((double)T[1]);
-        D = (float)sin((double)T[1]); E = (float)cos((double)T[0]); F = (float)sin((double)T[0]);
-    } else {
-        A = cosf(T[2]); B = sinf(T[2]); C = cosf(T[1]); D = sinf(T[1]); E = cosf(T[0]); F = sinf(T[0]);
-    }
+    if (trig) { A = trig[0]; B = trig[1]; C = trig[2]; D = trig[3]; E = trig[4]; F = trig[5]; }
+    else { A = cosf(T[2]); B = sinf(T[2]); C = cosf(T[1]); D = sinf(T[1]); E = cosf(T[0]); F = sinf(T[0]); }
     const float DE = D * E, DF = D * F;
     float* M = it->M;
     M[0] = A * C;  M[1] = A * DF - B * E;  M[2]  = B * F + A * DE;  M[3]  = T[3];
@@ -235,7 +231,7 @@ __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ item
     it->degenerate = it->degenerate_in;
     it->n_corr = 0;
     it->any_solved = 0;
-    write_pose_cache(it, P.exact != 0);
+    write_pose_cache(it);
 }
 
 constexpr int kSolveThreads = 512;
@@ -341,7 +337,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
             }
         }
         for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];          // :955-960
-        write_pose_cache(it, P.exact != 0);
+        write_pose_cache(it);
         const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
         const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
         const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
@@ -437,7 +433,30 @@ __global__ __launch_bounds__(64) void k_finalize(ItemState* __restrict__ items, 
     r[9] = (float)it->degenerate; r[10] = (float)it->n_corr; r[11] = (float)status;
 }
 
+// exact build: the poses out, and the pose caches rebuilt from trig values the host computed (six per registration)
+__global__ __launch_bounds__(64) void k_pose_gather(const ItemState* __restrict__ items, int n_items, float* __restrict__ T_out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_items) return;
+    for (int k = 0; k < 6; ++k) T_out[6 * i + k] = items[i].T[k];
+}
+__global__ __launch_bounds__(64) void k_pose_cache_from_trig(ItemState* __restrict__ items, int n_items, const float* __restrict__ trig)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_items) return;
+    write_pose_cache(&items[i], trig + 6 * i);
+}
+
 }  // namespace
+
+void launch_pose_gather(const ItemState* items, int n_items, float* T_out, hipStream_t st)
+{
+    if (n_items > 0) k_pose_gather<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, T_out);
+}
+void launch_pose_cache_from_trig(ItemState* items, int n_items, const float* trig, hipStream_t st)
+{
+    if (n_items > 0) k_pose_cache_from_trig<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, trig);
+}
 
 void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st)
 {

@@ -1,6 +1,6 @@
 """The exact-arithmetic build (lisreg_set_option("exact_arithmetic", 1): lisreg_assoc.hip compiled with -DLISREG_EXACT=1
 -ffp-contract=off — IEEE division / sqrt wherever the reference divides or calls sqrt, cv::eigen's pivoted Jacobi, /5, fp64
-sums, correctly rounded sin / cos in the pose cache) is the parity anchor: its INTEGER outputs must EQUAL the oracle's.
+sums, the pose cache's sin / cos from the host's libm) is the parity anchor: its INTEGER outputs must EQUAL the oracle's.
 
   * status, isDegenerate, iteration count: equal;
   * correspondence count of every Gauss-Newton iteration: equal (no "within a few threshold straddlers");
@@ -102,7 +102,9 @@ def check_exact(oracle, lisreg, case, p_o, imu, degenerate_in=0):
     return worst, n_checked
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+# 130: the configuration where a device-computed cosine (1 ulp from libm's) swapped two 5th-place candidates 8e-7 apart — the reason the
+# exact build takes the pose's sines / cosines from the host's libm; its poses must now be the oracle's to the bit
+@pytest.mark.parametrize("seed", list(range(12)) + [130])
 def test_exact_build_equals_oracle_on_the_sweep(oracle, seed):
     import lisreg
     case, variant, fixed, imu = sweep_case(seed)
@@ -110,6 +112,8 @@ def test_exact_build_equals_oracle_on_the_sweep(oracle, seed):
     p_o.fixed_iters = fixed
     worst, n = check_exact(oracle, lisreg, case, p_o, imu)
     print(f"[exact] sweep seed {seed}: worst pose difference over all iterations {worst:.2e}, {n} accept flags equal")
+    if seed == 130:
+        assert worst == 0.0
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
