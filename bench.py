@@ -171,7 +171,11 @@ def main():
         if os.environ.get("LISREG_BENCH_SHUFFLE"):      # robustness probe: destroy the scan order of the sources
             c = c[torch.randperm(c.shape[0], device=dev)].contiguous(); s = s[torch.randperm(s.shape[0], device=dev)].contiguous()
         scans.append((c, s)); T_true.append(tt)
-        T_init.append(synth.perturb_pose(tt, np.random.default_rng(seed + 7919)))
+        if os.environ.get("LISREG_BENCH_PERTURB"):      # probe: "trans_m,rot_deg" of the initial guess (default 0.3 m, 2 deg)
+            tr_, rd_ = (float(v) for v in os.environ["LISREG_BENCH_PERTURB"].split(","))
+            T_init.append(synth.perturb_pose(tt, np.random.default_rng(seed + 7919), trans=tr_, rot_deg=rd_))
+        else:
+            T_init.append(synth.perturb_pose(tt, np.random.default_rng(seed + 7919)))
     for i in range(n_distinct, batch):
         scans.append(scans[i % n_distinct]); T_true.append(T_true[i % n_distinct]); T_init.append(T_init[i % n_distinct])
     torch.cuda.synchronize()
@@ -333,10 +337,10 @@ def main():
         cnt = ctx.counters()
         print("searched fraction per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in cnt[:ITERS]], file=sys.stderr)
         print("wavefronts with a walking lane per GN iteration:", [round(float(a) / max(float(b), 1), 4) for a, b in ctx.wave_counters()[:ITERS]], file=sys.stderr)
-        if os.environ.get("LISREG_COUNT") == "3":
-            print("raw counters 96..127:", ctx.raw_counters()[96:128], file=sys.stderr)
-        if os.environ.get("LISREG_COUNT") == "3":
-            print("raw counters 96..127:", ctx.raw_counters()[96:128], file=sys.stderr)
+        if os.environ.get("LISREG_COUNT") == "3":       # experiment builds put their own tallies here
+            raw = ctx.raw_counters()
+            print("raw counters 32..63:", raw[32:64], file=sys.stderr)
+            print("raw counters 96..127:", raw[96:128], file=sys.stderr)
         if os.environ.get("LISREG_COUNT") == "2":
             raw = ctx.raw_counters()[96:96 + ITERS]
             print("queries with an unchanged ordered neighbour set / wavefronts where all are unchanged:", [(int(r >> 32), int(r & 0xffffffff)) for r in raw], file=sys.stderr)
