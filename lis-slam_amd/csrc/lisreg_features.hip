@@ -176,13 +176,17 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
         // that lane marks itself and its +-5 neighbours in LDS, and candidates suppressed meanwhile are skipped for
         // free (cloudNeighborPicked only ever goes 0 -> 1, so "not eligible when reached" == "never eligible").
         if (wave == 0) {
+// the pick's +-5 neighbours (:647-659, :681-693): each direction stops at the cloud's end or at the first column gap > 10.  Ten lanes test
+// one offset each, a ballot turns the tests into the run lengths, the lanes inside the runs mark — one LDS round instead of ten
 #define LISREG_SUPPRESS(ind_) do { \
-            for (int l = 1; l <= 5; l++) { if ((ind_) + l >= size || (ind_) + l - 1 < base) break; \
-                if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l - 1 - lo]) > 10) break; \
-                s_picked[(ind_) + l - lo] = 1; } \
-            for (int l = -1; l >= -5; l--) { if ((ind_) + l < base || (ind_) + l + 1 >= size) break; \
-                if (abs(s_col[(ind_) + l - lo] - s_col[(ind_) + l + 1 - lo]) > 10) break; \
-                s_picked[(ind_) + l - lo] = 1; } } while (0)
+            const int c_ = (ind_); \
+            bool ok_ = false; int a_ = 0; \
+            if (lane < 5) { a_ = c_ + lane + 1; ok_ = !(a_ >= size || a_ - 1 < base) && abs(s_col[a_ - lo] - s_col[a_ - 1 - lo]) <= 10; } \
+            else if (lane < 10) { a_ = c_ - (lane - 4); ok_ = !(a_ < base || a_ + 1 >= size) && abs(s_col[a_ - lo] - s_col[a_ + 1 - lo]) <= 10; } \
+            const unsigned okm_ = (unsigned)__ballot(ok_); \
+            const int nf_ = __ffs((int)((~okm_ & 0x1fu) | 0x20u)) - 1, nb_ = __ffs((int)(((~okm_ >> 5) & 0x1fu) | 0x20u)) - 1; \
+            if ((lane < 5 && lane < nf_) || (lane >= 5 && lane < 10 && lane - 5 < nb_)) s_picked[a_ - lo] = 1; \
+            __builtin_amdgcn_wave_barrier(); } while (0)
         {   // edge features: largest curvature first (:626-661), at most 20 per sector, the first 4 are "sharp"
             int largest = 0;
             bool stop = false;
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
                         lists[0 * kListCap + n_corner] = ind;
                         if (largest <= 4) lists[1 * kListCap + n_csharp] = ind;
                         s_picked[ind - lo] = 1;
-                        LISREG_SUPPRESS(ind);
                     }
+                    LISREG_SUPPRESS(__shfl(ind, f));
                     n_corner++;
                     if (largest <= 4) n_csharp++;
                 }
@@ -231,8 +235,8 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
                         fb.label[ind] = -1;
                         s_picked[ind - lo] = 1;
                         if (largest <= 10) lists[2 * kListCap + n_ssharp] = ind;
-                        LISREG_SUPPRESS(ind);
                     }
+                    LISREG_SUPPRESS(__shfl(ind, f));
                     if (largest <= 10) n_ssharp++;
                 }
             }

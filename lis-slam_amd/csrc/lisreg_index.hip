@@ -274,6 +274,7 @@ __device__ __forceinline__ int rank_in_bucket(int p, const uint32_t* __restrict_
     const uint32_t sub = tmp_sub[p];
     const int idx = tmp_idx[p];
     int rank = 0;
+#pragma unroll 8
     for (int j = s; j < e; ++j) {
         const uint32_t sj = tmp_sub[j];
         const int ij = tmp_idx[j];
@@ -830,9 +831,10 @@ __global__ __launch_bounds__(256) void k_voxel_starts(int n, const int* __restri
     if (p == n - 1) vstart[slot[p] + head[p]] = n;
 }
 
-constexpr int kVoteBig = 48;            // voxels with more points take their label vote in k_voxel_vote_big
+constexpr int kVoteBig = 24;            // voxels with more points are summed and voted by one wavefront each (k_voxel_big)
 // CentroidPoint (common/impl/accumulators.hpp): xyz and intensity = sequential float sums / n, label = most frequent
-// (smallest on ties).  One thread per output voxel; voxels hold a handful of points.
+// (smallest on ties).  One thread per output voxel with a handful of points; the loads of four points are in flight together, the
+// sums stay strictly in input order (that order is part of the result).
 // w_mode 0: .w is an intensity (averaged), labels (if any) in `labels`; w_mode 1: .w is a lisreg_dpoint payload whose
 // low 16 bits are the label (majority-voted into the output payload).
 __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4* __restrict__ pts,
@@ -843,43 +845,45 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= n_vox) return;
     const int a = vstart[v], b = vstart[v + 1];
+    if (b - a > kVoteBig) return;                              // k_voxel_big
+    const bool vote = w_mode == 1 || labels;
     float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-    for (int p = a; p < b; ++p) {
-        const float4 q = pts[order[p]];
-        sx += q.x; sy += q.y; sz += q.z;
-        if (w_mode == 0) sw += q.w;
+    // AccumulatorLabel through up to 8 distinct (label, count) slots held in registers (compile-time indices); a voxel with more
+    // distinct labels than that falls back to the quadratic count below
+    uint32_t sl[8]; int sc[8]; int ns = 0; bool overflow = false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { sl[s] = 0xffffffffu; sc[s] = 0; }
+#define LISREG_VOX_ADD(q_, e_) do { \
+        sx += (q_).x; sy += (q_).y; sz += (q_).z; \
+        if (w_mode == 0) sw += (q_).w; \
+        if (vote && !overflow) { \
+            const uint32_t lp_ = (w_mode == 1 ? __float_as_uint((q_).w) : labels[e_]) & 0xffffu; \
+            bool hit_ = false; \
+            _Pragma("unroll") for (int s = 0; s < 8; ++s) if (sl[s] == lp_) { ++sc[s]; hit_ = true; } \
+            if (!hit_) { \
+                if (ns < 8) { _Pragma("unroll") for (int s = 0; s < 8; ++s) if (s == ns) { sl[s] = lp_; sc[s] = 1; } ++ns; } \
+                else overflow = true; \
+            } \
+        } } while (0)
+    int p = a;
+    for (; p + 4 <= b; p += 4) {
+        const int e0 = order[p], e1 = order[p + 1], e2 = order[p + 2], e3 = order[p + 3];
+        const float4 q0 = pts[e0], q1 = pts[e1], q2 = pts[e2], q3 = pts[e3];
+        LISREG_VOX_ADD(q0, e0); LISREG_VOX_ADD(q1, e1); LISREG_VOX_ADD(q2, e2); LISREG_VOX_ADD(q3, e3);
     }
+    for (; p < b; ++p) { const int e = order[p]; const float4 q = pts[e]; LISREG_VOX_ADD(q, e); }
+#undef LISREG_VOX_ADD
     const float cnt = (float)(b - a);
     uint32_t best = 0u;
-    if ((w_mode == 1 || labels) && b - a <= kVoteBig) {          // bigger voxels: k_voxel_vote_big, one wavefront each
-        // AccumulatorLabel: most frequent label, smallest on ties.  Voxels next to the sensor can hold thousands of
-        // points, so count through up to 8 distinct (label, count) slots held in registers (compile-time indices);
-        // only a voxel with more distinct labels than that falls back to the quadratic count.
-        uint32_t sl[8]; int sc[8]; int ns = 0; bool overflow = false;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { sl[s] = 0xffffffffu; sc[s] = 0; }
-        for (int p = a; p < b; ++p) {
-            const int e = order[p];
-            const uint32_t lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
-            bool hit = false;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) if (sl[s] == lp) { ++sc[s]; hit = true; }
-            if (!hit) {
-                if (ns < 8) {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) if (s == ns) { sl[s] = lp; sc[s] = 1; }
-                    ++ns;
-                } else { overflow = true; break; }
-            }
-        }
+    if (vote) {
         int bestc = 0;
         if (!overflow) {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
                 if (sc[s] > bestc || (sc[s] == bestc && sc[s] > 0 && sl[s] < best)) { bestc = sc[s]; best = sl[s]; }
         } else {
-            for (int p = a; p < b; ++p) {
-                const int e = order[p];
+            for (int p2 = a; p2 < b; ++p2) {
+                const int e = order[p2];
                 const uint32_t lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
                 int c = 0;
                 for (int m = a; m < b; ++m) {
@@ -894,42 +898,66 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(int n_vox, const float4
     if (out_labels) out_labels[v] = best;
 }
 
-// AccumulatorLabel for the voxels k_voxel_centroids left out (more than kVoteBig points: the cells next to the sensor hold thousands, and
-// one lane counting them through eight label slots was 90 % of a grid's time).  One wavefront per voxel, one pass per DISTINCT label in
-// ascending order: every pass counts the current label and finds the next larger one (lanes stride over the points, wave reductions), so
-// the most frequent label — the smallest among equals, as the serial vote keeps it — falls out without any table.
-__global__ __launch_bounds__(64) void k_voxel_vote_big(int n_vox, const float4* __restrict__ pts, const uint32_t* __restrict__ labels, int w_mode,
-                                                       const int* __restrict__ order, const int* __restrict__ vstart,
-                                                       float4* __restrict__ out_pts, uint32_t* __restrict__ out_labels)
+// The voxels k_voxel_centroids left out (more than kVoteBig points: the cells next to the sensor hold hundreds to thousands, and one
+// lane walking through them — a dependent gather per point — was most of a grid's time).  One wavefront per voxel.  Centroid: the lanes
+// fetch 64 points at a time into LDS and lane 0 adds them up in input order, so the float sums are the serial ones bit for bit.  Label:
+// one pass per DISTINCT label in ascending order; every pass counts the current label and finds the next larger one (lanes stride over
+// the points, wave reductions), so the most frequent label — the smallest among equals, as the serial vote keeps it — falls out
+// without any table.
+__global__ __launch_bounds__(64) void k_voxel_big(int n_vox, const float4* __restrict__ pts, const uint32_t* __restrict__ labels, int w_mode,
+                                                  const int* __restrict__ order, const int* __restrict__ vstart,
+                                                  float4* __restrict__ out_pts, uint32_t* __restrict__ out_labels)
 {
+    __shared__ float4 s_q[64];
     const int v = blockIdx.x;
     if (v >= n_vox) return;
     const int a = vstart[v], b = vstart[v + 1];
     if (b - a <= kVoteBig) return;
     const int lane = threadIdx.x;
+    const bool vote = w_mode == 1 || labels;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
     unsigned cur = 0xffffffffu;
-    for (int p = a + lane; p < b; p += 64) {
-        const int e = order[p];
-        cur = min(cur, (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu);
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cur = min(cur, (unsigned)__shfl_xor((int)cur, d));
-    unsigned best = 0u; int bestc = 0;
-    while (cur != 0xffffffffu) {
-        int c = 0; unsigned nxt = 0xffffffffu;
-        for (int p = a + lane; p < b; p += 64) {
+    for (int p0 = a; p0 < b; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < b) {
             const int e = order[p];
-            const unsigned lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
-            c += lp == cur ? 1 : 0;
-            if (lp > cur) nxt = min(nxt, lp);
+            const float4 q = pts[e];
+            s_q[lane] = q;
+            if (vote) cur = min(cur, (w_mode == 1 ? __float_as_uint(q.w) : labels[e]) & 0xffffu);
         }
+        __builtin_amdgcn_wave_barrier();                       // one wavefront: its LDS operations execute in order
+        if (lane == 0) {
+            const int m = min(64, b - p0);
+            for (int i = 0; i < m; ++i) {
+                const float4 q = s_q[i];
+                sx += q.x; sy += q.y; sz += q.z;
+                if (w_mode == 0) sw += q.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    unsigned best = 0u;
+    if (vote) {
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d); nxt = min(nxt, (unsigned)__shfl_xor((int)nxt, d)); }
-        if (c > bestc) { bestc = c; best = cur; }              // ascending labels: a later equal count does not replace
-        cur = nxt;
+        for (int d = 32; d > 0; d >>= 1) cur = min(cur, (unsigned)__shfl_xor((int)cur, d));
+        int bestc = 0;
+        while (cur != 0xffffffffu) {
+            int c = 0; unsigned nxt = 0xffffffffu;
+            for (int p = a + lane; p < b; p += 64) {
+                const int e = order[p];
+                const unsigned lp = (w_mode == 1 ? __float_as_uint(pts[e].w) : labels[e]) & 0xffffu;
+                c += lp == cur ? 1 : 0;
+                if (lp > cur) nxt = min(nxt, lp);
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d); nxt = min(nxt, (unsigned)__shfl_xor((int)nxt, d)); }
+            if (c > bestc) { bestc = c; best = cur; }              // ascending labels: a later equal count does not replace
+            cur = nxt;
+        }
     }
     if (lane == 0) {
-        if (w_mode == 1) out_pts[v].w = __uint_as_float(best);
+        const float cnt = (float)(b - a);
+        out_pts[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, w_mode == 1 ? __uint_as_float(best) : sw / cnt);
         if (out_labels) out_labels[v] = best;
     }
 }
@@ -1112,7 +1140,7 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
 {
     k_voxel_starts<<<(n + 255) / 256, 256, 0, st>>>(n, head, slot, vstart);
     k_voxel_centroids<<<(n_vox + 255) / 256, 256, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
-    if (n_vox > 0 && (w_mode == 1 || labels)) k_voxel_vote_big<<<n_vox, 64, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
+    if (n_vox > 0) k_voxel_big<<<n_vox, 64, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
 }
 
 void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st)

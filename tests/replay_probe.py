@@ -20,7 +20,7 @@ for title, make, frames in (
         ("odometry loop, device-resident", lambda c: replay.DeviceOdomReplayer(c), [c for c, _ in replay.synthetic_raw_drive(n)])):
     ctx = lisreg.Context(0)
     T = {}
-    wrap(ctx, ("semantic_split", "semantic_split_device", "voxel_downsample", "voxel_downsample_device", "localmap_extract", "localmap_insert",
+    wrap(ctx, ("semantic_split", "semantic_split_device", "voxel_downsample", "voxel_downsample_device", "voxel_downsample_multi_device", "localmap_extract", "localmap_insert",
                "localmap_insert_device", "align", "align_device", "extract_features", "extract_features_device", "keyframes_target",
                "keyframes_push", "keyframes_push_device"), T)
     r = make(ctx)
