@@ -41,6 +41,59 @@ int grow_keep(lisreg_ctx* c, DevBuf& b, size_t bytes, size_t keep)
     return LISREG_OK;
 }
 
+// bbx_filter of the five class clouds + the assembly of both registration targets as ONE launch sequence (extractSlidingCloud
+// :1391-1419): flags over the concatenated index space, one scan, the survivors compacted class by class into scratch, then handed out —
+// back into their class cloud (the map keeps the cropped classes) and into the target they belong to.  The host reads the six class
+// boundaries once, after everything is enqueued.
+struct CropClasses {
+    const float4* in[5];        // class clouds (dynamic, pole, ground, building, outlier)
+    float4*       out[5];       // the same buffers (the hand-out runs after the compaction has left them)
+    int           off[6];       // class k = concatenated positions [off[k], off[k + 1])
+    float4*       tgt[2];       // corner target = pole; surf target = ground, building, dynamic
+    double        box[6];
+};
+
+__global__ __launch_bounds__(256) void k_crop_flags(CropClasses cc, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cc.off[5]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 5; ++j) if (i >= cc.off[j]) k = j;
+    const float4 p = cc.in[k][i - cc.off[k]];
+    // bbx_filter (subMap.h:1131-1144): float coordinate against double bounds, strictly inside
+    const bool in = (double)p.x > cc.box[0] && (double)p.x < cc.box[3] && (double)p.y > cc.box[1] && (double)p.y < cc.box[4] &&
+                    (double)p.z > cc.box[2] && (double)p.z < cc.box[5];
+    flag[i] = in ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_crop_compact(CropClasses cc, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                      float4* __restrict__ scratch, int* __restrict__ bounds_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 6) bounds_out[i] = pos[cc.off[i]];                 // survivors before class i (pos has n + 1 entries)
+    if (i >= cc.off[5] || !flag[i]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 5; ++j) if (i >= cc.off[j]) k = j;
+    scratch[pos[i]] = cc.in[k][i - cc.off[k]];
+}
+
+__global__ __launch_bounds__(256) void k_crop_hand_out(CropClasses cc, const float4* __restrict__ scratch, const int* __restrict__ bounds)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = bounds[0], b1 = bounds[1], b2 = bounds[2], b3 = bounds[3], b4 = bounds[4], b5 = bounds[5];
+    if (s >= b5) return;
+    const float4 p = scratch[s];
+    const int k = s >= b4 ? 4 : s >= b3 ? 3 : s >= b2 ? 2 : s >= b1 ? 1 : 0;
+    const int base = k == 4 ? b4 : k == 3 ? b3 : k == 2 ? b2 : k == 1 ? b1 : b0;
+    cc.out[k][s - base] = p;
+    if (k == 1) cc.tgt[0][s - b1] = p;
+    else if (k == 2) cc.tgt[1][s - b2] = p;
+    else if (k == 3) cc.tgt[1][(b3 - b2) + (s - b3)] = p;
+    else if (k == 0) cc.tgt[1][(b3 - b2) + (b4 - b3) + s] = p;
+}
+
 LocalMap* get_map(lisreg_ctx* c, int id, bool create)
 {
     if (id < 0 || id > 1023) return nullptr;
@@ -361,28 +414,36 @@ int lisreg_localmap_extract(lisreg_ctx* c, int map_id, const float cur_pose[6], 
         if (rc) return rc;
         for (int k = 0; k < 5; ++k) m->n[k] = vno[k];
     }
-    for (int k = 0; k < 5; ++k) {
-        if (m->n[k] > 0) {
-            int nk = 0;
-            int rc = lisreg_bbx_filter(c, m->cls[k].p, m->n[k], 16, LISREG_FMT_DEVICE, isect, 0, m->cls[k].p, &nk);
-            if (rc) return rc;
-            m->n[k] = nk;
+    // bbx_filter of every class, then laserCloudCornerFromSubMap = pole; laserCloudSurfFromSubMap = ground + building + dynamic (:1408-1419)
+    {
+        CropClasses cc;
+        int total = 0;
+        for (int k = 0; k < 5; ++k) { cc.in[k] = m->cls[k].as<float4>(); cc.out[k] = m->cls[k].as<float4>(); cc.off[k] = total; total += m->n[k]; }
+        cc.off[5] = total;
+        for (int d = 0; d < 6; ++d) cc.box[d] = isect[d];
+        HIPCHK(c, m->tgt[0].ensure(sizeof(float4) * (size_t)std::max(m->n[1], 1)));
+        HIPCHK(c, m->tgt[1].ensure(sizeof(float4) * (size_t)std::max(m->n[2] + m->n[3] + m->n[0], 1)));
+        cc.tgt[0] = m->tgt[0].as<float4>(); cc.tgt[1] = m->tgt[1].as<float4>();
+        int bounds[6] = { 0, 0, 0, 0, 0, 0 };
+        if (total > 0) {
+            HIPCHK(c, c->mp_flag.ensure(sizeof(int) * ((size_t)total + 1)));
+            HIPCHK(c, c->mp_pos.ensure(sizeof(int) * ((size_t)total + 2)));
+            HIPCHK(c, c->mp_cnt.ensure(sizeof(int) * 8));
+            HIPCHK(c, c->mp_out.ensure(sizeof(float4) * (size_t)total));
+            HIPCHK(c, c->scan_tmp.ensure(sizeof(int) * ((size_t)total / 2048 + 8)));
+            const unsigned nb = (unsigned)((total + 255) / 256);
+            k_crop_flags<<<nb, 256, 0, st>>>(cc, c->mp_flag.as<int>());
+            launch_exclusive_scan(c->mp_flag.as<int>(), c->mp_pos.as<int>(), c->scan_tmp.as<int>(), total, st);
+            k_crop_compact<<<nb, 256, 0, st>>>(cc, c->mp_flag.as<int>(), c->mp_pos.as<int>(), c->mp_out.as<float4>(), c->mp_cnt.as<int>());
+            k_crop_hand_out<<<nb, 256, 0, st>>>(cc, c->mp_out.as<float4>(), c->mp_cnt.as<int>());
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(bounds, c->mp_cnt.p, sizeof bounds, hipMemcpyDeviceToHost, st));
         }
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (int k = 0; k < 5; ++k) m->n[k] = bounds[k + 1] - bounds[k];
     }
-    // laserCloudCornerFromSubMap = pole; laserCloudSurfFromSubMap = ground + building + dynamic (:1408-1419)
     m->n_tgt[0] = m->n[1];
     m->n_tgt[1] = m->n[2] + m->n[3] + m->n[0];
-    HIPCHK(c, m->tgt[0].ensure(sizeof(float4) * (size_t)std::max(m->n_tgt[0], 1)));
-    HIPCHK(c, m->tgt[1].ensure(sizeof(float4) * (size_t)std::max(m->n_tgt[1], 1)));
-    if (m->n[1] > 0) HIPCHK(c, hipMemcpyAsync(m->tgt[0].p, m->cls[1].p, sizeof(float4) * (size_t)m->n[1], hipMemcpyDeviceToDevice, st));
-    size_t off = 0;
-    const int order[3] = { 2, 3, 0 };
-    for (int j = 0; j < 3; ++j) {
-        const int k = order[j];
-        if (m->n[k] > 0) HIPCHK(c, hipMemcpyAsync(m->tgt[1].as<float4>() + off, m->cls[k].p, sizeof(float4) * (size_t)m->n[k], hipMemcpyDeviceToDevice, st));
-        off += (size_t)m->n[k];
-    }
-    HIPCHK(c, hipStreamSynchronize(st));
     if (target_slot >= 0) {                          // kdtree{Corner,Surf}FromSubMap->setInputCloud (:1517-1518)
         int rc = lisreg_set_target_slot(c, target_slot, m->tgt[0].p, m->n_tgt[0], m->tgt[1].p, m->n_tgt[1], 16, LISREG_FMT_DEVICE);
         if (rc) return rc;

@@ -148,6 +148,10 @@ struct lisreg_ctx {
     bool      sort_now = false;          // decision for the prepared batch
     float     first_pass_r = 0.45f;
     int       wide_from = 0;
+    int       wide_from_small = 1;       // the same for batches searched with eight lanes per query (single frames, sequential use): their
+                                         // first guess is usually a frame step off, and the radius-limited first pass of the plain walk
+                                         // then settles iteration 0 in 160-200 us instead of 230-310 (replay of configs[2]); 1 % slower on
+                                         // a single frame with a 2-degree error (configs[0] stand-in)
     int       wide_until = 2;            // GN iterations wide_from..wide_until walk centre-first (no seeds, or seeds a pose step off)
     std::vector<lisreg::BlockDesc> h_blocks;      // 256-query workgroups: partial rows, sorts, probes
     std::vector<lisreg::BlockDesc> h_blocks_q;    // lanes_q > 1: kBlockQ / lanes_q queries per workgroup of the search kernel

@@ -18,3 +18,12 @@ for r in csv.DictReader(open(f)):
 print(f'{w}: kernel time per frame {tot/steps:.1f} us, launches per frame {sum(v[0] for v in d.values())/steps:.1f}')
 for k,v in sorted(d.items(), key=lambda kv:-kv[1][1])[:22]: print(f'  {k:46s} {v[0]/steps:6.1f} launches/frame {v[1]/steps:8.1f} us/frame')
 PY
+python - $W <<'PY'
+import csv,glob,sys
+w=sys.argv[1]
+f=glob.glob(f'/tmp/kt_{w}/**/*kernel_trace.csv',recursive=True)[0]
+rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r['Start_Timestamp']))
+seq=[(r['Kernel_Name'], (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3) for r in rows]
+a=[round(t,1) for k,t in seq if 'k_assoc_walk' in k]
+print('k_assoc_walk launch durations, last 24 (us):', a[-24:])
+PY
