@@ -467,7 +467,10 @@ void lisreg_submap_crop_boxes(const double pre_local_bound[6], const float pre_p
  *             most max_keep remain (the reference keeps fewer than 20: max_keep = 19);
  *   _target = laserCloudInfoHandler (:185-207) + the two kd-tree builds (:602-603): the kept frames concatenated NEWEST FIRST, voxel
  *             grids with the two leaf sizes (mappingCornerLeafSize 0.2, mappingSurfLeafSize 0.4), installed as target `target_slot`
- *             (-1: assembled only).  The target clouds live in the ring until the next _target / _reset of that ring. */
+ *             (-1: assembled only).  The target clouds live in the ring until the next _target / _reset of that ring.  The reference
+ *             rebuilds clouds and trees for every sweep although they only change with a key frame; here a call finds its work done —
+ *             and returns at once — while no frame was pushed since the last call, the leaf sizes are the same and `target_slot` still
+ *             holds what that call installed (any lisreg_set_target* on the slot in between makes the next call rebuild). */
 typedef struct lisreg_keyframes_info {
     int n_keyframes;                      /* frames kept now                                                 */
     int n_target_corner, n_target_surf;   /* laserCloud{Corner,Surf}FromMapDS sizes of the last _target call */

@@ -383,6 +383,17 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
     HIPCHK(c, hipSetDevice(c->device));
     if ((size_t)slot >= c->targets.size()) c->targets.resize((size_t)slot + 1);
     Target& t = c->targets[(size_t)slot];
+    t.gen = ++c->target_gen;
+    float bb_dev[2][8] = { { 0 }, { 0 } };
+    if (fmt == LISREG_FMT_DEVICE && (counts[0] > 0 || counts[1] > 0)) {          // both bounding boxes, one read-back
+        HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 16));
+        HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 2 * 6 * 256));
+        for (int k = 0; k < 2; ++k)
+            if (counts[k] > 0)
+                launch_bbox(static_cast<const float4*>(clouds[k]), counts[k], c->bbox_dev.as<float>() + 8 * k, c->bbox_scratch.as<float>() + 6 * 256 * k, c->stream);
+        HIPCHK(c, hipMemcpyAsync(bb_dev, c->bbox_dev.p, sizeof bb_dev, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     for (int k = 0; k < 2; ++k) {
         const int n = counts[k];
         t.n[k] = n;
@@ -390,13 +401,7 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
         if (fmt == LISREG_FMT_DEVICE) {
             t.raw_external[k] = true;
             t.raw_ptr[k] = static_cast<const float4*>(clouds[k]);
-            if (n > 0) {
-                HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 8));
-                HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
-                launch_bbox(t.raw_ptr[k], n, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), c->stream);
-                HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof bb, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-            }
+            if (n > 0) memcpy(bb, bb_dev[k], sizeof bb);
         } else {
             std::vector<lisreg_dpoint> h((size_t)std::max(n, 1));
             if (n > 0) pack_cloud(clouds[k], n, stride, fmt, h.data());

@@ -486,6 +486,7 @@ int lisreg_keyframes_reset(lisreg_ctx* c, int ring_id)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& f : r.frames) { f.cloud[0].release(); f.cloud[1].release(); }
     r.frames.clear();
+    r.built = false;
     r.n_tgt[0] = r.n_tgt[1] = 0;
     r.valid = true;
     return LISREG_OK;
@@ -528,6 +529,7 @@ int lisreg_keyframes_push(lisreg_ctx* c, int ring_id, const void* corner, int n_
         if (rc) { f.cloud[0].release(); f.cloud[1].release(); return rc; }
     }
     r.frames.push_back(f);
+    r.built = false;
     r.payload_is_label = fmt == LISREG_FMT_DEVICE || fmt == LISREG_FMT_XYZIL;       // what the ring's voxel grids do with the fourth channel
     while ((int)r.frames.size() > max_keep) {         // while (size() >= 20) erase(begin())  with max_keep = 19
         HIPCHK(c, hipStreamSynchronize(st));
@@ -547,32 +549,51 @@ int lisreg_keyframes_target(lisreg_ctx* c, int ring_id, float corner_leaf, float
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const float leaf[2] = { corner_leaf, surf_leaf };
+    if (r.built && r.built_leaf[0] == corner_leaf && r.built_leaf[1] == surf_leaf && r.built_slot == target_slot &&
+        (target_slot < 0 || ((size_t)target_slot < c->targets.size() && c->targets[(size_t)target_slot].valid &&
+                             c->targets[(size_t)target_slot].gen == r.built_gen))) {
+        // no key frame since the last call: the concatenation, both grids and both indexes would come out the same
+        if (info) { info->n_keyframes = (int)r.frames.size(); info->n_target_corner = r.n_tgt[0]; info->n_target_surf = r.n_tgt[1]; }
+        return LISREG_OK;
+    }
+    r.built = false;
+    size_t total[2] = { 0, 0 };
     for (int k = 0; k < 2; ++k) {
-        size_t total = 0;
-        for (const auto& f : r.frames) total += (size_t)f.n[k];
-        HIPCHK(c, r.cat[k].ensure(sizeof(float4) * std::max<size_t>(total, 1)));
-        HIPCHK(c, r.tgt[k].ensure(sizeof(float4) * std::max<size_t>(total, 1)));
+        for (const auto& f : r.frames) total[k] += (size_t)f.n[k];
+        HIPCHK(c, r.cat[k].ensure(sizeof(float4) * std::max<size_t>(total[k], 1)));
+        HIPCHK(c, r.tgt[k].ensure(sizeof(float4) * std::max<size_t>(total[k], 1)));
         size_t off = 0;
         for (size_t i = r.frames.size(); i-- > 0;) {                 // newest first (:191-194)
             const auto& f = r.frames[i];
             if (f.n[k] > 0) HIPCHK(c, hipMemcpyAsync(r.cat[k].as<float4>() + off, f.cloud[k].p, sizeof(float4) * (size_t)f.n[k], hipMemcpyDeviceToDevice, st));
             off += (size_t)f.n[k];
         }
-        int nv = 0;
-        if (total > 0) {
-            int rc = lisreg_voxel_downsample(c, r.cat[k].p, (int)total, 16, r.payload_is_label ? LISREG_FMT_DEVICE : LISREG_FMT_DEVICE_XYZI, leaf[k], r.tgt[k].p, (int)total, &nv);
+    }
+    const int vfmt = r.payload_is_label ? LISREG_FMT_DEVICE : LISREG_FMT_DEVICE_XYZI;
+    int nv[2] = { 0, 0 };
+    if (total[0] > 0 && total[1] > 0) {                              // both grids as one sort (lisreg_voxel_downsample_multi)
+        const void* vin[2] = { r.cat[0].p, r.cat[1].p }; void* vout[2] = { r.tgt[0].p, r.tgt[1].p };
+        const int vn[2] = { (int)total[0], (int)total[1] };
+        int rc = lisreg_voxel_downsample_multi(c, 2, vin, vn, leaf, vfmt, vout, vn, nv);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (total[k] > 0 && nv[k] == 0) {                            // alone, or a grid the joint call could not take
+            int rc = lisreg_voxel_downsample(c, r.cat[k].p, (int)total[k], 16, vfmt, leaf[k], r.tgt[k].p, (int)total[k], &nv[k]);
             if (rc == LISREG_LEAF_TOO_SMALL) {               // PCL warns and hands the input through
-                HIPCHK(c, hipMemcpyAsync(r.tgt[k].p, r.cat[k].p, sizeof(float4) * total, hipMemcpyDeviceToDevice, st));
-                nv = (int)total;
+                HIPCHK(c, hipMemcpyAsync(r.tgt[k].p, r.cat[k].p, sizeof(float4) * total[k], hipMemcpyDeviceToDevice, st));
+                nv[k] = (int)total[k];
             } else if (rc) return rc;
         }
-        r.n_tgt[k] = nv;
+        r.n_tgt[k] = nv[k];
     }
     HIPCHK(c, hipStreamSynchronize(st));
     if (target_slot >= 0) {
         int rc = lisreg_set_target_slot(c, target_slot, r.tgt[0].p, r.n_tgt[0], r.tgt[1].p, r.n_tgt[1], 16, LISREG_FMT_DEVICE);
         if (rc) return rc;
+        r.built_gen = c->targets[(size_t)target_slot].gen;
     }
+    r.built = true; r.built_leaf[0] = corner_leaf; r.built_leaf[1] = surf_leaf; r.built_slot = target_slot;
     if (info) { info->n_keyframes = (int)r.frames.size(); info->n_target_corner = r.n_tgt[0]; info->n_target_surf = r.n_tgt[1]; }
     return LISREG_OK;
 }

@@ -35,6 +35,7 @@ struct Target {
     bool      graph_valid[2] = { false, false };
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
     const float4* raw_ptr[2] = { nullptr, nullptr };
+    unsigned long long gen = 0;                        // bumped by every set_target of this slot (who built what is in here?)
 };
 
 // k = 1 search index over one cloud (lisreg_map_index_set)
@@ -65,6 +66,12 @@ struct KeyframeRing {
     std::vector<Frame> frames;      // oldest first
     DevBuf cat[2], tgt[2];
     int    n_tgt[2] = { 0, 0 };
+    // the target built by the last lisreg_keyframes_target: still current while no frame was pushed, the leaf sizes are the same and the
+    // registration slot still holds it (the reference rebuilds the identical clouds and kd-trees for every sweep, :185-207)
+    bool   built = false;
+    float  built_leaf[2] = { 0.f, 0.f };
+    int    built_slot = -1;
+    unsigned long long built_gen = 0;
 };
 
 struct PackPool;           // host feeder threads (lisreg_api_feed.hip)
@@ -85,6 +92,7 @@ struct lisreg_ctx {
     hipStream_t  own_stream = nullptr, stream = nullptr;
     std::string  err;
     std::vector<lisreg::Target> targets;
+    unsigned long long   target_gen = 0;
     lisreg::DevBuf       grids_dev;
     bool         grids_dirty = true;
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)

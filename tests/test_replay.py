@@ -308,6 +308,20 @@ def test_keyframe_ring_target_equals_oracle_bitwise(oracle, gpu_ctx):
             got = np.zeros((idx["n"], 3), np.float32)
             got[idx["sorted"][:, 3].view(np.int32)] = idx["sorted"][:, :3]          # back to the target cloud's own order
             assert np.array_equal(got, synth.pcl_xyz(want)), (k, kind)
+    # the built target is reused while the ring is unchanged (no key frame since the last call, same leaves, the slot still holds it)
+    # and rebuilt as soon as one of the three changes: another call, another cloud in the slot in between, other leaf sizes
+    def slot0():
+        return [gpu_ctx.target_index(0, kind) for kind in (0, 1)]
+    first = slot0()
+    again = gpu_ctx.keyframes_target(2, 0.2, 0.4, target_slot=0)
+    assert again == tinfo and all(np.array_equal(a["sorted"], b["sorted"]) for a, b in zip(first, slot0()))
+    other_c, other_s = synth.make_submap(3000, 5)
+    gpu_ctx.set_target(other_c, other_s)                                            # slot 0 now holds something else
+    assert gpu_ctx.target_index(0, 1)["n"] == len(other_s)
+    assert gpu_ctx.keyframes_target(2, 0.2, 0.4, target_slot=0) == tinfo           # ... and is rebuilt from the ring
+    assert all(np.array_equal(a["sorted"], b["sorted"]) for a, b in zip(first, slot0()))
+    coarse = gpu_ctx.keyframes_target(2, 0.4, 0.8, target_slot=0)
+    assert coarse["n_target_surf"] == len(oracle.voxel_grid(ro.cat(ks[::-1]), 0.8)[1]) < tinfo["n_target_surf"]
 
 
 @pytest.mark.gpu
