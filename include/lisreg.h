@@ -363,6 +363,12 @@ typedef struct lisreg_semantic_out {
 int  lisreg_semantic_split(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
                            const uint32_t* using_label /* [32] or NULL */, lisreg_semantic_out* out);
 
+/* One host cloud (the reference's PCL structs: LISREG_FMT_XYZI, or LISREG_FMT_XYZIL whose uint16 at byte 20 — label, or the ring of a
+ * raw sweep — becomes the payload) into a caller-owned device buffer of n 16-byte lisreg_dpoint records, through a pinned staging buffer
+ * packed by the feeder threads; returns when the records are in HBM.  What a node's callback does first with a sensor_msgs cloud
+ * (pcl::fromROSMsg in laserCloudInfoHandler, odomEstimationNode.cpp:164-175), for the *_DEVICE forms of the entry points. */
+int  lisreg_upload_cloud(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt, void* dev_out);
+
 /* ---- §8 f-3: local-map maintenance (src/include/subMap.h) -------------------------------------------------- */
 /* A k = 1 search index over one cloud, kept in HBM under `slot` (its own slot space, separate from the registration
  * targets).  Replaces pcl::search::KdTree<PointT>::setInputCloud (subMap.h:889 `local_map->tree_dynamic`,

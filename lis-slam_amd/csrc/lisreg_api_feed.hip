@@ -90,6 +90,8 @@ struct PackPool {
 void feeder_destroy(lisreg_ctx* c)
 {
     delete c->pack_pool; c->pack_pool = nullptr;
+    if (c->up_host) (void)hipHostFree(c->up_host);
+    c->up_host = nullptr; c->up_cap = 0;
     for (int b = 0; b < 2; ++b) {
         if (c->pack_host[b]) (void)hipHostFree(c->pack_host[b]);
         c->pack_host[b] = nullptr; c->pack_cap[b] = 0;
@@ -192,5 +194,48 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
     HIPCHK(c, hipEventRecord(c->pack_copied[b], c->copy_stream));
     c->pack_pending = c->pack_copied[b];          // the next batch_prepare makes the context's stream wait for it
     c->pack_last = b;
+    return LISREG_OK;
+}
+
+// One host cloud into a caller-owned device buffer as 16-byte records: packed into a pinned staging buffer (by the feeder threads when
+// the cloud is big enough to be worth waking them), one copy on the context's stream, and the call returns when the records are there.
+// The per-frame upload of the sequential chains (a sweep of 64 x 1800 structs: 0.1 ms instead of 0.4 ms through a pageable copy of
+// host-packed records).
+int lisreg_upload_cloud(lisreg_ctx* c, const void* cloud, int n, int stride_bytes, int fmt, void* dev_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n < 0 || (n > 0 && (!cloud || !dev_out))) return ctx_fail(c, LISREG_ERR_ARG, "upload_cloud: bad arguments");
+    if (fmt != LISREG_FMT_XYZIL && fmt != LISREG_FMT_XYZI) return ctx_fail(c, LISREG_ERR_ARG, "upload_cloud: host clouds only (LISREG_FMT_XYZI / _XYZIL)");
+    if (stride_bytes < 12 || (fmt == LISREG_FMT_XYZIL && stride_bytes < 22)) return ctx_fail(c, LISREG_ERR_ARG, "upload_cloud: bad stride");
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = sizeof(lisreg_dpoint) * (size_t)n;
+    if (bytes > c->up_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->up_host) (void)hipHostFree(c->up_host);
+        c->up_host = nullptr; c->up_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->up_host, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        c->up_cap = bytes + bytes / 4 + 4096;
+    }
+    lisreg_dpoint* host = reinterpret_cast<lisreg_dpoint*>(c->up_host);
+    constexpr int kChunk = 16384;
+    std::vector<PackChunk> chunks;
+    for (int s = 0; s < n; s += kChunk)
+        chunks.push_back(PackChunk{ static_cast<const unsigned char*>(cloud) + (size_t)s * (size_t)stride_bytes, host + s, std::min(kChunk, n - s), stride_bytes, fmt });
+    const int n_chunks = (int)chunks.size();
+    const int want = n >= 4 * kChunk ? std::max(0, std::min(std::min(c->feeder_threads, n_chunks - 1), (int)std::thread::hardware_concurrency() - 1)) : 0;
+    if (want > 0) {
+        if ((int)c->pack_done.size() < n_chunks) c->pack_done = std::vector<std::atomic<int>>((size_t)n_chunks);
+        for (int i = 0; i < n_chunks; ++i) c->pack_done[(size_t)i].store(0, std::memory_order_relaxed);
+        if (!c->pack_pool) c->pack_pool = new PackPool();
+        c->pack_pool->start(want);
+        c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data());
+        c->pack_pool->drain();                                   // the caller packs too
+        for (int i = 0; i < n_chunks; ++i) while (!c->pack_done[(size_t)i].load(std::memory_order_acquire)) std::this_thread::yield();
+    } else {
+        for (const auto& k : chunks) PackPool::pack(k);
+    }
+    HIPCHK(c, hipMemcpyAsync(dev_out, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LISREG_OK;
 }

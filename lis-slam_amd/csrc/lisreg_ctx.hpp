@@ -108,6 +108,8 @@ struct lisreg_ctx {
     unsigned char* pack_host[2] = { nullptr, nullptr };
     size_t       pack_cap[2] = { 0, 0 };
     lisreg::DevBuf pack_dev[2];
+    unsigned char* up_host = nullptr;          // pinned staging of lisreg_upload_cloud
+    size_t         up_cap = 0;
     hipEvent_t   pack_copied[2] = { nullptr, nullptr };   // the uploads into device buffer b are done (recorded on copy_stream)
     hipEvent_t   pack_free[2] = { nullptr, nullptr };     // the batch reading device buffer b has run (recorded on stream)
     hipEvent_t   pack_pending = nullptr;                  // uploads the next prepared batch has to wait for

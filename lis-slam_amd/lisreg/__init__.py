@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_voxel_downsample_multi", "lisreg_transform_cloud",
@@ -194,6 +194,7 @@ def lib():
         L.lisreg_batch_result_device.argtypes = [vp]
         L.lisreg_batch_result_device.restype = vp
         L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.lisreg_upload_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
         L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -576,6 +577,16 @@ class Context:
                 setattr(fos[s], k, C.c_void_p(ptr)); setattr(fos[s], "cap_" + k, cap)
         self._chk(self._L.lisreg_extract_features_batch(self._h, S, ptrs, ns, C.byref(params), fos))
         return [{k: getattr(fos[s], "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")} for s in range(S)]
+
+    def upload_cloud(self, cloud: np.ndarray, dev_ptr: int) -> int:
+        """lisreg_upload_cloud: a host PCL struct array (x, y, z at 0 / 4 / 8; the uint16 at byte 20 — label or ring — becomes the
+        payload when the dtype has one) into a device buffer of len(cloud) 16-byte records.  Returns the count."""
+        cloud = np.ascontiguousarray(cloud)
+        names = cloud.dtype.names or ()
+        has16 = any(cloud.dtype.fields[k][1] == 20 and cloud.dtype.fields[k][0].itemsize == 2 for k in names)
+        self._chk(self._L.lisreg_upload_cloud(self._h, cloud.ctypes.data_as(C.c_void_p), len(cloud), cloud.dtype.itemsize,
+                                              FMT_XYZIL if has16 else FMT_XYZI, C.c_void_p(dev_ptr)))
+        return len(cloud)
 
     def semantic_split_device(self, in_ptr: int, n: int, out_ptrs, cap: int, using_label=None) -> list:
         """categoryMapping on device records (label in the payload): out_ptrs = five device buffers of `cap` records

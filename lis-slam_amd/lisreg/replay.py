@@ -260,10 +260,7 @@ class DeviceOdomReplayer(OdomReplayer):
         t0 = time.perf_counter()
         n = len(sweep)
         assert n <= 2 * self.cap
-        rec4 = np.zeros((n, 4), np.float32)
-        rec4[:, 0], rec4[:, 1], rec4[:, 2] = sweep["x"], sweep["y"], sweep["z"]
-        rec4[:, 3] = sweep["ring"].astype(np.uint32).view(np.float32)
-        self.raw.upload(rec4)
+        self.ctx.upload_cloud(sweep, self.raw.ptr)                   # (x, y, z, ring) records
         cnt = self.ctx.extract_features_device(self.raw.ptr, n, self.fp, {k: v.ptr for k, v in self.feat.items()}, self.cap)
         n_c, n_s = cnt["corner"], cnt["surface"]
         self._guess()
@@ -368,7 +365,7 @@ class DeviceReplayer(Replayer):
         t0 = time.perf_counter()
         n = len(cloud)
         assert n <= self.cap
-        self.raw.upload(lisreg.pack_device_records(cloud))
+        self.ctx.upload_cloud(cloud, self.raw.ptr)
         nf = self.ctx.semantic_split_device(self.raw.ptr, n, [b.ptr for b in self.full], self.cap)
         order = ("dynamic", "ground", "building", "pole", "outlier")
         leaf = [FRAME_LEAF[k] for k in order]

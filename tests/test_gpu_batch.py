@@ -396,3 +396,26 @@ def test_staged_host_items_equal_align_batch(labelled):
     (Ta, sa), (Tb, sb) = out
     assert np.array_equal(Ta, T_ref) and sa == st_ref
     assert np.array_equal(Tb, T_ref[::-1]) and sb == st_ref[::-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 1000, 115200, 300001])
+def test_upload_cloud_equals_host_packing(gpu_ctx, n):
+    """lisreg_upload_cloud (pinned staging packed by the feeder threads — alone below 64 k points) leaves exactly the records
+    pack_device_records builds on the host: coordinates bit for bit, payload = the uint16 at byte 20 (label / ring), or 0 for XYZI."""
+    import lisreg
+    from lisreg import synth
+    rng = np.random.default_rng(n)
+    xyz = rng.normal(0, 30, (n, 3)).astype(np.float32)
+    lab = rng.integers(0, 300, n).astype(np.uint16)
+    labelled = synth.to_pcl(xyz, lab)
+    dev = lisreg.DeviceArray(np.zeros((n, 4), np.float32))
+    assert gpu_ctx.upload_cloud(labelled, dev.ptr) == n
+    assert np.array_equal(dev.download(n).view(np.uint32), lisreg.pack_device_records(labelled).view(np.uint32))
+    plain = np.zeros(n, np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4"] * 4, "offsets": [0, 4, 8, 16], "itemsize": 32}))
+    plain["x"], plain["y"], plain["z"], plain["intensity"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], 7.0
+    assert gpu_ctx.upload_cloud(plain, dev.ptr) == n
+    got = dev.download(n)
+    assert np.array_equal(got[:, :3], xyz) and not got[:, 3].view(np.uint32).any()
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx._chk(gpu_ctx._L.lisreg_upload_cloud(gpu_ctx._h, None, 5, 32, lisreg.FMT_XYZIL, C.c_void_p(dev.ptr)))
