@@ -1262,13 +1262,11 @@ int lisreg_voxel_downsample_multi(lisreg_ctx* c, int k, const void* const* in, c
     float4* cat = c->vox_in.as<float4>();
     for (int s = 0, o = 0; s < k; ++s) {
         m.off[s] = o;
-        if (n[s] > 0) {
-            HIPCHK(c, hipMemcpyAsync(cat + o, in[s], sizeof(float4) * (size_t)n[s], hipMemcpyDeviceToDevice, st));
-            launch_bbox(cat + o, n[s], c->bbox_dev.as<float>() + 6 * s, c->bbox_scratch.as<float>() + 6 * 256 * s, st);
-        }
+        if (n[s] > 0) HIPCHK(c, hipMemcpyAsync(cat + o, in[s], sizeof(float4) * (size_t)n[s], hipMemcpyDeviceToDevice, st));
         o += n[s];
         m.off[s + 1] = o;
     }
+    launch_bbox_multi(cat, m, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), st);
     float bb[6 * kVoxelMultiMax];
     HIPCHK(c, hipMemcpyAsync(bb, c->bbox_dev.p, sizeof(float) * 6 * (size_t)k, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -1317,8 +1315,10 @@ int lisreg_voxel_downsample_multi(lisreg_ctx* c, int k, const void* const* in, c
     launch_voxel_sort_multi(cat, N, m, n_buckets, sort_buffers(c), c->vox_order.as<int>(), c->vox_sidx.as<uint32_t>(),
                             c->vox_head.as<int>(), c->vox_slot.as<int>(), st);
     int vo[kVoxelMultiMax + 1];
-    for (int s = 0; s <= k; ++s)          // the sorted sequence is cloud by cloud: cloud s starts at sorted position off[s]
-        HIPCHK(c, hipMemcpyAsync(&vo[s], c->vox_slot.as<int>() + m.off[s], sizeof(int), hipMemcpyDeviceToHost, st));
+    // the sorted sequence is cloud by cloud: cloud s starts at sorted position off[s]; its voxels start at slot[off[s]]
+    HIPCHK(c, c->mp_cnt.ensure(sizeof(int) * (kVoxelMultiMax + 1)));
+    launch_multi_bounds(c->vox_slot.as<int>(), m, c->mp_cnt.as<int>(), st);
+    HIPCHK(c, hipMemcpyAsync(vo, c->mp_cnt.p, sizeof(int) * (size_t)(k + 1), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     const int n_vox = vo[k];
     for (int s = 0; s < k; ++s) {
@@ -1331,9 +1331,13 @@ int lisreg_voxel_downsample_multi(lisreg_ctx* c, int k, const void* const* in, c
     launch_voxel_centroids(N, n_vox, cat, nullptr, fmt == LISREG_FMT_DEVICE ? 1 : 0, c->vox_order.as<int>(), c->vox_head.as<int>(),
                            c->vox_slot.as<int>(), c->vox_start.as<int>(), c->vox_out.as<float4>(), nullptr, st);
     HIPCHK(c, hipGetLastError());
-    for (int s = 0; s < k; ++s)
-        if (n_out[s] > 0)
-            HIPCHK(c, hipMemcpyAsync(out[s], c->vox_out.as<float4>() + vo[s], sizeof(float4) * (size_t)n_out[s], hipMemcpyDeviceToDevice, st));
+    VoxelHandOut ho;
+    memset(&ho, 0, sizeof ho);
+    ho.k = k;
+    for (int s = 0; s <= k; ++s) ho.vo[s] = vo[s];
+    for (int s = 0; s < k; ++s) ho.out[s] = static_cast<float4*>(out[s]);
+    launch_hand_out(c->vox_out.as<float4>(), ho, st);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));           // like the single-cloud call: the outputs are complete on return
     return LISREG_OK;
 }

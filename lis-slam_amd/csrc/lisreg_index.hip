@@ -125,7 +125,7 @@ void exclusive_scan(const int* in, int* out /* [n+1] */, int* tmp, int n, hipStr
 }
 
 // ---- bounding box ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__ pts, int n, float* __restrict__ part)
+__device__ __forceinline__ void k_bbox_block(const float4* __restrict__ pts, int n, float* __restrict__ part)
 {
     __shared__ float s[4][6];
     float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__
     }
 }
 
-__global__ void k_bbox_final(const float* __restrict__ part, int nb, float* __restrict__ bbox6)
+__global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__ pts, int n, float* __restrict__ part) { k_bbox_block(pts, n, part); }
+
+__device__ __forceinline__ void k_bbox_fold(const float* __restrict__ part, int nb, float* __restrict__ bbox6)
 {
     // one wave: every lane folds the partial rows lane, lane + 64, ... , then a butterfly (the serial 6-thread version of
     // this kernel took 25 us — a quarter of a map-index build)
@@ -167,6 +169,7 @@ __global__ void k_bbox_final(const float* __restrict__ part, int nb, float* __re
 #pragma unroll
         for (int k = 0; k < 3; ++k) { bbox6[k] = lo[k]; bbox6[3 + k] = hi[k]; }
 }
+__global__ void k_bbox_final(const float* __restrict__ part, int nb, float* __restrict__ bbox6) { k_bbox_fold(part, nb, bbox6); }
 
 // ---- target keys -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int cell_coord(float v, float origin, float inv_cell, int n)
@@ -1141,6 +1144,46 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
     k_voxel_starts<<<(n + 255) / 256, 256, 0, st>>>(n, head, slot, vstart);
     k_voxel_centroids<<<(n_vox + 255) / 256, 256, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
     if (n_vox > 0) k_voxel_big<<<n_vox, 64, 0, st>>>(n_vox, pts, labels, w_mode, order, vstart, out_pts, out_labels);
+}
+
+// K bounding boxes of the clouds of a VoxelMulti (cloud s = records [off[s], off[s + 1]) of `cat`) in two launches: 64 partial rows per
+// cloud, then one wavefront per cloud; bbox_out[6 * s ...], scratch >= 6 * 64 * K floats.  An empty cloud gets the empty box.
+__global__ __launch_bounds__(256) void k_bbox_partial_multi(const float4* __restrict__ cat, VoxelMulti m, float* __restrict__ part)
+{
+    const int s = blockIdx.y;
+    k_bbox_block(cat + m.off[s], m.off[s + 1] - m.off[s], part + (size_t)s * 6 * gridDim.x);
+}
+__global__ void k_bbox_final_multi(const float* __restrict__ part, int nb, float* __restrict__ bbox_out)
+{
+    k_bbox_fold(part + (size_t)blockIdx.x * 6 * nb, nb, bbox_out + 6 * blockIdx.x);
+}
+void launch_bbox_multi(const float4* cat, const VoxelMulti& m, float* bbox_out, float* scratch, hipStream_t st)
+{
+    if (m.k <= 0) return;
+    k_bbox_partial_multi<<<dim3(64, (unsigned)m.k), 256, 0, st>>>(cat, m, scratch);
+    k_bbox_final_multi<<<m.k, 64, 0, st>>>(scratch, 64, bbox_out);
+}
+
+// slot[off[s]] for s = 0..k (the voxel count in front of every cloud of a joint sort) into k + 1 consecutive ints: one read-back
+__global__ void k_multi_bounds(const int* __restrict__ slot, VoxelMulti m, int* __restrict__ out)
+{
+    if ((int)threadIdx.x <= m.k) out[threadIdx.x] = slot[m.off[threadIdx.x]];
+}
+void launch_multi_bounds(const int* slot, const VoxelMulti& m, int* out, hipStream_t st) { k_multi_bounds<<<1, 64, 0, st>>>(slot, m, out); }
+
+// the joint output cloud handed out to its K destinations: voxel v of cloud s (vo[s] <= v < vo[s + 1]) -> out[s][v - vo[s]]
+__global__ __launch_bounds__(256) void k_hand_out(const float4* __restrict__ src, VoxelHandOut h)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= h.vo[h.k]) return;
+    int s = 0;
+#pragma unroll
+    for (int j = 1; j < kVoxelMultiMax; ++j) if (j < h.k && v >= h.vo[j]) s = j;
+    h.out[s][v - h.vo[s]] = src[v];
+}
+void launch_hand_out(const float4* src, const VoxelHandOut& h, hipStream_t st)
+{
+    if (h.vo[h.k] > 0) k_hand_out<<<(h.vo[h.k] + 255) / 256, 256, 0, st>>>(src, h);
 }
 
 void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st)

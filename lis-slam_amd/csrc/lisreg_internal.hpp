@@ -197,6 +197,10 @@ void launch_finalize(ItemState* items, int n_items, DevParams prm, float* result
 // §8 f-1 (lisreg_index.hip)
 void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
                        int* head, int* slot /* [n+1], slot[n] = number of voxels */, hipStream_t st);
+struct VoxelHandOut { int k; int vo[kVoxelMultiMax + 1]; float4* out[kVoxelMultiMax]; };
+void launch_bbox_multi(const float4* cat, const VoxelMulti& m, float* bbox_out /* [6 * k] */, float* scratch /* >= 6 * 64 * k floats */, hipStream_t st);
+void launch_multi_bounds(const int* slot, const VoxelMulti& m, int* out /* [k + 1] */, hipStream_t st);
+void launch_hand_out(const float4* src, const VoxelHandOut& h, hipStream_t st);
 void launch_voxel_sort_multi(const float4* pts, int n, const VoxelMulti& m, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
                              int* head, int* slot, hipStream_t st);
 void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t* labels, int w_mode, const int* order,
