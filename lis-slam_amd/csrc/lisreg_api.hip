@@ -1631,9 +1631,9 @@ int lisreg_semantic_split(lisreg_ctx* c, const void* cloud, int n, int stride, i
         HIPCHK(c, hipMemcpyAsync(c->vox_lab.p, h_lab.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
         pts = c->vox_in.as<float4>(); labels = c->vox_lab.as<uint32_t>();
     }
-    HIPCHK(c, c->vox_head.ensure(sizeof(int) * ((size_t)n + 1)));
-    HIPCHK(c, c->vox_slot.ensure(sizeof(int) * ((size_t)n + 2)));
-    HIPCHK(c, c->scan_tmp.ensure(sizeof(int) * ((size_t)n / 2048 + 8)));
+    HIPCHK(c, c->vox_head.ensure(sizeof(int) * (5 * (size_t)n + 1)));
+    HIPCHK(c, c->vox_slot.ensure(sizeof(int) * (5 * (size_t)n + 2)));
+    HIPCHK(c, c->scan_tmp.ensure(sizeof(int) * (5 * (size_t)n / 2048 + 8)));
     HIPCHK(c, c->ft_lists.ensure(sizeof(int) * 5 * (size_t)n));
     HIPCHK(c, c->ft_counts.ensure(sizeof(int) * 8));
     launch_semantic_split(pts, labels, n, map, c->vox_head.as<int>(), c->vox_slot.as<int>(), c->scan_tmp.as<int>(),
@@ -1646,11 +1646,15 @@ int lisreg_semantic_split(lisreg_ctx* c, const void* cloud, int n, int stride, i
     for (int k = 0; k < 5; ++k)
         if (out->cloud[k] && counts[k] > out->cap[k]) return fail(c, LISREG_ERR_ARG, "semantic_split: an output buffer is too small (counts written back)");
     std::vector<int> h_idx;
+    if (dev) {
+        SemanticGather sg;
+        for (int k = 0; k < 5; ++k) { sg.out[k] = static_cast<float4*>(out->cloud[k]); sg.count[k] = out->cloud[k] ? counts[k] : 0; }
+        launch_semantic_gather(pts, c->ft_lists.as<int>(), n, sg, st);
+    }
     for (int k = 0; k < 5; ++k) {
-        if (!out->cloud[k] || counts[k] == 0) continue;
+        if (dev || !out->cloud[k] || counts[k] == 0) continue;
         const int* idx = c->ft_lists.as<int>() + (size_t)k * n;
-        if (dev) launch_gather_points(pts, idx, counts[k], static_cast<float4*>(out->cloud[k]), st);
-        else {
+        {
             h_idx.resize((size_t)counts[k]);
             HIPCHK(c, hipMemcpyAsync(h_idx.data(), idx, sizeof(int) * (size_t)counts[k], hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));

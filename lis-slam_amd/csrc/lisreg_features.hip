@@ -353,22 +353,38 @@ __global__ __launch_bounds__(256) void k_feat_batch_gather(const float4* __restr
 
 // categoryMapping (/root/reference/src/node/semanticFusionNode.cpp:173-189): flag of "this point belongs to class k"
 struct LabelMap { uint32_t m[32]; };
+// categoryMapping as ONE stable five-way partition: the class flags of all points laid out class-major ([5][n]), one scan over the 5 n
+// flags — the position of a flag IS the point's place in "class 0 in input order, then class 1, ..." — and one kernel that turns it into the
+// five index lists and their sizes
 __global__ __launch_bounds__(256) void k_sem_flags(const float4* __restrict__ pts, const uint32_t* __restrict__ labels, int n,
-                                                   LabelMap map, int k, int* __restrict__ flag)
+                                                   LabelMap map, int* __restrict__ flag)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t u = map.m[(labels ? labels[i] : __float_as_uint(pts[i].w)) & 31u];
     const int c = u == 10u ? 0 : (u == 40u ? 1 : (u == 50u ? 2 : (u == 81u ? 3 : 4)));
-    flag[i] = c == k ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) flag[(size_t)k * n + i] = c == k ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_sem_write(int n, const int* __restrict__ flag, const int* __restrict__ pos,
                                                    int* __restrict__ idx_out, int* __restrict__ count_out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) *count_out = pos[n];
-    if (i < n && flag[i]) idx_out[pos[i]] = i;
+    if (i < 5) count_out[i] = pos[(size_t)(i + 1) * n] - pos[(size_t)i * n];
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const size_t f = (size_t)k * n + i;
+        if (flag[f]) idx_out[(size_t)k * n + (pos[f] - pos[(size_t)k * n])] = i;
+    }
+}
+
+// the five class clouds written by one launch (grid.y = class): out[k][j] = pts[idx[k * n + j]]
+__global__ __launch_bounds__(256) void k_sem_gather(const float4* __restrict__ pts, const int* __restrict__ idx, int n, SemanticGather g)
+{
+    const int k = blockIdx.y;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < g.count[k]; j += gridDim.x * 256) g.out[k][j] = pts[idx[(size_t)k * n + j]];
 }
 
 __global__ __launch_bounds__(256) void k_gather_points(const float4* __restrict__ pts, const int* __restrict__ idx, int n,
@@ -515,17 +531,22 @@ void launch_feature_batch_gather(const float4* cat, const int* idx, const void* 
     k_feat_batch_gather<<<dim3(gx, n_sweeps), 256, 0, st>>>(cat, idx, static_cast<const GatherJob*>(jobs_dev));
 }
 
-// stable five-way partition: idx_out[k*n ..] = input indices of class k in input order, counts[k] = its size
+// stable five-way partition: idx_out[k*n ..] = input indices of class k in input order, counts[k] = its size; flag and pos hold 5 n + 1 ints
 void launch_semantic_split(const float4* pts, const uint32_t* labels, int n, const uint32_t map[32], int* flag, int* pos,
                            int* scan_tmp, int* idx_out, int* counts, hipStream_t st)
 {
     LabelMap lm;
     for (int i = 0; i < 32; ++i) lm.m[i] = map[i];
-    for (int k = 0; k < 5; ++k) {
-        k_sem_flags<<<(n + 255) / 256, 256, 0, st>>>(pts, labels, n, lm, k, flag);
-        launch_exclusive_scan(flag, pos, scan_tmp, n, st);
-        k_sem_write<<<(n + 255) / 256, 256, 0, st>>>(n, flag, pos, idx_out + (size_t)k * n, counts + k);
-    }
+    k_sem_flags<<<(n + 255) / 256, 256, 0, st>>>(pts, labels, n, lm, flag);
+    launch_exclusive_scan(flag, pos, scan_tmp, 5 * n, st);
+    k_sem_write<<<(n + 255) / 256, 256, 0, st>>>(n, flag, pos, idx_out, counts);
+}
+
+void launch_semantic_gather(const float4* pts, const int* idx, int n, const SemanticGather& g, hipStream_t st)
+{
+    int mx = 0;
+    for (int k = 0; k < 5; ++k) mx = std::max(mx, g.count[k]);
+    if (mx > 0) k_sem_gather<<<dim3((unsigned)std::min(256, (mx + 255) / 256), 5), 256, 0, st>>>(pts, idx, n, g);
 }
 
 void launch_gather_points(const float4* pts, const int* idx, int n, float4* out, hipStream_t st)

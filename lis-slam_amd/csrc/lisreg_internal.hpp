@@ -272,6 +272,8 @@ void launch_icp_fitness(const float4* src, int n, const GridIndex* grid_dev, Icp
 void launch_bbx_flags(const float4* pts, int n, const double b[6], int delete_box, int* flag, hipStream_t st);
 // stable compaction: idx_out[0..count) = indices i with flag[i] != 0, ascending; pos [n+1]
 void launch_compact(int n, const int* flag, int* pos, int* scan_tmp, int* idx_out, int* count_out, hipStream_t st);
+struct SemanticGather { float4* out[5]; int count[5]; };     // count 0: that class is not wanted
+void launch_semantic_gather(const float4* pts, const int* idx /* [5][n] */, int n, const SemanticGather& g, hipStream_t st);
 void launch_semantic_split(const float4* pts, const uint32_t* labels /* null: payload */, int n, const uint32_t map[32],
                            int* flag /* [n] */, int* pos /* [n+1] */, int* scan_tmp, int* idx_out /* [5*n] */, int* counts /* [5] */,
                            hipStream_t st);
