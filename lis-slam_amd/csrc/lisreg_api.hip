@@ -1352,13 +1352,14 @@ int lisreg_transform_cloud(lisreg_ctx* c, const void* in, int n, int stride, int
     hipStream_t st = c->stream;
     float M[12];
     pose_to_matrix_host(T, M);                       // pcl::getTransformation (common.cpp:140-142)
-    HIPCHK(c, c->vox_M.ensure(sizeof M));
-    HIPCHK(c, hipMemcpyAsync(c->vox_M.p, M, sizeof M, hipMemcpyHostToDevice, st));
-    if (fmt == LISREG_FMT_DEVICE) {
-        launch_transform_cloud(static_cast<const float4*>(in), n, c->vox_M.as<float>(), static_cast<float4*>(out), st);
-        HIPCHK(c, hipStreamSynchronize(st));         // M is a local
+    if (fmt == LISREG_FMT_DEVICE) {                  // the matrix travels as a kernel argument
+        launch_transform_cloud_m(static_cast<const float4*>(in), n, M, static_cast<float4*>(out), st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));
         return LISREG_OK;
     }
+    HIPCHK(c, c->vox_M.ensure(sizeof M));
+    HIPCHK(c, hipMemcpyAsync(c->vox_M.p, M, sizeof M, hipMemcpyHostToDevice, st));
     std::vector<float4> h((size_t)n);
     const unsigned char* b = static_cast<const unsigned char*>(in);
     for (int i = 0; i < n; ++i) { float v[3]; memcpy(v, b + (size_t)i * (size_t)stride, 12); h[(size_t)i] = make_float4(v[0], v[1], v[2], 0.f); }

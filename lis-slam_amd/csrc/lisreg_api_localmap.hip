@@ -116,12 +116,15 @@ int update_bound(lisreg_ctx* c, LocalMap& m)
 {
     for (int d = 0; d < 3; ++d) { m.bound[d] = DBL_MAX; m.bound[3 + d] = -DBL_MAX; }
     HIPCHK(c, c->lm_bbox.ensure(sizeof(float) * 6 * 5));
-    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 256));
+    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 64 * 5));
     float bb[30];
     bool any = false;
-    for (int k = 0; k < 5; ++k)
-        if (m.n[k] > 0) { launch_bbox(m.cls[k].as<float4>(), m.n[k], c->lm_bbox.as<float>() + 6 * k, c->bbox_scratch.as<float>(), c->stream); any = true; }
+    BboxJobs jobs;
+    memset(&jobs, 0, sizeof jobs);
+    jobs.k = 5;
+    for (int k = 0; k < 5; ++k) { jobs.pts[k] = m.cls[k].as<float4>(); jobs.n[k] = m.n[k]; any = any || m.n[k] > 0; }
     if (!any) return LISREG_OK;
+    launch_bbox_jobs(jobs, c->lm_bbox.as<float>(), c->bbox_scratch.as<float>(), c->stream);     // five boxes, two launches
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(bb, c->lm_bbox.p, sizeof bb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -178,6 +181,8 @@ static int insert_classes(lisreg_ctx* c, LocalMap* m, int map_id, const void* co
     hipStream_t st = c->stream;
     // the reference widens the band first (subMap.h:884 / :1006): max(dynamic_dist_thre_max, (float)(dynamic_dist_thre_min + 0.1))
     const float thre_max = std::max(P->dynamic_dist_thre_max, (float)((double)P->dynamic_dist_thre_min + 0.1));
+    float Mpose[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    if (pose) lisreg_pose_to_matrix(pose, Mpose);      // pcl::getTransformation, as lisreg_transform_cloud forms it
     for (int k = 0; k < n_classes; ++k) {            // dynamic, pole, ground, building (, outlier)
         if (n[k] == 0) continue;
         // stage the frame's class cloud as device records, then transformPointCloud(.., &pose) into lm_tmp
@@ -192,13 +197,23 @@ static int insert_classes(lisreg_ctx* c, LocalMap* m, int map_id, const void* co
             HIPCHK(c, hipStreamSynchronize(st));     // pageable sources are free to change after the call
             src = c->lm_in.as<float4>();
         }
-        HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)n[k]));
         int rc = LISREG_OK;
-        if (pose) rc = lisreg_transform_cloud(c, src, n[k], 16, LISREG_FMT_DEVICE, pose, c->lm_tmp.p);
-        else HIPCHK(c, hipMemcpyAsync(c->lm_tmp.p, src, sizeof(float4) * (size_t)n[k], hipMemcpyDeviceToDevice, st));     // fisrt_submap: as it is
-        if (rc) return rc;
+        const bool filtered = pose && k == 0 && P->dynamic_removal_on && m->feature_point_num > P->max_num_pts / 5;
+        if (!filtered) {
+            // transformPointCloud straight onto the end of the class cloud (append_feature, subMap.h:742-753); the stream orders it
+            rc = grow_keep(c, m->cls[k], sizeof(float4) * ((size_t)m->n[k] + (size_t)n[k] + 1), sizeof(float4) * (size_t)m->n[k]);
+            if (rc) return rc;
+            if (pose) launch_transform_cloud_m(src, n[k], Mpose, m->cls[k].as<float4>() + m->n[k], st);
+            else HIPCHK(c, hipMemcpyAsync(m->cls[k].as<float4>() + m->n[k], src, sizeof(float4) * (size_t)n[k], hipMemcpyDeviceToDevice, st));   // fisrt_submap: as it is
+            HIPCHK(c, hipGetLastError());
+            m->n[k] += n[k];
+            continue;
+        }
+        HIPCHK(c, c->lm_tmp.ensure(sizeof(float4) * (size_t)n[k]));
+        launch_transform_cloud_m(src, n[k], Mpose, c->lm_tmp.as<float4>(), st);
+        HIPCHK(c, hipGetLastError());
         int n_add = n[k];
-        if (pose && k == 0 && P->dynamic_removal_on && m->feature_point_num > P->max_num_pts / 5) {
+        {
             // tree_dynamic->setInputCloud(submap_dynamic) + map_scan_feature_pts_distance_removal (:889-892 / :1008-1012)
             rc = lisreg_map_index_set(c, kMapSlotBase + map_id, m->cls[0].p, m->n[0], 16, LISREG_FMT_DEVICE);
             if (rc) return rc;
@@ -214,9 +229,8 @@ static int insert_classes(lisreg_ctx* c, LocalMap* m, int map_id, const void* co
             HIPCHK(c, hipMemcpyAsync(m->cls[k].as<float4>() + m->n[k], c->lm_tmp.p, sizeof(float4) * (size_t)n_add, hipMemcpyDeviceToDevice, st));
         m->n[k] += n_add;
     }
-    HIPCHK(c, hipStreamSynchronize(st));
     m->feature_point_num = m->n[0] + m->n[1] + m->n[2] + m->n[3] + m->n[4];
-    return update_bound(c, *m);
+    return update_bound(c, *m);                       // ends with the call's one wait for the stream
 }
 
 static int check_insert_args(lisreg_ctx* c, const char* who, const void* const clouds[5], const int n[5], int stride, int fmt)

@@ -988,8 +988,8 @@ __global__ __launch_bounds__(256) void k_pack_cloud(const unsigned char* __restr
 }
 
 // transformPointCloud (src/core/common.cpp:112-173): p' = R p + t, the fourth channel is copied
-__global__ __launch_bounds__(256) void k_transform_cloud(const float4* __restrict__ in, int n, const float* __restrict__ M12,
-                                                         float4* __restrict__ out)
+__device__ __forceinline__ void transform_cloud_point(const float4* __restrict__ in, int n, const float* __restrict__ M12,
+                                                      float4* __restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1005,6 +1005,11 @@ __global__ __launch_bounds__(256) void k_transform_cloud(const float4* __restric
     };
     out[i] = make_float4(row(0), row(1), row(2), p.w);
 }
+__global__ __launch_bounds__(256) void k_transform_cloud(const float4* __restrict__ in, int n, const float* __restrict__ M12,
+                                                         float4* __restrict__ out) { transform_cloud_point(in, n, M12, out); }
+// the same with the matrix as a kernel argument: nothing to upload, nothing to wait for
+__global__ __launch_bounds__(256) void k_transform_cloud_m(const float4* __restrict__ in, int n, Mat12 M, float4* __restrict__ out)
+{ transform_cloud_point(in, n, M.m, out); }
 
 }  // namespace
 
@@ -1164,6 +1169,18 @@ void launch_bbox_multi(const float4* cat, const VoxelMulti& m, float* bbox_out, 
     k_bbox_final_multi<<<m.k, 64, 0, st>>>(scratch, 64, bbox_out);
 }
 
+// the same for K clouds that live in buffers of their own
+__global__ __launch_bounds__(256) void k_bbox_partial_jobs(BboxJobs j, float* __restrict__ part)
+{
+    k_bbox_block(j.pts[blockIdx.y], j.n[blockIdx.y], part + (size_t)blockIdx.y * 6 * gridDim.x);
+}
+void launch_bbox_jobs(const BboxJobs& j, float* bbox_out, float* scratch, hipStream_t st)
+{
+    if (j.k <= 0) return;
+    k_bbox_partial_jobs<<<dim3(64, (unsigned)j.k), 256, 0, st>>>(j, scratch);
+    k_bbox_final_multi<<<j.k, 64, 0, st>>>(scratch, 64, bbox_out);
+}
+
 // slot[off[s]] for s = 0..k (the voxel count in front of every cloud of a joint sort) into k + 1 consecutive ints: one read-back
 __global__ void k_multi_bounds(const int* __restrict__ slot, VoxelMulti m, int* __restrict__ out)
 {
@@ -1202,6 +1219,12 @@ void launch_pack_cloud(const void* raw_dev, size_t n, int stride, int has_label,
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st)
 {
     if (n > 0) k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(in, n, M12_dev, out);
+}
+void launch_transform_cloud_m(const float4* in, int n, const float M12_host[12], float4* out, hipStream_t st)
+{
+    Mat12 M;
+    for (int i = 0; i < 12; ++i) M.m[i] = M12_host[i];
+    if (n > 0) k_transform_cloud_m<<<(n + 255) / 256, 256, 0, st>>>(in, n, M, out);
 }
 
 }  // namespace lisreg

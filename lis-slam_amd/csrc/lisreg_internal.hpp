@@ -199,6 +199,8 @@ void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, Sor
                        int* head, int* slot /* [n+1], slot[n] = number of voxels */, hipStream_t st);
 struct VoxelHandOut { int k; int vo[kVoxelMultiMax + 1]; float4* out[kVoxelMultiMax]; };
 void launch_bbox_multi(const float4* cat, const VoxelMulti& m, float* bbox_out /* [6 * k] */, float* scratch /* >= 6 * 64 * k floats */, hipStream_t st);
+struct BboxJobs { int k; int n[kVoxelMultiMax]; const float4* pts[kVoxelMultiMax]; };     // n == 0: the empty box (3e38, -3e38)
+void launch_bbox_jobs(const BboxJobs& j, float* bbox_out /* [6 * k] */, float* scratch /* >= 6 * 64 * k floats */, hipStream_t st);
 void launch_multi_bounds(const int* slot, const VoxelMulti& m, int* out /* [k + 1] */, hipStream_t st);
 void launch_hand_out(const float4* src, const VoxelHandOut& h, hipStream_t st);
 void launch_voxel_sort_multi(const float4* pts, int n, const VoxelMulti& m, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,
@@ -209,6 +211,8 @@ void launch_voxel_centroids(int n, int n_vox, const float4* pts, const uint32_t*
 // raw PCL structs already in device memory (n records of `stride` bytes) -> 16-byte records
 void launch_pack_cloud(const void* raw_dev, size_t n, int stride, int has_label, float4* out, hipStream_t st);
 void launch_transform_cloud(const float4* in, int n, const float* M12_dev, float4* out, hipStream_t st);
+struct Mat12 { float m[12]; };
+void launch_transform_cloud_m(const float4* in, int n, const float M12_host[12], float4* out, hipStream_t st);   // matrix by value
 // number of consecutive source points further apart than thr (coherence probe for sort_sources = auto)
 void launch_count_jumps(const BlockDesc* blocks, int n_blocks, const Segment* segs, float thr, int* jumps, hipStream_t st);
 // out[n+1] = exclusive scan of in[n] (out[n] = total); tmp: n/2048 + 4 ints
