@@ -812,9 +812,13 @@ constexpr int kWalkCap = 8;
             cx0_ = max(cx0_, hx_ - 1); cx1_ = min(cx1_, hx_ + 1); cy0_ = max(cy0_, hy_ - 1); cy1_ = min(cy1_, hy_ + 1); \
             sx0_ = cx0_; sx1_ = cx1_; sy0_ = cy0_; sy1_ = cy1_; \
         } \
+        /* kQ lanes per query: the columns of the box are dealt round-robin in box order (lane s takes columns s, s + kQ, ...), and every \
+           lane steps through ITS columns only — the probes of the kQ lanes are in flight together, a kQ-th of the dependent rounds */ \
+        const int nyb_ = cy1_ - cy0_ + 1; \
         int ix_ = cx0_, iy_ = cy0_; \
-        int ccol_ = 0; (void)ccol_; \
-        if (cz0_ > cz1_ || cy0_ > cy1_) ix_ = cx1_ + 1; \
+        /* an empty box first (a non-finite query has one: its cell coordinates saturate) — nothing below may step from there */ \
+        if (cz0_ > cz1_ || cy0_ > cy1_ || cx0_ > cx1_) ix_ = cx1_ + 1; \
+        else if (kQ > 1) { iy_ += sub_q; while (iy_ > cy1_) { iy_ -= nyb_; ++ix_; } } \
         while (ix_ <= cx1_) { \
             int cnt_ = 0; \
             /* phase 1: collect up to kWalkCap non-empty runs */ \
@@ -823,14 +827,13 @@ constexpr int kWalkCap = 8;
                 const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
                 const float dy_ = fmaxf(fmaxf(yl_ - qy, qy - (yl_ + g.cell)) - kEps, 0.f); \
                 const bool covered_ = (SKIP) && ix_ >= sx0_ && ix_ <= sx1_ && iy_ >= sy0_ && iy_ <= sy1_; \
-                /* kQ lanes per query: the columns of the pass are dealt round-robin (the box is the same for all of them) */ \
-                const bool mine_ = kQ == 1 || ((ccol_++) & (kQ - 1)) == sub_q; \
-                if (mine_ && !covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
+                if (!covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
                     const int base_ = (ix_ * g.ny + iy_) * g.nz; \
                     const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
                     if (js_ < je_) { s_runs[cnt_][tid] = make_int2(js_, je_); ++cnt_; } \
                 } \
-                if (++iy_ > cy1_) { iy_ = cy0_; ++ix_; } \
+                if (kQ == 1) { if (++iy_ > cy1_) { iy_ = cy0_; ++ix_; } } \
+                else { iy_ += kQ; while (iy_ > cy1_) { iy_ -= nyb_; ++ix_; } } \
             } \
             /* phase 2: one loop over all collected candidates */ \
             int r_ = 0, j_ = 0, e_ = 0; \
