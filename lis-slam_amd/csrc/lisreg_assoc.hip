@@ -796,11 +796,28 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 // per-column maxima.  Lists are flushed whenever a lane's list is full, which also re-prunes against the shrinking bound
 // during the wide early-iteration walks.  Same columns, same candidate order, same inserts: the result is identical.
 constexpr int kWalkCap = 8;
+constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of this length or more are shared by the kQ lanes
 // INNER: restrict this pass to the 3 x 3 columns around the query's own column and remember that box (sx0..sy1);
 // SKIP: leave out the columns of the remembered box (a preceding INNER pass covered them with a z-range at least as wide).
 // An INNER pass followed by a SKIP pass is the same walk centre-first: the bound is tight before the outer columns are
 // looked at, which then mostly fail the pruning test without touching memory (matters for the wide walks of the first
 // Gauss-Newton iterations, whose seeds are a pose step away from the truth).
+// four consecutive candidates j_ .. j_ + 3 of a run that ends at l_ (indices clamped into the run: a repeated candidate is a duplicate)
+#define LISREG_WALK_FOUR(j_, l_) do { \
+        const int j1_ = min((j_) + 1, (l_)), j2_ = min((j_) + 2, (l_)), j3_ = min((j_) + 3, (l_)); \
+        /* only x, y, z take part in the search: 12-byte loads (the original index in .w is read for the final five) */ \
+        const v3f c0_ = *(gptr_f3)(pts + (j_)), c1_ = *(gptr_f3)(pts + j1_), c2_ = *(gptr_f3)(pts + j2_), c3_ = *(gptr_f3)(pts + j3_); \
+        const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
+        const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
+        const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
+        const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
+        const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
+        const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
+        if (LISREG_GATE(fminf(fminf(e0_, e1_), fminf(e2_, e3_)))) { \
+            LISREG_TRY(e0_, (j_)); LISREG_TRY(e1_, j1_); LISREG_TRY(e2_, j2_); LISREG_TRY(e3_, j3_); \
+            LISREG_GROUP_TIES(e0_, (j_), e1_, j1_, e2_, j2_, e3_, j3_); \
+        } } while (0)
+
 #define LISREG_WALK_LIST(lim2_expr, INNER, SKIP) do { \
         const float lim_ = fminf(b4, (lim2_expr)); \
         const float rad_ = __builtin_amdgcn_sqrtf(lim_) * 1.0001f + kEps; \
@@ -819,7 +836,10 @@ constexpr int kWalkCap = 8;
         /* an empty box first (a non-finite query has one: its cell coordinates saturate) — nothing below may step from there */ \
         if (cz0_ > cz1_ || cy0_ > cy1_ || cx0_ > cx1_) ix_ = cx1_ + 1; \
         else if (kQ > 1) { iy_ += sub_q; while (iy_ > cy1_) { iy_ -= nyb_; ++ix_; } } \
-        while (ix_ <= cx1_) { \
+        for (;;) { \
+            /* kQ lanes per query: the group goes on while any of its lanes has columns left (its lanes share the candidates below) */ \
+            if (kQ == 1 || !kShare) { if (!(ix_ <= cx1_)) break; } \
+            else if (((__builtin_amdgcn_ballot_w64(ix_ <= cx1_) >> ((tid & 63) & ~(kQ - 1))) & ((1ull << kQ) - 1ull)) == 0ull) break; \
             int cnt_ = 0; \
             /* phase 1: collect up to kWalkCap non-empty runs */ \
             while (cnt_ < kWalkCap && ix_ <= cx1_) { \
@@ -836,24 +856,43 @@ constexpr int kWalkCap = 8;
                 else { iy_ += kQ; while (iy_ > cy1_) { iy_ -= nyb_; ++ix_; } } \
             } \
             /* phase 2: one loop over all collected candidates */ \
-            int r_ = 0, j_ = 0, e_ = 0; \
-            for (;;) { \
-                if (j_ >= e_) { if (r_ >= cnt_) break; const int2 t_ = s_runs[r_][tid]; j_ = t_.x; e_ = t_.y; ++r_; } \
-                const int l_ = e_ - 1; \
-                const int j1_ = min(j_ + 1, l_), j2_ = min(j_ + 2, l_), j3_ = min(j_ + 3, l_); \
-                /* only x, y, z take part in the search: 12-byte loads (the original index in .w is read for the final five) */ \
-                const v3f c0_ = *(gptr_f3)(pts + j_), c1_ = *(gptr_f3)(pts + j1_), c2_ = *(gptr_f3)(pts + j2_), c3_ = *(gptr_f3)(pts + j3_); \
-                const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
-                const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
-                const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
-                const float hx_ = qx - c3_.x, hy_ = qy - c3_.y, hz_ = qz - c3_.z; \
-                const float e0_ = ax_ * ax_ + ay_ * ay_ + az_ * az_, e1_ = bx_ * bx_ + by_ * by_ + bz_ * bz_; \
-                const float e2_ = gx_ * gx_ + gy_ * gy_ + gz_ * gz_, e3_ = hx_ * hx_ + hy_ * hy_ + hz_ * hz_; \
-                if (LISREG_GATE(fminf(fminf(e0_, e1_), fminf(e2_, e3_)))) { \
-                    LISREG_TRY(e0_, j_); LISREG_TRY(e1_, j1_); LISREG_TRY(e2_, j2_); LISREG_TRY(e3_, j3_); \
-                    LISREG_GROUP_TIES(e0_, j_, e1_, j1_, e2_, j2_, e3_, j3_); \
+            if (kQ == 1 || !kShare) { \
+                int r_ = 0, j_ = 0, e_ = 0; \
+                for (;;) { \
+                    if (j_ >= e_) { if (r_ >= cnt_) break; const int2 t_ = s_runs[r_][tid]; j_ = t_.x; e_ = t_.y; ++r_; } \
+                    LISREG_WALK_FOUR(j_, e_ - 1); \
+                    j_ += 4; \
                 } \
-                j_ += 4; \
+            } else { \
+                /* every lane its own SHORT runs; a long run — a column that holds a pole or a stretch of wall, hundreds of points — is \
+                   dealt out to all kQ lanes in groups of four candidates instead of keeping its lane busy alone */ \
+                bool long_ = false; \
+                { \
+                    int r_ = 0, j_ = 0, e_ = 0; \
+                    for (;;) { \
+                        if (j_ >= e_) { \
+                            if (r_ >= cnt_) break; \
+                            const int2 t_ = s_runs[r_][tid]; ++r_; \
+                            if (t_.y - t_.x >= kShareRun) { long_ = true; continue; } \
+                            j_ = t_.x; e_ = t_.y; \
+                        } \
+                        LISREG_WALK_FOUR(j_, e_ - 1); \
+                        j_ += 4; \
+                    } \
+                } \
+                if (((__builtin_amdgcn_ballot_w64(long_) >> ((tid & 63) & ~(kQ - 1))) & ((1ull << kQ) - 1ull)) != 0ull) { \
+                    __builtin_amdgcn_wave_barrier(); \
+                    _Pragma("unroll 1") for (int s_ = 0; s_ < kQ; ++s_) { \
+                        const int peer_ = (tid & ~(kQ - 1)) + s_; \
+                        const int pc_ = __shfl(long_ ? cnt_ : 0, ((tid & 63) & ~(kQ - 1)) + s_); \
+                        _Pragma("unroll 1") for (int r_ = 0; r_ < pc_; ++r_) { \
+                            const int2 t_ = s_runs[r_][peer_]; \
+                            if (t_.y - t_.x >= kShareRun) \
+                                _Pragma("unroll 1") for (int j_ = t_.x + 4 * sub_q; j_ < t_.y; j_ += 4 * kQ) LISREG_WALK_FOUR(j_, t_.y - 1); \
+                        } \
+                    } \
+                    __builtin_amdgcn_wave_barrier(); \
+                } \
             } \
         } } while (0)
 
@@ -1026,8 +1065,11 @@ constexpr int kWalkCap = 8;
 // few hundred waves on a chip with 8192 wave slots, i.e. one wave per SIMD with nothing to hide its dependent cell -> candidate
 // loads behind: there kQ = 8 lanes share one query (columns dealt round-robin, five-best lists merged by butterfly), which cuts
 // the serial chain of the walk by the same factor.  The five neighbours, and everything computed from them, are identical.
-template <bool kWide, bool kGraph, int kQ, bool kTies>
-__global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
+// kShare (kQ > 1 only): long candidate runs are shared by the kQ lanes of a query (LISREG_WALK_LIST); that variant needs ~90 registers, so it
+// runs four waves per SIMD — right for the few thousand wavefronts of a downsampled frame, wrong for a full 64 x 1800 sweep (14 k wavefronts),
+// which keeps the 64-register variant without sharing.  The launcher picks by size; the five neighbours are the same either way.
+template <bool kWide, bool kGraph, int kQ, bool kTies, bool kShare = false>
+__global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare ? 4 : 8, kShare ? 4 : 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
                                                         const ItemState* __restrict__ items, const DevParams P,
@@ -1363,7 +1405,14 @@ static void launch_assoc_impl(const BlockDesc* blocks, int n_blocks, const Segme
 {
     using namespace LISREG_ASSOC_NS;
     if (mode == 1 && lanes_q == 8) {
-        if (wide)
+        const bool share = n_blocks_q <= 2048;              // <= 8192 wavefronts: two generations at four waves per SIMD
+        if (wide && share)
+            k_assoc_walk<true, false, 8, kTies, true><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                                      first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+        else if (share)
+            k_assoc_walk<false, false, 8, kTies, true><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+        else if (wide)
             k_assoc_walk<true, false, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                                 first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
