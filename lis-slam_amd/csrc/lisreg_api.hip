@@ -285,7 +285,7 @@ void lisreg_destroy(lisreg_ctx* c)
                        &c->ft_picked, &c->ft_label, &c->ft_rlists, &c->ft_rcounts, &c->ft_lists, &c->ft_counts, &c->ft_rings,
                        &c->ft_gather, &c->ft_cat, &c->ft_bounds, &c->ft_dsk_tab, &c->ft_dsk_pts, &c->ft_dsk_misc, &c->ft_dsk_time };
     for (auto b : bufs) b->release();
-    for (auto& m : c->maps) { m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
+    for (auto& kv : c->maps) { auto& m = kv.second; m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
     for (auto& m : c->localmaps) { for (auto& b : m.cls) b.release(); m.tgt[0].release(); m.tgt[1].release(); }
     for (auto& r : c->keyrings) { for (auto& f : r.frames) { f.cloud[0].release(); f.cloud[1].release(); } r.cat[0].release(); r.cat[1].release(); r.tgt[0].release(); r.tgt[1].release(); }
     DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->exact_trig, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur };
@@ -777,6 +777,10 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     // thousands of workgroups (check every 3 iterations), a skipped launch of a single frame costs ~2 us (check every 6: one
     // round trip for the typical 3-6 iteration registration)
     const int chunk = c->early_stop_chunk > 0 ? c->early_stop_chunk : (c->n_blocks <= 1024 ? 6 : 3);
+    // sequential use: the last batch fetched from this context needed `last_launches` iterations — frames of a drive converge alike, so the
+    // first look is taken right there (a replay frame converges in 3: three no-op iterations, nine launches, not enqueued), later looks every 3
+    int next_check = chunk;
+    if (c->early_stop_chunk <= 0 && c->last_launches > 0) next_check = std::max(2, std::min(c->last_launches, chunk));
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
         (c->exact ? launch_assoc_exact : launch_assoc)(
@@ -793,10 +797,11 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                      c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
         prof_mark(c, -1);
         if (c->exact && it + 1 < c->prm.bound) { int rc = exact_pose_caches(c); if (rc) return rc; }
-        if (can_stop && (it + 1) % chunk == 0 && it + 1 < c->prm.bound) {
+        if (can_stop && it + 1 == next_check && it + 1 < c->prm.bound) {
             HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (*c->done_host >= c->n_items) break;
+            next_check += c->early_stop_chunk > 0 ? chunk : std::min(chunk, 3);
         }
     }
     launch_finalize(c->items.as<ItemState>(), c->n_items, c->prm, c->results.as<float>(), st);
@@ -832,8 +837,10 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_results.assign(c->fetch_host, c->fetch_host + res_floats);
     if (!c->ev.empty()) prof_collect(c);          // events of every profiled run since the last fetch (profiling may be off again by now)
+    c->last_launches = 0;
     for (int i = 0; i < c->n_items; ++i) {
         const float* r = &c->h_results[(size_t)i * kResultSize];
+        c->last_launches = std::max(c->last_launches, (int)r[6] + 1);
         if (T) memcpy(T + 6 * (size_t)i, r, 24);
         if (stats) {
             stats[i].iters = (int)r[6]; stats[i].deltaR = r[7]; stats[i].deltaT = r[8];

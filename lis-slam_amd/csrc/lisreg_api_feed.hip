@@ -212,10 +212,12 @@ int lisreg_upload_cloud(lisreg_ctx* c, const void* cloud, int n, int stride_byte
     const size_t bytes = sizeof(lisreg_dpoint) * (size_t)n;
     if (bytes > c->up_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        const size_t old_cap = c->up_cap;
         if (c->up_host) (void)hipHostFree(c->up_host);
         c->up_host = nullptr; c->up_cap = 0;
-        HIPCHK(c, hipHostMalloc((void**)&c->up_host, bytes + bytes / 4 + 4096, hipHostMallocDefault));
-        c->up_cap = bytes + bytes / 4 + 4096;
+        const size_t want = std::max(std::max(bytes + bytes / 4 + 4096, 2 * old_cap), (size_t)8 << 20);     // sweeps vary by a few per cent: no re-pinning per frame
+        HIPCHK(c, hipHostMalloc((void**)&c->up_host, want, hipHostMallocDefault));
+        c->up_cap = want;
     }
     lisreg_dpoint* host = reinterpret_cast<lisreg_dpoint*>(c->up_host);
     constexpr int kChunk = 16384;

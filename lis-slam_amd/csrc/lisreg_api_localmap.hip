@@ -33,7 +33,9 @@ int grow_keep(lisreg_ctx* c, DevBuf& b, size_t bytes, size_t keep)
 {
     if (bytes <= b.cap) return LISREG_OK;
     DevBuf nb;
-    HIPCHK(c, nb.ensure(bytes + bytes / 2));
+    // a class cloud of a sliding map: start at 16 MB (a million records) and double — a reallocation in the frame loop is a device-wide wait
+    // plus an allocation, 0.5 ms alone and tens of ms in a process that also hosts another HIP runtime user
+    HIPCHK(c, nb.ensure(std::max(std::max(bytes + bytes / 2, 2 * b.cap), (size_t)16 << 20)));
     if (keep > 0 && b.p) HIPCHK(c, hipMemcpyAsync(nb.p, b.p, keep, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     b.release();

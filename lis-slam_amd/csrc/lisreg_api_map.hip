@@ -95,8 +95,7 @@ int lisreg_map_index_set(lisreg_ctx* c, int slot, const void* cloud, int n, int 
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    if ((size_t)slot >= c->maps.size()) c->maps.resize((size_t)slot + 1);
-    MapIndex& m = c->maps[(size_t)slot];
+    MapIndex& m = c->maps[slot];
     m.valid = false;
     m.n = n;
     float bb[6] = { 0, 0, 0, 0, 0, 0 };
@@ -138,7 +137,7 @@ int lisreg_nearest(lisreg_ctx* c, int slot, const void* query, int n, int stride
                    float* sqd_out)
 {
     if (!c) return LISREG_ERR_ARG;
-    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+    if (slot < 0 || c->maps.count(slot) == 0 || !c->maps[slot].valid)
         return ctx_fail(c, LISREG_ERR_NO_TARGET, "nearest: no map index in this slot");
     int rc = check_cloud(c, query, n, stride, fmt, "nearest");
     if (rc) return rc;
@@ -147,7 +146,7 @@ int lisreg_nearest(lisreg_ctx* c, int slot, const void* query, int n, int stride
     if (n == 0) return LISREG_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const MapIndex& m = c->maps[(size_t)slot];
+    const MapIndex& m = c->maps[slot];
     const float4* q = nullptr;
     rc = stage_cloud(c, query, n, stride, fmt, &q);
     if (rc) return rc;
@@ -172,7 +171,7 @@ int lisreg_dynamic_filter(lisreg_ctx* c, int slot, const void* cloud, int n, int
                           float dist_thre_min, float dist_thre_max, float near_dist_thre, void* out, int* n_out)
 {
     if (!c) return LISREG_ERR_ARG;
-    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+    if (slot < 0 || c->maps.count(slot) == 0 || !c->maps[slot].valid)
         return ctx_fail(c, LISREG_ERR_NO_TARGET, "dynamic_filter: no map index in this slot");
     int rc = check_cloud(c, cloud, n, stride, fmt, "dynamic_filter");
     if (rc) return rc;
@@ -180,7 +179,7 @@ int lisreg_dynamic_filter(lisreg_ctx* c, int slot, const void* cloud, int n, int
     if (center_radius != center_radius || dist_thre_min != dist_thre_min || dist_thre_max != dist_thre_max || near_dist_thre != near_dist_thre)
         return bad(c, "dynamic_filter: NaN threshold");
     HIPCHK(c, hipSetDevice(c->device));
-    const MapIndex& m = c->maps[(size_t)slot];
+    const MapIndex& m = c->maps[slot];
     if (n <= 10 || m.n <= 0) {                      // subMap.h:1071-1072 returns false and leaves the cloud alone
         *n_out = n;
         rc = copy_through(c, cloud, n, stride, fmt, out);
@@ -253,7 +252,7 @@ int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int str
                      const float* guess, lisreg_icp_result* res, void* aligned_out)
 {
     if (!c) return LISREG_ERR_ARG;
-    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+    if (slot < 0 || c->maps.count(slot) == 0 || !c->maps[slot].valid)
         return ctx_fail(c, LISREG_ERR_NO_TARGET, "icp_align: no map index in this slot (setInputTarget)");
     int rc = check_cloud(c, source, n, stride, fmt, "icp_align");
     if (rc) return rc;
@@ -261,7 +260,7 @@ int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int str
     if (!(P->max_corr_dist >= 0) || P->max_iters < 1) return bad(c, "icp_align: bad max_corr_dist / max_iters");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const MapIndex& m = c->maps[(size_t)slot];
+    const MapIndex& m = c->maps[slot];
     const float4* src = nullptr;
     rc = stage_cloud(c, source, n, stride, fmt, &src);
     if (rc) return rc;
@@ -327,7 +326,7 @@ int lisreg_icp_gn_match(lisreg_ctx* c, int slot, const void* source, int n, int 
                         float max_correspond_distance, const float predict_pose[16], lisreg_icpgn_result* res, void* transformed_out)
 {
     if (!c) return LISREG_ERR_ARG;
-    if (slot < 0 || (size_t)slot >= c->maps.size() || !c->maps[(size_t)slot].valid)
+    if (slot < 0 || c->maps.count(slot) == 0 || !c->maps[slot].valid)
         return ctx_fail(c, LISREG_ERR_NO_TARGET, "icp_gn_match: no map index in this slot (SetTargetCloud)");
     int rc = check_cloud(c, source, n, stride, fmt, "icp_gn_match");
     if (rc) return rc;
@@ -335,7 +334,7 @@ int lisreg_icp_gn_match(lisreg_ctx* c, int slot, const void* source, int n, int 
     if (max_iterations > 100000u) return bad(c, "icp_gn_match: max_iterations out of range");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const MapIndex& m = c->maps[(size_t)slot];
+    const MapIndex& m = c->maps[slot];
     const float4* src = nullptr;
     rc = stage_cloud(c, source, n, stride, fmt, &src);
     if (rc) return rc;

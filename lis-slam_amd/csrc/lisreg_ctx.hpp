@@ -1,8 +1,10 @@
 // lisreg_ctx.hpp — the context behind the C ABI (shared by the lisreg_api*.hip translation units; not installed).
 #pragma once
+#include <algorithm>
 #include "lisreg_internal.hpp"
 
 #include <atomic>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -14,9 +16,12 @@ struct DevBuf {
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+        const size_t old_cap = cap;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
+        // doubling: a buffer that follows a growing map (the sliding local map, the key-frame ring) is reallocated a handful of times, not
+        // every few frames — hipFree waits for the device and hipMalloc costs 0.1-1 ms, which showed as spikes in the frame loops
+        size_t want = std::max(bytes + bytes / 4 + 256, 2 * old_cap);
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
@@ -117,7 +122,7 @@ struct lisreg_ctx {
     hipStream_t  copy_stream = nullptr;
     std::vector<lisreg::PackChunk> pack_chunks;
     std::vector<std::atomic<int>> pack_done;
-    std::vector<lisreg::MapIndex> maps;
+    std::map<int, lisreg::MapIndex> maps;             // by slot (sparse: the local maps keep theirs at 60000 + id)
     std::vector<lisreg::LocalMap> localmaps;
     std::vector<lisreg::KeyframeRing> keyrings;
     lisreg::DevBuf lm_in, lm_tmp, lm_bbox, exact_trig;
@@ -157,6 +162,7 @@ struct lisreg_ctx {
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch
     float     first_pass_r = 0.45f;
+    int       last_launches = 0;         // Gauss-Newton iterations the last fetched batch ran (its slowest item): where run_impl looks first
     int       wide_from = 0;
     int       wide_from_small = 1;       // the same for batches searched with eight lanes per query (single frames, sequential use): their
                                          // first guess is usually a frame step off, and the radius-limited first pass of the plain walk
