@@ -15,19 +15,25 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 
 namespace lisreg {
 
 struct PackPool {
+    // one packing job: the workers take chunk indices from `next` until they run out; a job object lives as long as anyone holds it, so a
+    // worker that wakes late (or is still leaving the previous job) never touches the tables of the next one
+    struct Job {
+        const PackChunk* chunks = nullptr;
+        std::atomic<int>* done = nullptr;      // done[i] = 1 once chunk i is in the staging buffer
+        int n_chunks = 0;
+        std::atomic<int> next{ 0 };
+    };
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv;
-    const PackChunk* chunks = nullptr;
-    std::atomic<int>* done = nullptr;          // done[i] = 1 once chunk i is in the staging buffer
-    int n_chunks = 0;
-    std::atomic<int> next{ 0 };
+    std::shared_ptr<Job> job;
     unsigned long long gen = 0;
     bool quit = false;
 
@@ -43,38 +49,44 @@ struct PackPool {
             o->payload = l;
         }
     }
-    void drain()
+    static void drain(Job& j)
     {
         for (;;) {
-            const int i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_chunks) return;
-            pack(chunks[i]);
-            done[i].store(1, std::memory_order_release);
+            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n_chunks) return;
+            pack(j.chunks[i]);
+            j.done[i].store(1, std::memory_order_release);
         }
     }
+    void drain() { std::shared_ptr<Job> j; { std::lock_guard<std::mutex> lk(mu); j = job; } if (j) drain(*j); }     // the publishing thread helps
     void worker()
     {
         unsigned long long seen = 0;
         for (;;) {
+            std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return quit || gen != seen; });
                 if (quit) return;
                 seen = gen;
+                j = job;
             }
-            drain();
+            if (j) drain(*j);
         }
     }
     void start(int n_threads)
     {
         for (int t = (int)th.size(); t < n_threads; ++t) th.emplace_back([this] { worker(); });
     }
-    // publish a job; the caller then waits on done[] in order (and may call drain() itself)
+    // publish a job; the caller then waits on done[] in order (and may call drain() itself).  The chunk table and the done flags must stay
+    // valid until every done flag is set — after that no worker reads them again (an index past n_chunks ends its loop)
     void run(const PackChunk* c, int n, std::atomic<int>* d)
     {
+        auto j = std::make_shared<Job>();
+        j->chunks = c; j->n_chunks = n; j->done = d;
         {
             std::lock_guard<std::mutex> lk(mu);
-            chunks = c; n_chunks = n; done = d; next.store(0, std::memory_order_relaxed);
+            job = std::move(j);
             ++gen;
         }
         cv.notify_all();
