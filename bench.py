@@ -478,6 +478,7 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
     torch.cuda.synchronize()
     dtp = time.perf_counter() - t0
     samep = bool(np.array_equal(a.T, T_ref))
+    by_engine, n_chunks = a.ctx.get_option("feeder_chunks_by_copy_engine"), a.ctx.get_option("feeder_chunks")
     # the upload alone (stage + wait), for the achieved link rate
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -488,10 +489,12 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
     return dict(value=round(n * ksteps / dtp, 2), unit="registrations/s", ms_per_step=round(1e3 * dtp / ksteps, 3), steps=ksteps,
                 h2d_struct_bytes_per_step=int(n_bytes), h2d_link_bytes_per_step=int(n_bytes // 2), d2h_bytes_per_step=int(n * 12 * 4),
                 note="pinned host PCL structs (32 B/pt) in, poses and stats out, every step, ONE context: lisreg_stage_host_items (feeder threads "
-                     "pack the structs to 16-byte records in pinned staging, chunks uploaded on a copy stream as they complete) for batch k+1 "
+                     "pack the structs to 16-byte records in pinned staging, chunks uploaded on a copy stream as they complete, the copy engine working the other end of the batch) for batch k+1 "
                      "runs underneath the kernels of batch k; then fetch(k), prepare + run(k+1).  The step includes the target index build and "
                      "10 GN iterations like `value` of the main line.  `in_series`: the synchronous lisreg_align_batch (stage, run, fetch back to back)",
                 poses_equal_device_resident_run=samep,
+                chunks_taken_by_copy_engine=f"{by_engine} of {n_chunks} in the last pipelined step (structs that cross as they are — 32 B per point — and are "
+                                            "packed on the device: the copy engine takes chunks from the far end of the batch whenever it is idle and the next packed chunk is not ready)",
                 stage_ms=round(1e3 * dtu, 3),
                 link_rate_GBps=round((n_bytes // 2) / dtu * 1e-9, 2),
                 link_rate_note="lisreg_stage_host_items alone, to completion: host packing of the structs (feeder threads) with the H2D copies of the 16-byte records following chunk by chunk; link bytes / that time — a lower bound of the achieved H2D rate",

@@ -899,6 +899,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!c || !name || !value) return LISREG_ERR_ARG;
     if (!strcmp(name, "search_mode")) { *value = c->search_mode; return LISREG_OK; }
     if (!strcmp(name, "exact_arithmetic")) { *value = c->exact ? 1 : 0; return LISREG_OK; }
+    if (!strcmp(name, "feeder_chunks_by_copy_engine")) { *value = c->pack_stolen; return LISREG_OK; }
+    if (!strcmp(name, "feeder_chunks")) { *value = c->pack_chunks_n; return LISREG_OK; }
     if (!strcmp(name, "canonical_ties")) { *value = (c->canonical_ties || c->exact) ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "index_build")) { *value = c->index_build; return LISREG_OK; }
     if (!strcmp(name, "index_build_now")) { *value = c->strip_now ? 1 : 0; return LISREG_OK; }

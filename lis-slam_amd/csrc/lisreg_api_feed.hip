@@ -28,7 +28,27 @@ struct PackPool {
         const PackChunk* chunks = nullptr;
         std::atomic<int>* done = nullptr;      // done[i] = 1 once chunk i is in the staging buffer
         int n_chunks = 0;
-        std::atomic<int> next{ 0 };
+        // chunks are handed out from both ends: the packing threads take the lowest index still free, the publishing thread may take the
+        // highest one for the copy engine (take_back); `span` = (front << 32) | back, free chunks are front .. back - 1
+        std::atomic<unsigned long long> span{ 0 };
+        int take_front()
+        {
+            unsigned long long v = span.load(std::memory_order_relaxed);
+            for (;;) {
+                const unsigned f = (unsigned)(v >> 32), b = (unsigned)v;
+                if (f >= b) return -1;
+                if (span.compare_exchange_weak(v, ((unsigned long long)(f + 1) << 32) | b, std::memory_order_relaxed)) return (int)f;
+            }
+        }
+        int take_back()
+        {
+            unsigned long long v = span.load(std::memory_order_relaxed);
+            for (;;) {
+                const unsigned f = (unsigned)(v >> 32), b = (unsigned)v;
+                if (f >= b) return -1;
+                if (span.compare_exchange_weak(v, ((unsigned long long)f << 32) | (b - 1), std::memory_order_relaxed)) return (int)(b - 1);
+            }
+        }
     };
     std::vector<std::thread> th;
     std::mutex mu;
@@ -52,8 +72,8 @@ struct PackPool {
     static void drain(Job& j)
     {
         for (;;) {
-            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= j.n_chunks) return;
+            const int i = j.take_front();
+            if (i < 0) return;
             pack(j.chunks[i]);
             j.done[i].store(1, std::memory_order_release);
         }
@@ -80,16 +100,18 @@ struct PackPool {
     }
     // publish a job; the caller then waits on done[] in order (and may call drain() itself).  The chunk table and the done flags must stay
     // valid until every done flag is set — after that no worker reads them again (an index past n_chunks ends its loop)
-    void run(const PackChunk* c, int n, std::atomic<int>* d)
+    std::shared_ptr<Job> run(const PackChunk* c, int n, std::atomic<int>* d)
     {
         auto j = std::make_shared<Job>();
         j->chunks = c; j->n_chunks = n; j->done = d;
+        j->span.store((unsigned long long)(unsigned)n, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(mu);
-            job = std::move(j);
+            job = j;
             ++gen;
         }
         cv.notify_all();
+        return j;
     }
     ~PackPool()
     {
@@ -171,9 +193,16 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         const void** dsts[2] = { &d.src_corner, &d.src_surf };
         for (int k = 0; k < 2; ++k) {
             *dsts[k] = dev + off;
+            // a cloud in pinned host memory can also cross the link as it is (the copy engine reads it) and be packed on the device
+            int pinned = 0;
+            if (cnts[k] > 0) {
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, srcs[k]) == hipSuccess && at.type == hipMemoryTypeHost) pinned = 1;
+                else (void)hipGetLastError();
+            }
             for (int s = 0; s < cnts[k]; s += kChunk)
                 chunks.push_back(PackChunk{ static_cast<const unsigned char*>(srcs[k]) + (size_t)s * (size_t)in.stride_bytes, host + off + s,
-                                            std::min(kChunk, cnts[k] - s), in.stride_bytes, in.fmt });
+                                            std::min(kChunk, cnts[k] - s), in.stride_bytes, in.fmt, pinned });
             off += (size_t)cnts[k];
         }
         d.fmt = LISREG_FMT_DEVICE; d.stride_bytes = (int)sizeof(lisreg_dpoint);
@@ -184,24 +213,66 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         for (int i = 0; i < n_chunks; ++i) c->pack_done[(size_t)i].store(0, std::memory_order_relaxed);
         // small batches are packed by the calling thread alone (a single odometry frame: waking threads costs more than it packs)
         const int want = total >= 262144 ? std::max(1, std::min(c->feeder_threads, (int)std::thread::hardware_concurrency() - 1)) : 0;
+        std::shared_ptr<PackPool::Job> job;
         if (want > 0) {
             if (!c->pack_pool) c->pack_pool = new PackPool();
             c->pack_pool->start(want);
-            c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data());
+            job = c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data());
         }
-        // copies follow the packing chunk by chunk, several chunks per copy (per-copy overhead is ~10 us; 4 MB copies run at link rate)
+        // Copies follow the packing chunk by chunk, several chunks per copy (per-copy overhead is ~10 us; 4 MB copies run at link rate).
+        // While the next packed chunk is not ready and the copy engine has nothing left to do, this thread hands the engine the LAST free
+        // chunk as it is — 32-byte structs over the link, packed by a kernel on the copy stream — so the two ends of the batch are worked
+        // on by the host threads and by the copy engine at once and the split follows their speeds (a contended host packs 2-3x slower
+        // than a quiet one; the engine's rate does not change).
         constexpr int kPerCopy = 4;
-        int next_copy = 0;
-        for (int i = 0; i < n_chunks; ++i) {
-            if (want > 0) { while (!c->pack_done[(size_t)i].load(std::memory_order_acquire)) std::this_thread::yield(); }
-            else PackPool::pack(chunks[(size_t)i]);
-            if (i + 1 - next_copy >= kPerCopy || i + 1 == n_chunks) {
+        int next_copy = 0, lowest_stolen = n_chunks;
+        size_t raw_off = 0;
+        unsigned char* raw_dev = nullptr;
+        for (int i = 0; i < lowest_stolen; ++i) {
+            if (want > 0) {
+                while (!c->pack_done[(size_t)i].load(std::memory_order_acquire)) {
+                    bool stole = false;
+                    if (job && chunks[(size_t)lowest_stolen - 1].pinned && hipStreamQuery(c->copy_stream) == hipSuccess) {
+                        const int k = job->take_back();
+                        if (k >= 0) {
+                            const PackChunk& ck = chunks[(size_t)k];
+                            const size_t bytes_k = (size_t)ck.n * (size_t)ck.stride;
+                            if (!raw_dev) {
+                                size_t worst = 0;
+                                for (int q = i; q < n_chunks; ++q) worst += (size_t)chunks[(size_t)q].n * (size_t)chunks[(size_t)q].stride + 64;
+                                HIPCHK(c, c->pack_raw[b].ensure(worst));
+                                raw_dev = static_cast<unsigned char*>(c->pack_raw[b].p);
+                            }
+                            HIPCHK(c, hipMemcpyAsync(raw_dev + raw_off, ck.src, bytes_k, hipMemcpyHostToDevice, c->copy_stream));
+                            launch_pack_cloud(raw_dev + raw_off, (size_t)ck.n, ck.stride, ck.fmt == LISREG_FMT_XYZIL ? 1 : 0,
+                                              reinterpret_cast<float4*>(dev + (ck.dst - host)), c->copy_stream);
+                            raw_off += (bytes_k + 63) & ~(size_t)63;
+                            lowest_stolen = k;
+                            stole = true;
+                            if (k <= i) break;                     // this very chunk went to the engine
+                        }
+                    } else (void)hipGetLastError();                // hipStreamQuery's "not ready" is not an error to keep
+                    if (!stole) std::this_thread::yield();
+                }
+                if (i >= lowest_stolen) break;
+            } else PackPool::pack(chunks[(size_t)i]);
+            if (i + 1 - next_copy >= kPerCopy || i + 1 == lowest_stolen) {
                 lisreg_dpoint* h0 = chunks[(size_t)next_copy].dst;
                 lisreg_dpoint* h1 = chunks[(size_t)i].dst + chunks[(size_t)i].n;
                 HIPCHK(c, hipMemcpyAsync(dev + (h0 - host), h0, sizeof(lisreg_dpoint) * (size_t)(h1 - h0), hipMemcpyHostToDevice, c->copy_stream));
                 next_copy = i + 1;
             }
         }
+        // packed chunks below the first stolen one that the loop left behind when it stopped
+        if (next_copy < lowest_stolen) {
+            for (int i = next_copy; i < lowest_stolen; ++i)
+                while (want > 0 && !c->pack_done[(size_t)i].load(std::memory_order_acquire)) std::this_thread::yield();
+            lisreg_dpoint* h0 = chunks[(size_t)next_copy].dst;
+            lisreg_dpoint* h1 = chunks[(size_t)lowest_stolen - 1].dst + chunks[(size_t)lowest_stolen - 1].n;
+            HIPCHK(c, hipMemcpyAsync(dev + (h0 - host), h0, sizeof(lisreg_dpoint) * (size_t)(h1 - h0), hipMemcpyHostToDevice, c->copy_stream));
+        }
+        HIPCHK(c, hipGetLastError());
+        c->pack_stolen = n_chunks - lowest_stolen; c->pack_chunks_n = n_chunks;
     }
     HIPCHK(c, hipEventRecord(c->pack_copied[b], c->copy_stream));
     c->pack_pending = c->pack_copied[b];          // the next batch_prepare makes the context's stream wait for it
@@ -235,7 +306,7 @@ int lisreg_upload_cloud(lisreg_ctx* c, const void* cloud, int n, int stride_byte
     constexpr int kChunk = 16384;
     std::vector<PackChunk> chunks;
     for (int s = 0; s < n; s += kChunk)
-        chunks.push_back(PackChunk{ static_cast<const unsigned char*>(cloud) + (size_t)s * (size_t)stride_bytes, host + s, std::min(kChunk, n - s), stride_bytes, fmt });
+        chunks.push_back(PackChunk{ static_cast<const unsigned char*>(cloud) + (size_t)s * (size_t)stride_bytes, host + s, std::min(kChunk, n - s), stride_bytes, fmt, 0 });
     const int n_chunks = (int)chunks.size();
     const int want = n >= 4 * kChunk ? std::max(0, std::min(std::min(c->feeder_threads, n_chunks - 1), (int)std::thread::hardware_concurrency() - 1)) : 0;
     if (want > 0) {

@@ -80,7 +80,7 @@ struct KeyframeRing {
 };
 
 struct PackPool;           // host feeder threads (lisreg_api_feed.hip)
-struct PackChunk { const unsigned char* src; lisreg_dpoint* dst; int n, stride, fmt; };      // <= 64 k points of one host cloud
+struct PackChunk { const unsigned char* src; lisreg_dpoint* dst; int n, stride, fmt; int pinned; };      // <= 64 k points of one host cloud; pinned: the DMA engine may read src
 
 struct RcclApi {
     void* handle = nullptr;
@@ -113,6 +113,8 @@ struct lisreg_ctx {
     unsigned char* pack_host[2] = { nullptr, nullptr };
     size_t       pack_cap[2] = { 0, 0 };
     lisreg::DevBuf pack_dev[2];
+    int            pack_stolen = 0, pack_chunks_n = 0;   // last lisreg_stage_host_items: chunks the copy engine took / all chunks
+    lisreg::DevBuf pack_raw[2];                // structs that crossed the link as they are (chunks the copy engine took over), packed on the device
     unsigned char* up_host = nullptr;          // pinned staging of lisreg_upload_cloud
     size_t         up_cap = 0;
     hipEvent_t   pack_copied[2] = { nullptr, nullptr };   // the uploads into device buffer b are done (recorded on copy_stream)
