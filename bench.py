@@ -94,6 +94,16 @@ def main():
     import lisreg
     from lisreg import synth, synth_torch
 
+    # The contract is ONE JSON line on stdout.  RCCL writes a five-line version banner to file descriptor 1 when its first communicator
+    # comes up (N > 1 ranks), so everything below runs with fd 1 pointing at stderr; emit_json() writes the line to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit_json(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,7 +153,7 @@ def main():
             dist.barrier(); dist.destroy_process_group()
         if out is not None:
             out.update(n_gpus=1, scaling="replicas only (a sequential drive does not shard)")
-            print(json.dumps(out), flush=True)
+            emit_json(out)
         return
 
     H, W, M_SUBMAP, BATCH, ITERS, own_targets, wl_desc = WORKLOADS[args.workload]
@@ -376,7 +386,7 @@ def main():
             ctypes.CDLL(None).fflush(None)  # C-level buffers (RCCL prints its version banner through stdio)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        emit_json(out)
 
 
 def host_cores():
