@@ -267,21 +267,24 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ el
     tmp_idx[pos] = i;
 }
 
-// final position of scattered slot p inside its bucket: rank by (sub-key, original index)
+// final position of scattered slot p inside its bucket: rank by (sub-key, original index).  kOneKey: every element of the bucket has the
+// same sub-key (a voxel grid whose buckets are single voxels — span 1: the key-frame ring's 1 M points, ~25 per voxel), so the original
+// index alone decides and the loop reads one array instead of two
+template <bool kOneKey = false>
 __device__ __forceinline__ int rank_in_bucket(int p, const uint32_t* __restrict__ tmp_bucket,
                                               const uint32_t* __restrict__ tmp_sub, const int* __restrict__ tmp_idx,
                                               const int* __restrict__ bucket_start, int* idx_out)
 {
     const uint32_t b = tmp_bucket[p];
     const int s = bucket_start[b], e = bucket_start[b + 1];
-    const uint32_t sub = tmp_sub[p];
+    const uint32_t sub = kOneKey ? 0u : tmp_sub[p];
     const int idx = tmp_idx[p];
     int rank = 0;
 #pragma unroll 8
     for (int j = s; j < e; ++j) {
-        const uint32_t sj = tmp_sub[j];
         const int ij = tmp_idx[j];
-        rank += (sj < sub || (sj == sub && ij < idx)) ? 1 : 0;
+        if (kOneKey) rank += ij < idx ? 1 : 0;
+        else { const uint32_t sj = tmp_sub[j]; rank += (sj < sub || (sj == sub && ij < idx)) ? 1 : 0; }
     }
     *idx_out = idx;
     return s + rank;
@@ -795,7 +798,8 @@ __global__ __launch_bounds__(256) void k_voxel_rank(int n, uint32_t span, const 
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     int e;
-    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
+    const int dst = span == 1u ? rank_in_bucket<true>(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e)
+                               : rank_in_bucket<false>(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
     order[dst] = e;
     sidx[dst] = tmp_bucket[p] * span + tmp_sub[p];
 }
@@ -807,13 +811,14 @@ __global__ __launch_bounds__(256) void k_voxel_rank_multi(int n, VoxelMulti m, c
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    int e;
-    const int dst = rank_in_bucket(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
-    order[dst] = e;
     const uint32_t b = tmp_bucket[p];
     int s = 0;
 #pragma unroll
     for (int k = 1; k < kVoxelMultiMax; ++k) if (k < m.k && b >= (uint32_t)m.bucket_base[k]) s = k;
+    int e;
+    const int dst = m.d[s].span == 1u ? rank_in_bucket<true>(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e)
+                                      : rank_in_bucket<false>(p, tmp_bucket, tmp_sub, tmp_idx, bucket_start, &e);
+    order[dst] = e;
     // joint voxel index: ascends through the sorted sequence and changes exactly where the voxel (or the cloud) changes
     sidx[dst] = m.idx_base[s] + (b - (uint32_t)m.bucket_base[s]) * m.d[s].span + tmp_sub[p];
 }
