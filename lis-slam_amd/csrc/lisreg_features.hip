@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
     __shared__ int   s_picked[kMaxRingPts];
     __shared__ float s_curv[kMaxRingPts];
     __shared__ int   s_col[kMaxRingPts];
-    __shared__ float s_val[kMaxSector];
-    __shared__ int   s_ind[kMaxSector];
+    __shared__ float s_val[6 * kMaxSector];          // the six sectors of the ring, each padded to SP entries, sorted together
+    __shared__ int   s_ind[6 * kMaxSector];
 
     const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves sort, wave 0 picks
     // the extracted cloud this ring belongs to: [base, size) — the whole cloud for one sweep, the sweep's own slice in a batch
@@ -145,32 +145,43 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
     for (int k = lo + tid; k < hi; k += 256) { s_picked[k - lo] = fb.picked[k]; s_curv[k - lo] = fb.curv[k]; s_col[k - lo] = fb.col[k]; }
     __syncthreads();
 
+    // std::sort of every sector's curvatures (:620) — the six sorts are independent of the picking, so they run as ONE bitonic network
+    // over the six sectors side by side (each padded to SP entries, the largest sector's power of two): 45 barriers for a 1800-column ring
+    // instead of 270, every thread busy in every stage
+    int SP = 1;
+    for (int j = 0; j < 6; ++j) {
+        const int sp = (startRing * (6 - j) + endRing * j) / 6, ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
+        while (SP < ep - sp) SP <<= 1;
+    }
+    for (int j = 0; j < 6; ++j) {
+        const int sp = (startRing * (6 - j) + endRing * j) / 6, ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
+        const int m = max(ep - sp, 0);                                 // std::sort range [sp, ep)
+        for (int t = tid; t < SP; t += 256) {
+            s_val[j * SP + t] = t < m ? s_curv[sp + t - lo] : 3.0e38f;
+            s_ind[j * SP + t] = t < m ? sp + t : 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    // bitonic sort ascending by (value, index), every sector inside its own aligned block of SP entries
+    for (int ksz = 2; ksz <= SP; ksz <<= 1)
+        for (int jj = ksz >> 1; jj > 0; jj >>= 1) {
+            for (int pr = tid; pr < 3 * SP; pr += 256) {                // 6 SP / 2 pairs
+                const int t = ((pr / jj) * 2 * jj) + (pr % jj), u = t + jj;
+                const float va = s_val[t], vb = s_val[u];
+                const int ia = s_ind[t], ib = s_ind[u];
+                const bool a_gt_b = va > vb || (va == vb && ia > ib);
+                const bool up = ((t & (SP - 1)) & ksz) == 0;           // the direction bit of the index INSIDE the sector (the last merge: all ascending)
+                if (a_gt_b == up) { s_val[t] = vb; s_val[u] = va; s_ind[t] = ib; s_ind[u] = ia; }
+            }
+            __syncthreads();
+        }
+    if (wave != 0) return;                                             // the picking below is one wavefront's work; no barrier follows
+
     for (int j = 0; j < 6; ++j) {
         const int sp = (startRing * (6 - j) + endRing * j) / 6;
         const int ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
         if (sp >= ep) continue;                                        // wave-uniform
-        const int m = ep - sp;                                         // std::sort range [sp, ep)
-        int np2 = 1; while (np2 < m) np2 <<= 1;
-        for (int t = tid; t < np2; t += 256) {
-            s_val[t] = t < m ? s_curv[sp + t - lo] : 3.0e38f;
-            s_ind[t] = t < m ? sp + t : 0x7fffffff;
-        }
-        __syncthreads();
-        // bitonic sort ascending by (value, index)
-        for (int ksz = 2; ksz <= np2; ksz <<= 1)
-            for (int jj = ksz >> 1; jj > 0; jj >>= 1) {
-                for (int t = tid; t < np2; t += 256) {
-                    const int u = t ^ jj;
-                    if (u > t) {
-                        const float va = s_val[t], vb = s_val[u];
-                        const int ia = s_ind[t], ib = s_ind[u];
-                        const bool a_gt_b = va > vb || (va == vb && ia > ib);
-                        const bool up = (t & ksz) == 0;
-                        if (a_gt_b == up) { s_val[t] = vb; s_val[u] = va; s_ind[t] = ib; s_ind[u] = ia; }
-                    }
-                }
-                __syncthreads();
-            }
+        const int* s_sorted = s_ind + j * SP;                           // this sector's indices, ascending by (curvature, index)
         // The greedy passes are sequential in the SORTED order, but a candidate only costs time when it is picked:
         // every lane holds one sorted candidate, ballot + ffs finds the next one that qualifies and is still unpicked,
         // that lane marks itself and its +-5 neighbours in LDS, and candidates suppressed meanwhile are skipped for
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
             for (int kb = ep; kb >= sp && !stop; kb -= 64) {
                 const int k = kb - lane;
                 const bool inr = k >= sp;
-                const int ind = inr ? ((k == ep) ? ep : s_ind[k - sp]) : lo;   // element ep lies outside the sorted range
+                const int ind = inr ? ((k == ep) ? ep : s_sorted[k - sp]) : lo;   // element ep lies outside the sorted range
                 const bool stat = inr && s_curv[ind - lo] > P.edge_threshold;
                 unsigned long long todo = __ballot(stat);
                 while (todo) {
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
             for (int kb = sp; kb <= ep; kb += 64) {
                 const int k = kb + lane;
                 const bool inr = k <= ep;
-                const int ind = inr ? ((k == ep) ? ep : s_ind[k - sp]) : lo;
+                const int ind = inr ? ((k == ep) ? ep : s_sorted[k - sp]) : lo;
                 const bool stat = inr && s_curv[ind - lo] < P.surf_threshold;
                 unsigned long long todo = __ballot(stat);
                 while (todo) {
@@ -243,7 +254,6 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
         }
 #undef LISREG_SUPPRESS
         }   // wave 0
-        __syncthreads();
     }
     if (tid == 0) {
         int* c = fb.ring_counts + ring * 4;
