@@ -363,6 +363,10 @@ typedef struct lisreg_semantic_out {
 int  lisreg_semantic_split(lisreg_ctx* ctx, const void* cloud, int n, int stride_bytes, int fmt,
                            const uint32_t* using_label /* [32] or NULL */, lisreg_semantic_out* out);
 
+/* `*a += *b` for device records: the K (<= 8) clouds end to end into `out` (capacity >= the sum), one launch on the context's stream;
+ * the call does not wait, every later call of this context is ordered behind it.  *n_out = the total (may be NULL). */
+int  lisreg_concat_device(lisreg_ctx* ctx, int k, const void* const* in, const int* n, void* out, int* n_out);
+
 /* One host cloud (the reference's PCL structs: LISREG_FMT_XYZI, or LISREG_FMT_XYZIL whose uint16 at byte 20 — label, or the ring of a
  * raw sweep — becomes the payload) into a caller-owned device buffer of n 16-byte lisreg_dpoint records, through a pinned staging buffer
  * packed by the feeder threads; returns when the records are in HBM.  What a node's callback does first with a sensor_msgs cloud

@@ -1271,9 +1271,15 @@ int lisreg_voxel_downsample_multi(lisreg_ctx* c, int k, const void* const* in, c
     float4* cat = c->vox_in.as<float4>();
     for (int s = 0, o = 0; s < k; ++s) {
         m.off[s] = o;
-        if (n[s] > 0) HIPCHK(c, hipMemcpyAsync(cat + o, in[s], sizeof(float4) * (size_t)n[s], hipMemcpyDeviceToDevice, st));
         o += n[s];
         m.off[s + 1] = o;
+    }
+    {
+        BboxJobs jobs;
+        memset(&jobs, 0, sizeof jobs);
+        jobs.k = k;
+        for (int s = 0; s < k; ++s) { jobs.pts[s] = static_cast<const float4*>(in[s]); jobs.n[s] = n[s]; }
+        launch_concat_jobs(jobs, m, cat, st);                  // one launch instead of K copies
     }
     launch_bbox_multi(cat, m, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), st);
     float bb[6 * kVoxelMultiMax];
@@ -1348,6 +1354,31 @@ int lisreg_voxel_downsample_multi(lisreg_ctx* c, int k, const void* const* in, c
     launch_hand_out(c->vox_out.as<float4>(), ho, st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));           // like the single-cloud call: the outputs are complete on return
+    return LISREG_OK;
+}
+
+// pcl's `*cloud += *other` for device records: K clouds end to end into `out` (one launch on the context's stream, nothing waited for —
+// every later call of this context is ordered behind it).  currentCloudInit's surf source = dynamic + building + ground (:866-889).
+int lisreg_concat_device(lisreg_ctx* c, int k, const void* const* in, const int* n, void* out, int* n_out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (k < 0 || k > kVoxelMultiMax || (k > 0 && (!in || !n))) return fail(c, LISREG_ERR_ARG, "concat_device: bad arguments (at most 8 clouds)");
+    VoxelMulti m;
+    BboxJobs jobs;
+    memset(&m, 0, sizeof m); memset(&jobs, 0, sizeof jobs);
+    m.k = jobs.k = k;
+    long long total = 0;
+    for (int s = 0; s < k; ++s) {
+        if (n[s] < 0 || (n[s] > 0 && !in[s])) return fail(c, LISREG_ERR_ARG, "concat_device: NULL cloud with n > 0");
+        m.off[s] = (int)total; jobs.pts[s] = static_cast<const float4*>(in[s]); jobs.n[s] = n[s];
+        total += n[s];
+    }
+    if (total > 2000000000LL || (total > 0 && !out)) return fail(c, LISREG_ERR_ARG, "concat_device: bad output");
+    m.off[k] = (int)total;
+    if (n_out) *n_out = (int)total;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_concat_jobs(jobs, m, static_cast<float4*>(out), c->stream);
+    HIPCHK(c, hipGetLastError());
     return LISREG_OK;
 }
 

@@ -1186,6 +1186,21 @@ void launch_bbox_jobs(const BboxJobs& j, float* bbox_out, float* scratch, hipStr
     k_bbox_final_multi<<<j.k, 64, 0, st>>>(scratch, 64, bbox_out);
 }
 
+// K clouds copied end to end into one array (cloud s to [off[s], off[s + 1])) by one launch
+__global__ __launch_bounds__(256) void k_concat_jobs(BboxJobs j, VoxelMulti m, float4* __restrict__ cat)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m.off[m.k]) return;
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < kVoxelMultiMax; ++q) if (q < m.k && i >= m.off[q]) s = q;
+    cat[i] = j.pts[s][i - m.off[s]];
+}
+void launch_concat_jobs(const BboxJobs& j, const VoxelMulti& m, float4* cat, hipStream_t st)
+{
+    if (m.off[m.k] > 0) k_concat_jobs<<<(m.off[m.k] + 255) / 256, 256, 0, st>>>(j, m, cat);
+}
+
 // slot[off[s]] for s = 0..k (the voxel count in front of every cloud of a joint sort) into k + 1 consecutive ints: one read-back
 __global__ void k_multi_bounds(const int* __restrict__ slot, VoxelMulti m, int* __restrict__ out)
 {

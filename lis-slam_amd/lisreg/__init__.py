@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_concat_device", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_voxel_downsample_multi", "lisreg_transform_cloud",
@@ -195,6 +195,7 @@ def lib():
         L.lisreg_batch_result_device.restype = vp
         L.lisreg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.lisreg_upload_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.lisreg_concat_device.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), vp, C.POINTER(C.c_int)]
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
         L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -577,6 +578,15 @@ class Context:
                 setattr(fos[s], k, C.c_void_p(ptr)); setattr(fos[s], "cap_" + k, cap)
         self._chk(self._L.lisreg_extract_features_batch(self._h, S, ptrs, ns, C.byref(params), fos))
         return [{k: getattr(fos[s], "n_" + k) for k in ("deskewed", "corner", "surface", "corner_sharp", "surface_sharp")} for s in range(S)]
+
+    def concat_device(self, in_ptrs, counts, out_ptr: int) -> int:
+        """lisreg_concat_device: K device clouds end to end into out_ptr (stream-ordered, no wait).  Returns the total count."""
+        k = len(in_ptrs)
+        p = (C.c_void_p * k)(*[C.c_void_p(int(x)) for x in in_ptrs])
+        n = (C.c_int * k)(*[int(x) for x in counts])
+        tot = C.c_int(0)
+        self._chk(self._L.lisreg_concat_device(self._h, k, p, n, C.c_void_p(int(out_ptr)), C.byref(tot)))
+        return tot.value
 
     def upload_cloud(self, cloud: np.ndarray, dev_ptr: int) -> int:
         """lisreg_upload_cloud: a host PCL struct array (x, y, z at 0 / 4 / 8; the uint16 at byte 20 — label or ring — becomes the

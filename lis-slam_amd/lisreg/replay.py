@@ -382,10 +382,7 @@ class DeviceReplayer(Replayer):
                 self.T_last = self.T.copy()
             info = self.ctx.localmap_extract(self.map_id, guess, self.lm_params, self.slot)
             # currentCloudInit (:866-889): corner = pole; surf = dynamic + building + ground
-            off = 0
-            for k in (0, 2, 1):
-                self.src_s.copy_from_device(self.down[k].ptr, 16 * nd[k], 16 * off)
-                off += nd[k]
+            off = self.ctx.concat_device([self.down[k].ptr for k in (0, 2, 1)], [nd[k] for k in (0, 2, 1)], self.src_s.ptr)
             T, st = self.ctx.align_device(self.down[3].ptr, nd[3], self.src_s.ptr, off, guess, self.params)
             self.T = T.astype(np.float32)
             rec.update(T=self.T.copy(), guess=guess.copy(), stats=st, n_target_corner=info["n_target_corner"],

@@ -99,3 +99,18 @@ def test_localmap_extract_with_empty_classes(oracle, gpu_ctx):
     far = np.array([0, 0, 0, 500.0, 500.0, 0.0], np.float32)        # the crop box 500 m away: nothing survives, nothing faults
     info = gpu_ctx.localmap_extract(9, far, lm, target_slot=3)
     assert info["n_target_surf"] == 0 and info["n_target_corner"] == 0 and sum(info["n"]) == 0
+
+
+def test_concat_device_equals_numpy(gpu_ctx):
+    """lisreg_concat_device: K clouds end to end (empty ones among them), stream-ordered before the next call of the context."""
+    import lisreg
+    rng = np.random.default_rng(5)
+    parts = [rng.normal(size=(n, 4)).astype(np.float32) for n in (1000, 0, 1, 70001)]
+    devs = [lisreg.DeviceArray(p if len(p) else np.zeros((1, 4), np.float32)) for p in parts]
+    out = lisreg.DeviceArray(np.zeros((sum(len(p) for p in parts), 4), np.float32))
+    tot = gpu_ctx.concat_device([d.ptr for d in devs], [len(p) for p in parts], out.ptr)
+    assert tot == sum(len(p) for p in parts)
+    gpu_ctx.upload_cloud(np.zeros(1, np.dtype({"names": ["x", "y", "z"], "formats": ["<f4"] * 3, "offsets": [0, 4, 8], "itemsize": 16})), devs[2].ptr)   # a later call: waits for the stream
+    assert np.array_equal(out.download(tot).view(np.uint32), np.concatenate(parts).view(np.uint32))
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.concat_device([0] * 9, [0] * 9, out.ptr)
