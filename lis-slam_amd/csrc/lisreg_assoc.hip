@@ -781,11 +781,15 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 // candidate that falls first.  Cost (measured): ~170 vector instructions per wavefront, +7 % on a steady-state launch.
 #define LISREG_GROUP_TIES(e0_, k0_, e1_, k1_, e2_, k2_, e3_, k3_) do { if (kTies) { \
         /* bitwise, not short-circuit: a dozen compares into lane masks and scalar ors, no branches */ \
-        const bool t_ = (int)(b0 == b1) | (int)(b1 == b2) | (int)(b2 == b3) | (int)(b3 == b4) | \
-                        ((int)((e0_) == b4) & (int)((k0_) != i4)) | ((int)((e1_) == b4) & (int)((k1_) != i4)) | \
-                        ((int)((e2_) == b4) & (int)((k2_) != i4)) | ((int)((e3_) == b4) & (int)((k3_) != i4)); \
-        tie = (int)tie | ((int)t_ & (int)(i4 >= 0)); } } while (0)
-#define LISREG_LIST_TIES() do { if (kTies) tie = (int)tie | ((int)(i4 >= 0) & ((int)(b0 == b1) | (int)(b1 == b2) | (int)(b2 == b3) | (int)(b3 == b4))); } while (0)
+        /* (2) between REAL entries only (empty slots all carry tau), whether or not the list is full yet: a pair that ties while the list \
+           still has room can lose its second member to closer candidates of a later group — the member that stays must be the canonical one */ \
+        const bool t_ = ((int)(b0 == b1) & (int)(i1 >= 0)) | ((int)(b1 == b2) & (int)(i2 >= 0)) | ((int)(b2 == b3) & (int)(i3 >= 0)) | \
+                        ((int)(b3 == b4) & (int)(i4 >= 0)) | \
+                        ((int)(i4 >= 0) & (((int)((e0_) == b4) & (int)((k0_) != i4)) | ((int)((e1_) == b4) & (int)((k1_) != i4)) | \
+                                           ((int)((e2_) == b4) & (int)((k2_) != i4)) | ((int)((e3_) == b4) & (int)((k3_) != i4)))); \
+        tie = (int)tie | (int)t_; } } while (0)
+#define LISREG_LIST_TIES() do { if (kTies) tie = (int)tie | ((int)(b0 == b1) & (int)(i1 >= 0)) | ((int)(b1 == b2) & (int)(i2 >= 0)) | \
+                                                  ((int)(b2 == b3) & (int)(i3 >= 0)) | ((int)(b3 == b4) & (int)(i4 >= 0)); } while (0)
 // the "nothing closer" gate of a group: with kTies a candidate AT the bound has to be looked at too
 #define LISREG_GATE(m_) (kTies ? (m_) <= b4 : (m_) < b4)
 
@@ -1035,7 +1039,9 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
         b1 = c1_ ? (c0_ ? b0 : (d2_)) : b1;  i1 = c1_ ? (c0_ ? i0 : (j_)) : i1;  o1 = c1_ ? (c0_ ? o0 : (o_)) : o1; \
         b0 = c0_ ? (d2_) : b0;               i0 = c0_ ? (j_) : i0;               o0 = c0_ ? (o_) : o0; } while (0)
 #define LISREG_CANONICAL_FIVE() do { if (kTies) { \
-        if (kQ > 1) { _Pragma("unroll") for (int d_ = 1; d_ < kQ; d_ <<= 1) tie = tie || __shfl_xor((int)tie, d_) != 0; } \
+        /* no short-circuit here: a lane that skipped the exchange because its own note is set would be INACTIVE in it, and the lanes \
+           reading from it would get nothing — the one lane that saw the tie is exactly the one the others have to hear from */ \
+        if (kQ > 1) { _Pragma("unroll") for (int d_ = 1; d_ < kQ; d_ <<= 1) { const int o_ = __shfl_xor((int)tie, d_); tie = (int)tie | (int)(o_ != 0); } } \
         LISREG_LIST_TIES(); \
         if (tie && i4 >= 0) { \
             const float lim_ = b4; \

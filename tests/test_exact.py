@@ -6,7 +6,7 @@ sums, the pose cache's sin / cos from the host's libm) is the parity anchor: its
   * correspondence count of every Gauss-Newton iteration: equal (no "within a few threshold straddlers");
   * per-point accept flags (the `flag[i] = true` of cornerOptimization / surfOptimization, odomEstimationNode.cpp:734, :814)
     at the first, second and last iteration: equal, element for element;
-  * poses of every iteration: within 2e-6 (they are bit-identical in most runs: the only arithmetic left that is not the
+  * poses of every iteration: within two float steps of the component (they are bit-identical in 300 of 300 swept configurations: the only arithmetic left that is not the
     oracle's own is the ORDER of the fp64 sums of AtA / AtB, ~1e-16 relative before the single rounding to float).
 
 The production build is then compared with the exact one at identical poses (GN iteration 0, same initial guess): every
@@ -62,6 +62,15 @@ def oracle_flags(oracle, case, p_o, T):
     return np.concatenate([fc, fs]).astype(bool)
 
 
+def pose_ulps(a, b):
+    """Largest component difference of two poses in units of the float spacing at that component's magnitude (at least the spacing at 1).
+    The exact build's poses are the oracle's to the bit in 300 of 300 swept configurations (tests/exact_sweep.py); the allowance of two
+    steps is for the order of the fp64 sums of AtA / AtB before their single rounding to float, which no test has needed so far."""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    mag = np.maximum(np.maximum(np.abs(a), np.abs(b)), np.float32(1.0))
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(mag).astype(np.float64)))
+
+
 def check_exact(oracle, lisreg, case, p_o, imu, degenerate_in=0):
     p_g = copy_params(p_o, lisreg.Params)
     To, so, tro = oracle.align(case["tgt_corner"], case["tgt_surf"], case["src_corner"], case["src_surf"], case["T_init"],
@@ -81,9 +90,8 @@ def check_exact(oracle, lisreg, case, p_o, imu, degenerate_in=0):
     for k in range(len(tro)):
         r, t = pose_err(trg[k, 49:55], tro[k, 49:55])
         worst = max(worst, r, t)
-    assert worst <= 2e-6, worst
-    r, t = pose_err(Tg, To)
-    assert max(r, t) <= 2e-6
+        assert pose_ulps(trg[k, 49:55], tro[k, 49:55]) <= 2.0, (k, trg[k, 49:55], tro[k, 49:55])
+    assert pose_ulps(Tg, To) <= 2.0
     if so["status"] != 0 or len(tro) == 0:
         return worst, 0
     # per-point accept flags at the first, second and last iteration, at the ORACLE's pose of that iteration
@@ -104,7 +112,9 @@ def check_exact(oracle, lisreg, case, p_o, imu, degenerate_in=0):
 
 # 130: the configuration where a device-computed cosine (1 ulp from libm's) swapped two 5th-place candidates 8e-7 apart — the reason the
 # exact build takes the pose's sines / cosines from the host's libm; its poses must now be the oracle's to the bit
-@pytest.mark.parametrize("seed", list(range(12)) + [130])
+# 330, 371: an exact tie at the fifth place seen by ONE of the eight lanes of a query — the note has to reach the other seven (the exchange
+# was short-circuited once: the lane that held the note sat out of it) and a tied pair may enter a list that is not full yet
+@pytest.mark.parametrize("seed", list(range(12)) + [130, 330, 371])
 def test_exact_build_equals_oracle_on_the_sweep(oracle, seed):
     import lisreg
     case, variant, fixed, imu = sweep_case(seed)
@@ -112,7 +122,7 @@ def test_exact_build_equals_oracle_on_the_sweep(oracle, seed):
     p_o.fixed_iters = fixed
     worst, n = check_exact(oracle, lisreg, case, p_o, imu)
     print(f"[exact] sweep seed {seed}: worst pose difference over all iterations {worst:.2e}, {n} accept flags equal")
-    if seed == 130:
+    if seed >= 100:
         assert worst == 0.0
 
 
@@ -201,7 +211,7 @@ def test_exact_build_equals_oracle_at_full_size(oracle):
         assert np.array_equal(trg[:, 0], tro[:, 0]), (trg[:, 0], tro[:, 0])
         worst = max(max(pose_err(trg[k, 49:55], tro[k, 49:55])) for k in range(10))
         print(f"[exact] 64x1800 vs {m_points}: n_corr per iteration equal ({int(tro[0, 0])} .. {int(tro[-1, 0])}), worst pose difference {worst:.2e}")
-        assert worst <= 2e-6
+        assert max(pose_ulps(trg[k, 49:55], tro[k, 49:55]) for k in range(10)) <= 2.0
 
 
 def test_exact_build_equals_oracle_on_the_dense_config(oracle):
@@ -224,4 +234,4 @@ def test_exact_build_equals_oracle_on_the_dense_config(oracle):
     assert np.array_equal(trg[:, 0], tro[:, 0]), (trg[:, 0] - tro[:, 0])
     worst = max(max(pose_err(trg[k, 49:55], tro[k, 49:55])) for k in range(30))
     print(f"[exact] 128x2048 vs 1 M: n_corr of all 30 iterations equal ({int(tro[0, 0])} .. {int(tro[-1, 0])}), worst pose difference {worst:.2e}")
-    assert worst <= 2e-6
+    assert max(pose_ulps(trg[k, 49:55], tro[k, 49:55]) for k in range(30)) <= 2.0
