@@ -201,3 +201,37 @@ def test_multi_cloud_grid_equals_single_calls_bitwise(gpu_ctx):
     assert cnt[0] == len(recs[0]) and np.array_equal(oa.download(cnt[0]), recs[0])
     for x in (a, b, oa, ob):
         x.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("labelled", [True, False])
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_hip_voxel_grid_crowded_voxels(oracle, gpu_ctx, labelled, seed):
+    """Voxels that hold tens to thousands of points (the cells next to the sensor, a key-frame ring's overlap): the wavefront-per-voxel
+    path sums them 64 at a time through LDS, in input order — centroid, intensity average and label vote equal the oracle's bit for bit,
+    for voxel populations around every chunk boundary (24 / 25, 63 / 64 / 65, 128, several thousand)."""
+    from lisreg import synth
+    rng = np.random.default_rng(seed)
+    pops = [1, 2, 23, 24, 25, 26, 63, 64, 65, 127, 128, 129, 500, 4097] + [int(v) for v in rng.integers(1, 300, 40)]
+    xyz, lab = [], []
+    for k, p in enumerate(pops):                       # voxel k: p points inside one 0.5 m cell of a 3-D lattice, 14 possible labels
+        cell = np.array([k % 7, (k // 7) % 7, k // 49], np.float64) * 0.5 + 10.0
+        xyz.append(cell + rng.uniform(0.01, 0.49, (p, 3)))
+        lab.append(rng.integers(0, 14, p) if k % 3 else np.full(p, 7))
+    xyz = np.concatenate(xyz).astype(np.float32); lab = np.concatenate(lab).astype(np.uint16)
+    perm = rng.permutation(len(xyz))                   # input order is not voxel order
+    cloud = synth.to_pcl(xyz[perm], lab[perm])
+    cloud["intensity"] = rng.uniform(0, 255, len(cloud)).astype(np.float32)
+    st_o, want = oracle.voxel_grid(cloud, 0.5, fmt=1 if labelled else 0)
+    st_g, got = gpu_ctx.voxel_downsample(cloud, 0.5) if labelled else gpu_ctx.voxel_downsample(_as_xyzi(cloud), 0.5)
+    assert st_o == st_g == 0 and len(got) == len(want) == len(pops)
+    for f in ("x", "y", "z", "intensity") + (("label",) if labelled else ()):
+        assert np.array_equal(got[f], want[f]), f
+
+
+def _as_xyzi(cloud):
+    """the same points as a PointXYZI array (no label field): the grid then averages the intensity and votes nothing"""
+    out = np.zeros(len(cloud), np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4"] * 4, "offsets": [0, 4, 8, 16], "itemsize": 32}))
+    for f in ("x", "y", "z", "intensity"):
+        out[f] = cloud[f]
+    return out
