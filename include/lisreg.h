@@ -228,6 +228,8 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * bit computed from them are the same in every front-end and batch shape — a frame registers identically alone and inside any batch —
  * at +7 % per correspondence launch; implied by "exact_arithmetic"),
  * "feeder_threads" (host threads of lisreg_stage_host_items, default 8; 0 = structs uploaded as they are and packed on the device),
+ * "feeder_copy_engine" (1 [default]: while the next packed chunk is not ready and the copy engine is idle, the engine takes the last free
+ * chunk of a pinned cloud as it is and a kernel packs it on the device; 0: never; 2: whenever a packed chunk is not ready — for tests),
  * "graph_min_ratio", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or

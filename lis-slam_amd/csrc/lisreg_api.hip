@@ -887,6 +887,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "lanes_per_query")) { c->lanes_per_query_auto = value != 1; c->prepared = false; return LISREG_OK; }   // 1 forces one lane per query, anything else = auto
     if (!strcmp(name, "dump_neighbors")) { c->dump_neighbors = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "exact_arithmetic")) { c->exact = value != 0; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "feeder_copy_engine")) { c->feeder_engine = value; return LISREG_OK; }
     if (!strcmp(name, "canonical_ties")) { c->canonical_ties = value != 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }

@@ -232,7 +232,8 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
             if (want > 0) {
                 while (!c->pack_done[(size_t)i].load(std::memory_order_acquire)) {
                     bool stole = false;
-                    if (job && chunks[(size_t)lowest_stolen - 1].pinned && hipStreamQuery(c->copy_stream) == hipSuccess) {
+                    if (job && c->feeder_engine > 0 && chunks[(size_t)lowest_stolen - 1].pinned &&
+                        (c->feeder_engine > 1 || hipStreamQuery(c->copy_stream) == hipSuccess)) {
                         const int k = job->take_back();
                         if (k >= 0) {
                             const PackChunk& ck = chunks[(size_t)k];

@@ -419,3 +419,46 @@ def test_upload_cloud_equals_host_packing(gpu_ctx, n):
     assert np.array_equal(got[:, :3], xyz) and not got[:, 3].view(np.uint32).any()
     with pytest.raises(lisreg.LisregError):
         gpu_ctx._chk(gpu_ctx._L.lisreg_upload_cloud(gpu_ctx._h, None, 5, 32, lisreg.FMT_XYZIL, C.c_void_p(dev.ptr)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("labelled", [False, True])
+def test_staged_items_through_the_copy_engine_equal_the_packed_ones(labelled):
+    """lisreg_stage_host_items works a batch from both ends: packing threads from the front, the copy engine from the back (whole chunks
+    of 32-byte structs, packed by a kernel).  With pinned clouds and "feeder_copy_engine" = 2 the engine takes chunks whenever a packed one
+    is not ready; the staged records — labels included — must be the ones the packing threads produce: same poses and statistics."""
+    import ctypes as C
+    import torch
+    import lisreg
+    from lisreg import synth
+    variant = 2 if labelled else 1
+    cases = [synth.make_case(h=64, w=900, m_points=40000, scan_seed=3400 + i, labelled=labelled) for i in range(6)]
+    p = lisreg.default_params(variant); p.fixed_iters = 4
+    ctx = lisreg.Context(0)
+    ctx.set_target(cases[0]["tgt_corner"], cases[0]["tgt_surf"])
+    n = len(cases)
+    T0 = np.stack([c["T_init"] for c in cases]).astype(np.float32)
+    T_ref, st_ref = ctx.align_batch([dict(src_corner=c["src_corner"], src_surf=c["src_surf"]) for c in cases], T0, p)
+    keep, arr = [], (lisreg.Item * n)()
+    for i, c in enumerate(cases):
+        for key in ("src_corner", "src_surf"):
+            a = np.ascontiguousarray(c[key])
+            t = torch.from_numpy(a.view(np.uint8).reshape(-1)).pin_memory()           # page-locked: the copy engine may read it
+            keep.append(t)
+            if key == "src_corner": arr[i].src_corner = C.c_void_p(t.data_ptr()); arr[i].n_corner = len(a)
+            else: arr[i].src_surf = C.c_void_p(t.data_ptr()); arr[i].n_surf = len(a)
+        arr[i].stride_bytes = cases[i]["src_surf"].dtype.itemsize; arr[i].fmt = lisreg.FMT_XYZIL if labelled else lisreg.FMT_XYZI
+    taken = []
+    for engine in (2, 0, 1):
+        ctx.set_option("feeder_copy_engine", engine)
+        staged = (lisreg.Item * n)()
+        assert ctx._L.lisreg_stage_host_items(ctx._h, n, arr, staged) == 0
+        taken.append((ctx.get_option("feeder_chunks_by_copy_engine"), ctx.get_option("feeder_chunks")))
+        assert ctx._L.lisreg_batch_prepare(ctx._h, n, staged, C.byref(p), T0.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        assert ctx._L.lisreg_batch_run(ctx._h) == 0
+        ctx._n_items = n
+        T, st = ctx.batch_fetch()
+        assert np.array_equal(T, T_ref) and st == st_ref, engine
+    ctx.close()
+    print(f"[feeder] chunks taken by the copy engine / all chunks: forced {taken[0]}, off {taken[1]}, default {taken[2]}")
+    assert taken[0][0] > 0 and taken[1][0] == 0
