@@ -71,13 +71,15 @@ def pose_ulps(a, b):
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(mag).astype(np.float64)))
 
 
-def check_exact(oracle, lisreg, case, p_o, imu, degenerate_in=0):
+def check_exact(oracle, lisreg, case, p_o, imu, degenerate_in=0, opts=()):
     p_g = copy_params(p_o, lisreg.Params)
     To, so, tro = oracle.align(case["tgt_corner"], case["tgt_surf"], case["src_corner"], case["src_surf"], case["T_init"],
                                p_o, oracle.Imu(*imu) if imu else None, degenerate_in=degenerate_in)
     c = lisreg.Context(0)
     c.set_option("exact_arithmetic", 1)
     assert c.get_option("exact_arithmetic") == 1
+    for name, value in opts:                      # e.g. (("search_mode", 3),) to pin the front-end
+        c.set_option(name, value)
     c.set_target(case["tgt_corner"], case["tgt_surf"])
     assert degenerate_in == 0                     # a fresh context starts with isDegenerate = false, like the node's member
     Tg, sg, trg = c.align(case["src_corner"], case["src_surf"], case["T_init"], p_g, lisreg.Imu(*imu) if imu else None)
