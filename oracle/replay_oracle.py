@@ -40,14 +40,33 @@ def pose_matrix_f32(T):
     return M.reshape(3, 4)
 
 
+def _libm():
+    import ctypes, ctypes.util
+    m = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    for f in ("atan2f", "asinf"):
+        getattr(m, f).restype = ctypes.c_float
+    m.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]; m.asinf.argtypes = [ctypes.c_float]
+    return m
+
+
 def predict_pose(T_last, T_cur):
-    """updateInitialGuess, constant-velocity branch: transFinal = transTobe * (transLast^-1 * transBack), float arithmetic."""
-    A = np.vstack([pose_matrix_f32(T_last), np.array([[0, 0, 0, 1]], np.float32)]).astype(np.float32)
-    B = np.vstack([pose_matrix_f32(T_cur), np.array([[0, 0, 0, 1]], np.float32)]).astype(np.float32)
-    inc = (np.linalg.inv(A.astype(np.float64)) @ B.astype(np.float64)).astype(np.float32)
-    F = (B @ inc).astype(np.float32)
-    # pcl::getTranslationAndEulerAngles
-    return np.array([np.arctan2(F[2, 1], F[2, 2]), np.arcsin(-F[2, 0]), np.arctan2(F[1, 0], F[0, 0]), F[0, 3], F[1, 3], F[2, 3]], np.float32)
+    """updateInitialGuess, constant-velocity branch (subMapOptmizationNode.cpp:1003-1020, odomEstimationNode.cpp:351-392):
+    transFinal = transTobe * (transLast.inverse() * transTobe) on Eigen::Affine3f — every operation in float, the inverse by cofactors
+    (Eigen's 3x3 path), products accumulated left to right; then pcl::getTranslationAndEulerAngles with the C library's float atan2 / asin."""
+    f = np.float32
+    A, B = pose_matrix_f32(T_last), pose_matrix_f32(T_cur)
+    Ai = _affine_inverse_f32(A)
+    def mul(X, Y):                                             # affine product, rows of X times columns of Y, float, left to right
+        Z = np.zeros((3, 4), np.float32)
+        for r in range(3):
+            for q in range(3):
+                Z[r, q] = f(f(f(X[r, 0] * Y[0, q]) + f(X[r, 1] * Y[1, q])) + f(X[r, 2] * Y[2, q]))
+            Z[r, 3] = f(f(f(f(X[r, 0] * Y[0, 3]) + f(X[r, 1] * Y[1, 3])) + f(X[r, 2] * Y[2, 3])) + X[r, 3])
+        return Z
+    F = mul(B, mul(Ai, B))
+    m = _libm()
+    return np.array([m.atan2f(float(F[2, 1]), float(F[2, 2])), m.asinf(float(-F[2, 0])), m.atan2f(float(F[1, 0]), float(F[0, 0])),
+                     F[0, 3], F[1, 3], F[2, 3]], np.float32)
 
 
 class LocalMapOracle:
