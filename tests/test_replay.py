@@ -445,11 +445,13 @@ def test_submap_composite_equals_oracle_bitwise(oracle, gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_submap_to_submap_chain_matches_oracle(oracle):
+@pytest.mark.parametrize("exact", [False, True])
+def test_submap_to_submap_chain_matches_oracle(oracle, exact):
     """Variant 3 as a sequence (subMapOptmizationThread): for every new submap extractSubMapCloud against the previous one, then
     subMap2SubMapOptimization (copy #3: label weights, 30 iterations at most, convergence 0.002 deg / 0.02 cm, corner stage skipped when
     the target has no poles) from a perturbed guess — HIP chain (device-resident, sources handed over as device records) vs oracle
-    chain; the registered pose becomes the submap's pose for the next pair on both sides."""
+    chain; the registered pose becomes the submap's pose for the next pair on both sides.  With the exact-arithmetic build the chain is
+    the oracle's to the bit: poses, iteration counts, target and source sizes."""
     import lisreg
     import replay_oracle as ro
     from helpers import copy_params
@@ -458,6 +460,7 @@ def test_submap_to_submap_chain_matches_oracle(oracle):
     p_o = oracle.default_params(3)
     p_g = copy_params(p_o, lisreg.Params)
     ctx = lisreg.Context(0)
+    ctx.set_option("exact_arithmetic", 1 if exact else 0)
     pose_o, pose_g, worst = None, None, 0.0
     pre_o = None
     for s, sub in enumerate(subs):
@@ -481,6 +484,9 @@ def test_submap_to_submap_chain_matches_oracle(oracle):
             assert abs(out["n_target_surf"] - len(ts)) <= max(3, 0.002 * len(ts)) and abs(out["n_src_surf"] - len(ss)) <= max(3, 0.002 * len(ss))
             e = max(pose_err(Tg, To))
             worst = max(worst, e)
+            if exact:
+                assert np.array_equal(np.asarray(Tg, np.float32), np.asarray(To, np.float32)) and st_g["iters"] == st_o["iters"], (s, Tg, To)
+                assert (out["n_target_corner"], out["n_target_surf"], out["n_src_corner"], out["n_src_surf"]) == (len(tc), len(ts), len(sc), len(ss))
             assert e <= 1e-3, (s, e, Tg, To)
             assert np.abs(np.asarray(Tg, np.float64)[3:5] - T_true[3:5]).max() < 0.05 and abs(float(Tg[2]) - float(T_true[2])) < 0.01
             pose_o, pose_g = To.astype(np.float32), Tg.astype(np.float32)
