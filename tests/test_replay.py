@@ -182,6 +182,11 @@ def test_kitti_tool_end_to_end_on_a_synthesised_sequence(tmp_path):
     direct = replay.replay(ctx, frames)
     ctx.close()
     assert np.allclose(summary["final_pose"], direct[-1]["T"], rtol=0, atol=0)
+    # --exact: the exact-arithmetic build in the loop -> every checked frame equal to the restatement's to the bit
+    res = subprocess.run([sys.executable, tool, "--root", str(tmp_path), "--seq", "05", "--check-oracle", "6", "--exact"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    chk = json.loads(res.stdout.strip().split("\n")[-1])["oracle_check"]
+    assert chk["frames_bit_identical"] == chk["frames"] == 6 and chk["max_trans_diff_m"] == 0.0
     rows = np.loadtxt(out)
     assert rows.shape == (6, 12) and np.allclose(rows[0].reshape(3, 4), np.eye(4)[:3])
     assert abs(rows[-1, 3] - truth[-1][3]) < 0.05 and abs(rows[-1, 7] - truth[-1][4]) < 0.05

@@ -41,6 +41,9 @@ def main(argv=None):
     ap.add_argument("--mode", choices=("submap", "odom"), default="submap",
                     help="submap: labelled sweeps through the sliding local map (copy #2); odom: raw sweeps, keyframe odometry (copy #1)")
     ap.add_argument("--check-oracle", type=int, default=0, metavar="N", help="also run the CPU restatement on the first N frames")
+    ap.add_argument("--exact", action="store_true",
+                    help="register with the exact-arithmetic build (the reference's arithmetic operation for operation, ~0.5x the speed): "
+                         "with --check-oracle the poses must then equal the restatement's to the bit (reported as frames_bit_identical)")
     args = ap.parse_args(argv)
     seq_dir = os.path.join(args.root, "sequences", args.seq, "velodyne")
     if not args.root or not os.path.isdir(seq_dir):
@@ -52,6 +55,8 @@ def main(argv=None):
     odom = args.mode == "odom"
     frames = (replay.kitti_raw_sequence if odom else replay.kitti_sequence)(args.root, args.seq, args.frames or None)
     ctx = lisreg.Context(args.device)
+    if args.exact:
+        ctx.set_option("exact_arithmetic", 1)
     # the device-resident drivers: the sweep goes up once, every cloud of the frame stays in HBM (bit-identical to the host-cloud drivers)
     r = replay.DeviceOdomReplayer(ctx) if odom else replay.DeviceReplayer(ctx, args.variant)
     recs, kept = [], []
@@ -76,7 +81,9 @@ def main(argv=None):
         ref = (ro.replay_odom if odom else ro.replay)(kept, n_threads=min(16, os.cpu_count() or 1))
         d = [np.abs(np.asarray(a["T"], np.float64) - np.asarray(b["T"], np.float64)) for a, b in zip(recs, ref)]
         summary["oracle_check"] = dict(frames=len(ref), max_rot_diff_rad=float(max(x[:3].max() for x in d)),
-                                       max_trans_diff_m=float(max(x[3:].max() for x in d)))
+                                       max_trans_diff_m=float(max(x[3:].max() for x in d)),
+                                       frames_bit_identical=int(sum(np.array_equal(np.asarray(a["T"], np.float32), np.asarray(b["T"], np.float32))
+                                                                    for a, b in zip(recs, ref))))
     print(json.dumps(summary))
     return 0
 
