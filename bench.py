@@ -329,6 +329,18 @@ def main():
         kk = len(T_cpu)
         d = np.abs(T_gpu[:kk].astype(np.float64) - T_cpu.astype(np.float64))
         parity = dict(items=kk, max_rot_err_rad=float(d[:, :3].max()), max_trans_err_m=float(d[:, 3:].max()))
+        if not own_targets:
+            # the same registrations through the exact-arithmetic build (lisreg_assoc.hip compiled with the reference's arithmetic): its
+            # poses are expected to BE the oracle's (tests/test_exact.py); reported, not timed
+            cx = lisreg.Context(dev_index)
+            cx.set_option("exact_arithmetic", 1)
+            cx.set_target(tc_host, ts_host)
+            Tx, sx = cx.align_batch([dict(src_corner=host_scans[i][0], src_surf=host_scans[i][1]) for i in range(kk)],
+                                    np.ascontiguousarray(T_init[:kk], np.float32), params)
+            cx.close()
+            parity["exact_build_poses_bit_identical"] = int(sum(np.array_equal(np.asarray(Tx[i], np.float32), np.asarray(T_cpu[i], np.float32))
+                                                                for i in range(kk)))
+            parity["exact_build_max_diff"] = float(np.abs(np.asarray(Tx, np.float64) - T_cpu.astype(np.float64)).max())
         cpu = dict(value=legs[1]["value"], unit="registrations/s", cores=1, kind="port",
                    sample=f"{kk} of the {batch} registrations of this batch ({H}x{W} vs {M_SUBMAP // 1000}k submap, {ITERS} GN iters, "
                           f"kd-tree leaf 15, two tree builds per registration) per leg; OpenMP over the feature points like the "
