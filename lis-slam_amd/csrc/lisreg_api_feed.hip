@@ -129,7 +129,7 @@ void feeder_destroy(lisreg_ctx* c)
     for (int b = 0; b < 2; ++b) {
         if (c->pack_host[b]) (void)hipHostFree(c->pack_host[b]);
         c->pack_host[b] = nullptr; c->pack_cap[b] = 0;
-        c->pack_dev[b].release();
+        c->pack_dev[b].release(); c->pack_raw[b].release();
         if (c->pack_copied[b]) (void)hipEventDestroy(c->pack_copied[b]);
         if (c->pack_free[b]) (void)hipEventDestroy(c->pack_free[b]);
         c->pack_copied[b] = c->pack_free[b] = nullptr;
