@@ -478,6 +478,9 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
 
     a = Lane()
     a.ctx.set_option("rebuild_targets_each_run", 1)
+    for kv in filter(None, os.environ.get("LISREG_OPTS", "").split(",")):        # tuning experiments, as for the main context
+        k_, v_ = kv.split("=")
+        a.ctx.set_option(k_, int(v_))
     a.one(); a.one()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
