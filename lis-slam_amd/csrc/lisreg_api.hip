@@ -254,7 +254,11 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (hipHostMalloc((void**)&c->done_host, sizeof(int), hipHostMallocDefault) != hipSuccess) c->done_host = nullptr;
     if (c->done_dev.ensure(sizeof(int)) != hipSuccess) { lisreg_destroy(c); return fail(nullptr, LISREG_ERR_HIP, "lisreg_create: hipMalloc failed"); }
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
-    if (const char* m = getenv("LISREG_SEARCH_MODE")) c->search_mode = atoi(m);
+    if (const char* m = getenv("LISREG_SEARCH_MODE")) {            // the same values lisreg_set_option("search_mode") takes
+        const int v = atoi(m);
+        if (v == 0 || v == 1 || v == 3 || v == 4) c->search_mode = v;
+        else fprintf(stderr, "[lisreg] LISREG_SEARCH_MODE=%s ignored (0, 1, 3 or 4)\n", m);
+    }
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
     if (const char* m = getenv("LISREG_EXACT")) c->exact = atoi(m) != 0;
     if (const char* m = getenv("LISREG_CANONICAL_TIES")) c->canonical_ties = atoi(m) != 0;
@@ -513,6 +517,10 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         }
         if (total_src > 2000000000LL) return fail(c, LISREG_ERR_ARG, "batch_prepare: more than 2e9 source points in one batch");
         c->mode_now = c->search_mode;
+        // the LDS-staged box (front-end 0, the first version of the search, kept for cross-checks) keeps the first point met on equal
+        // distances and has no canonical re-selection: it cannot honour "canonical_ties" / "exact_arithmetic", so it refuses them
+        if (c->search_mode == 0 && (c->canonical_ties || c->exact))
+            return fail(c, LISREG_ERR_ARG, "batch_prepare: search_mode 0 does not implement canonical_ties / exact_arithmetic (use 1, 3 or 4)");
         if (c->search_mode == 4)
             c->mode_now = (t_pts > 0 && (double)total_src * (double)c->prm.bound >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
         // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
@@ -1176,8 +1184,8 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
                     dz = (long long)((bb[5] - bb[2]) * inv) + 1;
     if (dx * dy * dz > 2147483647LL) {           // "Leaf size is too small for the input dataset": output = input
         if (n > out_capacity) { *n_out = n; return fail(c, LISREG_ERR_ARG, "voxel_downsample: out_capacity too small"); }
-        if (dev) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, st));
-        else memcpy(out, in, (size_t)n * (size_t)stride);
+        if (dev) { if (out != in) HIPCHK(c, hipMemcpyAsync(out, in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, st)); }
+        else if (out != in) memmove(out, in, (size_t)n * (size_t)stride);
         HIPCHK(c, hipStreamSynchronize(st));
         *n_out = n;
         return LISREG_LEAF_TOO_SMALL;
@@ -1209,8 +1217,12 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
     if (n_vox > out_capacity) return fail(c, LISREG_ERR_ARG, "voxel_downsample: out_capacity too small (see *n_out)");
     // ---- centroids ---------------------------------------------------------------------------------------------------
     HIPCHK(c, c->vox_start.ensure(sizeof(int) * ((size_t)n_vox + 2)));
-    float4* out_pts = dev ? static_cast<float4*>(out) : nullptr;
-    if (!dev) { HIPCHK(c, c->vox_out.ensure(sizeof(float4) * (size_t)n_vox)); out_pts = c->vox_out.as<float4>(); }
+    // in place (out inside the input records — lisreg_localmap_extract grids a class cloud onto itself): the centroid kernels read
+    // pts[order[..]] while other threads write out[v], so the result is formed in scratch and copied over the input afterwards
+    const bool aliased = dev && (const char*)out < (const char*)in + sizeof(float4) * (size_t)n &&
+                         (const char*)in < (const char*)out + sizeof(float4) * (size_t)std::max(out_capacity, 1);
+    float4* out_pts = dev && !aliased ? static_cast<float4*>(out) : nullptr;
+    if (!out_pts) { HIPCHK(c, c->vox_out.ensure(sizeof(float4) * (size_t)std::max(n_vox, 1))); out_pts = c->vox_out.as<float4>(); }
     uint32_t* out_lab = nullptr;
     if (fmt == LISREG_FMT_XYZIL) { HIPCHK(c, c->vox_outlab.ensure(sizeof(uint32_t) * (size_t)n_vox)); out_lab = c->vox_outlab.as<uint32_t>(); }
     launch_voxel_centroids(n, n_vox, pts, labels, fmt == LISREG_FMT_DEVICE ? 1 : 0 /* label vote on the payload, else .w averaged */, c->vox_order.as<int>(), c->vox_head.as<int>(),
@@ -1230,7 +1242,10 @@ int lisreg_voxel_downsample(lisreg_ctx* c, const void* in, int n, int stride, in
             if (has_intensity) memcpy(q + 16, &r[(size_t)i].w, 4);
             if (out_lab) { const uint16_t l = (uint16_t)rl[(size_t)i]; memcpy(q + 20, &l, 2); }
         }
-    } else HIPCHK(c, hipStreamSynchronize(st));
+    } else {
+        if (aliased && n_vox > 0) HIPCHK(c, hipMemcpyAsync(out, out_pts, sizeof(float4) * (size_t)n_vox, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     return LISREG_OK;
 }
 
@@ -1710,11 +1725,25 @@ int lisreg_semantic_split(lisreg_ctx* c, const void* cloud, int n, int stride, i
 }
 
 // ---- RCCL pose gather: librccl is loaded lazily so single-GPU users never pay for it ------------
+// ONE RCCL per process, and never in the global symbol scope.  A host process may carry an RCCL of its own already (a PyTorch wheel
+// bundles librccl.so.1 next to ITS librocm_smi64 — soname .so.7, the system's is .so.1, so the loader keeps both): the copy already
+// loaded is reused (RTLD_NOLOAD by soname); only a process without one gets the system's library, RTLD_LOCAL.  Round 3 loaded it
+// RTLD_GLOBAL: the system librocm_smi64's globals then interposed those of the wheel's copy imported later, both static destructors
+// freed the same std::map at exit, and glibc aborted the process ("double free or corruption", exit status 134) after every test had
+// passed.  tests/test_teardown.py runs that sequence in a subprocess.
+static void* rccl_dlopen()
+{
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    return h;
+}
+
 static int rccl_load(lisreg_ctx* c)
 {
     if (c->rccl.handle) return LISREG_OK;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void* h = rccl_dlopen();
     if (!h) return fail(c, LISREG_ERR_COMM, std::string("dlopen(librccl.so): ") + dlerror());
     c->rccl.handle = h;
     c->rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
@@ -1728,8 +1757,7 @@ static int rccl_load(lisreg_ctx* c)
 int lisreg_comm_unique_id(unsigned char id[128])
 {
     if (!id) return LISREG_ERR_ARG;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void* h = rccl_dlopen();                      // reference-counted by the loader; the library stays for the life of the process
     if (!h) return fail(nullptr, LISREG_ERR_COMM, "dlopen(librccl.so) failed");
     auto f = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
     if (!f || f(id) != 0) return fail(nullptr, LISREG_ERR_COMM, "ncclGetUniqueId failed");

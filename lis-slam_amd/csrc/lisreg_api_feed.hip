@@ -31,6 +31,8 @@ struct PackPool {
         // chunks are handed out from both ends: the packing threads take the lowest index still free, the publishing thread may take the
         // highest one for the copy engine (take_back); `span` = (front << 32) | back, free chunks are front .. back - 1
         std::atomic<unsigned long long> span{ 0 };
+        std::atomic<int> active{ 0 };          // threads inside drain() on this job (taken under the pool mutex together with the job)
+        void cancel() { span.store(0, std::memory_order_relaxed); }       // nothing is handed out any more
         int take_front()
         {
             unsigned long long v = span.load(std::memory_order_relaxed);
@@ -78,7 +80,22 @@ struct PackPool {
             j.done[i].store(1, std::memory_order_release);
         }
     }
-    void drain() { std::shared_ptr<Job> j; { std::lock_guard<std::mutex> lk(mu); j = job; } if (j) drain(*j); }     // the publishing thread helps
+    void drain()                                                  // the publishing thread helps
+    {
+        std::shared_ptr<Job> j;
+        { std::lock_guard<std::mutex> lk(mu); j = job; if (j) j->active.fetch_add(1, std::memory_order_relaxed); }
+        if (j) { drain(*j); j->active.fetch_sub(1, std::memory_order_release); }
+    }
+    // Ends a job whatever state it is in: no chunk is handed out any more, late wakers find no job, and the call returns only when no
+    // thread is inside it — after that the chunk table, the done flags, the staging buffer and the caller's clouds may go away.  Every
+    // exit of the publishing functions goes through here (JobGuard), the error returns included.
+    void finish(const std::shared_ptr<Job>& j)
+    {
+        if (!j) return;
+        j->cancel();
+        { std::lock_guard<std::mutex> lk(mu); if (job == j) job.reset(); }
+        while (j->active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
     void worker()
     {
         unsigned long long seen = 0;
@@ -90,8 +107,9 @@ struct PackPool {
                 if (quit) return;
                 seen = gen;
                 j = job;
+                if (j) j->active.fetch_add(1, std::memory_order_relaxed);
             }
-            if (j) drain(*j);
+            if (j) { drain(*j); j->active.fetch_sub(1, std::memory_order_release); }
         }
     }
     void start(int n_threads)
@@ -113,6 +131,10 @@ struct PackPool {
         cv.notify_all();
         return j;
     }
+    struct JobGuard {                          // scope of one published job
+        PackPool* pool; std::shared_ptr<Job> job;
+        ~JobGuard() { if (pool) pool->finish(job); }
+    };
     ~PackPool()
     {
         { std::lock_guard<std::mutex> lk(mu); quit = true; }
@@ -123,18 +145,23 @@ struct PackPool {
 
 void feeder_destroy(lisreg_ctx* c)
 {
+    // order: the copy stream drains first (its copies read the pinned staging buffers and write the device buffers), then the threads
+    // are joined (nothing packs into a buffer that is about to go), then events, pinned and device memory
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     delete c->pack_pool; c->pack_pool = nullptr;
-    if (c->up_host) (void)hipHostFree(c->up_host);
-    c->up_host = nullptr; c->up_cap = 0;
     for (int b = 0; b < 2; ++b) {
-        if (c->pack_host[b]) (void)hipHostFree(c->pack_host[b]);
-        c->pack_host[b] = nullptr; c->pack_cap[b] = 0;
-        c->pack_dev[b].release(); c->pack_raw[b].release();
         if (c->pack_copied[b]) (void)hipEventDestroy(c->pack_copied[b]);
         if (c->pack_free[b]) (void)hipEventDestroy(c->pack_free[b]);
         c->pack_copied[b] = c->pack_free[b] = nullptr;
+        if (c->pack_host[b]) (void)hipHostFree(c->pack_host[b]);
+        c->pack_host[b] = nullptr; c->pack_cap[b] = 0;
+        c->pack_dev[b].release(); c->pack_raw[b].release();
     }
-    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
+    if (c->pack_raw_done) (void)hipEventDestroy(c->pack_raw_done);
+    c->pack_raw_done = nullptr; c->pack_pending = nullptr;
+    if (c->up_host) (void)hipHostFree(c->up_host);
+    c->up_host = nullptr; c->up_cap = 0;
+    if (c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
 }
 
 }  // namespace lisreg
@@ -209,6 +236,7 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
     }
     const int n_chunks = (int)chunks.size();
     if (n_chunks > 0) {
+        // (no job is alive here: the previous call left through its JobGuard, so the flag array may be replaced)
         if ((int)c->pack_done.size() < n_chunks) c->pack_done = std::vector<std::atomic<int>>((size_t)n_chunks);
         for (int i = 0; i < n_chunks; ++i) c->pack_done[(size_t)i].store(0, std::memory_order_relaxed);
         // small batches are packed by the calling thread alone (a single odometry frame: waking threads costs more than it packs)
@@ -219,6 +247,8 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
             c->pack_pool->start(want);
             job = c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data());
         }
+        // every way out of this block — the HIPCHK returns too — first takes the job away from the threads and waits for them
+        PackPool::JobGuard guard{ want > 0 ? c->pack_pool : nullptr, job };
         // Copies follow the packing chunk by chunk, several chunks per copy (per-copy overhead is ~10 us; 4 MB copies run at link rate).
         // While the next packed chunk is not ready and the copy engine has nothing left to do, this thread hands the engine the LAST free
         // chunk as it is — 32-byte structs over the link, packed by a kernel on the copy stream — so the two ends of the batch are worked
@@ -248,6 +278,8 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
                             launch_pack_cloud(raw_dev + raw_off, (size_t)ck.n, ck.stride, ck.fmt == LISREG_FMT_XYZIL ? 1 : 0,
                                               reinterpret_cast<float4*>(dev + (ck.dst - host)), c->copy_stream);
                             raw_off += (bytes_k + 63) & ~(size_t)63;
+                            if (!c->pack_raw_done) HIPCHK(c, hipEventCreateWithFlags(&c->pack_raw_done, hipEventDisableTiming));
+                            HIPCHK(c, hipEventRecord(c->pack_raw_done, c->copy_stream));      // the engine has read the caller's memory up to here
                             lowest_stolen = k;
                             stole = true;
                             if (k <= i) break;                     // this very chunk went to the engine
@@ -274,6 +306,9 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         }
         HIPCHK(c, hipGetLastError());
         c->pack_stolen = n_chunks - lowest_stolen; c->pack_chunks_n = n_chunks;
+        // "the caller's clouds are not referenced after the call returns": chunks the copy engine took are read from the caller's own
+        // (pinned) memory by asynchronous copies — wait for the last of those; the packed chunks left the caller's memory on the host
+        if (c->pack_stolen > 0 && c->pack_raw_done) HIPCHK(c, hipEventSynchronize(c->pack_raw_done));
     }
     HIPCHK(c, hipEventRecord(c->pack_copied[b], c->copy_stream));
     c->pack_pending = c->pack_copied[b];          // the next batch_prepare makes the context's stream wait for it
@@ -315,7 +350,8 @@ int lisreg_upload_cloud(lisreg_ctx* c, const void* cloud, int n, int stride_byte
         for (int i = 0; i < n_chunks; ++i) c->pack_done[(size_t)i].store(0, std::memory_order_relaxed);
         if (!c->pack_pool) c->pack_pool = new PackPool();
         c->pack_pool->start(want);
-        c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data());
+        // `chunks` is a local: the guard ends the job (and waits for the threads) before the table goes out of scope, on every path
+        PackPool::JobGuard guard{ c->pack_pool, c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data()) };
         c->pack_pool->drain();                                   // the caller packs too
         for (int i = 0; i < n_chunks; ++i) while (!c->pack_done[(size_t)i].load(std::memory_order_acquire)) std::this_thread::yield();
     } else {

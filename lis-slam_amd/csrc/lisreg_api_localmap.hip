@@ -35,7 +35,11 @@ int grow_keep(lisreg_ctx* c, DevBuf& b, size_t bytes, size_t keep)
     DevBuf nb;
     // a class cloud of a sliding map: start at 16 MB (a million records) and double — a reallocation in the frame loop is a device-wide wait
     // plus an allocation, 0.5 ms alone and tens of ms in a process that also hosts another HIP runtime user
-    HIPCHK(c, nb.ensure(std::max(std::max(bytes + bytes / 2, 2 * b.cap), (size_t)16 << 20)));
+    // (the head-room is a wish: if the device refuses it, the size that is needed will do)
+    if (nb.ensure(std::max(std::max(bytes + bytes / 2, std::min(2 * b.cap, bytes + ((size_t)256 << 20))), (size_t)16 << 20)) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(c, nb.ensure(bytes));
+    }
     if (keep > 0 && b.p) HIPCHK(c, hipMemcpyAsync(nb.p, b.p, keep, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     b.release();

@@ -21,9 +21,12 @@ struct DevBuf {
         p = nullptr; cap = 0;
         // doubling: a buffer that follows a growing map (the sliding local map, the key-frame ring) is reallocated a handful of times, not
         // every few frames — hipFree waits for the device and hipMalloc costs 0.1-1 ms, which showed as spikes in the frame loops
-        size_t want = std::max(bytes + bytes / 4 + 256, 2 * old_cap);
+        // the head-room is capped (a GB-scale buffer growing by a byte must not ask for twice itself), and a refused request falls back
+        // to the size that is actually needed
+        size_t want = std::max(bytes + bytes / 4 + 256, std::min(2 * old_cap, bytes + ((size_t)256 << 20)));
         hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
+        if (e != hipSuccess && want > bytes + 256) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&p, want); }
+        if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -121,6 +124,7 @@ struct lisreg_ctx {
     hipEvent_t   pack_copied[2] = { nullptr, nullptr };   // the uploads into device buffer b are done (recorded on copy_stream)
     hipEvent_t   pack_free[2] = { nullptr, nullptr };     // the batch reading device buffer b has run (recorded on stream)
     hipEvent_t   pack_pending = nullptr;                  // uploads the next prepared batch has to wait for
+    hipEvent_t   pack_raw_done = nullptr;                 // the copy engine's last read of the CALLER's pinned memory (chunks it took over)
     int          pack_flip = 0, pack_last = -1, pack_in_use = -1;
     hipStream_t  copy_stream = nullptr;
     std::vector<lisreg::PackChunk> pack_chunks;

@@ -845,13 +845,60 @@ def pack_device_records(cloud: np.ndarray) -> np.ndarray:
     return out
 
 
+_HIP = None
+
+
+def hip_runtime():
+    """The HIP runtime liblisreg.so is bound to — the copy ALREADY in the process (soname libamdhip64.so.7: the system's, or the one a
+    PyTorch wheel brought along if torch was imported first), never a second one opened by file name."""
+    global _HIP
+    if _HIP is None:
+        lib()
+        for name in ("libamdhip64.so.7", "libamdhip64.so"):
+            try:
+                _HIP = C.CDLL(name, mode=os.RTLD_NOW | os.RTLD_NOLOAD)
+                break
+            except OSError:
+                continue
+        if _HIP is None:
+            _HIP = C.CDLL("libamdhip64.so")
+    return _HIP
+
+
+class PinnedArray:
+    """Page-locked host memory (hipHostMalloc through the library's own HIP runtime) viewed as a numpy array: what a caller's pinned
+    clouds look like to the feeder's copy engine (lisreg_stage_host_items), without torch in the process."""
+
+    def __init__(self, host: np.ndarray):
+        self._hip = hip_runtime()
+        host = np.ascontiguousarray(host)
+        p = C.c_void_p()
+        if self._hip.hipHostMalloc(C.byref(p), C.c_size_t(max(host.nbytes, 64)), C.c_uint(0)) != 0:
+            raise MemoryError("hipHostMalloc failed")
+        self.ptr = p.value
+        self.nbytes = host.nbytes
+        self.array = np.frombuffer((C.c_ubyte * max(host.nbytes, 1)).from_address(self.ptr), dtype=np.uint8, count=host.nbytes)
+        self.array[:] = host.view(np.uint8).reshape(-1)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._hip.hipHostFree(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceArray:
     """Minimal device buffer through the SAME HIP runtime liblisreg.so uses (hipMalloc/hipMemcpy via ctypes), for
     callers that hand device-resident clouds to the library without torch."""
 
     def __init__(self, host: np.ndarray):
-        lib()
-        self._hip = C.CDLL("libamdhip64.so")
+        self._hip = hip_runtime()
         host = np.ascontiguousarray(host)
         self.nbytes = host.nbytes
         self.shape = host.shape
@@ -917,7 +964,7 @@ Context.gather_results = _ctx_gather_results
 def device_to_host(ptr: int, shape, dtype=np.float32) -> np.ndarray:
     """Blocking D2H copy through the library's HIP runtime (tests only)."""
     out = np.zeros(shape, dtype)
-    hip = C.CDLL("libamdhip64.so")
+    hip = hip_runtime()
     hip.hipDeviceSynchronize()
     if hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) != 0:
         raise RuntimeError("hipMemcpy D2H failed")

@@ -428,7 +428,6 @@ def test_staged_items_through_the_copy_engine_equal_the_packed_ones(labelled):
     of 32-byte structs, packed by a kernel).  With pinned clouds and "feeder_copy_engine" = 2 the engine takes chunks whenever a packed one
     is not ready; the staged records — labels included — must be the ones the packing threads produce: same poses and statistics."""
     import ctypes as C
-    import torch
     import lisreg
     from lisreg import synth
     variant = 2 if labelled else 1
@@ -443,10 +442,12 @@ def test_staged_items_through_the_copy_engine_equal_the_packed_ones(labelled):
     for i, c in enumerate(cases):
         for key in ("src_corner", "src_surf"):
             a = np.ascontiguousarray(c[key])
-            t = torch.from_numpy(a.view(np.uint8).reshape(-1)).pin_memory()           # page-locked: the copy engine may read it
+            # page-locked by the library's own HIP runtime (the copy engine may read it).  No torch in this process: a PyTorch wheel
+            # brings its own ROCm libraries, and two copies of librocm_smi64 in one process abort it at exit (tests/test_teardown.py)
+            t = lisreg.PinnedArray(a)
             keep.append(t)
-            if key == "src_corner": arr[i].src_corner = C.c_void_p(t.data_ptr()); arr[i].n_corner = len(a)
-            else: arr[i].src_surf = C.c_void_p(t.data_ptr()); arr[i].n_surf = len(a)
+            if key == "src_corner": arr[i].src_corner = C.c_void_p(t.ptr); arr[i].n_corner = len(a)
+            else: arr[i].src_surf = C.c_void_p(t.ptr); arr[i].n_surf = len(a)
         arr[i].stride_bytes = cases[i]["src_surf"].dtype.itemsize; arr[i].fmt = lisreg.FMT_XYZIL if labelled else lisreg.FMT_XYZI
     taken = []
     for engine in (2, 0, 1):
@@ -459,6 +460,19 @@ def test_staged_items_through_the_copy_engine_equal_the_packed_ones(labelled):
         ctx._n_items = n
         T, st = ctx.batch_fetch()
         assert np.array_equal(T, T_ref) and st == st_ref, engine
+        if engine == 2:
+            # "the caller's clouds are not referenced after the call returns" holds for pinned clouds too: overwrite them right after
+            # staging (before the batch is even prepared) and the staged records must still be the original ones
+            staged2 = (lisreg.Item * n)()
+            assert ctx._L.lisreg_stage_host_items(ctx._h, n, arr, staged2) == 0
+            saved = [t.array.copy() for t in keep]
+            for t in keep: t.array[:] = 0xFF
+            assert ctx._L.lisreg_batch_prepare(ctx._h, n, staged2, C.byref(p), T0.ctypes.data_as(C.POINTER(C.c_float))) == 0
+            assert ctx._L.lisreg_batch_run(ctx._h) == 0
+            T2, st2 = ctx.batch_fetch()
+            assert np.array_equal(T2, T_ref) and st2 == st_ref
+            for t, sv in zip(keep, saved): t.array[:] = sv
     ctx.close()
+    for t in keep: t.free()
     print(f"[feeder] chunks taken by the copy engine / all chunks: forced {taken[0]}, off {taken[1]}, default {taken[2]}")
     assert taken[0][0] > 0 and taken[1][0] == 0

@@ -130,7 +130,7 @@ def test_feature_extraction_at_scale_is_permutation_consistent(gpu_ctx):
 def test_context_life_cycle_does_not_leak_device_memory():
     import lisreg
     from lisreg import synth
-    hip = C.CDLL("libamdhip64.so")
+    hip = lisreg.hip_runtime()
     def free_bytes():
         fr, tot = C.c_size_t(), C.c_size_t()
         assert hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0

@@ -1,0 +1,132 @@
+"""Round-4 edge cases: in-place voxel grids (lisreg_localmap_extract grids a class cloud onto itself; the single-cloud
+fallback of lisreg_voxel_downsample_multi wrote the output over records other threads were still reading), the search_mode
+environment override, and front-end 0 refusing the tie / exact options it does not implement."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(n, seed, spread=40.0, labelled=True):
+    rng = np.random.default_rng(seed)
+    rec = np.zeros((n, 4), np.float32)
+    rec[:, :3] = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+    rec[:, 2] *= 0.1
+    if labelled:
+        rec[:, 3] = rng.integers(0, 20, n).astype(np.uint32).view(np.float32)
+    return rec
+
+
+@pytest.mark.parametrize("n,leaf", [(150000, 0.4), (120001, 1.0), (5000, 0.2)])
+def test_single_cloud_voxel_grid_in_place_equals_out_of_place(gpu_ctx, n, leaf):
+    import lisreg
+    rec = _records(n, 4100 + n)
+    src = lisreg.DeviceArray(rec)
+    dst = lisreg.DeviceArray(np.zeros_like(rec))
+    rc, m = gpu_ctx.voxel_downsample_device(src.ptr, n, leaf, dst.ptr, n)
+    assert rc == 0 and 0 < m < n
+    want = dst.download(m)
+    rc2, m2 = gpu_ctx.voxel_downsample_device(src.ptr, n, leaf, src.ptr, n)        # out == in
+    assert rc2 == 0 and m2 == m
+    assert np.array_equal(src.download(m).view(np.uint32), want.view(np.uint32))
+
+
+def test_multi_cloud_grid_with_one_live_class_in_place(gpu_ctx):
+    """five class slots, only one of them holds points (> 100 k): lisreg_voxel_downsample_multi takes its one-by-one path, with
+    in[k] == out[k] exactly as lisreg_localmap_extract calls it."""
+    import lisreg
+    n = 130000
+    rec = _records(n, 4200)
+    ref_in = lisreg.DeviceArray(rec); ref_out = lisreg.DeviceArray(np.zeros_like(rec))
+    rc, m = gpu_ctx.voxel_downsample_device(ref_in.ptr, n, 0.4, ref_out.ptr, n)
+    assert rc == 0
+    want = ref_out.download(m)
+    live = lisreg.DeviceArray(rec)
+    empty = lisreg.DeviceArray(np.zeros((1, 4), np.float32))
+    ptrs = [empty.ptr, empty.ptr, live.ptr, empty.ptr, empty.ptr]
+    counts = [0, 0, n, 0, 0]
+    got = gpu_ctx.voxel_downsample_multi_device(ptrs, counts, [0.4] * 5, ptrs, [1, 1, n, 1, 1])
+    assert got == [0, 0, m, 0, 0]
+    assert np.array_equal(live.download(m).view(np.uint32), want.view(np.uint32))
+
+
+def test_localmap_extract_with_a_single_class_over_100k_points(oracle, gpu_ctx):
+    """A sliding map that only ever received ground points (> 100 k of them): extract crops and re-grids the one class in place;
+    the class cloud and the surf target must equal the host restatement's."""
+    import lisreg
+    import replay_oracle as ro
+    from lisreg import synth
+    rng = np.random.default_rng(4300)
+    n = 140000
+    xyz = np.zeros((n, 3), np.float32)
+    xyz[:, 0] = rng.uniform(-35, 35, n); xyz[:, 1] = rng.uniform(-35, 35, n); xyz[:, 2] = rng.normal(-1.7, 0.02, n)
+    ground = synth.to_pcl(xyz, np.full(n, 9, np.uint16))
+    none = ground[:0]
+    clouds = dict(dynamic=none, ground=ground, building=none, pole=none, outlier=none)
+    P = lisreg.localmap_default_params()
+    T = np.zeros(6, np.float32)
+    lm = ro.LocalMapOracle(ground.dtype)
+    lm.insert([clouds[c] for c in ro.CLASSES], T)
+    gpu_ctx.localmap_reset(7)
+    info = gpu_ctx.localmap_insert(7, [clouds[c] for c in ro.CLASSES], T, P)
+    assert info["n"] == [len(c) for c in lm.cls]
+    T2 = np.array([0, 0, 0.01, 0.5, 0.2, 0], np.float32)
+    tc, ts, isect = lm.extract(T2)
+    info = gpu_ctx.localmap_extract(7, T2, P, target_slot=0)
+    assert info["n_target_corner"] == len(tc) == 0 and info["n_target_surf"] == len(ts) > 1000
+
+    def rec(cloud):
+        out = np.zeros((len(cloud), 4), np.float32)
+        out[:, 0], out[:, 1], out[:, 2] = cloud["x"], cloud["y"], cloud["z"]
+        out[:, 3] = cloud["label"].astype(np.uint32).view(np.float32)
+        return out
+    assert np.array_equal(gpu_ctx.localmap_get(7, 6).view(np.uint32), rec(ts).view(np.uint32))
+    for c in range(5):
+        assert np.array_equal(gpu_ctx.localmap_get(7, c).view(np.uint32), rec(lm.cls[c]).view(np.uint32)), c
+
+
+def test_front_end_0_refuses_canonical_ties_and_exact(gpu_ctx):
+    import lisreg
+    from lisreg import synth
+    case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=4400)
+    gpu_ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+    p = lisreg.default_params(1)
+    try:
+        gpu_ctx.set_option("search_mode", 0)
+        T, st, _ = gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)      # plain: fine
+        assert st["status"] == 0
+        for opt in ("canonical_ties", "exact_arithmetic"):
+            gpu_ctx.set_option(opt, 1)
+            with pytest.raises(lisreg.LisregError):
+                gpu_ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+            gpu_ctx.set_option(opt, 0)
+    finally:
+        gpu_ctx.set_option("canonical_ties", 0); gpu_ctx.set_option("exact_arithmetic", 0); gpu_ctx.set_option("search_mode", 4)
+
+
+def test_search_mode_environment_override_is_validated():
+    """LISREG_SEARCH_MODE outside {0, 1, 3, 4} is ignored with a message (it used to select the graph kernel without a graph)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.join(root, 'lis-slam_amd')!r})
+import lisreg
+from lisreg import synth
+case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=4500)
+ctx = lisreg.Context(0)
+assert ctx.get_option("search_mode") == 4
+ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+T, st, _ = ctx.align(case["src_corner"], case["src_surf"], case["T_init"], lisreg.default_params(1))
+assert st["status"] == 0
+ctx.close()
+print("OK")
+"""
+    env = dict(os.environ, LISREG_SEARCH_MODE="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr
+    assert "LISREG_SEARCH_MODE=2 ignored" in r.stderr
