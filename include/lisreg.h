@@ -533,6 +533,24 @@ int  lisreg_icp_default_params(int kind, lisreg_icp_params* p);
 int  lisreg_icp_align(lisreg_ctx* ctx, int slot, const void* source, int n, int stride_bytes, int fmt,
                       const lisreg_icp_params* params, const float* guess, lisreg_icp_result* result, void* aligned_out);
 
+/* The candidate loop of loop-closure verification as one call (detectLoopClosureForSubMap, subMapOptmizationNode.cpp:2776-2840; BASELINE
+ * configs[3]: per candidate setInputTarget(:2793) / setInputSource(:2823) / align(:2831) / getFitnessScore(:2835) / hasConverged(:2836) /
+ * getFinalTransformation(:2841)).  Item k aligns ITS source against the map index of ITS slot from ITS guess; every ICP iteration is one
+ * launch sequence over all items, an item that has converged drops out of the launches that follow, results[k] is what
+ * lisreg_icp_align returns for item k alone — to the bit (the sums are formed by one tree whatever the batch size).
+ * chain_prev_mse: 0 = every item starts from params->prev_mse (fresh ICP objects); 1 = the reference's `static` object (:2763), whose
+ * DefaultConvergenceCriteria carries correspondences_prev_mse_ from one align() to the next: item 0 starts from params->prev_mse, item
+ * k from results[k - 1].prev_mse, in array order (results as if the items had been aligned one after the other).
+ * Sources: host PCL structs or LISREG_FMT_DEVICE records (one stride / format for the batch); n = 0 items are allowed. */
+typedef struct lisreg_icp_item {
+    const void*  source;                /* setInputSource */
+    int          n;
+    int          slot;                  /* setInputTarget: lisreg_map_index_set(slot) */
+    const float* guess;                 /* row-major 4x4, NULL = identity */
+} lisreg_icp_item;
+int  lisreg_icp_align_batch(lisreg_ctx* ctx, const lisreg_icp_item* items, int n_items, int stride_bytes, int fmt,
+                            const lisreg_icp_params* params, int chain_prev_mse, lisreg_icp_result* results);
+
 /* OptimizedICPGN (src/core/registration.cpp:19-115, src/include/registration.h:44-70): Gauss-Newton point-to-point ICP — per
  * iteration k = 1 correspondences, J = [I, -R hat(p)], H += J^T J, B -= J^T e, delta = H^-1 B, t += delta[0:3],
  * R = R exp(delta[3:6]) (Sophus SO3).  The class is never instantiated in the reference (commented-out call sites only); it is

@@ -248,6 +248,84 @@ int lisreg_icp_default_params(int kind, lisreg_icp_params* p)
     return LISREG_OK;
 }
 
+// ---- the ICP core: n alignments, each a source against the map index of ITS slot, one launch sequence per iteration ------------------
+namespace {
+struct IcpHostItem {
+    const float4* src;      // device records
+    int           n, slot;
+    const float*  guess;    // row-major 4 x 4 or NULL
+    double        prev_mse; // correspondences_prev_mse_ going in
+    int           defer;    // the first MSE comparison is made by the caller (chained batch)
+};
+
+int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp_params* P, std::vector<IcpState>& hs)
+{
+    hipStream_t st = c->stream;
+    const int n_items = (int)its.size();
+    hs.assign((size_t)n_items, IcpState());
+    if (n_items == 0) return LISREG_OK;
+    long long total = 0;
+    for (const IcpHostItem& it : its) total += it.n;
+    if (total > 0x7fffffffLL / 4) return bad(c, "icp: more than 2^29 source points in one batch");
+    const int q = icp_batch_lanes(total);
+    std::vector<IcpItem> hi((size_t)n_items + 1);
+    HIPCHK(c, c->icp_cur.ensure(sizeof(float4) * (size_t)std::max<long long>(total, 1)));
+    long long off = 0; int blk = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const IcpHostItem& it = its[(size_t)k];
+        IcpState& h = hs[(size_t)k];
+        memset(&h, 0, sizeof h);
+        for (int j = 0; j < 16; ++j) h.F[j] = it.guess ? it.guess[j] : ((j % 5 == 0) ? 1.f : 0.f);
+        for (int j = 0; j < 16; ++j) h.Tm[j] = h.F[j];        // the first pass moves the working copy by the guess (icp.hpp:129-137)
+        h.prev_mse = it.prev_mse; h.cur_mse = DBL_MAX; h.first_mse = -1.0; h.defer_first = it.defer;
+        IcpItem& d = hi[(size_t)k];
+        d.src = it.src; d.cur = c->icp_cur.as<float4>() + off; d.grid = c->maps[it.slot].g_dev.as<GridIndex>();
+        d.n = it.n; d.blk0 = blk; d.nblk = icp_batch_blocks(it.n, q); d.pad_ = 0;
+        off += it.n; blk += d.nblk;
+    }
+    memset(&hi[(size_t)n_items], 0, sizeof(IcpItem));
+    hi[(size_t)n_items].blk0 = blk;
+    const int total_blocks = blk;
+    HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)n_items + 64));
+    HIPCHK(c, c->icp_items.ensure(sizeof(IcpItem) * ((size_t)n_items + 1)));
+    HIPCHK(c, c->icp_partials.ensure(sizeof(double) * 17 * (size_t)std::max(total_blocks, 1)));
+    IcpState* sd = c->icp_state.as<IcpState>();
+    int* n_done_dev = reinterpret_cast<int*>(reinterpret_cast<char*>(c->icp_state.p) + sizeof(IcpState) * (size_t)n_items);
+    HIPCHK(c, hipMemcpyAsync(sd, hs.data(), sizeof(IcpState) * (size_t)n_items, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->icp_items.p, hi.data(), sizeof(IcpItem) * ((size_t)n_items + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(n_done_dev, 0, sizeof(int), st));
+    // (double) d2 > max_distance^2 rejects (correspondence_estimation.hpp): the largest float that still passes
+    const double max_d2 = P->max_corr_dist * P->max_corr_dist;
+    float cap2 = max_d2 >= 3.0e38 ? 3.0e38f : (float)max_d2;
+    if ((double)cap2 > max_d2) cap2 = std::nextafterf(cap2, 0.f);
+    const IcpItem* di = c->icp_items.as<IcpItem>();
+    int n_done = 0;
+    for (int it = 0; it < P->max_iters && n_done < n_items;) {
+        const int chunk = std::min(4, P->max_iters - it);
+        for (int k = 0; k < chunk; ++k)
+            launch_icp_iteration(di, n_items, total_blocks, q, sd, cap2, c->icp_partials.as<double>(), P->max_iters,
+                                 P->transformation_epsilon, P->euclidean_fitness_epsilon, n_done_dev, st);
+        HIPCHK(c, hipGetLastError());
+        it += chunk;
+        HIPCHK(c, hipMemcpyAsync(&n_done, n_done_dev, sizeof n_done, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    launch_icp_fitness_batch(di, n_items, total_blocks, q, sd, c->icp_partials.as<double>(), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hs.data(), sd, sizeof(IcpState) * (size_t)n_items, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return LISREG_OK;
+}
+
+void icp_fill_result(const IcpState& h, lisreg_icp_result* res)
+{
+    memcpy(res->final_transform, h.F, sizeof h.F);
+    res->converged = h.converged; res->iters = h.iters; res->state = h.state; res->n_corr_last = h.n_corr;
+    res->fitness = h.fit_n > 0 ? h.fit_sum / (double)h.fit_n : DBL_MAX;
+    res->prev_mse = h.prev_mse;
+}
+}  // namespace
+
 int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int stride, int fmt, const lisreg_icp_params* P,
                      const float* guess, lisreg_icp_result* res, void* aligned_out)
 {
@@ -260,45 +338,16 @@ int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int str
     if (!(P->max_corr_dist >= 0) || P->max_iters < 1) return bad(c, "icp_align: bad max_corr_dist / max_iters");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const MapIndex& m = c->maps[slot];
     const float4* src = nullptr;
     rc = stage_cloud(c, source, n, stride, fmt, &src);
     if (rc) return rc;
-    IcpState h;
-    memset(&h, 0, sizeof h);
-    for (int k = 0; k < 16; ++k) h.F[k] = guess ? guess[k] : ((k % 5 == 0) ? 1.f : 0.f);
-    for (int k = 0; k < 16; ++k) h.Tm[k] = h.F[k];        // the first pass moves the working copy by the guess (icp.hpp:129-137)
-    HIPCHK(c, c->icp_cur.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
-    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->icp_cur.p, src, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    h.prev_mse = P->prev_mse; h.cur_mse = DBL_MAX;
-    const int nb = icp_blocks(n);
-    HIPCHK(c, c->icp_state.ensure(sizeof(IcpState)));
-    HIPCHK(c, c->icp_partials.ensure(sizeof(double) * 17 * (size_t)std::max(nb, 1)));
-    HIPCHK(c, hipMemcpyAsync(c->icp_state.p, &h, sizeof h, hipMemcpyHostToDevice, st));
-    // (double) d2 > max_distance^2 rejects (correspondence_estimation.hpp): the largest float that still passes
-    const double max_d2 = P->max_corr_dist * P->max_corr_dist;
-    float cap2 = max_d2 >= 3.0e38 ? 3.0e38f : (float)max_d2;
-    if ((double)cap2 > max_d2) cap2 = std::nextafterf(cap2, 0.f);
-    IcpState* sd = c->icp_state.as<IcpState>();
-    int done = 0;
-    for (int it = 0; it < P->max_iters && !done;) {
-        const int chunk = std::min(4, P->max_iters - it);
-        for (int k = 0; k < chunk; ++k)
-            launch_icp_iteration(c->icp_cur.as<float4>(), n, m.g_dev.as<GridIndex>(), sd, cap2, c->icp_partials.as<double>(), P->max_iters,
-                                 P->transformation_epsilon, P->euclidean_fitness_epsilon, st);
-        HIPCHK(c, hipGetLastError());
-        it += chunk;
-        HIPCHK(c, hipMemcpyAsync(&done, &sd->done, sizeof done, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-    }
-    launch_icp_fitness(src, n, m.g_dev.as<GridIndex>(), sd, c->icp_partials.as<double>(), st);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&h, sd, sizeof h, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    memcpy(res->final_transform, h.F, sizeof h.F);
-    res->converged = h.converged; res->iters = h.iters; res->state = h.state; res->n_corr_last = h.n_corr;
-    res->fitness = h.fit_n > 0 ? h.fit_sum / (double)h.fit_n : DBL_MAX;
-    res->prev_mse = h.prev_mse;
+    std::vector<IcpHostItem> its(1);
+    its[0] = IcpHostItem{ src, n, slot, guess, P->prev_mse, 0 };
+    std::vector<IcpState> hs;
+    rc = icp_run(c, its, P, hs);
+    if (rc) return rc;
+    const IcpState& h = hs[0];
+    icp_fill_result(h, res);
     if (aligned_out && n > 0) {                       // `output` of align(): the source under the final transformation
         HIPCHK(c, c->vox_M.ensure(sizeof(float) * 12));
         HIPCHK(c, hipMemcpyAsync(c->vox_M.p, h.F, sizeof(float) * 12, hipMemcpyHostToDevice, st));     // rows 0..2 of F = [R|t]
@@ -318,6 +367,73 @@ int lisreg_icp_align(lisreg_ctx* c, int slot, const void* source, int n, int str
                 memcpy(o + (size_t)i * (size_t)stride, &hp[(size_t)i], 12);
             }
         }
+    }
+    return LISREG_OK;
+}
+
+// The candidate loop of detectLoopClosureForSubMap (subMapOptmizationNode.cpp:2776-2840: setInputTarget / setInputSource / align /
+// getFitnessScore / hasConverged / getFinalTransformation per candidate) as ONE call.
+int lisreg_icp_align_batch(lisreg_ctx* c, const lisreg_icp_item* items, int n_items, int stride, int fmt, const lisreg_icp_params* P,
+                           int chain_prev_mse, lisreg_icp_result* results)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n_items < 0 || (n_items > 0 && (!items || !results))) return bad(c, "icp_align_batch: NULL items / results");
+    if (!P) return bad(c, "icp_align_batch: NULL params");
+    if (!(P->max_corr_dist >= 0) || P->max_iters < 1) return bad(c, "icp_align_batch: bad max_corr_dist / max_iters");
+    long long total = 0;
+    for (int k = 0; k < n_items; ++k) {
+        if (items[k].slot < 0 || c->maps.count(items[k].slot) == 0 || !c->maps[items[k].slot].valid)
+            return ctx_fail(c, LISREG_ERR_NO_TARGET, "icp_align_batch: an item names a slot without a map index (setInputTarget)");
+        const int rc = check_cloud(c, items[k].source, items[k].n, stride, fmt, "icp_align_batch");
+        if (rc) return rc;
+        total += items[k].n;
+    }
+    if (n_items == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    std::vector<IcpHostItem> its((size_t)n_items);
+    if (fmt == LISREG_FMT_DEVICE) {
+        for (int k = 0; k < n_items; ++k) its[(size_t)k].src = static_cast<const float4*>(items[k].source);
+    } else {
+        // all host sources through one packed upload
+        std::vector<lisreg_dpoint> h((size_t)std::max<long long>(total, 1));
+        long long off = 0;
+        for (int k = 0; k < n_items; ++k) { pack_cloud(items[k].source, items[k].n, stride, fmt, h.data() + off); off += items[k].n; }
+        HIPCHK(c, c->mp_pts.ensure(sizeof(float4) * (size_t)std::max<long long>(total, 1)));
+        if (total > 0) HIPCHK(c, hipMemcpyAsync(c->mp_pts.p, h.data(), sizeof(float4) * (size_t)total, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));      // h is a local
+        off = 0;
+        for (int k = 0; k < n_items; ++k) { its[(size_t)k].src = c->mp_pts.as<float4>() + off; off += items[k].n; }
+    }
+    for (int k = 0; k < n_items; ++k) {
+        IcpHostItem& it = its[(size_t)k];
+        it.n = items[k].n; it.slot = items[k].slot; it.guess = items[k].guess;
+        it.prev_mse = P->prev_mse;
+        it.defer = (chain_prev_mse && k > 0) ? 1 : 0;
+    }
+    std::vector<IcpState> hs;
+    int rc = icp_run(c, its, P, hs);
+    if (rc) return rc;
+    for (int k = 0; k < n_items; ++k) icp_fill_result(hs[(size_t)k], &results[k]);
+    if (!chain_prev_mse) return LISREG_OK;
+    // The reference's ICP object is `static`: DefaultConvergenceCriteria keeps correspondences_prev_mse_ from one align() to the next, so
+    // candidate k's FIRST MSE comparison is against what candidate k - 1 left behind.  The batch ran items 1.. with that comparison
+    // left out; here it is made, in order, with the values now known.  An item it would have stopped (a first-iteration MSE within the
+    // absolute / relative bound of its predecessor's last one — rare) is aligned again alone with the right value going in.
+    double carry = results[0].prev_mse;
+    for (int k = 1; k < n_items; ++k) {
+        const IcpState& h = hs[(size_t)k];
+        if (h.first_mse < 0.0) { results[k].prev_mse = carry; continue; }      // ended before any MSE test: the value passes through
+        const double diff = std::fabs(h.first_mse - carry);
+        if (diff < 1e-12 || diff / carry < P->euclidean_fitness_epsilon) {
+            std::vector<IcpHostItem> one(1, its[(size_t)k]);
+            one[0].prev_mse = carry; one[0].defer = 0;
+            std::vector<IcpState> h1;
+            rc = icp_run(c, one, P, h1);
+            if (rc) return rc;
+            icp_fill_result(h1[0], &results[k]);
+        }
+        carry = results[k].prev_mse;
     }
     return LISREG_OK;
 }

@@ -264,12 +264,24 @@ struct IcpState {
     float  Tm[16];           // transformation_ of the last iteration
     int    iters, done, state, converged, n_corr, fit_n;
     double prev_mse, cur_mse, fit_sum;
+    double first_mse;        // MSE of the first iteration, < 0 while its MSE test has not been reached
+    int    defer_first, pad_;// chained batch: the first MSE comparison is left to the host (lisreg_icp_align_batch)
 };
+// one alignment of an ICP batch (device): blocks blk0 .. blk0 + nblk of the launch work on it, one partial row per block
+struct IcpItem {
+    const float4*    src;    // source records
+    float4*          cur;    // working copy (input_transformed)
+    const GridIndex* grid;   // its target's k = 1 index
+    int n, blk0, nblk, pad_;
+};
+int  icp_batch_lanes(long long total_points);
+int  icp_batch_blocks(int n, int q);
 int  icp_blocks(int n);
 // one ICP iteration on the working copy `cur` (input_transformed): apply st->Tm in place, correspondences + sums
 // (partials: icp_blocks(n) * 17 doubles), then transform estimate + convergence (st->Tm = the new transformation_)
-void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
-                          int max_iters, double eps_t, double eps_mse, hipStream_t stream);
+void launch_icp_iteration(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
+                          int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream);
+void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream);
 // one OptimizedICPGN iteration (partials: icp_blocks(n) * 22 doubles); st->F is T, st->iters counts the applied steps
 void launch_icpgn_iteration(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
                             hipStream_t stream);

@@ -153,6 +153,42 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The sums of pcl::IterativeClosestPoint are formed by ONE tree whatever the number of lanes per query, so that an alignment gives the
+// same bits alone (four lanes per query: a scan-sized cloud does not fill the chip otherwise) and inside a batch of candidates (one
+// lane per query).  Leaves = queries in index order (the non-lead lanes of a query hold exact zeros); levels = bit 0, 1, 2, ... of the
+// query index: inside a wavefront by an ascending butterfly, across the four wavefronts of a workgroup as (w0 + w1) + (w2 + w3); a
+// workgroup row covers 256 / Q queries, and the summing kernels first fold Q consecutive rows the same way (icp_row256) — from there
+// on both forms hold one value per 256 queries.
+__device__ __forceinline__ double wave_sum_up(double v)
+{
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// the block -> item table of a batch: items[k].blk0 ascending, items[n_items].blk0 = total
+__device__ __forceinline__ int icp_find_item(const IcpItem* __restrict__ items, int n_items, int blk)
+{
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// value `k` of the b-th 256-query row of an item (rows of 256 / Q queries are folded pairwise: Q = 4 -> (r0 + r1) + (r2 + r3))
+template <int kAcc>
+__device__ __forceinline__ double icp_row256(const double* __restrict__ rows, int n_rows, int q, int b, int k)
+{
+    if (q == 1) return rows[(size_t)b * kAcc + k];
+    const int r = 4 * b;
+    const double r0 = rows[(size_t)r * kAcc + k];
+    const double r1 = r + 1 < n_rows ? rows[(size_t)(r + 1) * kAcc + k] : 0.0;
+    const double r2 = r + 2 < n_rows ? rows[(size_t)(r + 2) * kAcc + k] : 0.0;
+    const double r3 = r + 3 < n_rows ? rows[(size_t)(r + 3) * kAcc + k] : 0.0;
+    return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ void apply4(const float* F, float x, float y, float z, float& ox, float& oy, float& oz)
 {
     ox = ((F[0] * x + F[1] * y) + F[2] * z) + F[3];
@@ -164,23 +200,27 @@ __device__ __forceinline__ void apply4(const float* F, float x, float y, float z
 // iteration — kept that way rather than re-deriving the points from the cumulative transform), then determineCorrespondences
 // and the sums TransformationEstimationSVD needs.
 template <int Q>
-__global__ __launch_bounds__(256) void k_icp_assoc(float4* __restrict__ cur, int n, const GridIndex* __restrict__ gp,
-                                                   const IcpState* __restrict__ stp, float cap2, double* __restrict__ partials)
+__global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ items, int n_items, const IcpState* __restrict__ states,
+                                                   float cap2, double* __restrict__ partials)
 {
     __shared__ double red[4][kIcpAcc];
+    const int item = icp_find_item(items, n_items, blockIdx.x);
+    const IcpState* stp = &states[item];
     if (stp->done) return;
-    const int i = (blockIdx.x * 256 + threadIdx.x) / Q;
+    const IcpItem I = items[item];
+    const int i = (int)((((long long)blockIdx.x - I.blk0) * 256 + threadIdx.x) / Q);
     const bool lead = (threadIdx.x & (Q - 1)) == 0;
     double acc[kIcpAcc];
 #pragma unroll
     for (int k = 0; k < kIcpAcc; ++k) acc[k] = 0.0;
-    if (i < n) {
-        const GridIndex g = *gp;
-        const float4 s = cur[i];
+    if (i < I.n) {
+        const GridIndex g = *I.grid;
+        // the first pass reads the source itself (and moves it by the guess), later ones the working copy: no copy up front
+        const float4 s = stp->iters == 0 ? I.src[i] : I.cur[i];
         float px, py, pz, d2;
         apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
-        const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2);      // (reads cur[i] on all Q lanes before the lead lane rewrites it)
-        if (lead) cur[i] = make_float4(px, py, pz, s.w);
+        const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2);      // (all Q lanes have read their record before the lead lane writes)
+        if (lead) I.cur[i] = make_float4(px, py, pz, s.w);
         if (bi >= 0 && lead) {
             const float4 q = g.pts[bi];
             acc[0] = 1.0;
@@ -195,7 +235,7 @@ __global__ __launch_bounds__(256) void k_icp_assoc(float4* __restrict__ cur, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kIcpAcc; ++k) {
-        const double v = wave_sum(acc[k]);
+        const double v = wave_sum_up(acc[k]);
         if (lane == 0) red[wave][k] = v;
     }
     __syncthreads();
@@ -262,33 +302,8 @@ __device__ __forceinline__ double det3(const double* M)
 }
 
 // estimateRigidTransformation (Umeyama, no scale) + final_transformation_ update + DefaultConvergenceCriteria::hasConverged
-__global__ __launch_bounds__(1024) void k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st,
-                                                    int max_iters, double eps_t, double eps_mse)
+__device__ void icp_solve_step(const double* tot, IcpState* st, int max_iters, double eps_t, double eps_mse)
 {
-    __shared__ double red[32][32];
-    __shared__ double tot[kIcpAcc];
-    if (st->done) return;
-    // fixed-order sum of the partial rows: 32 row groups x 17 columns in parallel, 4 independent loads in flight per thread
-    // (a scan at 4 lanes per query is ~1 800 rows; summing them 8 ways with one load in flight took 45 us per iteration)
-    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-    if (k < kIcpAcc) {
-        int b = grp;
-        for (; b + 96 < n_blocks; b += 128) {
-            v0 += partials[(size_t)b * kIcpAcc + k];        v1 += partials[(size_t)(b + 32) * kIcpAcc + k];
-            v2 += partials[(size_t)(b + 64) * kIcpAcc + k]; v3 += partials[(size_t)(b + 96) * kIcpAcc + k];
-        }
-        for (; b < n_blocks; b += 32) v0 += partials[(size_t)b * kIcpAcc + k];
-    }
-    red[grp][k] = (v0 + v1) + (v2 + v3);
-    __syncthreads();
-    if (threadIdx.x < kIcpAcc) {
-        double s = 0;
-        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
-        tot[threadIdx.x] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
     const double cnt = tot[0];
     st->n_corr = (int)cnt;
     if (cnt < 3.0) { st->state = LISREG_ICP_NO_CORRESPONDENCES; st->converged = 0; st->done = 1; return; }    // icp.hpp: min_number_correspondences_
@@ -319,9 +334,51 @@ __global__ __launch_bounds__(1024) void k_icp_solve(const double* __restrict__ p
     if (cos_angle >= 1.0 - eps_t && tr2 <= eps_t) { st->state = LISREG_ICP_TRANSFORM; st->converged = 1; st->done = 1; return; }
     const double cur = tot[16] * inv, prev = st->prev_mse;
     st->cur_mse = cur;
+    if (iters == 1) st->first_mse = cur;                 // the MSE test of the first iteration was reached (chained batches)
+    // chained batch (the reference's `static` ICP object, subMapOptmizationNode.cpp:2763): this item's correspondences_prev_mse_ is the
+    // value the item before it leaves behind, unknown while both run together — the first comparison is made by the host afterwards
+    if (iters == 1 && st->defer_first) { st->prev_mse = cur; return; }
     if (fabs(cur - prev) < 1e-12) { st->state = LISREG_ICP_ABS_MSE; st->converged = 1; st->done = 1; return; }
     if (fabs(cur - prev) / prev < eps_mse) { st->state = LISREG_ICP_REL_MSE; st->converged = 1; st->done = 1; return; }
     st->prev_mse = cur;
+}
+
+
+// estimateRigidTransformation (Umeyama, no scale) + final_transformation_ update + DefaultConvergenceCriteria::hasConverged
+__global__ __launch_bounds__(1024) void k_icp_solve(const double* __restrict__ all_partials, const IcpItem* __restrict__ items,
+                                                    IcpState* __restrict__ states, int q, int max_iters, double eps_t, double eps_mse,
+                                                    int* __restrict__ n_done)
+{
+    __shared__ double red[32][32];
+    __shared__ double tot[kIcpAcc];
+    IcpState* st = &states[blockIdx.x];
+    if (st->done) return;
+    const IcpItem I = items[blockIdx.x];
+    const double* partials = all_partials + (size_t)I.blk0 * kIcpAcc;
+    const int n_rows = I.nblk, n_blocks = q == 1 ? n_rows : (n_rows + 3) / 4;      // rows of 256 queries
+    // fixed-order sum of the 256-query rows: 32 row groups x 17 columns in parallel, 4 independent loads in flight per thread
+    // (a scan at 4 lanes per query is ~1 800 rows; summing them 8 ways with one load in flight took 45 us per iteration)
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (k < kIcpAcc) {
+        int b = grp;
+        for (; b + 96 < n_blocks; b += 128) {
+            v0 += icp_row256<kIcpAcc>(partials, n_rows, q, b, k);      v1 += icp_row256<kIcpAcc>(partials, n_rows, q, b + 32, k);
+            v2 += icp_row256<kIcpAcc>(partials, n_rows, q, b + 64, k); v3 += icp_row256<kIcpAcc>(partials, n_rows, q, b + 96, k);
+        }
+        for (; b < n_blocks; b += 32) v0 += icp_row256<kIcpAcc>(partials, n_rows, q, b, k);
+    }
+    red[grp][k] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (threadIdx.x < kIcpAcc) {
+        double s = 0;
+        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    icp_solve_step(tot, st, max_iters, eps_t, eps_mse);
+    if (st->done && n_done) atomicAdd(n_done, 1);
 }
 
 // getFitnessScore(): unbounded k = 1 of the source under the final transformation
@@ -344,6 +401,48 @@ __global__ __launch_bounds__(256) void k_icp_fitness(const float4* __restrict__ 
     if (lane == 0) { red[wave][0] = sum; red[wave][1] = cnt; }
     __syncthreads();
     if (threadIdx.x < 2) partials[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// the batch forms of the two kernels above: block -> item table, rows of 256 / Q queries summed by the Q-independent tree
+template <int Q>
+__global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict__ items, int n_items, const IcpState* __restrict__ states,
+                                                       double* __restrict__ partials)
+{
+    __shared__ double red[4][2];
+    const int item = icp_find_item(items, n_items, blockIdx.x);
+    const IcpItem I = items[item];
+    const int i = (int)((((long long)blockIdx.x - I.blk0) * 256 + threadIdx.x) / Q);
+    double sum = 0, cnt = 0;
+    if (i < I.n) {
+        const GridIndex g = *I.grid;
+        const float4 s = I.src[i];
+        float px, py, pz, d2;
+        apply4(states[item].F, s.x, s.y, s.z, px, py, pz);
+        if (nn1_search<Q>(px, py, pz, g, 3.0e38f, &d2) >= 0 && (threadIdx.x & (Q - 1)) == 0) { sum = d2; cnt = 1; }
+    }
+    sum = wave_sum_up(sum); cnt = wave_sum_up(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = sum; red[wave][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 2) partials[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_icp_fit_reduce_b(const double* __restrict__ all_partials, const IcpItem* __restrict__ items,
+                                                          IcpState* __restrict__ states, int q)
+{
+    __shared__ double red[256][2];
+    const IcpItem I = items[blockIdx.x];
+    const double* partials = all_partials + (size_t)I.blk0 * 2;
+    const int n_rows = I.nblk, n_blocks = q == 1 ? n_rows : (n_rows + 3) / 4;
+    double s = 0, c = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) { s += icp_row256<2>(partials, n_rows, q, b, 0); c += icp_row256<2>(partials, n_rows, q, b, 1); }
+    red[threadIdx.x][0] = s; red[threadIdx.x][1] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { states[blockIdx.x].fit_sum = red[0][0]; states[blockIdx.x].fit_n = (int)red[0][1]; }
 }
 
 __global__ __launch_bounds__(256) void k_icp_fit_reduce(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st)
@@ -520,15 +619,29 @@ int icp_blocks(int n) { return (int)(((long long)n * icp_lanes(n) + 255) / 256);
 
 #define LISREG_DISPATCH_Q(q_, call1, call4, call8) do { if ((q_) == 1) { call1; } else if ((q_) == 4) { call4; } else { call8; } } while (0)
 
-void launch_icp_iteration(float4* cur, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
-                          int max_iters, double eps_t, double eps_mse, hipStream_t stream)
+// lanes per query of an ICP batch with `total` source points in all (results do not depend on it: wave_sum_up / icp_row256)
+int icp_batch_lanes(long long total) { return icp_lanes((int)std::min<long long>(total, 0x7fffffff)); }
+int icp_batch_blocks(int n, int q) { return (int)(((long long)n * q + 255) / 256); }
+
+void launch_icp_iteration(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
+                          int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream)
 {
-    const int nb = icp_blocks(n), q = icp_lanes(n);
-    if (nb > 0)
-        LISREG_DISPATCH_Q(q, (k_icp_assoc<1><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
-                             (k_icp_assoc<4><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)),
-                             (k_icp_assoc<8><<<nb, 256, 0, stream>>>(cur, n, grid_dev, st, cap2, partials)));
-    k_icp_solve<<<1, 1024, 0, stream>>>(partials, nb, st, max_iters, eps_t, eps_mse);
+    if (n_items <= 0) return;
+    if (total_blocks > 0) {
+        if (q == 1) k_icp_assoc<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
+        else        k_icp_assoc<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
+    }
+    k_icp_solve<<<n_items, 1024, 0, stream>>>(partials, items, states, q, max_iters, eps_t, eps_mse, n_done);
+}
+
+void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream)
+{
+    if (n_items <= 0) return;
+    if (total_blocks > 0) {
+        if (q == 1) k_icp_fitness_b<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, partials);
+        else        k_icp_fitness_b<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, partials);
+    }
+    k_icp_fit_reduce_b<<<n_items, 256, 0, stream>>>(partials, items, states, q);
 }
 
 void launch_icpgn_iteration(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,

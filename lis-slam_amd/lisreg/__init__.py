@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
     "lisreg_localmap_get", "lisreg_predict_pose", "lisreg_submap_insert", "lisreg_submap_extract", "lisreg_submap_crop_boxes",
-    "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_gn_match",
+    "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_align_batch", "lisreg_icp_gn_match",
 ]
 
 
@@ -56,6 +56,10 @@ class IcpResult(C.Structure):
     def as_dict(self):
         return dict(T=np.array(list(self.final_transform), np.float32).reshape(4, 4), converged=bool(self.converged),
                     iters=self.iters, state=self.state, n_corr_last=self.n_corr_last, fitness=self.fitness, prev_mse=self.prev_mse)
+
+
+class IcpItem(C.Structure):
+    _fields_ = [("source", C.c_void_p), ("n", C.c_int), ("slot", C.c_int), ("guess", C.POINTER(C.c_float))]
 
 
 class Deskew(C.Structure):
@@ -250,6 +254,7 @@ def lib():
         L.lisreg_icp_default_params.argtypes = [C.c_int, C.POINTER(IcpParams)]
         L.lisreg_icp_gn_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_float, fp, C.POINTER(IcpGnResult), vp]
         L.lisreg_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult), vp]
+        L.lisreg_icp_align_batch.argtypes = [vp, C.POINTER(IcpItem), C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), C.c_int, C.POINTER(IcpResult)]
         _lib = L
     return _lib
 
@@ -801,6 +806,37 @@ class Context:
         if want_aligned:
             d["aligned"] = out
         return d
+
+    def icp_align_batch(self, items, params: "IcpParams", chain_prev_mse: bool = False):
+        """lisreg_icp_align_batch: items = [(slot, source, guess or None), ...] — host PCL-struct arrays (one dtype for the batch), or
+        (slot, (device_ptr, n), guess) tuples for LISREG_FMT_DEVICE records.  Returns the list of result dicts, one per item."""
+        n = len(items)
+        arr = (IcpItem * max(n, 1))()
+        keep = []
+        fmt, stride = None, 16
+        for k, (slot, source, guess) in enumerate(items):
+            if isinstance(source, tuple):
+                ptr, cnt = source
+                arr[k].source = C.c_void_p(ptr); arr[k].n = cnt
+                f, st = FMT_DEVICE, 16
+            else:
+                source = np.ascontiguousarray(source)
+                keep.append(source)
+                arr[k].source = C.c_void_p(source.ctypes.data if len(source) else 0); arr[k].n = len(source)
+                f, st = _fmt_of(source), source.dtype.itemsize
+            if fmt is None:
+                fmt, stride = f, st
+            elif (fmt, stride) != (f, st):
+                raise ValueError("icp_align_batch: one point format per batch")
+            arr[k].slot = slot
+            if guess is not None:
+                g = np.ascontiguousarray(guess, np.float32).ravel()
+                keep.append(g)
+                arr[k].guess = g.ctypes.data_as(C.POINTER(C.c_float))
+        res = (IcpResult * max(n, 1))()
+        self._chk(self._L.lisreg_icp_align_batch(self._h, arr, n, stride, FMT_DEVICE if fmt is None else fmt, C.byref(params),
+                                                 1 if chain_prev_mse else 0, res))
+        return [res[k].as_dict() for k in range(n)]
 
     def icp_gn_match(self, slot: int, source: np.ndarray, max_iterations: int, max_correspond_distance: float, predict_pose,
                      want_transformed: bool = False):

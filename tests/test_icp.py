@@ -219,6 +219,90 @@ def test_hip_icp_edges_guess_and_device(oracle, gpu_ctx):
     assert np.array_equal(got[:, :3], synth.pcl_xyz(rh["aligned"])) and np.array_equal(got[:, 3].view(np.uint32), rs[:, 3].view(np.uint32))
 
 
+# ---------------------------------------------------------------- the candidate loop as one call (lisreg_icp_align_batch)
+def _same(a, b):
+    return (np.array_equal(a["T"], b["T"]) and a["iters"] == b["iters"] and a["state"] == b["state"] and a["converged"] == b["converged"]
+            and a["n_corr_last"] == b["n_corr_last"] and a["fitness"] == b["fitness"] and a["prev_mse"] == b["prev_mse"])
+
+
+@pytest.mark.gpu
+def test_hip_icp_batch_equals_single_calls_bitwise_and_oracle(oracle, gpu_ctx):
+    """Loop-closure verification (subMapOptmizationNode.cpp:2776-2840): candidates with their OWN targets, sources and guesses in one
+    call — each result equal to lisreg_icp_align on that candidate alone TO THE BIT (one lane per query in the batch, four alone: the
+    sums are formed by the same tree), and within the ICP bar of the oracle."""
+    import lisreg
+    from lisreg import synth
+    cases = [_case(61, n_map=30000, trans=0.5, rot_deg=2.0, hw=(16, 450)), _case(62, n_map=50000, trans=1.0, rot_deg=4.0, hw=(32, 900)),
+             _case(63, n_map=20000, trans=0.2, rot_deg=1.0, hw=(16, 450))]
+    for k, (tgt, _, _) in enumerate(cases):
+        gpu_ctx.map_index_set(20 + k, tgt)
+    g1 = synth.pose_matrix([0.01, -0.02, 0.03, 0.2, -0.1, 0.05]).astype(f32)
+    far = cases[0][1].copy(); far["x"] += 1000.0
+    items = [(20, cases[0][1], None), (21, cases[1][1], g1), (22, cases[2][1], None), (21, cases[0][1][:2], None), (20, far, None),
+             (22, cases[2][1][:0], None), (20, cases[0][1], None)]
+    pg, po = lisreg.icp_default_params(0), oracle.icp_default_params(0)
+    rb = gpu_ctx.icp_align_batch(items, pg)
+    assert len(rb) == len(items)
+    for (slot, src, g), r in zip(items, rb):
+        rs = gpu_ctx.icp_align(slot, src, pg, guess=g)
+        assert _same(r, rs), (slot, len(src), r, rs)
+        if len(src) > 2 and r["state"] != lisreg.ICP_NO_CORRESPONDENCES:
+            _check(r, oracle.icp_align(cases[slot - 20][0], src, po, guess=g))
+    assert _same(rb[0], rb[6])                                             # the same candidate twice
+    assert rb[4]["state"] == lisreg.ICP_NO_CORRESPONDENCES and rb[5]["fitness"] == DBL_MAX and not rb[5]["converged"]
+    # a bigger batch switches to one lane per query (>= 500 k source points): still the same bits
+    many = [(20 + (k % 3), cases[k % 3][1], None) for k in range(45)]
+    rm = gpu_ctx.icp_align_batch(many, pg)
+    assert sum(len(s) for _, s, _ in many) >= 500000
+    for k in range(45):
+        assert _same(rm[k], rm[k % 3]), k
+    assert _same(rm[0], rb[0]) and _same(rm[2], rb[2])
+    # device records
+    recs = [lisreg.pack_device_records(cases[k][1]) for k in range(3)]
+    devs = [lisreg.DeviceArray(r) for r in recs]
+    rd = gpu_ctx.icp_align_batch([(20 + k, (devs[k].ptr, len(recs[k])), None) for k in range(3)], pg)
+    assert _same(rd[0], rb[0]) and _same(rd[2], rb[2])
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.icp_align_batch([(77, cases[0][1], None)], pg)
+    assert gpu_ctx.icp_align_batch([], pg) == []
+
+
+@pytest.mark.gpu
+def test_hip_icp_batch_chained_prev_mse_follows_the_static_object(oracle, gpu_ctx):
+    """The reference's ICP object is `static` (subMapOptmizationNode.cpp:2763): correspondences_prev_mse_ of candidate k - 1 is what
+    candidate k's first MSE comparison sees.  chain_prev_mse = 1 must give what a sequential loop gives — including the case where that
+    first comparison stops the alignment (a candidate that starts where its predecessor ended)."""
+    import lisreg
+    tgt, src, _ = _case(64, n_map=30000, trans=0.4, rot_deg=2.0, hw=(16, 450))
+    tgt2, src2, _ = _case(65, n_map=30000, trans=0.3, rot_deg=1.0, hw=(16, 450))
+    gpu_ctx.map_index_set(30, tgt); gpu_ctx.map_index_set(31, tgt2)
+    pg = lisreg.icp_default_params(0)
+    r0 = gpu_ctx.icp_align(30, src, pg)
+    assert r0["converged"]
+    items = [(30, src, None), (30, src, r0["T"]), (31, src2, None), (30, src[:2], None), (31, src2, None)]
+    # sequential loop through the single entry point, feeding prev_mse forward
+    seq, p = [], lisreg.icp_default_params(0)
+    for slot, s, g in items:
+        r = gpu_ctx.icp_align(slot, s, p, guess=g)
+        seq.append(r)
+        p.prev_mse = r["prev_mse"]
+    rb = gpu_ctx.icp_align_batch(items, pg, chain_prev_mse=True)
+    for k in range(len(items)):
+        assert _same(rb[k], seq[k]), (k, rb[k], seq[k])
+    # the second candidate starts at the first one's answer: its first MSE is within the relative bound of the carried one -> one iteration
+    assert seq[1]["iters"] == 1 and seq[1]["state"] in (lisreg.ICP_REL_MSE, lisreg.ICP_ABS_MSE, lisreg.ICP_TRANSFORM)
+    ind = gpu_ctx.icp_align_batch(items, pg, chain_prev_mse=False)
+    assert _same(ind[0], seq[0]) and _same(ind[2], gpu_ctx.icp_align(31, src2, pg))
+    # and the oracle driven the same way
+    po = oracle.icp_default_params(0)
+    tg = {30: tgt, 31: tgt2}
+    for k, (slot, s, g) in enumerate(items):
+        ro = oracle.icp_align(tg[slot], s, po, guess=g)
+        if len(s) > 2:
+            _check(rb[k], ro)
+        po.prev_mse = ro["prev_mse"]
+
+
 # ---------------------------------------------------------------- OptimizedICPGN (registration.cpp:19-115)
 def _numpy_icp_gn(tgt, src, iters, max_corr, T0):
     """all-double Gauss-Newton point-to-point ICP with the reference's update rule (t += d[:3], R = R exp(d[3:]))"""
