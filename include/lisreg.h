@@ -227,6 +227,9 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * 1: such ties are noted during the search and resolved by (distance, original index), so the five neighbours, their order and every
  * bit computed from them are the same in every front-end and batch shape — a frame registers identically alone and inside any batch —
  * at +7 % per correspondence launch; implied by "exact_arithmetic"),
+ * "cell_anchor_until" (graph front-end: during GN iterations 1 .. this [default 1] a query also tries an anchor out of its own grid column
+ * and takes the nearer of the two — the pose moves by decimetres in the first step, last iteration's nearest neighbour is a poor start;
+ * results do not depend on it),
  * "feeder_threads" (host threads of lisreg_stage_host_items, default 8; 0 = structs uploaded as they are and packed on the device),
  * "feeder_copy_engine" (1 [default]: while the next packed chunk is not ready and the copy engine is idle, the engine takes the last free
  * chunk of a pinned cloud as it is and a kernel packs it on the device; 0: never; 2: whenever a packed chunk is not ready — for tests),
@@ -494,6 +497,33 @@ int  lisreg_keyframes_target(lisreg_ctx* ctx, int ring_id, float corner_leaf, fl
 /* updateInitialGuess with neither IMU nor odometry (odomEstimationNode.cpp:351-392; subMapOptmizationNode.cpp:984-1020): the
  * constant-velocity guess T_cur * (T_last^-1 * T_cur). */
 void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6]);
+/* updateInitialGuess as a whole (odomEstimationNode.cpp:297-419 = variant 0; subMapOptmizationNode.cpp:896-1032 = variant 1): the first
+ * call takes the IMU attitude (yaw 0 unless useImuHeadingInitialization); with odometry (cloudInfo.odomAvailable, the IMU pre-integration
+ * guess initialGuess*) the increment between consecutive guesses is applied to the pose; with the IMU alone the increment of its attitude;
+ * with neither the constant-velocity guess above.  The copies differ where the reference's do: #1 tests `odomAvailable == false` alone for
+ * the constant-velocity branch and lets the FIRST odometry message fall through to the IMU increment; #2 saves the IMU attitude in the
+ * odometry branch only when there is an IMU and takes the constant-velocity branch only with neither input.  The function-local statics
+ * of the reference live in lisreg_guess_state (zero-initialise; one per node).  T = transformTobeMapped / transformTobeSubMapped
+ * {roll,pitch,yaw,x,y,z}, updated in place; T_prediction (may be NULL) receives transPredictionMapped where the reference sets it.
+ * Host arithmetic, Eigen's Affine3f operations step by step in float. */
+typedef struct lisreg_guess_input {
+    int   odom_available, imu_available;                                  /* cloudInfo.odomAvailable, .imuAvailable           */
+    float imu_roll_init, imu_pitch_init, imu_yaw_init;                    /* cloudInfo.imuRollInit, ...                       */
+    float initial_guess_x, initial_guess_y, initial_guess_z;              /* cloudInfo.initialGuessX, ...                     */
+    float initial_guess_roll, initial_guess_pitch, initial_guess_yaw;
+} lisreg_guess_input;
+typedef struct lisreg_guess_state {
+    int   first_trans_available;                 /* firstTransAvailable                                  */
+    int   last_imu_pre_trans_available;          /* lastImuPreTransAvailable                             */
+    int   first;                                 /* `first` of the constant-velocity branch              */
+    int   reserved;
+    float last_imu_transformation[12];           /* lastImuTransformation, row-major 3x4                 */
+    float last_imu_pre_transformation[12];       /* lastImuPreTransformation                             */
+    float last_transform_tobe_mapped[6];         /* lastTransformTobeMapped / lastTransformTobeSubMapped */
+} lisreg_guess_state;
+void lisreg_guess_state_init(lisreg_guess_state* st);
+void lisreg_update_initial_guess(int variant, int use_imu_heading_initialization, const lisreg_guess_input* in, lisreg_guess_state* st,
+                                 float T[6], float T_prediction[6]);
 
 /* ---- §8 f-4: pcl::IterativeClosestPoint as the loop-closure / relocalisation code drives it ------------------- */
 /* Call sites: src/node/subMapOptmizationNode.cpp:2763-2833 (loop closure: 10 m, 30 iterations, 1e-4, 1e-4),

@@ -266,6 +266,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_WIDE_UNTIL")) c->graph_wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_HOPS")) c->graph_hops = atoi(m);
+    if (const char* m = getenv("LISREG_CELL_ANCHOR_UNTIL")) c->cell_anchor_until = std::max(atoi(m), 0);
     if (const char* m = getenv("LISREG_XCD_ORDER")) c->xcd_order = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_MIN_RATIO")) c->graph_min_ratio = atoi(m);
     if (const char* m = getenv("LISREG_WIDE_FROM")) c->wide_from = c->wide_from_small = atoi(m);
@@ -789,6 +790,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     // first look is taken right there (a replay frame converges in 3: three no-op iterations, nine launches, not enqueued), later looks every 3
     int next_check = chunk;
     if (c->early_stop_chunk <= 0 && c->last_launches > 0) next_check = std::max(2, std::min(c->last_launches, chunk));
+    c->prm.cell_anchor_until = c->cell_anchor_until;
     for (int it = 0; it < c->prm.bound; ++it) {
         prof_mark(c, 0);
         (c->exact ? launch_assoc_exact : launch_assoc)(
@@ -873,6 +875,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         return LISREG_OK;
     }
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
+    if (!strcmp(name, "cell_anchor_until")) { c->cell_anchor_until = std::max(value, 0); return LISREG_OK; }
     if (!strcmp(name, "search_mode")) {
         if (value < 0 || value > 4 || value == 2) return fail(c, LISREG_ERR_ARG, "search_mode: 0 LDS-staged box, 1 cell walk, 3 k-NN graph scan, 4 auto");
         c->search_mode = value; c->prepared = false; return LISREG_OK;
@@ -916,6 +919,7 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "front_end")) { *value = c->mode_now; return LISREG_OK; }
     if (!strcmp(name, "lanes_per_query")) { *value = c->lanes_q; return LISREG_OK; }          // what the prepared batch runs (auto resolved)
     if (!strcmp(name, "sort_sources")) { *value = c->sort_sources; return LISREG_OK; }
+    if (!strcmp(name, "cell_anchor_until")) { *value = c->cell_anchor_until; return LISREG_OK; }
     if (!strcmp(name, "sorted_now")) { *value = c->sort_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { *value = c->graph_min_ratio; return LISREG_OK; }

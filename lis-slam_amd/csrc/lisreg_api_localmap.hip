@@ -618,34 +618,120 @@ int lisreg_keyframes_target(lisreg_ctx* c, int ring_id, float corner_leaf, float
     return LISREG_OK;
 }
 
-void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6])
+// Eigen::Affine3f arithmetic of updateInitialGuess, step by step in float: row-major 3 x 4 [R|t]
+namespace {
+// Affine3f::inverse(): linear part by the cofactor 3x3 inverse, t' = -L^-1 t
+void aff_inverse(const float A[12], float I[12])
 {
-    float A[12], B[12];
-    lisreg_pose_to_matrix(T_last, A);
-    lisreg_pose_to_matrix(T_cur, B);
-    // inverse of the rigid A as Eigen's Affine inverse computes it: linear part by the cofactor 3x3 inverse, t' = -L^-1 t
     const float a = A[0], b = A[1], cc = A[2], d = A[4], e = A[5], f = A[6], g = A[8], h = A[9], i = A[10];
     const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
     const float det = a * c00 + b * c01 + cc * c02, id = 1.f / det;
-    float L[9] = { c00 * id, (cc * h - b * i) * id, (b * f - cc * e) * id,
-                   c01 * id, (a * i - cc * g) * id, (cc * d - a * f) * id,
-                   c02 * id, (b * g - a * h) * id, (a * e - b * d) * id };
-    float ti[3];
-    for (int r = 0; r < 3; ++r) ti[r] = -(L[3 * r] * A[3] + L[3 * r + 1] * A[7] + L[3 * r + 2] * A[11]);
-    float Inc[12], F[12];                              // Inc = A^-1 * B ; F = B * Inc
+    const float L[9] = { c00 * id, (cc * h - b * i) * id, (b * f - cc * e) * id,
+                         c01 * id, (a * i - cc * g) * id, (cc * d - a * f) * id,
+                         c02 * id, (b * g - a * h) * id, (a * e - b * d) * id };
     for (int r = 0; r < 3; ++r) {
-        for (int q = 0; q < 3; ++q) Inc[4 * r + q] = L[3 * r] * B[q] + L[3 * r + 1] * B[4 + q] + L[3 * r + 2] * B[8 + q];
-        Inc[4 * r + 3] = L[3 * r] * B[3] + L[3 * r + 1] * B[7] + L[3 * r + 2] * B[11] + ti[r];
+        for (int q = 0; q < 3; ++q) I[4 * r + q] = L[3 * r + q];
+        I[4 * r + 3] = -(L[3 * r] * A[3] + L[3 * r + 1] * A[7] + L[3 * r + 2] * A[11]);
     }
+}
+// Z = X * Y (affine product, accumulated left to right)
+void aff_mul(const float X[12], const float Y[12], float Z[12])
+{
     for (int r = 0; r < 3; ++r) {
-        for (int q = 0; q < 3; ++q) F[4 * r + q] = B[4 * r] * Inc[q] + B[4 * r + 1] * Inc[4 + q] + B[4 * r + 2] * Inc[8 + q];
-        F[4 * r + 3] = B[4 * r] * Inc[3] + B[4 * r + 1] * Inc[7] + B[4 * r + 2] * Inc[11] + B[4 * r + 3];
+        for (int q = 0; q < 3; ++q) Z[4 * r + q] = X[4 * r] * Y[q] + X[4 * r + 1] * Y[4 + q] + X[4 * r + 2] * Y[8 + q];
+        Z[4 * r + 3] = X[4 * r] * Y[3] + X[4 * r + 1] * Y[7] + X[4 * r + 2] * Y[11] + X[4 * r + 3];
     }
-    // pcl::getTranslationAndEulerAngles: x,y,z = t; roll = atan2(m21, m22); pitch = asin(-m20); yaw = atan2(m10, m00)
-    T_guess[3] = F[3]; T_guess[4] = F[7]; T_guess[5] = F[11];
-    T_guess[0] = atan2f(F[9], F[10]);
-    T_guess[1] = asinf(-F[8]);
-    T_guess[2] = atan2f(F[4], F[0]);
+}
+// pcl::getTranslationAndEulerAngles: x,y,z = t; roll = atan2(m21, m22); pitch = asin(-m20); yaw = atan2(m10, m00)
+void aff_to_pose(const float F[12], float T[6])
+{
+    T[3] = F[3]; T[4] = F[7]; T[5] = F[11];
+    T[0] = atan2f(F[9], F[10]);
+    T[1] = asinf(-F[8]);
+    T[2] = atan2f(F[4], F[0]);
+}
+// T <- T * (from^-1 * to)
+void apply_increment(const float from[12], const float to[12], float T[6])
+{
+    float inv[12], inc[12], cur[12], fin[12];
+    aff_inverse(from, inv);
+    aff_mul(inv, to, inc);
+    lisreg_pose_to_matrix(T, cur);
+    aff_mul(cur, inc, fin);
+    aff_to_pose(fin, T);
+}
+}  // namespace
+
+void lisreg_predict_pose(const float T_last[6], const float T_cur[6], float T_guess[6])
+{
+    float A[12], B[12], T[6];
+    lisreg_pose_to_matrix(T_last, A);
+    lisreg_pose_to_matrix(T_cur, B);
+    for (int k = 0; k < 6; ++k) T[k] = T_cur[k];
+    apply_increment(A, B, T);
+    for (int k = 0; k < 6; ++k) T_guess[k] = T[k];
+}
+
+void lisreg_guess_state_init(lisreg_guess_state* st) { if (st) memset(st, 0, sizeof *st); }
+
+void lisreg_update_initial_guess(int variant, int use_imu_heading_initialization, const lisreg_guess_input* in, lisreg_guess_state* st,
+                                 float T[6], float T_prediction[6])
+{
+    if (!in || !st || !T) return;
+    const float imu_pose[6] = { in->imu_roll_init, in->imu_pitch_init, in->imu_yaw_init, 0.f, 0.f, 0.f };
+    float imu_now[12];
+    lisreg_pose_to_matrix(imu_pose, imu_now);                       // pcl::getTransformation(0, 0, 0, roll, pitch, yaw)
+    if (!st->first_trans_available) {                               // :305-318 | :902-923
+        T[0] = in->imu_roll_init; T[1] = in->imu_pitch_init; T[2] = in->imu_yaw_init;
+        if (!use_imu_heading_initialization) T[2] = 0.f;
+        memcpy(st->last_imu_transformation, imu_now, sizeof imu_now);
+        st->first_trans_available = 1;
+        return;
+    }
+    auto predict = [&]() { if (T_prediction) for (int k = 0; k < 6; ++k) T_prediction[k] = T[k]; };
+    auto constant_velocity = [&]() {                                // :351-392 | :986-1020
+        if (!st->first) { for (int k = 0; k < 6; ++k) st->last_transform_tobe_mapped[k] = T[k]; st->first = 1; return; }
+        float back[12], last[12];
+        lisreg_pose_to_matrix(T, back);
+        lisreg_pose_to_matrix(st->last_transform_tobe_mapped, last);
+        for (int k = 0; k < 6; ++k) st->last_transform_tobe_mapped[k] = T[k];
+        apply_increment(last, back, T);
+    };
+    auto imu_increment = [&]() {                                    // :394-415 | :962-982
+        apply_increment(st->last_imu_transformation, imu_now, T);
+        predict();
+        memcpy(st->last_imu_transformation, imu_now, sizeof imu_now);
+    };
+    if (in->odom_available) {                                       // :322-347 | :928-959
+        const float gp[6] = { in->initial_guess_roll, in->initial_guess_pitch, in->initial_guess_yaw,
+                              in->initial_guess_x, in->initial_guess_y, in->initial_guess_z };
+        float back[12];
+        lisreg_pose_to_matrix(gp, back);
+        const bool had = st->last_imu_pre_trans_available != 0;
+        if (!had) {
+            memcpy(st->last_imu_pre_transformation, back, sizeof back);
+            st->last_imu_pre_trans_available = 1;
+        } else {
+            apply_increment(st->last_imu_pre_transformation, back, T);
+            predict();
+            memcpy(st->last_imu_pre_transformation, back, sizeof back);
+        }
+        if (variant == 0) {
+            // copy #1 returns only from the increment branch (saving the IMU attitude on the way, :344); the very first odometry message
+            // falls through to the tests below: `odomAvailable == false` fails, the IMU increment applies if there is an IMU
+            if (had) { memcpy(st->last_imu_transformation, imu_now, sizeof imu_now); return; }
+        } else {
+            if (in->imu_available) memcpy(st->last_imu_transformation, imu_now, sizeof imu_now);      // :954-955
+            return;
+        }
+    }
+    if (variant == 0) {
+        if (!in->odom_available) { constant_velocity(); return; }   // :351 tests odomAvailable alone
+        if (in->imu_available) imu_increment();
+    } else {
+        if (in->imu_available) { imu_increment(); return; }
+        constant_velocity();                                        // neither IMU nor odometry
+    }
 }
 
 }  // extern "C"

@@ -912,6 +912,34 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
                 LISREG_GROUP_TIES(p0_, j0_, p1_, j1_, p2_, j2_, p3_, j3_); if (kTies && i4 >= 0 && p4_ == b4 && j4_ != i4) tie = true; \
             } } } while (0)
 
+// A second candidate for a query's anchor while the pose still moves by decimetres per iteration (GN iterations 1 .. P.cell_anchor_until):
+// the nearest of up to four points out of the z-window [hz - 1, hz + 1] of the query's own (x, y) column of the grid — one contiguous
+// run of the cell-sorted array, two table reads.  Any point will do for exactness (the scan certifies against whatever anchor it is
+// given); a near one keeps the certificate radius c5 + d_a small.  -1: nothing there.
+__device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, gptr_f4 pts, float qx, float qy, float qz, float& d2)
+{
+    d2 = 3.0e38f;
+    const int hx = grid_coord(qx, g.ox, g.inv_cell), hy = grid_coord(qy, g.oy, g.inv_cell), hz = grid_coord(qz, g.oz, g.inv_cell);
+    if (hx < 0 || hx >= g.nx || hy < 0 || hy >= g.ny || hz < -1 || hz > g.nz) return -1;      // (a non-finite query saturates: out)
+    const int z0 = min(max(hz - 1, 0), g.nz - 1), z1 = min(max(hz + 1, 0), g.nz - 1);
+    const int base = (hx * g.ny + hy) * g.nz;
+    const int js = cells[base + z0], je = cells[base + z1 + 1];
+    if (js >= je) return -1;
+    const int n = je - js;
+    const int p1 = js + (n >> 2), p2 = js + (n >> 1), p3 = je - 1;
+    const v3f c0 = LISREG_LD3(pts, js), c1 = LISREG_LD3(pts, p1), c2 = LISREG_LD3(pts, p2), c3 = LISREG_LD3(pts, p3);
+    const float ax = qx - c0.x, ay = qy - c0.y, az = qz - c0.z, bx = qx - c1.x, by = qy - c1.y, bz = qz - c1.z;
+    const float ex = qx - c2.x, ey = qy - c2.y, ez = qz - c2.z, fx = qx - c3.x, fy = qy - c3.y, fz = qz - c3.z;
+    const float d0 = ax * ax + ay * ay + az * az, d1 = bx * bx + by * by + bz * bz;
+    const float e2 = ex * ex + ey * ey + ez * ez, d3 = fx * fx + fy * fy + fz * fz;
+    int a = js; float d = d0;
+    if (d1 < d) { d = d1; a = p1; }
+    if (e2 < d) { d = e2; a = p2; }
+    if (d3 < d) { d = d3; a = p3; }
+    d2 = d;
+    return a;
+}
+
 // Graph scan (search_mode 3, GN iterations >= 1).  The target carries a k-NN graph (lisreg_index.hip: kGraphK nearest other
 // points per point, ascending, plus the coverage radius rho with "|x - a| < rho(a) => x is listed").  The query keeps ONE id
 // from the last iteration — its nearest neighbour, the anchor a — and scans {a} + list(a) in list order.  With d_a = |q - a|
@@ -1139,7 +1167,16 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
         // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
         bool need_walk = valid, scanned = false;
         if (valid && it->iter > 0 && g.nbr) {
-            const int anchor = nn[qflat];
+            int anchor = nn[qflat];
+            if (it->iter <= P.cell_anchor_until) {
+                float cd2;
+                const int ca = cell_anchor(g, cells, pts, qx, qy, qz, cd2);
+                if (ca >= 0) {
+                    float od2 = 3.0e38f;
+                    if (anchor >= 0) { const v3f ap = LISREG_LD3(pts, anchor); const float x = qx - ap.x, y = qy - ap.y, z = qz - ap.z; od2 = x * x + y * y + z * z; }
+                    if (cd2 < od2) anchor = ca;
+                }
+            }
             if (anchor >= 0) {
                 const gptr_f4 nbr = (gptr_f4)g.nbr;
                 const gptr_f2 meta = (gptr_f2)g.nbr_meta;

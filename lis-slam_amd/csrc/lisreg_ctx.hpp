@@ -162,6 +162,7 @@ struct lisreg_ctx {
     int       graph_min_ratio = 60;      // auto: query-iterations per target point from which the graph build pays (measured break-even ~55)
     int       xcd_order = 2;             // XCD-aware dispatch order of the correspondence launches: 0 off, 1 on (graph front-end), 2 auto (graph front-end, >= 32 registrations, >= 2048 blocks)
     bool      xcd_now = false;           // what the last run used
+    int       cell_anchor_until = 1;     // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
     bool      canonical_ties = false;    // "canonical_ties" (always on with exact_arithmetic)

@@ -77,6 +77,7 @@ struct DevParams {
     int   ties;                // "canonical_ties": equal distances resolved by (distance, original index) in every front-end
     int   exact;               // "exact_arithmetic" (the launches pick launch_assoc_exact; the host supplies the pose caches' sin / cos)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
+    int   cell_anchor_until;   // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
 };
 
 // Mutable per-registration state (device resident for the whole GN loop — no host sync per iteration).

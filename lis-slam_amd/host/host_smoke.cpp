@@ -141,6 +141,29 @@ int main()
         std::printf("KeyframeTarget: %d frames kept; target corner %d, surf %d\n", kept, ti.n_target_corner, ti.n_target_surf);
         ok = ok && kept == 2 && ti.n_keyframes == 2 && ti.n_target_surf > 0 && ti.n_target_surf <= 2 * (int)mapSurf.size();
     }
+    // loop-closure verification: the candidate loop as one call (detectLoopClosureForSubMap, :2776-2840) — two candidates, same target
+    {
+        std::vector<lisreg_icp_item> cand(2);
+        const float g2[16] = { 1, 0, 0, 0.05f, 0, 1, 0, -0.05f, 0, 0, 1, 0, 0, 0, 0, 1 };
+        cand[0] = lisreg_icp_item{ surf.points.data(), (int)surf.size(), 2, nullptr };       // slot 2: OptimizedICPGN::SetTargetCloud above
+        cand[1] = lisreg_icp_item{ surf.points.data(), (int)surf.size(), 2, g2 };
+        lisreg_icp_params ip; lisreg_icp_default_params(0, &ip);
+        std::vector<lisreg_icp_result> rr = alignLoopCandidates<PointType>(reg.handle(), cand, ip, true);
+        std::printf("alignLoopCandidates: fitness %g / %g, iterations %d / %d\n", rr[0].fitness, rr[1].fitness, rr[0].iters, rr[1].iters);
+        ok = ok && rr[0].converged && rr[1].converged && std::fabs(rr[0].final_transform[3] - tx) < 5e-2f && std::fabs(rr[1].final_transform[3] - tx) < 5e-2f;
+    }
+    // updateInitialGuess with its statics (odomEstimationNode.cpp:297-419): first call = IMU attitude, then odometry increments
+    {
+        InitialGuess guess(NodeCopy::Odom);
+        cloud_info ci; ci.imuAvailable = true; ci.odomAvailable = true; ci.imuRollInit = 0.01f; ci.imuPitchInit = -0.02f; ci.imuYawInit = 0.3f;
+        float T[6] = { 0, 0, 0, 0, 0, 0 }, pred[6] = { 0, 0, 0, 0, 0, 0 };
+        guess.updateInitialGuess(ci, T);                                         // first: roll / pitch from the IMU, yaw 0
+        ok = ok && T[0] == 0.01f && T[1] == -0.02f && T[2] == 0.f;
+        ci.initialGuessX = 1.f; guess.updateInitialGuess(ci, T);                 // first odometry message: recorded (+ IMU increment: none)
+        ci.initialGuessX = 2.f; guess.updateInitialGuess(ci, T, pred);           // second: the increment (1 m along x of the guess frame) applied
+        std::printf("updateInitialGuess: T = [%g %g %g %g %g %g]\n", T[0], T[1], T[2], T[3], T[4], T[5]);
+        ok = ok && std::fabs(std::sqrt(T[3] * T[3] + T[4] * T[4] + T[5] * T[5]) - 1.f) < 1e-4f && pred[3] == T[3];
+    }
     std::printf(ok ? "host_smoke ok\n" : "host_smoke FAILED\n");
     return ok ? 0 : 1;
 }

@@ -504,4 +504,39 @@ inline void updateInitialGuess(const float lastTransformTobeMapped[6], float tra
     for (int k = 0; k < 6; ++k) transformTobeMapped[k] = g[k];
 }
 
+// updateInitialGuess as a whole (odomEstimationNode.cpp:297-419 = NodeCopy::Odom; subMapOptmizationNode.cpp:896-1032 = NodeCopy::SubMap):
+// the function-local statics of the reference are this object's state.  One instance per node; call once per sweep BEFORE
+// scan2SubMapOptimization, exactly where the reference calls updateInitialGuess().
+enum class NodeCopy { Odom = 0, SubMap = 1 };
+class InitialGuess {
+public:
+    explicit InitialGuess(NodeCopy copy, bool useImuHeadingInitialization = false) : copy_(copy), heading_(useImuHeadingInitialization) {
+        lisreg_guess_state_init(&st_);
+    }
+    // transformTobeMapped is updated in place; transPredictionMapped (may be null) where the reference assigns it
+    void updateInitialGuess(const cloud_info& cloudInfo, float transformTobeMapped[6], float* transPredictionMapped = nullptr) {
+        lisreg_guess_input in{ cloudInfo.odomAvailable ? 1 : 0, cloudInfo.imuAvailable ? 1 : 0,
+                               cloudInfo.imuRollInit, cloudInfo.imuPitchInit, cloudInfo.imuYawInit,
+                               cloudInfo.initialGuessX, cloudInfo.initialGuessY, cloudInfo.initialGuessZ,
+                               cloudInfo.initialGuessRoll, cloudInfo.initialGuessPitch, cloudInfo.initialGuessYaw };
+        lisreg_update_initial_guess((int)copy_, heading_ ? 1 : 0, &in, &st_, transformTobeMapped, transPredictionMapped);
+    }
+    const lisreg_guess_state& state() const { return st_; }
+private:
+    NodeCopy copy_; bool heading_; lisreg_guess_state st_;
+};
+
+// The candidate loop of detectLoopClosureForSubMap (subMapOptmizationNode.cpp:2776-2840) as one call: candidate k = (target slot set by
+// IterativeClosestPoint::setInputTarget / lisreg_map_index_set, source cloud, guess).  chain = true reproduces the reference's `static`
+// ICP object (correspondences_prev_mse_ carried from one align() to the next, :2763).
+template <class PointT>
+inline std::vector<lisreg_icp_result> alignLoopCandidates(lisreg_ctx* ctx, const std::vector<lisreg_icp_item>& candidates,
+                                                          const lisreg_icp_params& params, bool chain = true) {
+    std::vector<lisreg_icp_result> res(candidates.size());
+    const int fmt = std::is_same<PointT, PointXYZIL>::value ? LISREG_FMT_XYZIL : LISREG_FMT_XYZI;
+    const int rc = lisreg_icp_align_batch(ctx, candidates.data(), (int)candidates.size(), (int)sizeof(PointT), fmt, &params, chain ? 1 : 0, res.data());
+    if (rc != LISREG_OK) throw RegistrationError(rc, lisreg_last_error(ctx));
+    return res;
+}
+
 }  // namespace lis_slam

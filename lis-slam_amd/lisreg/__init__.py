@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_extract_features_batch", "lisreg_default_feature_params", "lisreg_semantic_split",
     "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
-    "lisreg_localmap_get", "lisreg_predict_pose", "lisreg_submap_insert", "lisreg_submap_extract", "lisreg_submap_crop_boxes",
+    "lisreg_localmap_get", "lisreg_predict_pose", "lisreg_guess_state_init", "lisreg_update_initial_guess", "lisreg_submap_insert", "lisreg_submap_extract", "lisreg_submap_crop_boxes",
     "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_align_batch", "lisreg_icp_gn_match",
 ]
 
@@ -56,6 +56,19 @@ class IcpResult(C.Structure):
     def as_dict(self):
         return dict(T=np.array(list(self.final_transform), np.float32).reshape(4, 4), converged=bool(self.converged),
                     iters=self.iters, state=self.state, n_corr_last=self.n_corr_last, fitness=self.fitness, prev_mse=self.prev_mse)
+
+
+class GuessInput(C.Structure):
+    _fields_ = [("odom_available", C.c_int), ("imu_available", C.c_int),
+                ("imu_roll_init", C.c_float), ("imu_pitch_init", C.c_float), ("imu_yaw_init", C.c_float),
+                ("initial_guess_x", C.c_float), ("initial_guess_y", C.c_float), ("initial_guess_z", C.c_float),
+                ("initial_guess_roll", C.c_float), ("initial_guess_pitch", C.c_float), ("initial_guess_yaw", C.c_float)]
+
+
+class GuessState(C.Structure):
+    _fields_ = [("first_trans_available", C.c_int), ("last_imu_pre_trans_available", C.c_int), ("first", C.c_int), ("reserved", C.c_int),
+                ("last_imu_transformation", C.c_float * 12), ("last_imu_pre_transformation", C.c_float * 12),
+                ("last_transform_tobe_mapped", C.c_float * 6)]
 
 
 class IcpItem(C.Structure):
@@ -251,6 +264,10 @@ def lib():
         L.lisreg_submap_crop_boxes.restype = None
         L.lisreg_predict_pose.argtypes = [fp, fp, fp]
         L.lisreg_predict_pose.restype = None
+        L.lisreg_guess_state_init.argtypes = [C.POINTER(GuessState)]
+        L.lisreg_guess_state_init.restype = None
+        L.lisreg_update_initial_guess.argtypes = [C.c_int, C.c_int, C.POINTER(GuessInput), C.POINTER(GuessState), fp, fp]
+        L.lisreg_update_initial_guess.restype = None
         L.lisreg_icp_default_params.argtypes = [C.c_int, C.POINTER(IcpParams)]
         L.lisreg_icp_gn_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_float, fp, C.POINTER(IcpGnResult), vp]
         L.lisreg_icp_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult), vp]
@@ -272,6 +289,25 @@ def predict_pose(T_last, T_cur) -> np.ndarray:
     f = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
     lib().lisreg_predict_pose(f(a), f(b), f(out))
     return out
+
+
+class InitialGuess:
+    """updateInitialGuess with its function-local statics (lisreg_update_initial_guess): variant 0 = odomEstimationNode.cpp:297-419,
+    1 = subMapOptmizationNode.cpp:896-1032.  update(T, ...) returns (T_new, transPredictionMapped or None)."""
+
+    def __init__(self, variant: int = 0, use_imu_heading_initialization: bool = False):
+        self.variant, self.heading = variant, use_imu_heading_initialization
+        self.state = GuessState()
+        lib().lisreg_guess_state_init(C.byref(self.state))
+
+    def update(self, T, odom_available=False, imu_available=False, imu_rpy=(0.0, 0.0, 0.0), initial_guess=(0.0,) * 6):
+        """initial_guess = (x, y, z, roll, pitch, yaw) of cloudInfo.initialGuess*"""
+        inp = GuessInput(1 if odom_available else 0, 1 if imu_available else 0, *[float(v) for v in imu_rpy], *[float(v) for v in initial_guess])
+        T = np.array(T, np.float32)
+        pred = np.full(6, np.nan, np.float32)
+        f = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        lib().lisreg_update_initial_guess(self.variant, 1 if self.heading else 0, C.byref(inp), C.byref(self.state), f(T), f(pred))
+        return T, (None if np.isnan(pred).any() else pred)
 
 
 def _info_dict(info: LocalMapInfo) -> dict:

@@ -309,6 +309,7 @@ class Replayer:
         self.T = np.zeros(6, np.float32)
         self.T_last = None
         self.k = 0
+        self.guess_obj = None
         ctx.localmap_reset(map_id)
 
     def _split_and_downsample(self, cloud):
@@ -317,15 +318,29 @@ class Replayer:
         down = {k: (self.ctx.voxel_downsample(c, FRAME_LEAF[k])[1] if len(c) else c) for k, c in full.items()}
         return full, down
 
-    def step(self, cloud) -> dict:
+    def _initial_guess(self, guess_input):
+        """updateInitialGuess as a whole (:896-1032) when the frame comes with cloudInfo's IMU / odometry fields; returns the lisreg.Imu
+        that transformUpdate blends with, or None"""
+        import lisreg
+        if self.guess_obj is None:
+            self.guess_obj = lisreg.InitialGuess(1)
+        self.T, _ = self.guess_obj.update(self.T, **guess_input)
+        if guess_input.get("imu_available"):
+            return lisreg.Imu(1, float(guess_input["imu_rpy"][0]), float(guess_input["imu_rpy"][1]))
+        return None
+
+    def step(self, cloud, guess_input=None) -> dict:
         import lisreg
         t0 = time.perf_counter()
         full, down = self._split_and_downsample(cloud)
         rec = dict(frame=self.k)
+        imu = self._initial_guess(guess_input) if guess_input is not None else None
         if self.k == 0:                                             # subMapFirstFlag branch (:634-651)
             rec.update(T=self.T.copy(), guess=self.T.copy(), stats=None)
         else:
-            if self.T_last is None:                                 # updateInitialGuess: the first call only records (:1003-1011)
+            if guess_input is not None:
+                guess = self.T.copy()
+            elif self.T_last is None:                               # updateInitialGuess: the first call only records (:1003-1011)
                 self.T_last = self.T.copy()
                 guess = self.T.copy()
             else:
@@ -334,7 +349,7 @@ class Replayer:
             info = self.ctx.localmap_extract(self.map_id, guess, self.lm_params, self.slot)
             src_c = down["pole"]                                                              # currentCloudInit :866-868
             src_s = synth.concat_clouds([down["dynamic"], down["building"], down["ground"]])   # :873-889
-            T, st, _ = self.ctx.align(src_c, src_s, guess, self.params)
+            T, st, _ = self.ctx.align(src_c, src_s, guess, self.params, imu=imu)
             self.T = T.astype(np.float32)
             rec.update(T=self.T.copy(), guess=guess.copy(), stats=st, n_target_corner=info["n_target_corner"],
                        n_target_surf=info["n_target_surf"], n_src_corner=len(src_c), n_src_surf=len(src_s), crop=info["crop"])
@@ -395,11 +410,13 @@ class DeviceReplayer(Replayer):
         return rec
 
 
-def replay(ctx, frames, variant: int = 2, on_frame=None, device_resident: bool = False):
-    r = DeviceReplayer(ctx, variant) if device_resident else Replayer(ctx, variant)
+def replay(ctx, frames, variant: int = 2, on_frame=None, device_resident: bool = False, guess_inputs=None):
+    """guess_inputs: per frame the cloudInfo fields of updateInitialGuess (dict: odom_available, imu_available, imu_rpy, initial_guess);
+    host-cloud replayer only"""
+    r = DeviceReplayer(ctx, variant) if (device_resident and guess_inputs is None) else Replayer(ctx, variant)
     out = []
-    for cloud in frames:
-        rec = r.step(cloud)
+    for k, cloud in enumerate(frames):
+        rec = r.step(cloud) if guess_inputs is None else r.step(cloud, guess_inputs[k])
         out.append(rec)
         if on_frame:
             on_frame(rec)

@@ -69,6 +69,94 @@ def predict_pose(T_last, T_cur):
                      F[0, 3], F[1, 3], F[2, 3]], np.float32)
 
 
+def _aff_mul_f32(X, Y):
+    """Eigen::Affine3f product, float, accumulated left to right"""
+    f = np.float32
+    Z = np.zeros((3, 4), np.float32)
+    for r in range(3):
+        for q in range(3):
+            Z[r, q] = f(f(f(X[r, 0] * Y[0, q]) + f(X[r, 1] * Y[1, q])) + f(X[r, 2] * Y[2, q]))
+        Z[r, 3] = f(f(f(f(X[r, 0] * Y[0, 3]) + f(X[r, 1] * Y[1, 3])) + f(X[r, 2] * Y[2, 3])) + X[r, 3])
+    return Z
+
+
+def _aff_to_pose(F):
+    m = _libm()
+    return np.array([m.atan2f(float(F[2, 1]), float(F[2, 2])), m.asinf(float(-F[2, 0])), m.atan2f(float(F[1, 0]), float(F[0, 0])),
+                     F[0, 3], F[1, 3], F[2, 3]], np.float32)
+
+
+class InitialGuessOracle:
+    """updateInitialGuess with its statics: variant 0 = odomEstimationNode.cpp:297-419, variant 1 = subMapOptmizationNode.cpp:896-1032.
+    Written from the two listings branch by branch (test infrastructure; the product's lisreg_update_initial_guess is compared with it)."""
+
+    def __init__(self, variant=0, use_imu_heading_initialization=False):
+        self.variant, self.heading = variant, use_imu_heading_initialization
+        self.firstTransAvailable = False
+        self.lastImuPreTransAvailable = False
+        self.first = False
+        self.lastImuTransformation = None
+        self.lastImuPreTransformation = None
+        self.lastT = np.zeros(6, np.float32)
+
+    @staticmethod
+    def _incr(frm, to, T):
+        transIncre = _aff_mul_f32(_affine_inverse_f32(frm), to)
+        transFinal = _aff_mul_f32(pose_matrix_f32(T), transIncre)
+        return _aff_to_pose(transFinal)
+
+    def update(self, T, odom_available=False, imu_available=False, imu_rpy=(0.0, 0.0, 0.0), initial_guess=(0.0,) * 6):
+        T = np.array(T, np.float32); pred = None
+        imu = pose_matrix_f32([imu_rpy[0], imu_rpy[1], imu_rpy[2], 0, 0, 0])
+        if not self.firstTransAvailable:                                  # :305-318 | :902-923
+            T[0], T[1], T[2] = np.float32(imu_rpy[0]), np.float32(imu_rpy[1]), np.float32(imu_rpy[2])
+            if not self.heading:
+                T[2] = 0
+            self.lastImuTransformation = imu
+            self.firstTransAvailable = True
+            return T, pred
+        if odom_available:                                                # :322-347 | :928-959
+            x, y, z, ro, pi, ya = initial_guess
+            transBack = pose_matrix_f32([ro, pi, ya, x, y, z])
+            if not self.lastImuPreTransAvailable:
+                self.lastImuPreTransformation = transBack
+                self.lastImuPreTransAvailable = True
+                if self.variant == 1:
+                    if imu_available:
+                        self.lastImuTransformation = imu
+                    return T, pred
+                # copy #1 has no return here: control reaches the tests below
+            else:
+                T = self._incr(self.lastImuPreTransformation, transBack, T)
+                pred = T.copy()
+                self.lastImuPreTransformation = transBack
+                if self.variant == 0 or imu_available:
+                    self.lastImuTransformation = imu
+                return T, pred
+        if self.variant == 0:
+            if not odom_available:                                        # :351
+                return self._cv(T), pred
+            if imu_available:                                             # :394-415
+                T = self._incr(self.lastImuTransformation, imu, T)
+                pred = T.copy()
+                self.lastImuTransformation = imu
+            return T, pred
+        if imu_available:                                                 # :962-982
+            T = self._incr(self.lastImuTransformation, imu, T)
+            pred = T.copy()
+            self.lastImuTransformation = imu
+            return T, pred
+        return self._cv(T), pred                                          # :986-1020 (neither input)
+
+    def _cv(self, T):
+        if not self.first:
+            self.lastT = T.copy(); self.first = True
+            return T
+        transBack, transLast = pose_matrix_f32(T), pose_matrix_f32(self.lastT)
+        self.lastT = T.copy()
+        return self._incr(transLast, transBack, T)
+
+
 class LocalMapOracle:
     """localMap_t + insert_local_map + extractSlidingCloud on host struct arrays."""
 
@@ -191,24 +279,35 @@ def split_and_downsample(labelled_cloud):
     return full, down
 
 
-def replay(frames, n_threads=8, params=None, on_frame=None):
+def replay(frames, n_threads=8, params=None, on_frame=None, guess_inputs=None):
     """frames: iterable of labelled PointXYZIL clouds (one sweep each).  Returns a list of per-frame dicts
-    (T = transformTobeSubMapped after the frame, guess, stats, n_target_corner / n_target_surf, n_src_corner / n_src_surf)."""
+    (T = transformTobeSubMapped after the frame, guess, stats, n_target_corner / n_target_surf, n_src_corner / n_src_surf).
+    guess_inputs: per frame the cloudInfo fields updateInitialGuess reads (dict: odom_available, imu_available, imu_rpy, initial_guess) —
+    the whole of subMapOptmizationNode.cpp:896-1032 then runs every frame, and an available IMU also enters transformUpdate."""
     p = params or oc.default_params(2)
     out = []
     lm = None
     T = np.zeros(6, np.float32)
     T_last = None
     have_last = False
+    gs = InitialGuessOracle(1) if guess_inputs is not None else None
     for k, cloud in enumerate(frames):
         full, down = split_and_downsample(cloud)
         if lm is None:
             lm = LocalMapOracle(cloud.dtype)
         rec = dict(frame=k)
+        imu = None
+        if gs is not None:
+            gi = guess_inputs[k]
+            T, _ = gs.update(T, **gi)
+            if gi.get("imu_available"):
+                imu = oc.Imu(1, float(gi["imu_rpy"][0]), float(gi["imu_rpy"][1]))
         if k == 0:                                             # subMapFirstFlag branch (:634-651)
             rec.update(T=T.copy(), guess=T.copy(), stats=None)
         else:
-            if not have_last:                                  # updateInitialGuess: the first call only records (:1003-1011)
+            if gs is not None:
+                guess = T.copy()
+            elif not have_last:                                # updateInitialGuess: the first call only records (:1003-1011)
                 T_last = T.copy(); have_last = True
                 guess = T.copy()
             else:
@@ -217,7 +316,7 @@ def replay(frames, n_threads=8, params=None, on_frame=None):
             tc, ts, isect = lm.extract(guess)
             src_c = down["pole"]                                                                  # currentCloudInit :866-868
             src_s = cat([down["dynamic"], down["building"], down["ground"]])                     # :873-889
-            Tn, st, _ = oc.align(tc, ts, src_c, src_s, guess, p, n_threads=n_threads, max_trace=1)
+            Tn, st, _ = oc.align(tc, ts, src_c, src_s, guess, p, imu=imu, n_threads=n_threads, max_trace=1)
             T = Tn.astype(np.float32)
             rec.update(T=T.copy(), guess=guess.copy(), stats=st, n_target_corner=len(tc), n_target_surf=len(ts),
                        n_src_corner=len(src_c), n_src_surf=len(src_s), crop=isect)

@@ -45,6 +45,43 @@ def test_predict_pose_helper_matches_oracle():
     assert max(pose_err(lisreg.predict_pose(a, a), a)) < 1e-6          # no motion -> the same pose
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_update_initial_guess_follows_the_reference_branches(variant):
+    """updateInitialGuess with odometry / IMU input (odomEstimationNode.cpp:297-419, subMapOptmizationNode.cpp:896-1032): random
+    availability patterns through lisreg_update_initial_guess and through the branch-by-branch restatement — poses and
+    transPredictionMapped equal to the bit after every call, including the first-odometry-message fall-through of copy #1."""
+    import lisreg
+    import replay_oracle as ro
+    for seed in range(12):
+        rng = np.random.default_rng(100 * variant + seed)
+        heading = bool(seed & 1)
+        g, o = lisreg.InitialGuess(variant, heading), ro.InitialGuessOracle(variant, heading)
+        T = np.zeros(6, np.float32)
+        imu = rng.uniform(-0.05, 0.05, 3); imu[2] = rng.uniform(-3, 3)
+        odo = np.concatenate([rng.uniform(-20, 20, 3), rng.uniform(-0.05, 0.05, 2), rng.uniform(-3, 3, 1)])
+        # patterns: all three kinds of drives + one that switches its inputs on and off
+        mode = seed % 4
+        for frame in range(25):
+            imu = imu + rng.normal(0, 0.004, 3)
+            odo = odo + np.concatenate([rng.normal(0.5, 0.1, 1), rng.normal(0, 0.05, 2), rng.normal(0, 0.003, 3)])
+            oa = {0: False, 1: True, 2: False, 3: bool(rng.integers(0, 2))}[mode]
+            ia = {0: False, 1: True, 2: True, 3: bool(rng.integers(0, 2))}[mode]
+            if mode == 1 and frame < 3:
+                oa = False                                           # odometry arrives a few frames late
+            Tg, pg = g.update(T, oa, ia, imu, odo)
+            To, po = o.update(T, oa, ia, imu, odo)
+            assert np.array_equal(Tg, To), (variant, seed, frame, Tg, To)
+            assert (pg is None) == (po is None) and (pg is None or np.array_equal(pg, po)), (variant, seed, frame)
+            # what scan2SubMapOptimization would do next: move the pose a little (the registration's correction)
+            T = (Tg + np.concatenate([rng.normal(0, 1e-3, 3), rng.normal(0, 0.02, 3)])).astype(np.float32)
+    # the constant-velocity branch of the new entry point is lisreg_predict_pose
+    g = lisreg.InitialGuess(variant)
+    T0, _ = g.update(np.zeros(6, np.float32)); T1, _ = g.update(np.array([0, 0, 0.1, 1, 0, 0], np.float32))
+    assert np.array_equal(T1, np.array([0, 0, 0.1, 1, 0, 0], np.float32))   # the first constant-velocity call only records
+    T2, _ = g.update(np.array([0.01, 0, 0.2, 2, 0.5, 0], np.float32))
+    assert np.array_equal(T2, lisreg.predict_pose(np.array([0, 0, 0.1, 1, 0, 0], np.float32), np.array([0.01, 0, 0.2, 2, 0.5, 0], np.float32)))
+
+
 def test_trajectory_file_format(tmp_path):
     from lisreg import replay
     poses = [np.array([0, 0, 0.1 * k, 1.0 * k, 0.5 * k, 0], np.float32) for k in range(3)]
@@ -521,6 +558,40 @@ def test_exact_frame_loop_equals_oracle_chain_bitwise(oracle, device_resident):
             assert a["stats"]["iters"] == b["stats"]["iters"] and a["stats"]["n_corr_last"] == b["stats"]["n_corr_last"], a["frame"]
             assert (a["n_target_corner"], a["n_target_surf"], a["n_src_corner"], a["n_src_surf"]) == \
                    (b["n_target_corner"], b["n_target_surf"], b["n_src_corner"], b["n_src_surf"]), a["frame"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern", ["odom+imu", "imu", "mixed"])
+def test_exact_frame_loop_with_imu_and_odometry_guess_equals_oracle_chain_bitwise(oracle, pattern):
+    """The frame loop with cloudInfo.odomAvailable / imuAvailable set: updateInitialGuess's odometry-increment and IMU-increment branches
+    (subMapOptmizationNode.cpp:928-982) feed the registration, and the IMU attitude enters transformUpdate (:1980-2001) — HIP chain in the
+    exact build vs the oracle chain, every pose equal to the bit."""
+    import lisreg
+    import replay_oracle as ro
+    from lisreg import replay, synth
+    n = 12
+    frames, truth = zip(*replay.synthetic_drive(n, h=32, w=900))
+    rng = np.random.default_rng(77)
+    gi = []
+    for k in range(n):
+        t = np.asarray(truth[k], np.float64)                                  # {roll, pitch, yaw, x, y, z} of the drive
+        odo = (float(t[3] + 5.0), float(t[4] - 2.0), float(t[5] + 0.3), float(t[0] + rng.normal(0, 2e-4)), float(t[1] + rng.normal(0, 2e-4)),
+               float(t[2] + rng.normal(0, 2e-4)))                              # the pre-integration guess lives in ITS OWN (shifted) frame: only increments count
+        imu = (float(t[0] + rng.normal(0, 3e-4)), float(t[1] + rng.normal(0, 3e-4)), float(t[2] + rng.normal(0, 3e-4)))
+        oa = {"odom+imu": k >= 2, "imu": False, "mixed": k % 3 != 1}[pattern]
+        ia = {"odom+imu": True, "imu": True, "mixed": k % 4 != 2}[pattern]
+        gi.append(dict(odom_available=oa, imu_available=ia, imu_rpy=imu, initial_guess=odo))
+    ref = ro.replay(frames, n_threads=16, guess_inputs=gi)
+    ctx = lisreg.Context(0)
+    ctx.set_option("exact_arithmetic", 1)
+    got = replay.replay(ctx, frames, guess_inputs=gi)
+    ctx.close()
+    for a, b, t in zip(got, ref, truth):
+        assert np.array_equal(np.asarray(a["guess"], np.float32), np.asarray(b["guess"], np.float32)), a["frame"]
+        assert np.array_equal(np.asarray(a["T"], np.float32), np.asarray(b["T"], np.float32)), a["frame"]
+        if a["stats"]:
+            assert a["stats"]["iters"] == b["stats"]["iters"] and a["stats"]["n_corr_last"] == b["stats"]["n_corr_last"], a["frame"]
+            assert np.abs(np.asarray(a["T"], np.float64)[3:5] - np.asarray(t)[3:5]).max() < 0.1, (a["frame"], a["T"], t)     # and it follows the drive
 
 
 @pytest.mark.gpu
