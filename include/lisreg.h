@@ -231,6 +231,8 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * and takes the nearer of the two — the pose moves by decimetres in the first step, last iteration's nearest neighbour is a poor start;
  * results do not depend on it),
  * "feeder_threads" (host threads of lisreg_stage_host_items, default 8; 0 = structs uploaded as they are and packed on the device),
+ * "feeder_numa" (1 [default]: the packing threads are bound to those CPUs of the device's NUMA node that the process may run on — the
+ * pinned staging buffers are on that node already; read-only "feeder_numa_node" / "feeder_numa_cpus" say what was found),
  * "feeder_copy_engine" (1 [default]: while the next packed chunk is not ready and the copy engine is idle, the engine takes the last free
  * chunk of a pinned cloud as it is and a kernel packs it on the device; 0: never; 2: whenever a packed chunk is not ready — for tests),
  * "graph_min_ratio", "first_pass_mm", "count_searches", "early_stop_chunk". */

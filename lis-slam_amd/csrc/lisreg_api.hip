@@ -224,6 +224,11 @@ void prof_collect(lisreg_ctx* c)
 }
 
 }  // namespace
+namespace lisreg {
+// HIP-event marks for the other translation units (lisreg_set_profiling / lisreg_get_timing)
+void ctx_prof_mark(lisreg_ctx* c, int kind_of_next_interval) { prof_mark(c, kind_of_next_interval); }
+void ctx_prof_collect(lisreg_ctx* c) { if (!c->ev.empty()) prof_collect(c); }
+}  // namespace lisreg
 
 // =============================================================================================================
 extern "C" {
@@ -903,6 +908,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "first_pass_mm")) { c->first_pass_r = 1e-3f * (float)value; return LISREG_OK; }
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "feeder_threads")) { c->feeder_threads = std::min(std::max(value, 0), 64); return LISREG_OK; }
+    if (!strcmp(name, "feeder_numa")) { c->feeder_numa = value != 0; return LISREG_OK; }       // takes effect when the thread pool is created
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
 
@@ -920,6 +926,10 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "lanes_per_query")) { *value = c->lanes_q; return LISREG_OK; }          // what the prepared batch runs (auto resolved)
     if (!strcmp(name, "sort_sources")) { *value = c->sort_sources; return LISREG_OK; }
     if (!strcmp(name, "cell_anchor_until")) { *value = c->cell_anchor_until; return LISREG_OK; }
+    if (!strcmp(name, "feeder_threads")) { *value = c->feeder_threads; return LISREG_OK; }
+    if (!strcmp(name, "feeder_numa_node")) { *value = c->feeder_node; return LISREG_OK; }
+    if (!strcmp(name, "feeder_numa_cpus")) { *value = c->feeder_cpus; return LISREG_OK; }
+    if (!strcmp(name, "comm_nranks")) { *value = c->comm ? c->comm_nranks : 0; return LISREG_OK; }
     if (!strcmp(name, "sorted_now")) { *value = c->sort_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { *value = c->graph_min_ratio; return LISREG_OK; }

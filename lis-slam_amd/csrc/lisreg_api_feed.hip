@@ -18,8 +18,47 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <cctype>
+#include <cstdio>
+#include <pthread.h>
+#include <sched.h>
 
 namespace lisreg {
+
+// The host side of the feeder is memory-bound (two passes over the batch), and the pool's hosts are multi-socket: the same binary staged a
+// batch in 2.7 ms on one box and 5.9 ms on another.  The staging buffers come from hipHostMalloc, which places them on the
+// NUMA node nearest the device; the packing threads are bound to the CPUs of that node that this process may run on (option
+// "feeder_numa", default 1; nothing happens when sysfs says nothing or the process owns no CPU there).
+static int feeder_numa_cpus(int device, std::vector<int>& cpus)
+{
+    cpus.clear();
+    char bdf[64] = { 0 };
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return -1;
+    for (char* p = bdf; *p; ++p) *p = (char)tolower(*p);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return -1;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    std::vector<int> on_node;
+    if (FILE* f = fopen(path, "r")) {
+        int a = 0, b = 0; char sep = 0;
+        while (fscanf(f, "%d", &a) == 1) {
+            b = a;
+            int ch = fgetc(f);
+            if (ch == '-') { if (fscanf(f, "%d", &b) != 1) b = a; ch = fgetc(f); }
+            for (int k = a; k <= b && k < CPU_SETSIZE; ++k) on_node.push_back(k);
+            if (ch != ',') break;
+            (void)sep;
+        }
+        fclose(f);
+    }
+    cpu_set_t mine; CPU_ZERO(&mine);
+    if (sched_getaffinity(0, sizeof mine, &mine) != 0) return node;
+    for (int k : on_node) if (CPU_ISSET(k, &mine)) cpus.push_back(k);
+    return node;
+}
 
 struct PackPool {
     // one packing job: the workers take chunk indices from `next` until they run out; a job object lives as long as anyone holds it, so a
@@ -112,9 +151,18 @@ struct PackPool {
             if (j) { drain(*j); j->active.fetch_sub(1, std::memory_order_release); }
         }
     }
+    // cpus the packing threads are bound to (the GPU's NUMA node, lisreg_feeder_numa below); empty = wherever the scheduler puts them
+    std::vector<int> cpus;
     void start(int n_threads)
     {
-        for (int t = (int)th.size(); t < n_threads; ++t) th.emplace_back([this] { worker(); });
+        for (int t = (int)th.size(); t < n_threads; ++t) {
+            th.emplace_back([this] { worker(); });
+            if (!cpus.empty()) {
+                cpu_set_t set; CPU_ZERO(&set);
+                for (int cpu : cpus) if (cpu >= 0 && cpu < CPU_SETSIZE) CPU_SET(cpu, &set);
+                (void)pthread_setaffinity_np(th.back().native_handle(), sizeof set, &set);
+            }
+        }
     }
     // publish a job; the caller then waits on done[] in order (and may call drain() itself).  The chunk table and the done flags must stay
     // valid until every done flag is set — after that no worker reads them again (an index past n_chunks ends its loop)
@@ -243,7 +291,7 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         const int want = total >= 262144 ? std::max(1, std::min(c->feeder_threads, (int)std::thread::hardware_concurrency() - 1)) : 0;
         std::shared_ptr<PackPool::Job> job;
         if (want > 0) {
-            if (!c->pack_pool) c->pack_pool = new PackPool();
+            if (!c->pack_pool) { c->pack_pool = new PackPool(); if (c->feeder_numa) c->feeder_node = feeder_numa_cpus(c->device, c->pack_pool->cpus); c->feeder_cpus = (int)c->pack_pool->cpus.size(); }
             c->pack_pool->start(want);
             job = c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data());
         }
@@ -348,7 +396,7 @@ int lisreg_upload_cloud(lisreg_ctx* c, const void* cloud, int n, int stride_byte
     if (want > 0) {
         if ((int)c->pack_done.size() < n_chunks) c->pack_done = std::vector<std::atomic<int>>((size_t)n_chunks);
         for (int i = 0; i < n_chunks; ++i) c->pack_done[(size_t)i].store(0, std::memory_order_relaxed);
-        if (!c->pack_pool) c->pack_pool = new PackPool();
+        if (!c->pack_pool) { c->pack_pool = new PackPool(); if (c->feeder_numa) c->feeder_node = feeder_numa_cpus(c->device, c->pack_pool->cpus); c->feeder_cpus = (int)c->pack_pool->cpus.size(); }
         c->pack_pool->start(want);
         // `chunks` is a local: the guard ends the job (and waits for the threads) before the table goes out of scope, on every path
         PackPool::JobGuard guard{ c->pack_pool, c->pack_pool->run(chunks.data(), n_chunks, c->pack_done.data()) };

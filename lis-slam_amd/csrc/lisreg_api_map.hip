@@ -302,9 +302,14 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     int n_done = 0;
     for (int it = 0; it < P->max_iters && n_done < n_items;) {
         const int chunk = std::min(4, P->max_iters - it);
-        for (int k = 0; k < chunk; ++k)
-            launch_icp_iteration(di, n_items, total_blocks, q, sd, cap2, c->icp_partials.as<double>(), P->max_iters,
-                                 P->transformation_epsilon, P->euclidean_fitness_epsilon, n_done_dev, st);
+        for (int k = 0; k < chunk; ++k) {
+            ctx_prof_mark(c, 0);
+            launch_icp_assoc(di, n_items, total_blocks, q, sd, cap2, c->icp_partials.as<double>(), st);
+            ctx_prof_mark(c, 1);
+            launch_icp_solve(di, n_items, q, sd, c->icp_partials.as<double>(), P->max_iters, P->transformation_epsilon,
+                             P->euclidean_fitness_epsilon, n_done_dev, st);
+            ctx_prof_mark(c, -1);
+        }
         HIPCHK(c, hipGetLastError());
         it += chunk;
         HIPCHK(c, hipMemcpyAsync(&n_done, n_done_dev, sizeof n_done, hipMemcpyDeviceToHost, st));
@@ -314,6 +319,7 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hs.data(), sd, sizeof(IcpState) * (size_t)n_items, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    ctx_prof_collect(c);
     return LISREG_OK;
 }
 

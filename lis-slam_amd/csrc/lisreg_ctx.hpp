@@ -162,6 +162,8 @@ struct lisreg_ctx {
     int       graph_min_ratio = 60;      // auto: query-iterations per target point from which the graph build pays (measured break-even ~55)
     int       xcd_order = 2;             // XCD-aware dispatch order of the correspondence launches: 0 off, 1 on (graph front-end), 2 auto (graph front-end, >= 32 registrations, >= 2048 blocks)
     bool      xcd_now = false;           // what the last run used
+    int       feeder_numa = 1;           // packing threads bound to the CPUs of the device's NUMA node (those this process owns)
+    int       feeder_node = -1, feeder_cpus = 0;       // what that found: the node, the CPUs bound to
     int       cell_anchor_until = 1;     // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
@@ -212,6 +214,8 @@ void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* ou
 void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells);
 SortBuffers sort_buffers(lisreg_ctx* c);
 int  ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets);
+void ctx_prof_mark(lisreg_ctx* c, int kind_of_next_interval);      // 0 correspondence kernel, 1 solve, 2 index build, -1 nothing
+void ctx_prof_collect(lisreg_ctx* c);
 }  // namespace lisreg
 
 #define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \

@@ -280,8 +280,10 @@ int  icp_batch_blocks(int n, int q);
 int  icp_blocks(int n);
 // one ICP iteration on the working copy `cur` (input_transformed): apply st->Tm in place, correspondences + sums
 // (partials: icp_blocks(n) * 17 doubles), then transform estimate + convergence (st->Tm = the new transformation_)
-void launch_icp_iteration(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
-                          int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream);
+void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
+                      hipStream_t stream);
+void launch_icp_solve(const IcpItem* items, int n_items, int q, IcpState* states, const double* partials,
+                      int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream);
 void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream);
 // one OptimizedICPGN iteration (partials: icp_blocks(n) * 22 doubles); st->F is T, st->iters counts the applied steps
 void launch_icpgn_iteration(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,

@@ -623,15 +623,20 @@ int icp_blocks(int n) { return (int)(((long long)n * icp_lanes(n) + 255) / 256);
 int icp_batch_lanes(long long total) { return icp_lanes((int)std::min<long long>(total, 0x7fffffff)); }
 int icp_batch_blocks(int n, int q) { return (int)(((long long)n * q + 255) / 256); }
 
-void launch_icp_iteration(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
-                          int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream)
+void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
+                      hipStream_t stream)
 {
     if (n_items <= 0) return;
     if (total_blocks > 0) {
         if (q == 1) k_icp_assoc<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
         else        k_icp_assoc<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
     }
-    k_icp_solve<<<n_items, 1024, 0, stream>>>(partials, items, states, q, max_iters, eps_t, eps_mse, n_done);
+}
+
+void launch_icp_solve(const IcpItem* items, int n_items, int q, IcpState* states, const double* partials,
+                      int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream)
+{
+    if (n_items > 0) k_icp_solve<<<n_items, 1024, 0, stream>>>(partials, items, states, q, max_iters, eps_t, eps_mse, n_done);
 }
 
 void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream)

@@ -1029,8 +1029,17 @@ def _ctx_gather_results(self, local_ptr: int, n_local: int, out_ptr: int):
     self._chk(self._L.lisreg_gather_results(self._h, C.c_void_p(local_ptr), n_local, C.c_void_p(out_ptr)))
 
 
+def _ctx_comm_destroy(self):
+    self._L.lisreg_comm_destroy(self._h)
+
+
+def device_count() -> int:
+    return int(lib().lisreg_device_count())
+
+
 Context.comm_init = _ctx_comm_init
 Context.gather_results = _ctx_gather_results
+Context.comm_destroy = _ctx_comm_destroy
 
 
 def device_to_host(ptr: int, shape, dtype=np.float32) -> np.ndarray:
