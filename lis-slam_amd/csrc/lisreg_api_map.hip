@@ -269,7 +269,8 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     if (total > 0x7fffffffLL / 4) return bad(c, "icp: more than 2^29 source points in one batch");
     const int q = icp_batch_lanes(total);
     std::vector<IcpItem> hi((size_t)n_items + 1);
-    HIPCHK(c, c->icp_cur.ensure(sizeof(float4) * (size_t)std::max<long long>(total, 1)));
+    HIPCHK(c, c->icp_cur.ensure((sizeof(float4) + sizeof(int)) * (size_t)std::max<long long>(total, 1)));
+    int* nn_base = reinterpret_cast<int*>(c->icp_cur.as<float4>() + std::max<long long>(total, 1));
     long long off = 0; int blk = 0;
     for (int k = 0; k < n_items; ++k) {
         const IcpHostItem& it = its[(size_t)k];
@@ -279,7 +280,7 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
         for (int j = 0; j < 16; ++j) h.Tm[j] = h.F[j];        // the first pass moves the working copy by the guess (icp.hpp:129-137)
         h.prev_mse = it.prev_mse; h.cur_mse = DBL_MAX; h.first_mse = -1.0; h.defer_first = it.defer;
         IcpItem& d = hi[(size_t)k];
-        d.src = it.src; d.cur = c->icp_cur.as<float4>() + off; d.grid = c->maps[it.slot].g_dev.as<GridIndex>();
+        d.src = it.src; d.cur = c->icp_cur.as<float4>() + off; d.nn = nn_base + off; d.grid = c->maps[it.slot].g_dev.as<GridIndex>();
         d.n = it.n; d.blk0 = blk; d.nblk = icp_batch_blocks(it.n, q); d.pad_ = 0;
         off += it.n; blk += d.nblk;
     }

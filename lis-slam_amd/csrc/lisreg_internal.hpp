@@ -272,6 +272,7 @@ struct IcpState {
 struct IcpItem {
     const float4*    src;    // source records
     float4*          cur;    // working copy (input_transformed)
+    int*             nn;     // last iteration's neighbour of every source point (position in the sorted target, -1 none): the next search's seed
     const GridIndex* grid;   // its target's k = 1 index
     int n, blk0, nblk, pad_;
 };

@@ -29,8 +29,11 @@ __device__ __forceinline__ int gcoord(float v, float origin, float inv_cell) { r
 // waves of queries — a fifth of the chip's wave slots — so one-lane-per-query leaves the walk latency-bound; splitting a
 // query's columns over Q lanes shortens every dependent-load chain by Q and fills the machine (launchers pick Q from n).
 // All Q lanes of a query must call this together (same q, g, max_d2) and all of them get the merged result.
+// seed (optional): the position of a target point that is probably near — last ICP iteration's neighbour.  It enters as an ordinary
+// candidate (same distance expression, same tie rule), so the result does not depend on it; what it buys is a first pass whose radius is
+// the distance to that point instead of 0.5 m.
 template <int Q>
-__device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const GridIndex& g, float max_d2, float* d2_out)
+__device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const GridIndex& g, float max_d2, float* d2_out, int seed = -1)
 {
     constexpr float kEps = 1e-3f;
     const gptr_f4 pts = (gptr_f4)g.pts;
@@ -39,6 +42,12 @@ __device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const Gr
     int bi = -1, bw = 0x7fffffff;                                    // bw = original index of the best (ties: smallest wins)
     if (g.n <= 0) { *d2_out = best; return -1; }
     const int sub = Q > 1 ? (int)(threadIdx.x & (Q - 1)) : 0;
+    if (seed >= 0 && seed < g.n) {
+        const v4f c = pts[seed];
+        const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        if (d2 < best) { best = d2; bi = seed; bw = __float_as_int(c.w); }
+    }
 #define LISREG_NN1_TRY(c_, j_) do { \
         const float ex_ = qx - (c_).x, ey_ = qy - (c_).y, ez_ = qz - (c_).z; \
         const float d2_ = ex_ * ex_ + ey_ * ey_ + ez_ * ez_;        /* flann::L2_Simple order */ \
@@ -219,8 +228,9 @@ __global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ i
         const float4 s = stp->iters == 0 ? I.src[i] : I.cur[i];
         float px, py, pz, d2;
         apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
-        const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2);      // (all Q lanes have read their record before the lead lane writes)
-        if (lead) I.cur[i] = make_float4(px, py, pz, s.w);
+        const int seed = stp->iters == 0 ? -1 : I.nn[i];              // last iteration's neighbour (position in the sorted target)
+        const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2, seed);      // (all Q lanes have read their record before the lead lane writes)
+        if (lead) { I.cur[i] = make_float4(px, py, pz, s.w); I.nn[i] = bi; }
         if (bi >= 0 && lead) {
             const float4 q = g.pts[bi];
             acc[0] = 1.0;
@@ -418,7 +428,8 @@ __global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict
         const float4 s = I.src[i];
         float px, py, pz, d2;
         apply4(states[item].F, s.x, s.y, s.z, px, py, pz);
-        if (nn1_search<Q>(px, py, pz, g, 3.0e38f, &d2) >= 0 && (threadIdx.x & (Q - 1)) == 0) { sum = d2; cnt = 1; }
+        // seed: the neighbour of the last ICP iteration (every item has run at least one; -1 where nothing was within reach)
+        if (nn1_search<Q>(px, py, pz, g, 3.0e38f, &d2, I.nn[i]) >= 0 && (threadIdx.x & (Q - 1)) == 0) { sum = d2; cnt = 1; }
     }
     sum = wave_sum_up(sum); cnt = wave_sum_up(cnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
