@@ -505,8 +505,11 @@ def bench_icp(args, lisreg, torch, np, synth, synth_torch, dev, dev_index, rank,
     last = {}
 
     def step():
-        for i in range(batch):
-            ctx.map_index_set_device(i, tgts[i].data_ptr(), tgts[i].shape[0])        # setInputTarget (:2793)
+        if os.environ.get("LISREG_BENCH_ICP_SINGLE_SETS"):
+            for i in range(batch):
+                ctx.map_index_set_device(i, tgts[i].data_ptr(), tgts[i].shape[0])    # setInputTarget (:2793), one call per candidate
+        else:                                                                        # ... or all candidates' targets in one call
+            ctx.map_index_set_batch(list(range(batch)), [(tgts[i].data_ptr(), tgts[i].shape[0]) for i in range(batch)])
         res = ctx.icp_align_batch(items, prm, chain_prev_mse=True)
         last["res"] = res
         if use_dist:

@@ -385,6 +385,12 @@ int  lisreg_upload_cloud(lisreg_ctx* ctx, const void* cloud, int n, int stride_b
  * targets).  Replaces pcl::search::KdTree<PointT>::setInputCloud (subMap.h:889 `local_map->tree_dynamic`,
  * subMapOptmizationNode.cpp:2779 icp.setInputTarget).  LISREG_FMT_DEVICE clouds are referenced, not copied. */
 int  lisreg_map_index_set(lisreg_ctx* ctx, int slot, const void* cloud, int n, int stride_bytes, int fmt);
+/* The same for n clouds at once — setInputTarget of every candidate of a loop-closure batch (subMapOptmizationNode.cpp:2793 inside the
+ * candidate loop of :2776-2840): one bounding-box launch, one read-back and ONE sort launch sequence for all of them.  slots[k] receives
+ * clouds[k] (counts[k] points; one stride / format for the batch; a slot may not be named twice).  Each index equals what
+ * lisreg_map_index_set builds for that cloud, bit for bit. */
+int  lisreg_map_index_set_batch(lisreg_ctx* ctx, int n_maps, const int* slots, const void* const* clouds, const int* counts,
+                                int stride_bytes, int fmt);
 /* nearestKSearch(query, k = 1) for a whole cloud: idx_out[i] = index into the map cloud of the nearest point, or -1 when it
  * is farther than max_dist (pass a huge value for the reference's unbounded search); sqd_out[i] = squared distance in float,
  * accumulated x, y, z like FLANN's L2_Simple.  Equidistant candidates resolve to the smallest index.  idx_out / sqd_out are

@@ -298,7 +298,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& kv : c->maps) { auto& m = kv.second; m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
     for (auto& m : c->localmaps) { for (auto& b : m.cls) b.release(); m.tgt[0].release(); m.tgt[1].release(); }
     for (auto& r : c->keyrings) { for (auto& f : r.frames) { f.cloud[0].release(); f.cloud[1].release(); } r.cat[0].release(); r.cat[1].release(); r.tgt[0].release(); r.tgt[1].release(); }
-    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->exact_trig, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur, &c->icp_items };
+    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->exact_trig, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur, &c->icp_items, &c->map_tab, &c->map_tsegs, &c->map_tblocks };
     for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);

@@ -133,6 +133,98 @@ int lisreg_map_index_set(lisreg_ctx* c, int slot, const void* cloud, int n, int 
     return LISREG_OK;
 }
 
+// setInputTarget for every candidate of a loop-closure batch at once (subMapOptmizationNode.cpp:2793 inside the candidate loop): one
+// bounding-box launch, one read-back, ONE bucket-sort launch sequence over all clouds — instead of n x (8 launches of a few microseconds
+// and two host synchronisations).  Same index per map as lisreg_map_index_set, bit for bit (records by (cell, original index)).
+int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, const void* const* clouds, const int* counts, int stride, int fmt)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if (n_maps < 0 || (n_maps > 0 && (!slots || !clouds || !counts))) return bad(c, "map_index_set_batch: NULL argument");
+    long long total = 0, total_cells = 0;
+    for (int k = 0; k < n_maps; ++k) {
+        if (slots[k] < 0 || slots[k] > 65535) return bad(c, "map_index_set_batch: bad slot");
+        for (int j = 0; j < k; ++j) if (slots[j] == slots[k]) return bad(c, "map_index_set_batch: a slot is named twice");
+        const int rc = check_cloud(c, clouds[k], counts[k], stride, fmt, "map_index_set_batch");
+        if (rc) return rc;
+        total += counts[k];
+    }
+    if (n_maps == 0) return LISREG_OK;
+    if (total > 0x7fffffffLL / 2) return bad(c, "map_index_set_batch: more than 2^30 points in one batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    std::vector<MapIndex*> ms((size_t)n_maps);
+    for (int k = 0; k < n_maps; ++k) { ms[(size_t)k] = &c->maps[slots[k]]; ms[(size_t)k]->valid = false; ms[(size_t)k]->n = counts[k]; }
+    if (fmt == LISREG_FMT_DEVICE) {
+        for (int k = 0; k < n_maps; ++k) ms[(size_t)k]->raw_ptr = static_cast<const float4*>(clouds[k]);
+    } else {
+        for (int k = 0; k < n_maps; ++k) {
+            MapIndex& m = *ms[(size_t)k];
+            std::vector<lisreg_dpoint> h((size_t)std::max(counts[k], 1));
+            pack_cloud(clouds[k], counts[k], stride, fmt, h.data());
+            HIPCHK(c, m.raw.ensure(sizeof(float4) * (size_t)std::max(counts[k], 1)));
+            if (counts[k] > 0) HIPCHK(c, hipMemcpy(m.raw.p, h.data(), sizeof(float4) * (size_t)counts[k], hipMemcpyHostToDevice));
+            m.raw_ptr = m.raw.as<float4>();
+        }
+    }
+    // bounding boxes of all clouds: one launch pair, one read-back
+    std::vector<CloudRef> refs((size_t)n_maps);
+    for (int k = 0; k < n_maps; ++k) refs[(size_t)k] = CloudRef{ ms[(size_t)k]->raw_ptr, counts[k], 0 };
+    HIPCHK(c, c->map_tab.ensure(sizeof(CloudRef) * (size_t)n_maps));
+    HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 6 * (size_t)n_maps + 64));
+    HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 64 * (size_t)n_maps + 6 * 256 * sizeof(float)));
+    HIPCHK(c, hipMemcpyAsync(c->map_tab.p, refs.data(), sizeof(CloudRef) * (size_t)n_maps, hipMemcpyHostToDevice, st));
+    launch_bbox_refs(c->map_tab.as<CloudRef>(), n_maps, c->bbox_dev.as<float>(), c->bbox_scratch.as<float>(), st);
+    HIPCHK(c, hipGetLastError());
+    std::vector<float> bbs((size_t)n_maps * 6);
+    HIPCHK(c, hipMemcpyAsync(bbs.data(), c->bbox_dev.p, sizeof(float) * 6 * (size_t)n_maps, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));            // (also: refs is a local)
+    // grid geometry per map, then one table for the batched build
+    std::vector<TargetSeg> tsegs((size_t)n_maps);
+    std::vector<BlockDesc> tblocks;
+    int tflat = 0;
+    for (int k = 0; k < n_maps; ++k) {
+        MapIndex& m = *ms[(size_t)k];
+        const float* bb = &bbs[(size_t)k * 6];
+        const int n = counts[k];
+        float zero[6] = { 0, 0, 0, 0, 0, 0 };
+        if (n > 0) {
+            for (int d = 0; d < 6; ++d) if (!std::isfinite(bb[d])) return bad(c, "map_index_set_batch: a cloud has infinite coordinates");
+            if (!(bb[0] <= bb[3] && bb[1] <= bb[4] && bb[2] <= bb[5])) return bad(c, "map_index_set_batch: a cloud has no finite point (every coordinate is NaN)");
+        }
+        make_grid(n > 0 ? bb : zero, n, &m.g, &m.n_cells);
+        HIPCHK(c, m.cell_start.ensure(sizeof(int) * ((size_t)m.n_cells + 2)));
+        HIPCHK(c, m.sorted.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+        HIPCHK(c, m.g_dev.ensure(sizeof(GridIndex)));
+        m.g.pts = m.sorted.as<float4>();
+        m.g.cell_start = m.cell_start.as<int>();
+        TargetSeg& ts = tsegs[(size_t)k];
+        memset(&ts, 0, sizeof ts);
+        ts.raw = m.raw_ptr; ts.sorted_out = m.sorted.as<float4>(); ts.cell_start_out = m.cell_start.as<int>();
+        ts.n = n; ts.n_cells = m.n_cells;
+        ts.flat_base = tflat; ts.bucket_base = (int)total_cells;
+        ts.ox = m.g.ox; ts.oy = m.g.oy; ts.oz = m.g.oz; ts.inv_cell = m.g.inv_cell;
+        ts.nx = m.g.nx; ts.ny = m.g.ny; ts.nz = m.g.nz;
+        ts.grid_id = k;
+        for (int s0 = 0; s0 < n; s0 += kBlockQ) tblocks.push_back(BlockDesc{ k, s0, std::min(kBlockQ, n - s0), 0 });
+        tflat += n; total_cells += m.n_cells;
+        if (total_cells > 0x7fffffffLL / 2) return bad(c, "map_index_set_batch: the grids of this batch have more than 2^30 cells in all — set them in smaller groups");
+    }
+    int rc = ensure_sort_scratch(c, (size_t)std::max(tflat, 1), (size_t)std::max<long long>(total_cells, 1));
+    if (rc) return rc;
+    HIPCHK(c, c->map_tsegs.ensure(sizeof(TargetSeg) * (size_t)n_maps));
+    HIPCHK(c, c->map_tblocks.ensure(sizeof(BlockDesc) * std::max<size_t>(tblocks.size(), 1)));
+    HIPCHK(c, hipMemcpyAsync(c->map_tsegs.p, tsegs.data(), sizeof(TargetSeg) * (size_t)n_maps, hipMemcpyHostToDevice, st));
+    if (!tblocks.empty()) HIPCHK(c, hipMemcpyAsync(c->map_tblocks.p, tblocks.data(), sizeof(BlockDesc) * tblocks.size(), hipMemcpyHostToDevice, st));
+    for (int k = 0; k < n_maps; ++k)
+        HIPCHK(c, hipMemcpyAsync(ms[(size_t)k]->g_dev.p, &ms[(size_t)k]->g, sizeof(GridIndex), hipMemcpyHostToDevice, st));
+    launch_build_targets_batched(c->map_tblocks.as<BlockDesc>(), (int)tblocks.size(), c->map_tsegs.as<TargetSeg>(), n_maps, tflat,
+                                 (int)std::max<long long>(total_cells, 1), sort_buffers(c), st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));            // the tables are locals
+    for (int k = 0; k < n_maps; ++k) ms[(size_t)k]->valid = true;
+    return LISREG_OK;
+}
+
 int lisreg_nearest(lisreg_ctx* c, int slot, const void* query, int n, int stride, int fmt, float max_dist, int* idx_out,
                    float* sqd_out)
 {

@@ -133,7 +133,7 @@ struct lisreg_ctx {
     std::vector<lisreg::LocalMap> localmaps;
     std::vector<lisreg::KeyframeRing> keyrings;
     lisreg::DevBuf lm_in, lm_tmp, lm_bbox, exact_trig;
-    lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur, icp_items;
+    lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur, icp_items, map_tab, map_tsegs, map_tblocks;
     int*      done_host = nullptr;          // pinned
     unsigned char* stage_host = nullptr;    // pinned staging of the per-batch tables
     size_t    stage_cap = 0;

@@ -1186,6 +1186,19 @@ void launch_bbox_jobs(const BboxJobs& j, float* bbox_out, float* scratch, hipStr
     k_bbox_final_multi<<<j.k, 64, 0, st>>>(scratch, 64, bbox_out);
 }
 
+// the same for ANY number of clouds, described by a device table (lisreg_map_index_set_batch)
+__global__ __launch_bounds__(256) void k_bbox_partial_refs(const CloudRef* __restrict__ refs, float* __restrict__ part)
+{
+    const CloudRef r = refs[blockIdx.y];
+    k_bbox_block(r.pts, r.n, part + (size_t)blockIdx.y * 6 * gridDim.x);
+}
+void launch_bbox_refs(const CloudRef* refs_dev, int k, float* bbox_out, float* scratch, hipStream_t st)
+{
+    if (k <= 0) return;
+    k_bbox_partial_refs<<<dim3(64, (unsigned)k), 256, 0, st>>>(refs_dev, scratch);
+    k_bbox_final_multi<<<k, 64, 0, st>>>(scratch, 64, bbox_out);
+}
+
 // K clouds copied end to end into one array (cloud s to [off[s], off[s + 1])) by one launch
 __global__ __launch_bounds__(256) void k_concat_jobs(BboxJobs j, VoxelMulti m, float4* __restrict__ cat)
 {

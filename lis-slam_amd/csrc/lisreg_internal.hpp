@@ -202,6 +202,8 @@ struct VoxelHandOut { int k; int vo[kVoxelMultiMax + 1]; float4* out[kVoxelMulti
 void launch_bbox_multi(const float4* cat, const VoxelMulti& m, float* bbox_out /* [6 * k] */, float* scratch /* >= 6 * 64 * k floats */, hipStream_t st);
 struct BboxJobs { int k; int n[kVoxelMultiMax]; const float4* pts[kVoxelMultiMax]; };     // n == 0: the empty box (3e38, -3e38)
 void launch_bbox_jobs(const BboxJobs& j, float* bbox_out /* [6 * k] */, float* scratch /* >= 6 * 64 * k floats */, hipStream_t st);
+struct CloudRef { const float4* pts; int n; int pad_; };
+void launch_bbox_refs(const CloudRef* refs_dev, int k, float* bbox_out /* [6 * k] */, float* scratch /* >= 6 * 64 * k floats */, hipStream_t st);
 void launch_concat_jobs(const BboxJobs& j, const VoxelMulti& m, float4* cat, hipStream_t st);
 void launch_multi_bounds(const int* slot, const VoxelMulti& m, int* out /* [k + 1] */, hipStream_t st);
 void launch_hand_out(const float4* src, const VoxelHandOut& h, hipStream_t st);

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_voxel_downsample_multi", "lisreg_transform_cloud",
     "lisreg_extract_features", "lisreg_extract_features_deskew", "lisreg_extract_features_batch", "lisreg_default_feature_params", "lisreg_semantic_split",
-    "lisreg_map_index_set", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
+    "lisreg_map_index_set", "lisreg_map_index_set_batch", "lisreg_nearest", "lisreg_dynamic_filter", "lisreg_bbx_filter", "lisreg_cloud_bounds",
     "lisreg_localmap_default_params", "lisreg_localmap_reset", "lisreg_localmap_insert", "lisreg_localmap_extract",
     "lisreg_localmap_get", "lisreg_predict_pose", "lisreg_guess_state_init", "lisreg_update_initial_guess", "lisreg_submap_insert", "lisreg_submap_extract", "lisreg_submap_crop_boxes",
     "lisreg_icp_default_params", "lisreg_icp_align", "lisreg_icp_align_batch", "lisreg_icp_gn_match",
@@ -243,6 +243,7 @@ def lib():
         L.lisreg_semantic_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(SemanticOut)]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
         L.lisreg_map_index_set.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.lisreg_map_index_set_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
         L.lisreg_nearest.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
         L.lisreg_dynamic_filter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                             C.c_float, vp, ip]
@@ -769,6 +770,21 @@ class Context:
     def map_index_set(self, slot: int, cloud: np.ndarray):
         cloud = np.ascontiguousarray(cloud)
         self._chk(self._L.lisreg_map_index_set(self._h, slot, _vp(cloud), len(cloud), cloud.dtype.itemsize, _fmt_of(cloud)))
+
+    def map_index_set_batch(self, slots, clouds):
+        """lisreg_map_index_set_batch: clouds = host PCL-struct arrays (one dtype), or (device_ptr, n) tuples"""
+        k = len(slots)
+        sl = (C.c_int * max(k, 1))(*[int(v) for v in slots])
+        ptrs = (C.c_void_p * max(k, 1))(); cnt = (C.c_int * max(k, 1))()
+        keep, fmt, stride = [], FMT_DEVICE, 16
+        for i, cl in enumerate(clouds):
+            if isinstance(cl, tuple):
+                ptrs[i], cnt[i] = C.c_void_p(cl[0]), cl[1]
+            else:
+                cl = np.ascontiguousarray(cl); keep.append(cl)
+                ptrs[i], cnt[i] = C.c_void_p(cl.ctypes.data if len(cl) else 0), len(cl)
+                fmt, stride = _fmt_of(cl), cl.dtype.itemsize
+        self._chk(self._L.lisreg_map_index_set_batch(self._h, k, sl, ptrs, cnt, stride, fmt))
 
     def map_index_set_device(self, slot: int, ptr: int, n: int):
         self._chk(self._L.lisreg_map_index_set(self._h, slot, C.c_void_p(ptr), n, 16, FMT_DEVICE))

@@ -268,6 +268,36 @@ def test_hip_icp_batch_equals_single_calls_bitwise_and_oracle(oracle, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_map_index_set_batch_equals_single_sets(gpu_ctx):
+    """setInputTarget of all candidates in one call (lisreg_map_index_set_batch): k = 1 queries and ICP alignments against the maps it
+    builds equal those against maps built one by one — host clouds, device records, an empty and a one-point cloud among them."""
+    import lisreg
+    from lisreg import synth
+    cases = [_case(71 + k, n_map=int(15000 + 9000 * k), trans=0.3, rot_deg=1.5, hw=(16, 450)) for k in range(5)]
+    clouds = [c[0] for c in cases] + [cases[0][0][:0], cases[1][0][:1]]
+    for k, cl in enumerate(clouds):
+        gpu_ctx.map_index_set(60 + k, cl)
+    gpu_ctx.map_index_set_batch([80 + k for k in range(len(clouds))], clouds)
+    pg = lisreg.icp_default_params(0)
+    q = cases[2][1][:4000]
+    for k in range(len(clouds)):
+        i1, d1 = gpu_ctx.nearest(60 + k, q, 5.0)
+        i2, d2 = gpu_ctx.nearest(80 + k, q, 5.0)
+        assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), k
+    for k in range(5):
+        assert _same(gpu_ctx.icp_align(60 + k, cases[k][1], pg), gpu_ctx.icp_align(80 + k, cases[k][1], pg)), k
+    # device records, re-using slots (a second batch over the same slots replaces the maps)
+    recs = [lisreg.DeviceArray(lisreg.pack_device_records(c[0])) for c in cases]
+    gpu_ctx.map_index_set_batch([80 + k for k in range(5)], [(r.ptr, r.shape[0]) for r in reversed(recs)])
+    for k in range(5):
+        i1, d1 = gpu_ctx.nearest(60 + (4 - k), q, 5.0)
+        i2, d2 = gpu_ctx.nearest(80 + k, q, 5.0)
+        assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), k
+    with pytest.raises(lisreg.LisregError):
+        gpu_ctx.map_index_set_batch([90, 90], clouds[:2])
+
+
+@pytest.mark.gpu
 def test_hip_icp_batch_chained_prev_mse_follows_the_static_object(oracle, gpu_ctx):
     """The reference's ICP object is `static` (subMapOptmizationNode.cpp:2763): correspondences_prev_mse_ of candidate k - 1 is what
     candidate k's first MSE comparison sees.  chain_prev_mse = 1 must give what a sequential loop gives — including the case where that
