@@ -257,8 +257,25 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
         if (col < kNumAcc) {
             const double* p = partials + (size_t)it->blk_begin * kNumAcc + col;
             const int nb = it->blk_count;
-#pragma unroll 4
-            for (int b = grp; b < nb; b += kSolveThreads / 32) s += p[(size_t)b * kNumAcc];
+            // the rows of a group are added in ascending order whatever the unrolling; sixteen loads in flight instead of four: a launch of
+            // this kernel is a chain of load round trips on one workgroup per registration (450 rows / 16 groups = 28 loads per thread)
+            int b = grp;
+            constexpr int kG = kSolveThreads / 32;
+            for (; b + 15 * kG < nb; b += 16 * kG) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(b + u * kG) * kNumAcc];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+            for (; b + 3 * kG < nb; b += 4 * kG) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(b + u * kG) * kNumAcc];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += v[u];
+            }
+            for (; b < nb; b += kG) s += p[(size_t)b * kNumAcc];
         }
         s_part[grp][col] = s;
     }
