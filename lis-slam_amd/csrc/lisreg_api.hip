@@ -43,6 +43,12 @@ float env_float(const char* name, float dflt)
     return s ? (float)atof(s) : dflt;
 }
 
+int env_int(const char* name, int dflt)
+{
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
 void pose_to_matrix_host(const float T[6], float M[12])
 {
     // pcl::getTransformation via trans2Affine3f (src/core/common.cpp:54-57)
@@ -121,8 +127,9 @@ namespace {
 // grid geometry from a bounding box; cell edge grows if the box would need too many cells
 }  // namespace
 namespace lisreg {
-void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells)
+void make_grid(const float bb_in[6], int n, GridIndex* g, int* n_cells, int margin_cells)
 {
+    float bb[6] = { bb_in[0], bb_in[1], bb_in[2], bb_in[3], bb_in[4], bb_in[5] };
     memset(g, 0, sizeof *g);
     g->n = n;
     // Cell edge: 0.5 m is the measured optimum for the 200 k-point submap of BASELINE configs[1]; the optimum
@@ -136,7 +143,11 @@ void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells)
     cell = env_float("LISREG_CELL", cell);
     if (n <= 0) { g->cell = cell; g->inv_cell = 1.f / cell; g->nx = g->ny = g->nz = 0; *n_cells = 1; return; }
     const double max_cells = 1 << 24;
+    // registration targets: the grid reaches `margin_cells` cells past the cloud on every side, so that a query a pose error away from
+    // a wall that bounds the cloud still has a cell of its own (cell rows, search_mode 5); empty cells cost four bytes of table each
+    const float bb0[6] = { bb[0], bb[1], bb[2], bb[3], bb[4], bb[5] };
     for (;;) {
+        for (int d = 0; d < 3; ++d) { bb[d] = bb0[d] - (float)margin_cells * cell; bb[3 + d] = bb0[3 + d] + (float)margin_cells * cell; }
         double nx = floor((bb[3] - bb[0]) / cell) + 1, ny = floor((bb[4] - bb[1]) / cell) + 1,
                nz = floor((bb[5] - bb[2]) / cell) + 1;
         if (nx * ny * nz <= max_cells) { g->nx = (int)nx; g->ny = (int)ny; g->nz = (int)nz; break; }
@@ -177,6 +188,45 @@ int ensure_graph(lisreg_ctx* c, Target& t, int k, bool launch)
         HIPCHK(c, hipGetLastError());
         t.graph_valid[k] = true;
     }
+    return LISREG_OK;
+}
+
+// search_mode 5: cell rows of target kind k (the index itself must already be enqueued on the stream).  The row count depends on the
+// data, so the first build of a target classifies its cells, reads the count back (one host round trip, at set / prepare time) and sizes the
+// buffers; rebuilds inside a run (rebuild_targets_each_run) reuse that capacity — a cell that does not fit gets no row and its queries walk.
+lisreg::CrowBuffers crow_buffers(Target& t, int k)
+{
+    lisreg::CrowBuffers cb;
+    cb.need = t.crow_need[k].as<int>(); cb.scan = t.crow_scan[k].as<int>(); cb.scan_tmp = t.crow_scan_tmp[k].as<int>();
+    cb.cap_rows = t.crow_cap[k];
+    return cb;
+}
+
+int ensure_crows(lisreg_ctx* c, Target& t, int k)
+{
+    if (t.crow_valid[k] && t.g[k].crow_tab) return LISREG_OK;
+    const size_t nc = (size_t)std::max(t.n_cells[k], 1);
+    HIPCHK(c, t.crow_need[k].ensure(sizeof(int) * (nc + 8)));
+    HIPCHK(c, t.crow_scan[k].ensure(sizeof(int) * (nc + 8)));
+    HIPCHK(c, t.crow_scan_tmp[k].ensure(sizeof(int) * (nc / 2048 + 8)));
+    HIPCHK(c, t.crow_tab[k].ensure(sizeof(int) * (nc + 8)));
+    t.g[k].crow_tab = t.crow_tab[k].as<int>();
+    int rows = 0;
+    if (t.n[k] > 0) {
+        launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream);
+        HIPCHK(c, hipMemcpyAsync(&rows, t.crow_scan[k].as<int>() + t.n_cells[k], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    t.crow_cap[k] = std::max(rows, 1);
+    if (getenv("LISREG_CROW_DEBUG")) fprintf(stderr, "[lisreg] cell rows of kind %d: %d rows for %d points in %d cells (%d x %d x %d of %.3f m)\n", k, rows, t.n[k], t.n_cells[k], t.g[k].nx, t.g[k].ny, t.g[k].nz, t.g[k].cell);
+    HIPCHK(c, t.crow[k].ensure(sizeof(float4) * kGraphK * (size_t)t.crow_cap[k]));
+    HIPCHK(c, t.crow_meta[k].ensure(sizeof(float2) * (size_t)t.crow_cap[k]));
+    t.g[k].crow = t.crow[k].as<float4>();
+    t.g[k].crow_meta = t.crow_meta[k].as<float2>();
+    if (t.n[k] > 0) launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream);
+    else HIPCHK(c, hipMemsetAsync(t.crow_tab[k].p, 0xff, sizeof(int) * nc, c->stream));
+    HIPCHK(c, hipGetLastError());
+    t.crow_valid[k] = true;
     return LISREG_OK;
 }
 
@@ -261,7 +311,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     lisreg_default_params(LISREG_VARIANT_ODOM, &c->params);
     if (const char* m = getenv("LISREG_SEARCH_MODE")) {            // the same values lisreg_set_option("search_mode") takes
         const int v = atoi(m);
-        if (v == 0 || v == 1 || v == 3 || v == 4) c->search_mode = v;
+        if (v == 0 || v == 1 || v == 3 || v == 4 || v == 5) c->search_mode = v;
         else fprintf(stderr, "[lisreg] LISREG_SEARCH_MODE=%s ignored (0, 1, 3 or 4)\n", m);
     }
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
@@ -286,7 +336,8 @@ void lisreg_destroy(lisreg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     lisreg_comm_destroy(c);
     feeder_destroy(c);
-    for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release(); }
+    for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release();
+        t.crow[k].release(); t.crow_meta[k].release(); t.crow_tab[k].release(); t.crow_need[k].release(); t.crow_scan[k].release(); t.crow_scan_tmp[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
                        &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->xcd_tab, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
@@ -429,11 +480,14 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
             if (n > 0 && !std::isfinite(bb[d])) return fail(c, LISREG_ERR_ARG, "set_target: the cloud has infinite coordinates (NaN points are ignored, Inf is not indexable)");
         if (n > 0 && !(bb[0] <= bb[3] && bb[1] <= bb[4] && bb[2] <= bb[5]))
             return fail(c, LISREG_ERR_ARG, "set_target: the cloud has no finite point (every coordinate is NaN)");
-        make_grid(bb, n, &t.g[k], &t.n_cells[k]);
+        make_grid(bb, n, &t.g[k], &t.n_cells[k], env_int("LISREG_GRID_MARGIN", 2));
         prof_mark(c, 2);
         int rc = build_target_kind(c, t, k);
         t.graph_valid[k] = false;
+        t.crow_valid[k] = false;
+        t.g[k].crow = nullptr; t.g[k].crow_meta = nullptr; t.g[k].crow_tab = nullptr;
         if (!rc && c->search_mode == 3) rc = ensure_graph(c, t, k, true);
+        if (!rc && c->search_mode == 5) rc = ensure_crows(c, t, k);
         prof_mark(c, -1);
         if (rc) return rc;
     }
@@ -611,6 +665,12 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
                 Target& t = c->targets[(size_t)slot];
                 if (!t.graph_valid[k] || !t.g[k].nbr) { rc = ensure_graph(c, t, k, true); if (rc) return rc; c->grids_dirty = true; }
             }
+    if (c->mode_now == 5)
+        for (int slot : c->batch_slots)
+            for (int k = 0; k < 2; ++k) {
+                Target& t = c->targets[(size_t)slot];
+                if (!t.crow_valid[k] || !t.g[k].crow_tab) { rc = ensure_crows(c, t, k); if (rc) return rc; c->grids_dirty = true; }
+            }
     if (c->grids_dirty) { rc = upload_grids(c); if (rc) return rc; }
     // table for rebuilding every target index of this batch in ONE launch sequence (rebuild_targets_each_run)
     c->h_tsegs.clear(); c->h_tblocks.clear(); c->h_tchunks.clear();
@@ -769,6 +829,14 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         if (c->mode_now == 3)
             launch_build_graph(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
                                c->grids_dev.as<GridIndex>(), st);
+        if (c->mode_now == 5)
+            for (int slot : c->batch_slots)
+                for (int k = 0; k < 2; ++k) {
+                    Target& t = c->targets[(size_t)slot];
+                    if (t.n[k] <= 0) continue;
+                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), st);
+                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), st);
+                }
         prof_mark(c, -1);
     }
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
@@ -780,7 +848,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     // XCD-aware dispatch order (lisreg_assoc.hip, launch_xcd_order): two small launches per run, at the initial poses.  Auto: the graph
     // front-end with >= 32 registrations (measured: +2.5 % at 64 scans, +4.9 % at 256; with 8 big scans the sectors are unevenly loaded
     // and it costs 2 %; the walk front-end gains nothing)
-    c->xcd_now = c->mode_now == 3 && c->lanes_q != 8 && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32));
+    c->xcd_now = (c->mode_now == 3 || c->mode_now == 5) && c->lanes_q != 8 && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32));
     if (c->xcd_now) {
         HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
         launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
@@ -802,7 +870,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                      c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
                      c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>(),
                      c->mode_now, c->nn.as<int>(), c->n_elems, c->first_pass_r * c->first_pass_r,
-                     it >= (c->lanes_q == 8 ? c->wide_from_small : c->wide_from) && it <= (c->mode_now == 3 ? c->graph_wide_until : c->wide_until), c->graph_hops,
+                     it >= (c->lanes_q == 8 ? c->wide_from_small : c->wide_from) && it <= (c->mode_now == 3 || c->mode_now == 5 ? c->graph_wide_until : c->wide_until), c->graph_hops,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
                      c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, c->lanes_q,
                      c->blocks_q.as<BlockDesc>(), (int)c->h_blocks_q.size(), c->coef.as<float4>(), c->coef_ok.as<int>(),
@@ -882,7 +950,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "sort_sources")) { c->sort_sources = value; return LISREG_OK; }
     if (!strcmp(name, "cell_anchor_until")) { c->cell_anchor_until = std::max(value, 0); return LISREG_OK; }
     if (!strcmp(name, "search_mode")) {
-        if (value < 0 || value > 4 || value == 2) return fail(c, LISREG_ERR_ARG, "search_mode: 0 LDS-staged box, 1 cell walk, 3 k-NN graph scan, 4 auto");
+        if (value < 0 || value > 5 || value == 2) return fail(c, LISREG_ERR_ARG, "search_mode: 0 LDS-staged box, 1 cell walk, 3 k-NN graph scan, 4 auto, 5 cell rows");
         c->search_mode = value; c->prepared = false; return LISREG_OK;
     }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
@@ -1069,7 +1137,7 @@ int lisreg_get_counters(lisreg_ctx* c, unsigned long long* out, int n)
     if (!c->counters.p) return LISREG_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->counters.p, sizeof(unsigned long long) * (size_t)std::min(n, 128), hipMemcpyDeviceToHost));
-    if (c->mode_now == 3) {              // the graph scan packs (walked << 32 | valid) per GN iteration: unpack to the pair layout
+    if (c->mode_now == 3 || c->mode_now == 5) {              // the graph scan packs (walked << 32 | valid) per GN iteration: unpack to the pair layout
         unsigned long long tmp[64] = { 0 };
         for (int i = 0; i < 32 && 2 * i + 1 < n; ++i) { tmp[2 * i] = out[i] >> 32; tmp[2 * i + 1] = out[i] & 0xffffffffull; }
         for (int i = 0; i < std::min(n, 64); ++i) out[i] = tmp[i];
@@ -1122,7 +1190,7 @@ int lisreg_get_target_graph(lisreg_ctx* c, int slot, int kind, int* k_out, float
 int lisreg_get_neighbors(lisreg_ctx* c, int* out, int n_elems)
 {
     if (!c || !out || n_elems < 0) return LISREG_ERR_ARG;
-    if (!c->dump_neighbors || !c->dbg_nn.p || n_elems != c->n_elems || (c->mode_now != 1 && c->mode_now != 3))
+    if (!c->dump_neighbors || !c->dbg_nn.p || n_elems != c->n_elems || (c->mode_now != 1 && c->mode_now != 3 && c->mode_now != 5))
         return fail(c, LISREG_ERR_ARG, "get_neighbors: set option dump_neighbors before preparing the batch (search modes 1, 3); n_elems must be the batch's source point count");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->dbg_nn.p, sizeof(int) * 6 * (size_t)n_elems, hipMemcpyDeviceToHost));

@@ -1051,6 +1051,55 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
             } \
         } } while (0)
 
+// Cell rows (search_mode 5, every GN iteration).  The row is anchored at the centre m of the grid cell — or of the octant of it — the query
+// falls into (lisreg_index.hip, k_crow_build), so d_m = |q - m| is bounded by the cell size whatever the query's distance from the surface:
+// the same certificate as the graph scan (stop at the first entry farther from m than c5 + d_m; an exhausted list certifies through
+// rho(m) > c5 + d_m), no anchor carried between iterations, no anchor point to fetch, no hop.  No certificate -> the cell walk, seeded.
+#define LISREG_CELL_SCAN() do { \
+            const gptr_f4 R_ = (gptr_f4)(crow + (size_t)row_ * kGraphK); \
+            const v4f r0_ = R_[0], r1_ = R_[1], r2_ = R_[2], r3_ = R_[3]; \
+            const v2f am_ = cmeta[row_]; \
+            const float rho2_ = am_.x; \
+            const int cnt_ = __float_as_int(am_.y); \
+            v4f ap_; ap_.x = mx_; ap_.y = my_; ap_.z = mz_; ap_.w = 0.f; \
+            const float ux_ = qx - ap_.x, uy_ = qy - ap_.y, uz_ = qz - ap_.z; \
+            const float da2_ = ux_ * ux_ + uy_ * uy_ + uz_ * uz_; \
+            const float da_ = __builtin_amdgcn_sqrtf(da2_) * 1.0001f + kEps; \
+            bool stop_ = false; \
+            float thr2_; \
+            if (cnt_ >= 4) { \
+                /* the first four entries: all distinct, nothing in the list yet -> sort them and take what is inside tau */ \
+                float sd[4]; int sid[4] = { __float_as_int(r0_.w), __float_as_int(r1_.w), __float_as_int(r2_.w), __float_as_int(r3_.w) }; \
+                { const float x_ = qx - r0_.x, y_ = qy - r0_.y, z_ = qz - r0_.z; sd[0] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - r1_.x, y_ = qy - r1_.y, z_ = qz - r1_.z; sd[1] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - r2_.x, y_ = qy - r2_.y, z_ = qz - r2_.z; sd[2] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                { const float x_ = qx - r3_.x, y_ = qy - r3_.y, z_ = qz - r3_.z; sd[3] = x_ * x_ + y_ * y_ + z_ * z_; } \
+                const float lx_ = ap_.x - r3_.x, ly_ = ap_.y - r3_.y, lz_ = ap_.z - r3_.z; \
+                const float l3_ = lx_ * lx_ + ly_ * ly_ + lz_ * lz_; \
+                LISREG_CE5(0, 1); LISREG_CE5(2, 3); LISREG_CE5(0, 2); LISREG_CE5(1, 3); LISREG_CE5(1, 2); \
+                if (__builtin_amdgcn_ballot_w64(!(sd[3] < P.tau)) == 0) {           /* the usual case: all four inside tau in every lane */ \
+                    b0 = sd[0]; b1 = sd[1]; b2 = sd[2]; b3 = sd[3]; i0 = sid[0]; i1 = sid[1]; i2 = sid[2]; i3 = sid[3]; \
+                } else { \
+                    b0 = fminf(sd[0], P.tau); b1 = fminf(sd[1], P.tau); b2 = fminf(sd[2], P.tau); b3 = fminf(sd[3], P.tau); \
+                    i0 = sd[0] < P.tau ? sid[0] : -1; i1 = sd[1] < P.tau ? sid[1] : -1; i2 = sd[2] < P.tau ? sid[2] : -1; \
+                    i3 = sd[3] < P.tau ? sid[3] : -1; \
+                } \
+                b4 = P.tau; i4 = -1; \
+                LISREG_LIST_TIES(); \
+                const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
+                if (l3_ > thr2_) stop_ = true; \
+            } else { \
+                LISREG_LIST_INIT(); \
+                const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
+                if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY_ND); \
+            } \
+            _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
+                const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
+                LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); \
+            } \
+            if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
+            certified = stop_; } while (0)
+
 #define LISREG_CE5(a, b) do { const bool sw_ = sd[b] < sd[a]; const float ta_ = sd[a]; const int ia_ = sid[a]; \
                               sd[a] = sw_ ? sd[b] : ta_; sd[b] = sw_ ? ta_ : sd[b]; sid[a] = sw_ ? sid[b] : ia_; sid[b] = sw_ ? ia_ : sid[b]; } while (0)
 
@@ -1102,7 +1151,7 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
 // kShare (kQ > 1 only): long candidate runs are shared by the kQ lanes of a query (LISREG_WALK_LIST); that variant needs ~90 registers, so it
 // runs four waves per SIMD — right for the few thousand wavefronts of a downsampled frame, wrong for a full 64 x 1800 sweep (14 k wavefronts),
 // which keeps the 64-register variant without sharing.  The launcher picks by size; the five neighbours are the same either way.
-template <bool kWide, bool kGraph, int kQ, bool kTies, bool kShare = false>
+template <bool kWide, int kGraph, int kQ, bool kTies, bool kShare = false>
 __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare ? 4 : 8, kShare ? 4 : 8))) void k_assoc_walk(const BlockDesc* __restrict__ blocks,
                                                         const Segment* __restrict__ segs,
                                                         const GridIndex* __restrict__ grids,
@@ -1166,6 +1215,39 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     if (kGraph) {
         // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
         bool need_walk = valid, scanned = false;
+        if (kGraph == 2) {
+            // search_mode 5: the row of the cell (or octant) the query is in — nothing carried between iterations
+            if (valid && g.crow_tab) {
+                // a query outside the grid (the target's bounding box: a wall seen from a pose that is still off puts half of its points
+                // there) takes the row of the nearest boundary cell — any row is valid for any query, the certificate works with the
+                // actual |q - m|
+                // (a NaN query lands in some cell and never certifies: every comparison with its distances is false)
+                const float tx = (qx - g.ox) * g.inv_cell, ty = (qy - g.oy) * g.inv_cell, tz = (qz - g.oz) * g.inv_cell;
+                const int gx = (int)floorf(tx), gy = (int)floorf(ty), gz = (int)floorf(tz);
+                const int hx = min(max(gx, 0), g.nx - 1), hy = min(max(gy, 0), g.ny - 1), hz = min(max(gz, 0), g.nz - 1);
+                {
+                    const int v = ((gptr_i32)g.crow_tab)[(hx * g.ny + hy) * g.nz + hz];
+                    if (v >= 0) {
+                        float fx = 0.5f, fy = 0.5f, fz = 0.5f;
+                        int row_ = v >> 1;
+                        if (v & 1) {
+                            const bool ux = tx - (float)hx >= 0.5f, uy = ty - (float)hy >= 0.5f, uz = tz - (float)hz >= 0.5f;
+                            fx = ux ? 0.75f : 0.25f; fy = uy ? 0.75f : 0.25f; fz = uz ? 0.75f : 0.25f;
+                            row_ += 1 + (int)ux + 2 * (int)uy + 4 * (int)uz;
+                        }
+                        const float mx_ = crow_centre(g.ox, g.cell, hx, fx), my_ = crow_centre(g.oy, g.cell, hy, fy), mz_ = crow_centre(g.oz, g.cell, hz, fz);
+                        const gptr_f4 crow = (gptr_f4)g.crow;
+                        const gptr_f2 cmeta = (gptr_f2)g.crow_meta;
+                        bool certified = false;
+                        scanned = true;
+                        LISREG_CELL_SCAN();
+                        need_walk = !certified;
+                    } else if (v == -2 && hx == gx && hy == gy && hz == gz && P.tau <= (2.f * g.cell - 2.f * kEps) * (2.f * g.cell - 2.f * kEps)) {
+                        need_walk = false;                     // nothing within two cells of this one: no neighbour inside sqrt(tau)
+                    }
+                }
+            }
+        } else
         if (valid && it->iter > 0 && g.nbr) {
             int anchor = nn[qflat];
             if (it->iter <= P.cell_anchor_until) {
@@ -1187,7 +1269,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
             }
         }
         if (!scanned) LISREG_LIST_INIT();
-        if (counters && it->iter > 0 && it->iter < 32) {       // diagnostics: lanes that fell back to the cell walk
+        if (counters && (kGraph == 2 || it->iter > 0) && it->iter < 32) {       // diagnostics: lanes that fell back to the cell walk
             const int nw = __popcll(__ballot(need_walk)), nv = __popcll(__ballot(valid));
             if ((tid & 63) == 0) {
                 atomicAdd(&counters[it->iter], ((unsigned long long)nw << 32) | (unsigned long long)nv);
@@ -1205,7 +1287,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
             (void)sx0_; (void)sx1_; (void)sy0_; (void)sy1_;
         }
         LISREG_CANONICAL_FIVE();
-        if (valid) nn[qflat] = i0;                             // next iteration's anchor: the nearest neighbour (-1: none)
+        if (kGraph == 1 && valid) nn[qflat] = i0;              // next iteration's anchor: the nearest neighbour (-1: none)
     } else if (!valid) {
         LISREG_LIST_INIT();
     } else {
@@ -1450,16 +1532,16 @@ static void launch_assoc_impl(const BlockDesc* blocks, int n_blocks, const Segme
     if (mode == 1 && lanes_q == 8) {
         const bool share = n_blocks_q <= 2048;              // <= 8192 wavefronts: two generations at four waves per SIMD
         if (wide && share)
-            k_assoc_walk<true, false, 8, kTies, true><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+            k_assoc_walk<true, 0, 8, kTies, true><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                                       first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else if (share)
-            k_assoc_walk<false, false, 8, kTies, true><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+            k_assoc_walk<false, 0, 8, kTies, true><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                                        first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else if (wide)
-            k_assoc_walk<true, false, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+            k_assoc_walk<true, 0, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                                 first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
-            k_assoc_walk<false, false, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
+            k_assoc_walk<false, 0, 8, kTies><<<n_blocks_q, kBlockQ, 0, st>>>(blocks_q, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                                  first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         k_rows_reduce<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, coef, coef_ok, partials);
         return;
@@ -1468,18 +1550,25 @@ static void launch_assoc_impl(const BlockDesc* blocks, int n_blocks, const Segme
         k_assoc_staged<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, partials);
     else if (mode == 1) {
         if (wide)
-            k_assoc_walk<true, false, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+            k_assoc_walk<true, 0, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                               first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
         else
-            k_assoc_walk<false, false, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+            k_assoc_walk<false, 0, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                                first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+    } else if (mode == 5) {
+        if (wide)
+            k_assoc_walk<true, 2, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                          first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
+        else
+            k_assoc_walk<false, 2, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                           first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
     } else {
         if (wide)
-            k_assoc_walk<true, true, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                             first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
+            k_assoc_walk<true, 1, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                          first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
         else
-            k_assoc_walk<false, true, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                              first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
+            k_assoc_walk<false, 1, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
+                                                                           first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
     }
 }
 

@@ -41,6 +41,9 @@ struct Target {
     lisreg::DevBuf    raw[2], sorted[2], cell_start[2];
     lisreg::DevBuf    nbr[2], nbr_meta[2];                // k-NN graph of the sorted points (search_mode 3)
     bool      graph_valid[2] = { false, false };
+    lisreg::DevBuf    crow[2], crow_meta[2], crow_tab[2], crow_need[2], crow_scan[2], crow_scan_tmp[2];   // cell rows (search_mode 5)
+    int       crow_cap[2] = { 0, 0 };                  // rows allocated (= rows the classified index asked for when it was last sized)
+    bool      crow_valid[2] = { false, false };
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
     const float4* raw_ptr[2] = { nullptr, nullptr };
     unsigned long long gen = 0;                        // bumped by every set_target of this slot (who built what is in here?)
@@ -154,7 +157,7 @@ struct lisreg_ctx {
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
     bool      dump_neighbors = false;   // tests: keep the five neighbour ids of every query of the last iteration run
-    int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 3 k-NN graph scan,
+    int       search_mode = 4;           // 0 LDS-staged box, 1 per-lane cell walk, 3 k-NN graph scan, 5 cell rows,
                                          // 4 auto: 3 when the prepared batch asks enough queries per target point to pay for the graph, else 1
     int       mode_now = 1;              // front-end of the prepared batch
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
@@ -211,7 +214,7 @@ int  ctx_fail(lisreg_ctx* c, int code, const std::string& msg);
 // pack PCL structs (stride/format of common.h:9,25-35) into 16-B device records
 void pack_cloud(const void* cloud, int n, int stride, int fmt, lisreg_dpoint* out);
 // grid geometry from a bounding box; cell edge grows if the box would need too many cells
-void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells);
+void make_grid(const float bb[6], int n, GridIndex* g, int* n_cells, int margin_cells = 0);
 SortBuffers sort_buffers(lisreg_ctx* c);
 int  ensure_sort_scratch(lisreg_ctx* c, size_t n_elems, size_t n_buckets);
 void ctx_prof_mark(lisreg_ctx* c, int kind_of_next_interval);      // 0 correspondence kernel, 1 solve, 2 index build, -1 nothing

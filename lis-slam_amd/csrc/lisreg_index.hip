@@ -613,14 +613,24 @@ __device__ __forceinline__ unsigned long long sort64(unsigned long long k, int l
     return k;
 }
 
-__device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int (*s_off)[32], int (*s_js)[32])
+// One row: the kGraphK target points nearest to the location q (home cell hx, hy, hz; `s` = a sorted point to leave out, or -1), ascending,
+// with the coverage radius of the 5 x 5 x 5 block — the k-NN graph's rows are anchored at the points themselves (graph_build_wave), the
+// cell rows of search_mode 5 at cell and octant centres (k_crow_build).
+// kOct: the row is a cell-centre row whose cell also gets its eight octant rows (row_out + kGraphK * (1 + octant), meta_out + 1 + octant).
+// They are derived from the row just built instead of from the block: a point closer than rho - |octant centre - cell centre| to an octant
+// centre is closer than rho to the cell centre, hence among the 64 listed — so one 64-key sort per octant re-orders the SAME entries by
+// their distance from the octant centre, and that difference is the octant row's coverage radius.  (A quarter of the cost of a row built
+// from the block: no column probes, no candidate gather, one sort instead of two or three chunk sorts and merges.)
+template <int R, bool kOct>               // block = (2 R + 1)^3 cells
+__device__ __forceinline__ void row_build_wave(const GridIndex& g, const float4 q, int hx, int hy, int hz, int s,
+                                               float4* __restrict__ row_out, float2* __restrict__ meta_out, int (*s_off)[64], int (*s_js)[64])
 {
+    constexpr int W = 2 * R + 1, NR = W * W;
+    static_assert(NR <= 64, "one lane per z-run");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr float kEps = 1e-3f;
-    const float4 q = g.pts[s];
-    const int hx = cell_coord(q.x, g.ox, g.inv_cell, g.nx), hy = cell_coord(q.y, g.oy, g.inv_cell, g.ny), hz = cell_coord(q.z, g.oz, g.inv_cell, g.nz);
-    const int x0 = max(hx - 2, 0), x1 = min(hx + 2, g.nx - 1), y0 = max(hy - 2, 0), y1 = min(hy + 2, g.ny - 1);
-    const int z0 = max(hz - 2, 0), z1 = min(hz + 2, g.nz - 1);
+    const int x0 = max(hx - R, 0), x1 = min(hx + R, g.nx - 1), y0 = max(hy - R, 0), y1 = min(hy + R, g.ny - 1);
+    const int z0 = max(hz - R, 0), z1 = min(hz + R, g.nz - 1);
     // inscribed radius: faces of the block that coincide with the grid boundary have nothing beyond them
     float rc = 3.0e18f;
     if (x0 > 0)        rc = fminf(rc, q.x - (g.ox + (float)x0 * g.cell));
@@ -632,8 +642,8 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
     rc = fmaxf(rc - kEps, 0.f);
     // the 25 z-runs of the block, their exclusive prefix
     int js = 0, len = 0;
-    if (lane < 25) {
-        const int ix = hx + lane / 5 - 2, iy = hy + lane % 5 - 2;
+    if (lane < NR) {
+        const int ix = hx + lane / W - R, iy = hy + lane % W - R;
         if (ix >= x0 && ix <= x1 && iy >= y0 && iy <= y1) {
             const int base = (ix * g.ny + iy) * g.nz;
             js = g.cell_start[base + z0];
@@ -642,10 +652,10 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
     }
     int inc = len;
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    const int total = __shfl(inc, 31);
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    const int total = __shfl(inc, 63);
     __builtin_amdgcn_wave_barrier();
-    if (lane < 32) { s_off[wave][lane] = inc - len; s_js[wave][lane] = js; }
+    s_off[wave][lane] = inc - len; s_js[wave][lane] = js;
     __builtin_amdgcn_wave_barrier();
 
     constexpr unsigned long long kEmpty = ((unsigned long long)0x7f800000u << 32) | 0xffffffffull;      // (+inf, id -1)
@@ -655,9 +665,9 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
         const int t = c0 + lane;
         unsigned long long k = kEmpty;
         if (t < total) {
-            int lo = 0, hi = 24;                            // last run whose offset is <= t
+            int lo = 0, hi = NR - 1;                        // last run whose offset is <= t
 #pragma unroll
-            for (int it = 0; it < 5; ++it) { const int mid = (lo + hi + 1) >> 1; if (s_off[wave][mid] <= t) lo = mid; else hi = mid - 1; }
+            for (int it = 0; it < (NR > 32 ? 6 : 5); ++it) { const int mid = (lo + hi + 1) >> 1; if (s_off[wave][mid] <= t) lo = mid; else hi = mid - 1; }
             const int j = s_js[wave][lo] + (t - s_off[wave][lo]);
             const float4 c = g.pts[j];
             const float ex = q.x - c.x, ey = q.y - c.y, ez = q.z - c.z;
@@ -690,14 +700,64 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
         // kernel then scans a row without an id -> point gather.  Entries that are not kept alias the point itself.
         float4 e = make_float4(q.x, q.y, q.z, __int_as_float(-1));
         if (keep) { const float4 c = g.pts[ti]; e = make_float4(c.x, c.y, c.z, __int_as_float(ti)); }
-        const_cast<float4*>(g.nbr)[(size_t)s * kGraphK + lane] = e;
+        row_out[lane] = e;
+        if constexpr (kOct) {
+            const float off = 0.25f * g.cell * 1.7320508f;                     // |octant centre - cell centre|
+            const float rho_o = fmaxf(sqrtf(rho2) - off - 2.f * kEps, 0.f), rho_o2 = rho_o * rho_o;
+#pragma unroll 1
+            for (int o = 0; o < 8; ++o) {
+                const float mx = crow_centre(g.ox, g.cell, hx, o & 1 ? 0.75f : 0.25f), my = crow_centre(g.oy, g.cell, hy, o & 2 ? 0.75f : 0.25f);
+                const float mz = crow_centre(g.oz, g.cell, hz, o & 4 ? 0.75f : 0.25f);
+                unsigned long long k = kEmpty;
+                if (keep) {
+                    const float ex = mx - e.x, ey = my - e.y, ez = mz - e.z;
+                    k = ((unsigned long long)__float_as_uint(ex * ex + ey * ey + ez * ez) << 32) | (unsigned)ti;
+                }
+                k = sort64(k, lane);
+                const float ok = __uint_as_float((unsigned)(k >> 32));
+                const int oi = (int)(unsigned)k;
+                const bool okeep = oi >= 0 && ok <= rho_o2;
+                const int ocnt = __popcll(__ballot(okeep));
+                float4 oe = make_float4(mx, my, mz, __int_as_float(-1));
+                if (okeep) { const float4 c = g.pts[oi]; oe = make_float4(c.x, c.y, c.z, __int_as_float(oi)); }
+                row_out[(size_t)(1 + o) * kGraphK + lane] = oe;
+                if (lane == 0) meta_out[1 + o] = make_float2(rho_o2, __int_as_float(ocnt));
+            }
+        }
     }
-    if (lane == 0) const_cast<float2*>(g.nbr_meta)[s] = make_float2(rho2, __int_as_float(cnt));
+    if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
+}
+
+// target points in the (2 R + 1)^3 block around a cell (one wave)
+template <int R>
+__device__ __forceinline__ int block_population(const GridIndex& g, int hx, int hy, int hz)
+{
+    constexpr int W = 2 * R + 1, NR = W * W;
+    const int lane = threadIdx.x & 63;
+    const int z0 = max(hz - R, 0), z1 = min(hz + R, g.nz - 1);
+    int len = 0;
+    if (lane < NR) {
+        const int ix = hx + lane / W - R, iy = hy + lane % W - R;
+        if (ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny) {
+            const int base = (ix * g.ny + iy) * g.nz;
+            len = g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) len += __shfl_xor(len, d);
+    return len;
+}
+
+__device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int (*s_off)[64], int (*s_js)[64])
+{
+    const float4 q = g.pts[s];
+    const int hx = cell_coord(q.x, g.ox, g.inv_cell, g.nx), hy = cell_coord(q.y, g.oy, g.inv_cell, g.ny), hz = cell_coord(q.z, g.oz, g.inv_cell, g.nz);
+    row_build_wave<2, false>(g, q, hx, hy, hz, s, const_cast<float4*>(g.nbr) + (size_t)s * kGraphK, const_cast<float2*>(g.nbr_meta) + s, s_off, s_js);
 }
 
 __global__ __launch_bounds__(256) void k_graph_build_one(GridIndex g)
 {
-    __shared__ int s_off[4][32], s_js[4][32];
+    __shared__ int s_off[4][64], s_js[4][64];
     const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kGraphPPW;
 #pragma unroll 1
     for (int i = 0; i < kGraphPPW; ++i) {
@@ -711,7 +771,7 @@ __global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __
                                                              const TargetSeg* __restrict__ tsegs,
                                                              const GridIndex* __restrict__ grids)
 {
-    __shared__ int s_off[4][32], s_js[4][32];
+    __shared__ int s_off[4][64], s_js[4][64];
     constexpr int kSub = kBlockQ / (4 * kGraphPPW);         // workgroups per 256-point block descriptor
     const BlockDesc bd = blocks[blockIdx.x / kSub];
     const int first = ((int)(blockIdx.x % kSub) * 4 + (int)(threadIdx.x >> 6)) * kGraphPPW;
@@ -721,6 +781,88 @@ __global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __
         const int e = first + i;
         if (e >= bd.count) break;
         graph_build_wave(g, bd.start + e, s_off, s_js);
+    }
+}
+
+// ---- cell rows (search_mode 5) -------------------------------------------------------------------------------------------
+// Which cells get rows.  A cell with no target point in the 5 x 5 x 5 block around it gets none (need 0: a query in it has nothing within
+// two cells); a cell with a point within `fine_margin` of its box gets a row at its centre plus eight octant rows (need 9: the cells the
+// surface runs through or next to — where the queries are once the pose has settled; |q - octant centre| <= 0.43 of a half cell); every
+// other cell one row at its centre (need 1).
+__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells, float fine_margin, int* __restrict__ need)
+{
+    const int cid = blockIdx.x * 256 + threadIdx.x;
+    if (cid >= n_cells) return;
+    const int iz = cid % g.nz, t = cid / g.nz, iy = t % g.ny, ix = t / g.ny;
+    const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1);
+    int any = 0;
+#pragma unroll 1
+    for (int dx = -2; dx <= 2; ++dx) {
+        const int x = ix + dx;
+        if (x < 0 || x >= g.nx) continue;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int y = iy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const int base = (x * g.ny + y) * g.nz;
+            any += g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
+        }
+    }
+    if (!any) { need[cid] = 0; return; }
+    const float lx = g.ox + (float)ix * g.cell, ly = g.oy + (float)iy * g.cell, lz = g.oz + (float)iz * g.cell;
+    const int zz0 = max(iz - 1, 0), zz1 = min(iz + 1, g.nz - 1);
+    float best = 3.0e38f;
+#pragma unroll 1
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int x = ix + dx;
+        if (x < 0 || x >= g.nx) continue;
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = iy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const int base = (x * g.ny + y) * g.nz;
+            const int js = g.cell_start[base + zz0], je = g.cell_start[base + zz1 + 1];
+#pragma unroll 1
+            for (int j = js; j < je; ++j) {
+                const float4 p = g.pts[j];
+                const float ex = fmaxf(fmaxf(lx - p.x, p.x - (lx + g.cell)), 0.f), ey = fmaxf(fmaxf(ly - p.y, p.y - (ly + g.cell)), 0.f);
+                const float ez = fmaxf(fmaxf(lz - p.z, p.z - (lz + g.cell)), 0.f);
+                best = fminf(best, ex * ex + ey * ey + ez * ez);
+            }
+        }
+    }
+    need[cid] = best <= fine_margin * fine_margin ? 9 : 1;
+}
+
+// One wave per cell (kCrowCPW of them in a row): the table entry, the row at the cell's centre, the octant rows behind it.
+// crow_tab[cell] = -2: nothing within two cells; -1: no row (its rows did not fit the capacity the buffers were sized for); else
+// (first row << 1) | has-octants, rows = [centre, octant 0 .. 7].
+constexpr int kCrowCPW = 8;
+__global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ scan, int cap)
+{
+    __shared__ int s_off[4][64], s_js[4][64];
+    const int lane = threadIdx.x & 63;
+    const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kCrowCPW);
+    int* tab = const_cast<int*>(g.crow_tab);
+#pragma unroll 1
+    for (int i = 0; i < kCrowCPW; ++i) {
+        const int cid = first + i;
+        if (cid >= n_cells) break;
+        const int n = need[cid];
+        if (n == 0) { if (lane == 0) tab[cid] = -2; continue; }
+        const int b = scan[cid];
+        if (b + n > cap) { if (lane == 0) tab[cid] = -1; continue; }
+        if (lane == 0) tab[cid] = (b << 1) | (n == 9 ? 1 : 0);
+        const int hz = cid % g.nz, t = cid / g.nz, hy = t % g.ny, hx = t / g.ny;
+        const float4 q = make_float4(crow_centre(g.ox, g.cell, hx, 0.5f), crow_centre(g.oy, g.cell, hy, 0.5f), crow_centre(g.oz, g.cell, hz, 0.5f), 0.f);
+        float4* row = const_cast<float4*>(g.crow) + (size_t)b * kGraphK;
+        float2* meta = const_cast<float2*>(g.crow_meta) + b;
+        // a centre row serves queries up to 0.87 cells from the centre wherever they are relative to the surface; one with fewer than five
+        // points inside sqrt(tau) is certified by the coverage radius alone, which then has to reach sqrt(tau) + 0.87 cells: where the
+        // 5 x 5 x 5 block does not fill the row (2.5 cells of coverage), the 7 x 7 x 7 block is searched (3.5 cells; few candidates there)
+        if (n == 9) row_build_wave<2, true>(g, q, hx, hy, hz, -1, row, meta, s_off, s_js);
+        else if (block_population<2>(g, hx, hy, hz) >= kGraphK) row_build_wave<2, false>(g, q, hx, hy, hz, -1, row, meta, s_off, s_js);
+        else row_build_wave<3, false>(g, q, hx, hy, hz, -1, row, meta, s_off, s_js);
     }
 }
 
@@ -1101,6 +1243,20 @@ void launch_build_graph_one(GridIndex g, hipStream_t st)
 {
     if (g.n <= 0 || !g.nbr) return;
     k_graph_build_one<<<(g.n + 4 * kGraphPPW - 1) / (4 * kGraphPPW), 256, 0, st>>>(g);
+}
+
+void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
+{
+    if (g.n <= 0 || n_cells <= 0) return;
+    static const float margin = getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.5f;      // in cells
+    k_crow_classify<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, margin * g.cell, cb.need);
+    exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
+}
+
+void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
+{
+    if (g.n <= 0 || n_cells <= 0 || cb.cap_rows <= 0 || !g.crow) return;
+    k_crow_build<<<(n_cells + 4 * kCrowCPW - 1) / (4 * kCrowCPW), 256, 0, st>>>(g, n_cells, cb.need, cb.scan, cb.cap_rows);
 }
 
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,

@@ -67,7 +67,7 @@ def test_neighbour_sets_are_exact(h, w, m_points, variant):
     nc, ns = len(src[0]), len(src[1])
     dumps = {}
     for iters in (1, 4):
-        for mode in (1, 3):
+        for mode in (1, 3, 5):
             ctx = lisreg.Context(0)
             ctx.set_option("search_mode", mode); ctx.set_option("dump_neighbors", 1)
             ctx.set_target(case["tgt_corner"], case["tgt_surf"])
@@ -88,6 +88,12 @@ def test_neighbour_sets_are_exact(h, w, m_points, variant):
         assert differing <= a[2] + b[2] + 2, (iters, differing)
         if differing == 0:
             assert np.array_equal(a[1], b[1])
+        cells = dumps[(5, iters)]                              # cell rows (search_mode 5) against the walk, the same way
+        differing = int((a[0] != cells[0]).any(0).sum())
+        print(f"{h}x{w} vs {m_points}: iteration {iters - 1}: cell rows: rounding-level ties {cells[2]}; queries where walk and cell rows differ: {differing}")
+        assert differing <= a[2] + cells[2] + 2, (iters, differing)
+        if differing == 0:
+            assert np.array_equal(a[1], cells[1])
 
 
 @pytest.mark.gpu
@@ -111,7 +117,7 @@ def test_equal_distances_resolve_by_original_index_in_every_front_end(oracle):
     p.fixed_iters = 3
     n = len(case["src_corner"]) + len(case["src_surf"])
     out = {}
-    for name, mode, lanes, exact in (("walk1", 1, 1, 0), ("walk8", 1, 0, 0), ("graph", 3, 1, 0), ("exact", 1, 1, 1)):
+    for name, mode, lanes, exact in (("walk1", 1, 1, 0), ("walk8", 1, 0, 0), ("graph", 3, 1, 0), ("cells", 5, 1, 0), ("exact", 1, 1, 1)):
         c = lisreg.Context(0)
         c.set_option("search_mode", mode); c.set_option("lanes_per_query", lanes); c.set_option("exact_arithmetic", exact)
         c.set_option("canonical_ties", 1)                      # (implied by exact_arithmetic)
@@ -133,7 +139,7 @@ def test_equal_distances_resolve_by_original_index_in_every_front_end(oracle):
         for k in range(4):
             if np.array_equal(xyz[k], xyz[k + 1]):
                 assert nb[k, q] < nb[k + 1, q]                              # the smaller original index first among equals
-    for name in ("walk8", "graph"):
+    for name in ("walk8", "graph", "cells"):
         # (queries with fewer than five neighbours inside tau contribute nothing; the partial lists they keep are not canonicalised)
         assert np.array_equal(out[name][3][4] >= 0, found), name
         bad = np.flatnonzero((out[name][3][:, found] != nb[:, found]).any(0))
