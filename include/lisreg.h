@@ -205,8 +205,12 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * "trace_cap" (per-item trace records kept on the device for batches; 0 = off), "search_mode" (the exact 5-NN front-end
  * that stands in for pcl::KdTreeFLANN::nearestKSearch: 0 LDS-staged workgroup box, 1 per-lane grid walk,
  * 3 k-NN graph scan with the walk as its fall-back — costs 1 KB of device memory per target point for the
- * neighbour rows —, 4 auto [default]: 3 when the prepared batch asks at least "graph_min_ratio" query-iterations per target
- * point, else 1 — all return the same neighbours; the one exception is two candidates at exactly equal float distance from a query
+ * neighbour rows —, 5 cell rows: the same certified list scan, but the list belongs to the grid cell (or the octant of it) the query
+ * falls into instead of to last iteration's nearest neighbour, so nothing is carried between Gauss-Newton iterations and the first
+ * iterations of a batch — queries a pose error away from every surface — cost the same scan as the last ones; ~3-5 KB of device memory
+ * per target point, built in ~3 ns per target point —, 4 auto [default]: 5 when the prepared batch asks at least "cell_min_ratio"
+ * [default 120] query-iterations per target point and its targets' rows fit "cell_rows_max_mb" [default 16384], else 3 from
+ * "graph_min_ratio" [default 60] query-iterations per target point on, else 1 — all return the same neighbours; the one exception is two candidates at exactly equal float distance from a query
  * competing for the fifth place: the first one met wins, and the front-ends meet them in different orders),
  * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
  * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
@@ -235,7 +239,7 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * pinned staging buffers are on that node already; read-only "feeder_numa_node" / "feeder_numa_cpus" say what was found),
  * "feeder_copy_engine" (1 [default]: while the next packed chunk is not ready and the copy engine is idle, the engine takes the last free
  * chunk of a pinned cloud as it is and a kernel packs it on the device; 0: never; 2: whenever a packed chunk is not ready — for tests),
- * "graph_min_ratio", "first_pass_mm", "count_searches", "early_stop_chunk". */
+ * "graph_min_ratio", "cell_min_ratio", "cell_rows_max_mb", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
  * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the
@@ -267,6 +271,16 @@ int  lisreg_get_target_index(lisreg_ctx* ctx, int slot, int kind, int* dims, flo
  * by distance, padded with (p's own coordinates, -1); meta_out[p] = (rho^2, count as int bits): every point closer to p than rho
  * is in its row.  Either output may be NULL.  capacity_points >= the target's point count. */
 int  lisreg_get_target_graph(lisreg_ctx* ctx, int slot, int kind, int* k, float* rows_out, float* meta_out, int capacity_points);
+
+/* Diagnostics: the cell rows of a target's search index (search front-end 5; built now if they were not yet).  *n_rows = rows in all,
+ * *k = entries per row.  table_out[cell] (the index's n_cells entries, cell = (ix * ny + iy) * nz + iz): -2 = no target point within two
+ * cells of this one, -1 = no row, else (first row << 8) | octant mask — the cell's rows are [the row at its centre, then one row per
+ * octant of the mask in ascending octant order, octant = (x upper half) + 2 (y upper half) + 4 (z upper half)]; rows_out[r * k + j] =
+ * (x, y, z, sorted position as int bits) of the j-th nearest target point of the row's centre, ascending (to 2^-16 relative), padded with
+ * (the centre's coordinates, -1); meta_out[r] = (rho^2, count as int bits): every point closer to the centre than rho is in the row.
+ * Outputs may be NULL; capacity_rows >= *n_rows when rows_out / meta_out are given (call once with NULLs to learn it). */
+int  lisreg_get_target_cell_rows(lisreg_ctx* ctx, int slot, int kind, int* n_rows, int* k, int* table_out, int capacity_cells,
+                                 float* rows_out, float* meta_out, int capacity_rows);
 
 /* Trace of the LAST lisreg_align call: copies min(n_iters_run, max_iters) records; returns the count. */
 int  lisreg_get_trace(lisreg_ctx* ctx, float* buf, int max_iters);

@@ -197,7 +197,7 @@ int ensure_graph(lisreg_ctx* c, Target& t, int k, bool launch)
 lisreg::CrowBuffers crow_buffers(Target& t, int k)
 {
     lisreg::CrowBuffers cb;
-    cb.need = t.crow_need[k].as<int>(); cb.scan = t.crow_scan[k].as<int>(); cb.scan_tmp = t.crow_scan_tmp[k].as<int>();
+    cb.need = t.crow_need[k].as<int>(); cb.omask = t.crow_omask[k].as<int>(); cb.scan = t.crow_scan[k].as<int>(); cb.scan_tmp = t.crow_scan_tmp[k].as<int>();
     cb.cap_rows = t.crow_cap[k];
     return cb;
 }
@@ -207,6 +207,7 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k)
     if (t.crow_valid[k] && t.g[k].crow_tab) return LISREG_OK;
     const size_t nc = (size_t)std::max(t.n_cells[k], 1);
     HIPCHK(c, t.crow_need[k].ensure(sizeof(int) * (nc + 8)));
+    HIPCHK(c, t.crow_omask[k].ensure(sizeof(int) * (nc + 8)));
     HIPCHK(c, t.crow_scan[k].ensure(sizeof(int) * (nc + 8)));
     HIPCHK(c, t.crow_scan_tmp[k].ensure(sizeof(int) * (nc / 2048 + 8)));
     HIPCHK(c, t.crow_tab[k].ensure(sizeof(int) * (nc + 8)));
@@ -324,6 +325,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_CELL_ANCHOR_UNTIL")) c->cell_anchor_until = std::max(atoi(m), 0);
     if (const char* m = getenv("LISREG_XCD_ORDER")) c->xcd_order = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_MIN_RATIO")) c->graph_min_ratio = atoi(m);
+    if (const char* m = getenv("LISREG_CELL_MIN_RATIO")) c->cell_min_ratio = atoi(m);
     if (const char* m = getenv("LISREG_WIDE_FROM")) c->wide_from = c->wide_from_small = atoi(m);
     *out = c;
     return LISREG_OK;
@@ -337,7 +339,7 @@ void lisreg_destroy(lisreg_ctx* c)
     lisreg_comm_destroy(c);
     feeder_destroy(c);
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release();
-        t.crow[k].release(); t.crow_meta[k].release(); t.crow_tab[k].release(); t.crow_need[k].release(); t.crow_scan[k].release(); t.crow_scan_tmp[k].release(); }
+        t.crow[k].release(); t.crow_meta[k].release(); t.crow_tab[k].release(); t.crow_need[k].release(); t.crow_omask[k].release(); t.crow_scan[k].release(); t.crow_scan_tmp[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
                        &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->xcd_tab, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
@@ -581,8 +583,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         // distances and has no canonical re-selection: it cannot honour "canonical_ties" / "exact_arithmetic", so it refuses them
         if (c->search_mode == 0 && (c->canonical_ties || c->exact))
             return fail(c, LISREG_ERR_ARG, "batch_prepare: search_mode 0 does not implement canonical_ties / exact_arithmetic (use 1, 3 or 4)");
-        if (c->search_mode == 4)
-            c->mode_now = (t_pts > 0 && (double)total_src * (double)c->prm.bound >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
+        if (c->search_mode == 4) {
+            const double qi = (double)total_src * (double)c->prm.bound;
+            c->mode_now = (t_pts > 0 && qi >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
+            if (t_pts > 0 && qi >= (double)c->cell_min_ratio * t_pts && t_pts * 5120.0 <= (double)c->cell_rows_max_mb * 1048576.0) c->mode_now = 5;
+        }
         // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
         c->lanes_q = (c->mode_now == 1 && c->lanes_per_query_auto && total_src > 0 && total_src <= 131072) ? 8 : 1;
     }
@@ -954,6 +959,8 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         c->search_mode = value; c->prepared = false; return LISREG_OK;
     }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "cell_min_ratio")) { c->cell_min_ratio = value; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "cell_rows_max_mb")) { c->cell_rows_max_mb = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; return LISREG_OK; }
     if (!strcmp(name, "index_build")) {
@@ -1001,6 +1008,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "sorted_now")) { *value = c->sort_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { *value = c->graph_min_ratio; return LISREG_OK; }
+    if (!strcmp(name, "cell_min_ratio")) { *value = c->cell_min_ratio; return LISREG_OK; }
+    if (!strcmp(name, "cell_rows_max_mb")) { *value = c->cell_rows_max_mb; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { *value = c->xcd_order; return LISREG_OK; }
     if (!strcmp(name, "xcd_order_now")) { *value = c->xcd_now ? 1 : 0; return LISREG_OK; }
     return LISREG_ERR_ARG;
@@ -1184,6 +1193,34 @@ int lisreg_get_target_graph(lisreg_ctx* c, int slot, int kind, int* k_out, float
     const size_t n = (size_t)t.n[kind];
     if (rows_out && n) HIPCHK(c, hipMemcpy(rows_out, t.nbr[kind].p, sizeof(float4) * kGraphK * n, hipMemcpyDeviceToHost));
     if (meta_out && n) HIPCHK(c, hipMemcpy(meta_out, t.nbr_meta[kind].p, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    return LISREG_OK;
+}
+
+int lisreg_get_target_cell_rows(lisreg_ctx* c, int slot, int kind, int* n_rows, int* k_out, int* table_out, int capacity_cells,
+                                float* rows_out, float* meta_out, int capacity_rows)
+{
+    if (!c || slot < 0 || (size_t)slot >= c->targets.size() || kind < 0 || kind > 1 || !c->targets[(size_t)slot].valid)
+        return fail(c, LISREG_ERR_ARG, "get_target_cell_rows: no such target");
+    HIPCHK(c, hipSetDevice(c->device));
+    Target& t = c->targets[(size_t)slot];
+    if (k_out) *k_out = kGraphK;
+    if (!t.crow_valid[kind] || !t.g[kind].crow_tab) {
+        int rc = ensure_crows(c, t, kind);
+        if (rc) return rc;
+        c->grids_dirty = true;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rows = 0;
+    if (t.n[kind] > 0) HIPCHK(c, hipMemcpy(&rows, t.crow_scan[kind].as<int>() + t.n_cells[kind], sizeof(int), hipMemcpyDeviceToHost));
+    rows = std::min(rows, t.crow_cap[kind]);
+    if (n_rows) *n_rows = rows;
+    if (table_out) {
+        if (capacity_cells < t.n_cells[kind]) return fail(c, LISREG_ERR_ARG, "get_target_cell_rows: capacity_cells too small");
+        HIPCHK(c, hipMemcpy(table_out, t.crow_tab[kind].p, sizeof(int) * (size_t)t.n_cells[kind], hipMemcpyDeviceToHost));
+    }
+    if ((rows_out || meta_out) && capacity_rows < rows) return fail(c, LISREG_ERR_ARG, "get_target_cell_rows: capacity_rows too small");
+    if (rows_out && rows) HIPCHK(c, hipMemcpy(rows_out, t.crow[kind].p, sizeof(float4) * kGraphK * (size_t)rows, hipMemcpyDeviceToHost));
+    if (meta_out && rows) HIPCHK(c, hipMemcpy(meta_out, t.crow_meta[kind].p, sizeof(float2) * (size_t)rows, hipMemcpyDeviceToHost));
     return LISREG_OK;
 }
 

@@ -1229,11 +1229,14 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
                     const int v = ((gptr_i32)g.crow_tab)[(hx * g.ny + hy) * g.nz + hz];
                     if (v >= 0) {
                         float fx = 0.5f, fy = 0.5f, fz = 0.5f;
-                        int row_ = v >> 1;
-                        if (v & 1) {
+                        int row_ = v >> 8;
+                        {
                             const bool ux = tx - (float)hx >= 0.5f, uy = ty - (float)hy >= 0.5f, uz = tz - (float)hz >= 0.5f;
-                            fx = ux ? 0.75f : 0.25f; fy = uy ? 0.75f : 0.25f; fz = uz ? 0.75f : 0.25f;
-                            row_ += 1 + (int)ux + 2 * (int)uy + 4 * (int)uz;
+                            const int oct = (int)ux + 2 * (int)uy + 4 * (int)uz, bit = 1 << oct;
+                            if (v & bit) {                     // the octant has a row of its own
+                                fx = ux ? 0.75f : 0.25f; fy = uy ? 0.75f : 0.25f; fz = uz ? 0.75f : 0.25f;
+                                row_ += 1 + __popc(v & (bit - 1));
+                            }
                         }
                         const float mx_ = crow_centre(g.ox, g.cell, hx, fx), my_ = crow_centre(g.oy, g.cell, hy, fy), mz_ = crow_centre(g.oz, g.cell, hz, fz);
                         const gptr_f4 crow = (gptr_f4)g.crow;

@@ -41,7 +41,7 @@ struct Target {
     lisreg::DevBuf    raw[2], sorted[2], cell_start[2];
     lisreg::DevBuf    nbr[2], nbr_meta[2];                // k-NN graph of the sorted points (search_mode 3)
     bool      graph_valid[2] = { false, false };
-    lisreg::DevBuf    crow[2], crow_meta[2], crow_tab[2], crow_need[2], crow_scan[2], crow_scan_tmp[2];   // cell rows (search_mode 5)
+    lisreg::DevBuf    crow[2], crow_meta[2], crow_tab[2], crow_need[2], crow_omask[2], crow_scan[2], crow_scan_tmp[2];   // cell rows (search_mode 5)
     int       crow_cap[2] = { 0, 0 };                  // rows allocated (= rows the classified index asked for when it was last sized)
     bool      crow_valid[2] = { false, false };
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
@@ -162,6 +162,9 @@ struct lisreg_ctx {
     int       mode_now = 1;              // front-end of the prepared batch
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
     bool      lanes_per_query_auto = true;
+    int       cell_min_ratio = 120;      // auto: query-iterations per target point from which the cell rows pay (they cost ~3x the graph to build and
+                                         // halve the first iterations of a batch; measured break-even ~100)
+    int       cell_rows_max_mb = 16384;  // auto: cell rows only while the targets' rows are expected to fit this (about 5 KB per target point)
     int       graph_min_ratio = 60;      // auto: query-iterations per target point from which the graph build pays (measured break-even ~55)
     int       xcd_order = 2;             // XCD-aware dispatch order of the correspondence launches: 0 off, 1 on (graph front-end), 2 auto (graph front-end, >= 32 registrations, >= 2048 blocks)
     bool      xcd_now = false;           // what the last run used

@@ -616,12 +616,7 @@ __device__ __forceinline__ unsigned long long sort64(unsigned long long k, int l
 // One row: the kGraphK target points nearest to the location q (home cell hx, hy, hz; `s` = a sorted point to leave out, or -1), ascending,
 // with the coverage radius of the 5 x 5 x 5 block — the k-NN graph's rows are anchored at the points themselves (graph_build_wave), the
 // cell rows of search_mode 5 at cell and octant centres (k_crow_build).
-// kOct: the row is a cell-centre row whose cell also gets its eight octant rows (row_out + kGraphK * (1 + octant), meta_out + 1 + octant).
-// They are derived from the row just built instead of from the block: a point closer than rho - |octant centre - cell centre| to an octant
-// centre is closer than rho to the cell centre, hence among the 64 listed — so one 64-key sort per octant re-orders the SAME entries by
-// their distance from the octant centre, and that difference is the octant row's coverage radius.  (A quarter of the cost of a row built
-// from the block: no column probes, no candidate gather, one sort instead of two or three chunk sorts and merges.)
-template <int R, bool kOct>               // block = (2 R + 1)^3 cells
+template <int R>                          // block = (2 R + 1)^3 cells
 __device__ __forceinline__ void row_build_wave(const GridIndex& g, const float4 q, int hx, int hy, int hz, int s,
                                                float4* __restrict__ row_out, float2* __restrict__ meta_out, int (*s_off)[64], int (*s_js)[64])
 {
@@ -701,29 +696,6 @@ __device__ __forceinline__ void row_build_wave(const GridIndex& g, const float4 
         float4 e = make_float4(q.x, q.y, q.z, __int_as_float(-1));
         if (keep) { const float4 c = g.pts[ti]; e = make_float4(c.x, c.y, c.z, __int_as_float(ti)); }
         row_out[lane] = e;
-        if constexpr (kOct) {
-            const float off = 0.25f * g.cell * 1.7320508f;                     // |octant centre - cell centre|
-            const float rho_o = fmaxf(sqrtf(rho2) - off - 2.f * kEps, 0.f), rho_o2 = rho_o * rho_o;
-#pragma unroll 1
-            for (int o = 0; o < 8; ++o) {
-                const float mx = crow_centre(g.ox, g.cell, hx, o & 1 ? 0.75f : 0.25f), my = crow_centre(g.oy, g.cell, hy, o & 2 ? 0.75f : 0.25f);
-                const float mz = crow_centre(g.oz, g.cell, hz, o & 4 ? 0.75f : 0.25f);
-                unsigned long long k = kEmpty;
-                if (keep) {
-                    const float ex = mx - e.x, ey = my - e.y, ez = mz - e.z;
-                    k = ((unsigned long long)__float_as_uint(ex * ex + ey * ey + ez * ez) << 32) | (unsigned)ti;
-                }
-                k = sort64(k, lane);
-                const float ok = __uint_as_float((unsigned)(k >> 32));
-                const int oi = (int)(unsigned)k;
-                const bool okeep = oi >= 0 && ok <= rho_o2;
-                const int ocnt = __popcll(__ballot(okeep));
-                float4 oe = make_float4(mx, my, mz, __int_as_float(-1));
-                if (okeep) { const float4 c = g.pts[oi]; oe = make_float4(c.x, c.y, c.z, __int_as_float(oi)); }
-                row_out[(size_t)(1 + o) * kGraphK + lane] = oe;
-                if (lane == 0) meta_out[1 + o] = make_float2(rho_o2, __int_as_float(ocnt));
-            }
-        }
     }
     if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
 }
@@ -752,7 +724,7 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
 {
     const float4 q = g.pts[s];
     const int hx = cell_coord(q.x, g.ox, g.inv_cell, g.nx), hy = cell_coord(q.y, g.oy, g.inv_cell, g.ny), hz = cell_coord(q.z, g.oz, g.inv_cell, g.nz);
-    row_build_wave<2, false>(g, q, hx, hy, hz, s, const_cast<float4*>(g.nbr) + (size_t)s * kGraphK, const_cast<float2*>(g.nbr_meta) + s, s_off, s_js);
+    row_build_wave<2>(g, q, hx, hy, hz, s, const_cast<float4*>(g.nbr) + (size_t)s * kGraphK, const_cast<float2*>(g.nbr_meta) + s, s_off, s_js);
 }
 
 __global__ __launch_bounds__(256) void k_graph_build_one(GridIndex g)
@@ -786,10 +758,10 @@ __global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __
 
 // ---- cell rows (search_mode 5) -------------------------------------------------------------------------------------------
 // Which cells get rows.  A cell with no target point in the 5 x 5 x 5 block around it gets none (need 0: a query in it has nothing within
-// two cells); a cell with a point within `fine_margin` of its box gets a row at its centre plus eight octant rows (need 9: the cells the
-// surface runs through or next to — where the queries are once the pose has settled; |q - octant centre| <= 0.43 of a half cell); every
-// other cell one row at its centre (need 1).
-__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells, float fine_margin, int* __restrict__ need)
+// two cells); every other cell a row at its centre; and each of its eight octants whose box has a point within `oct_margin` its own row
+// behind that (omask bit: the octants the surface runs through or next to — where the queries are once the pose has settled, at most 0.43
+// of a half cell from the octant's centre).  need = 1 + the number of such octants.
+__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells, float oct_margin, int* __restrict__ need, int* __restrict__ omask)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;
     if (cid >= n_cells) return;
@@ -808,10 +780,13 @@ __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells,
             any += g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
         }
     }
-    if (!any) { need[cid] = 0; return; }
+    if (!any) { need[cid] = 0; omask[cid] = 0; return; }
+    const float h = 0.5f * g.cell;
     const float lx = g.ox + (float)ix * g.cell, ly = g.oy + (float)iy * g.cell, lz = g.oz + (float)iz * g.cell;
     const int zz0 = max(iz - 1, 0), zz1 = min(iz + 1, g.nz - 1);
-    float best = 3.0e38f;
+    float best[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) best[o] = 3.0e38f;
 #pragma unroll 1
     for (int dx = -1; dx <= 1; ++dx) {
         const int x = ix + dx;
@@ -825,20 +800,213 @@ __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells,
 #pragma unroll 1
             for (int j = js; j < je; ++j) {
                 const float4 p = g.pts[j];
-                const float ex = fmaxf(fmaxf(lx - p.x, p.x - (lx + g.cell)), 0.f), ey = fmaxf(fmaxf(ly - p.y, p.y - (ly + g.cell)), 0.f);
-                const float ez = fmaxf(fmaxf(lz - p.z, p.z - (lz + g.cell)), 0.f);
-                best = fminf(best, ex * ex + ey * ey + ez * ez);
+                // squared distance of p from the lower / upper half of the cell, per axis
+                const float x0 = fmaxf(fmaxf(lx - p.x, p.x - (lx + h)), 0.f), x1 = fmaxf(fmaxf(lx + h - p.x, p.x - (lx + g.cell)), 0.f);
+                const float y0 = fmaxf(fmaxf(ly - p.y, p.y - (ly + h)), 0.f), y1 = fmaxf(fmaxf(ly + h - p.y, p.y - (ly + g.cell)), 0.f);
+                const float w0 = fmaxf(fmaxf(lz - p.z, p.z - (lz + h)), 0.f), w1 = fmaxf(fmaxf(lz + h - p.z, p.z - (lz + g.cell)), 0.f);
+                const float xx[2] = { x0 * x0, x1 * x1 }, yy[2] = { y0 * y0, y1 * y1 }, zz[2] = { w0 * w0, w1 * w1 };
+#pragma unroll
+                for (int o = 0; o < 8; ++o) best[o] = fminf(best[o], xx[o & 1] + yy[(o >> 1) & 1] + zz[(o >> 2) & 1]);
             }
         }
     }
-    need[cid] = best <= fine_margin * fine_margin ? 9 : 1;
+    int m = 0;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) if (best[o] <= oct_margin * oct_margin) m |= 1 << o;
+    need[cid] = 1 + __popc(m);
+    omask[cid] = m;
 }
 
-// One wave per cell (kCrowCPW of them in a row): the table entry, the row at the cell's centre, the octant rows behind it.
+// The sorts of the cell-row build work on 32-bit keys: the squared distance's float bits with the low 7 bits replaced by a payload (the
+// lane the candidate sits in, and which of two lists it came from) — one min / max per network stage instead of a 64-bit compare and
+// four selects, the ids fetched once per sort through the payload.  Distances are thereby ordered up to 2^-16 relative, far inside the
+// millimetre the scan's stop test allows for (kEps in LISREG_GRAPH_GROUP), and the coverage radius is taken from the QUANTISED key of the
+// first point left out (a floor: every point left out is at least that far), so "closer than rho => listed" holds exactly.
+template <int M, int LowBit> __device__ __forceinline__ unsigned cmpx32(unsigned k, int lane)
+{
+    const unsigned pk = (unsigned)lane_xor<M>((int)k);
+    const unsigned lo = min(k, pk), hi = max(k, pk);
+    return (lane & LowBit) == 0 ? lo : hi;
+}
+template <int H> __device__ __forceinline__ unsigned half_cleaners32(unsigned k, int lane)
+{
+    if constexpr (H > 0) { k = cmpx32<H, H>(k, lane); return half_cleaners32<(H >> 1)>(k, lane); }
+    else return k;
+}
+template <int H> __device__ __forceinline__ unsigned merge_blocks32(unsigned k, int lane)
+{
+    k = cmpx32<2 * H - 1, H>(k, lane);
+    return half_cleaners32<(H >> 1)>(k, lane);
+}
+__device__ __forceinline__ unsigned sort64x32(unsigned k, int lane)
+{
+    k = merge_blocks32<1>(k, lane); k = merge_blocks32<2>(k, lane); k = merge_blocks32<4>(k, lane);
+    k = merge_blocks32<8>(k, lane); k = merge_blocks32<16>(k, lane); k = merge_blocks32<32>(k, lane);
+    return k;
+}
+
+// The rows of one cell (one wave).  crow_runs: the z-runs of the (2 R + 1)^3 block around the cell (shared by all its rows);
+// crow_list: the kGraphK block points nearest to a location q, ascending (quantised key + id per lane); crow_emit: one row from such a list.
+template <int R>
+struct CrowBlock { int x0, x1, y0, y1, z0, z1, total; };
+
+template <int R>
+__device__ __forceinline__ CrowBlock<R> crow_runs(const GridIndex& g, int hx, int hy, int hz, int (*s_off)[64], int (*s_js)[64])
+{
+    constexpr int W = 2 * R + 1, NR = W * W;
+    static_assert(NR <= 64, "one lane per z-run");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    CrowBlock<R> b;
+    b.x0 = max(hx - R, 0); b.x1 = min(hx + R, g.nx - 1); b.y0 = max(hy - R, 0); b.y1 = min(hy + R, g.ny - 1);
+    b.z0 = max(hz - R, 0); b.z1 = min(hz + R, g.nz - 1);
+    int js = 0, len = 0;
+    if (lane < NR) {
+        const int ix = hx + lane / W - R, iy = hy + lane % W - R;
+        if (ix >= b.x0 && ix <= b.x1 && iy >= b.y0 && iy <= b.y1) {
+            const int base = (ix * g.ny + iy) * g.nz;
+            js = g.cell_start[base + b.z0];
+            len = g.cell_start[base + b.z1 + 1] - js;
+        }
+    }
+    int inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    b.total = __shfl(inc, 63);
+    __builtin_amdgcn_wave_barrier();
+    s_off[wave][lane] = inc - len; s_js[wave][lane] = js;
+    __builtin_amdgcn_wave_barrier();
+    return b;
+}
+
+// distance from q to the nearest face of the block that has cells beyond it (faces on the grid boundary have nothing beyond them)
+template <int R>
+__device__ __forceinline__ float crow_inscribed(const GridIndex& g, const CrowBlock<R>& b, float qx, float qy, float qz)
+{
+    float rc = 3.0e18f;
+    if (b.x0 > 0)        rc = fminf(rc, qx - (g.ox + (float)b.x0 * g.cell));
+    if (b.x1 < g.nx - 1) rc = fminf(rc, (g.ox + (float)(b.x1 + 1) * g.cell) - qx);
+    if (b.y0 > 0)        rc = fminf(rc, qy - (g.oy + (float)b.y0 * g.cell));
+    if (b.y1 < g.ny - 1) rc = fminf(rc, (g.oy + (float)(b.y1 + 1) * g.cell) - qy);
+    if (b.z0 > 0)        rc = fminf(rc, qz - (g.oz + (float)b.z0 * g.cell));
+    if (b.z1 < g.nz - 1) rc = fminf(rc, (g.oz + (float)(b.z1 + 1) * g.cell) - qz);
+    return fmaxf(rc - 1e-3f, 0.f);
+}
+
+constexpr unsigned kInfQ = 0x7f800000u;                     // +inf, payload bits clear
+
+template <int R>
+__device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>& b, float qx, float qy, float qz,
+                                          int (*s_off)[64], int (*s_js)[64], unsigned& topk, int& topi)
+{
+    constexpr int W = 2 * R + 1, NR = W * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    topk = kInfQ; topi = -1;                                // running kGraphK best, ascending: quantised key and id per lane
+#pragma unroll 1
+    for (int c0 = 0; c0 < b.total; c0 += 64) {
+        const int t = c0 + lane;
+        unsigned k = kInfQ | (unsigned)lane;
+        int cj = -1;
+        if (t < b.total) {
+            int lo = 0, hi = NR - 1;                        // last run whose offset is <= t
+#pragma unroll
+            for (int it = 0; it < (NR > 32 ? 6 : 5); ++it) { const int mid = (lo + hi + 1) >> 1; if (s_off[wave][mid] <= t) lo = mid; else hi = mid - 1; }
+            const int j = s_js[wave][lo] + (t - s_off[wave][lo]);
+            const float4 c = g.pts[j];
+            const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < 3.0e38f) { k = (__float_as_uint(d2) & ~0x7Fu) | (unsigned)lane; cj = j; }     // NaN / Inf points are never listed
+        }
+        k = sort64x32(k, lane);
+        const int cs = __shfl(cj, (int)(k & 63u));
+        const unsigned ck = k & ~0x7Fu;
+        if (c0 == 0) { topk = ck; topi = cs; }
+        else {
+            // the lane-wise minimum of the running list and the reversed chunk is the 64 smallest of both as one bitonic sequence
+            const unsigned kt = topk | 64u | (unsigned)lane;
+            const unsigned kcr = (unsigned)__shfl((int)(ck | (unsigned)lane), 63 - lane);
+            const unsigned m = half_cleaners32<32>(min(kt, kcr), lane);
+            const int pos = (int)(m & 63u);
+            const int from_top = __shfl(topi, pos), from_chunk = __shfl(cs, pos);
+            topi = (m & 64u) ? from_top : from_chunk;
+            topk = m & ~0x7Fu;
+        }
+    }
+}
+
+// one row: the entries of the list inside rho (the block's inscribed radius, or the first point left out), padded with (q, -1)
+__device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float qy, float qz, float rc, unsigned topk, int topi,
+                                           float4* __restrict__ row_out, float2* __restrict__ meta_out, bool& keep, float4& e)
+{
+    const int lane = threadIdx.x & 63;
+    const float tk = __uint_as_float(topk);
+    const float dK = __shfl(tk, kGraphK - 1);
+    const float rho2 = fminf(rc * rc, dK);
+    keep = topi >= 0 && tk <= rho2;
+    const int cnt = __popcll(__ballot(keep));
+    e = make_float4(qx, qy, qz, __int_as_float(-1));
+    if (keep) { const float4 c = g.pts[topi]; e = make_float4(c.x, c.y, c.z, __int_as_float(topi)); }
+    row_out[lane] = e;
+    if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
+    return rho2;
+}
+
+// The row at the cell's centre q and, behind it, one row per octant in `mask`.  An octant row is derived from the centre row where that
+// leaves it a useful reach: a point closer than rho - |octant centre - cell centre| to an octant centre is closer than rho to the cell
+// centre, hence among the 64 listed — one 64-key sort re-orders the SAME entries by their distance from the octant centre, and that
+// difference is the octant row's coverage radius (no candidate gather, one sort instead of chunk sorts + merges).  Where the centre row
+// is cut short by its 64th entry (a dense spot: rho under 2.5 offsets), the octant row is built from the block like the centre row.
+template <int R>
+__device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4 q, int hx, int hy, int hz, unsigned mask,
+                                                float4* __restrict__ row_out, float2* __restrict__ meta_out, int (*s_off)[64], int (*s_js)[64])
+{
+    const int lane = threadIdx.x & 63;
+    constexpr float kEps = 1e-3f;
+    const CrowBlock<R> b = crow_runs<R>(g, hx, hy, hz, s_off, s_js);
+    unsigned topk; int topi;
+    crow_list<R>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi);
+    bool keep; float4 e;
+    const float rho2 = crow_emit(g, q.x, q.y, q.z, crow_inscribed<R>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e);
+    if (mask) {
+        const float off = 0.25f * g.cell * 1.7320508f;                         // |octant centre - cell centre|
+        const float rho_o = fmaxf(sqrtf(rho2) - off - 2.f * kEps, 0.f), rho_o2 = rho_o * rho_o;
+        const bool derive = rho_o >= 1.5f * off;
+        int slot = 1;
+#pragma unroll 1
+        for (int o = 0; o < 8; ++o) {
+            if (!((mask >> o) & 1u)) continue;
+            const float mx = crow_centre(g.ox, g.cell, hx, o & 1 ? 0.75f : 0.25f), my = crow_centre(g.oy, g.cell, hy, o & 2 ? 0.75f : 0.25f);
+            const float mz = crow_centre(g.oz, g.cell, hz, o & 4 ? 0.75f : 0.25f);
+            float4* orow = row_out + (size_t)slot * kGraphK;
+            if (derive) {
+                unsigned k = kInfQ | (unsigned)lane;
+                if (keep) {
+                    const float ex = mx - e.x, ey = my - e.y, ez = mz - e.z;
+                    k = (__float_as_uint(ex * ex + ey * ey + ez * ez) & ~0x7Fu) | (unsigned)lane;
+                }
+                k = sort64x32(k, lane);
+                const int oi = __shfl(keep ? topi : -1, (int)(k & 63u));
+                const bool okeep = oi >= 0 && __uint_as_float(k & ~0x7Fu) <= rho_o2;
+                const int ocnt = __popcll(__ballot(okeep));
+                float4 oe = make_float4(mx, my, mz, __int_as_float(-1));
+                if (okeep) { const float4 c = g.pts[oi]; oe = make_float4(c.x, c.y, c.z, __int_as_float(oi)); }
+                orow[lane] = oe;
+                if (lane == 0) meta_out[slot] = make_float2(rho_o2, __int_as_float(ocnt));
+            } else {
+                unsigned ok; int oi; bool okeep; float4 oe;
+                crow_list<R>(g, b, mx, my, mz, s_off, s_js, ok, oi);
+                (void)crow_emit(g, mx, my, mz, crow_inscribed<R>(g, b, mx, my, mz), ok, oi, orow, meta_out + slot, okeep, oe);
+            }
+            ++slot;
+        }
+    }
+}
+
+// One wave per cell (kCrowCPW of them in a row): the table entry and the cell's rows.
 // crow_tab[cell] = -2: nothing within two cells; -1: no row (its rows did not fit the capacity the buffers were sized for); else
-// (first row << 1) | has-octants, rows = [centre, octant 0 .. 7].
-constexpr int kCrowCPW = 8;
-__global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ scan, int cap)
+// (first row << 8) | octant mask, rows = [centre, the octants of the mask in ascending order].
+constexpr int kCrowCPW = 2;
+__global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
+                                                    const int* __restrict__ scan, int cap, int use_r3)
 {
     __shared__ int s_off[4][64], s_js[4][64];
     const int lane = threadIdx.x & 63;
@@ -851,8 +1019,9 @@ __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, co
         const int n = need[cid];
         if (n == 0) { if (lane == 0) tab[cid] = -2; continue; }
         const int b = scan[cid];
-        if (b + n > cap) { if (lane == 0) tab[cid] = -1; continue; }
-        if (lane == 0) tab[cid] = (b << 1) | (n == 9 ? 1 : 0);
+        if (b + n > cap || b >= (1 << 23)) { if (lane == 0) tab[cid] = -1; continue; }
+        const unsigned mask = (unsigned)omask[cid];
+        if (lane == 0) tab[cid] = (b << 8) | (int)mask;
         const int hz = cid % g.nz, t = cid / g.nz, hy = t % g.ny, hx = t / g.ny;
         const float4 q = make_float4(crow_centre(g.ox, g.cell, hx, 0.5f), crow_centre(g.oy, g.cell, hy, 0.5f), crow_centre(g.oz, g.cell, hz, 0.5f), 0.f);
         float4* row = const_cast<float4*>(g.crow) + (size_t)b * kGraphK;
@@ -860,9 +1029,8 @@ __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, co
         // a centre row serves queries up to 0.87 cells from the centre wherever they are relative to the surface; one with fewer than five
         // points inside sqrt(tau) is certified by the coverage radius alone, which then has to reach sqrt(tau) + 0.87 cells: where the
         // 5 x 5 x 5 block does not fill the row (2.5 cells of coverage), the 7 x 7 x 7 block is searched (3.5 cells; few candidates there)
-        if (n == 9) row_build_wave<2, true>(g, q, hx, hy, hz, -1, row, meta, s_off, s_js);
-        else if (block_population<2>(g, hx, hy, hz) >= kGraphK) row_build_wave<2, false>(g, q, hx, hy, hz, -1, row, meta, s_off, s_js);
-        else row_build_wave<3, false>(g, q, hx, hy, hz, -1, row, meta, s_off, s_js);
+        if (mask != 0u || !use_r3 || block_population<2>(g, hx, hy, hz) >= kGraphK) crow_build_wave<2>(g, q, hx, hy, hz, mask, row, meta, s_off, s_js);
+        else crow_build_wave<3>(g, q, hx, hy, hz, 0u, row, meta, s_off, s_js);
     }
 }
 
@@ -1248,15 +1416,16 @@ void launch_build_graph_one(GridIndex g, hipStream_t st)
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
 {
     if (g.n <= 0 || n_cells <= 0) return;
-    static const float margin = getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.5f;      // in cells
-    k_crow_classify<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, margin * g.cell, cb.need);
+    static const float margin = getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.25f;      // in cells
+    k_crow_classify<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, margin * g.cell, cb.need, cb.omask);
     exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
 }
 
 void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
 {
     if (g.n <= 0 || n_cells <= 0 || cb.cap_rows <= 0 || !g.crow) return;
-    k_crow_build<<<(n_cells + 4 * kCrowCPW - 1) / (4 * kCrowCPW), 256, 0, st>>>(g, n_cells, cb.need, cb.scan, cb.cap_rows);
+    static const int use_r3 = getenv("LISREG_CROW_R3") ? atoi(getenv("LISREG_CROW_R3")) : 1;
+    k_crow_build<<<(n_cells + 4 * kCrowCPW - 1) / (4 * kCrowCPW), 256, 0, st>>>(g, n_cells, cb.need, cb.omask, cb.scan, cb.cap_rows, use_r3);
 }
 
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,

@@ -32,8 +32,8 @@ struct GridIndex {
     const float2* nbr_meta;
     // cell rows (search_mode 5; null otherwise): the same kind of row — kGraphK entries (x, y, z, sorted position), ascending by distance,
     // (rho^2, count) beside it — but anchored at a LOCATION, not at a point: the centre of a grid cell ("coarse" row) or of one of its eight
-    // octants (cells that have a point within half a cell of their box).  crow_tab[cell] = -2: no target point within two cells
-    // of this one; -1: no row (capacity); else (first row << 1) | has-octants, rows = [centre, octant 0 .. 7].  A query reads the row of the cell / octant it falls into, whatever
+    // octants (those with a point within a quarter cell of their box).  crow_tab[cell] = -2: no target point within two cells
+    // of this one; -1: no row (capacity); else (first row << 8) | octant mask, rows = [centre, the mask's octants in ascending order].  A query reads the row of the cell / octant it falls into, whatever
     // its distance from the surface, so the certificate radius c5 + |q - centre| is bounded by the cell size in every Gauss-Newton iteration.
     const float4* crow;
     const float2* crow_meta;
@@ -41,8 +41,9 @@ struct GridIndex {
 };
 
 // centre coordinate of cell h (off = 0.5f) or of one of its halves (0.25f / 0.75f) along one axis: the build and the scan must agree to
-// the bit (the scan re-derives the list distances of a row from this centre), so the two roundings are spelled out
-__device__ __forceinline__ float crow_centre(float origin, float cell, int h, float off) { return __fadd_rn(origin, __fmul_rn((float)h + off, cell)); }
+// the bit (the scan re-derives the list distances of a row from this centre) although their translation units are compiled with different
+// contraction settings: ONE fused multiply-add, whatever the flags (hipcc's __fmul_rn / __fadd_rn are plain operators and do get contracted)
+__device__ __forceinline__ float crow_centre(float origin, float cell, int h, float off) { return __builtin_fmaf((float)h + off, cell, origin); }
 
 // One (item, kind) source segment; kind 0 = edge features vs corner target, 1 = planar features vs surf target.
 struct Segment {
@@ -176,7 +177,7 @@ void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* 
 void launch_build_graph_one(GridIndex g, hipStream_t st);
 // cell rows of one target (search_mode 5).  classify: need[cell] = rows the cell wants (0 / 1 / 8), scan[cell] = first row, scan[n_cells] = rows
 // in all; build: crow_tab, then one wave per row (at most cap_rows of them: cells past the capacity get no row and their queries walk)
-struct CrowBuffers { int* need; int* scan; int* scan_tmp; int cap_rows; };
+struct CrowBuffers { int* need; int* omask; int* scan; int* scan_tmp; int cap_rows; };
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st);
 void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st);
 // sources of a whole batch: tile-sort every segment under its item's initial pose

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_concat_device", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_concat_device", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_get_target_cell_rows", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_voxel_downsample_multi", "lisreg_transform_cloud",
@@ -217,6 +217,8 @@ def lib():
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
         L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lisreg_get_target_graph.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+        L.lisreg_get_target_cell_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.lisreg_get_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         L.lisreg_get_trace.argtypes = [vp, fp, C.c_int]
         L.lisreg_set_profiling.argtypes = [vp, C.c_int]
@@ -530,6 +532,20 @@ class Context:
                                                   meta.ctypes.data_as(C.POINTER(C.c_float)), n))
         return dict(k=k.value, ids=rows[:n, :, 3].copy().view(np.int32), xyz=rows[:n, :, :3], rho2=meta[:n, 0],
                     count=meta[:n, 1].copy().view(np.int32))
+
+    def target_cell_rows(self, slot: int = 0, kind: int = 1) -> dict:
+        """Diagnostics: the cell rows of a target (see lisreg_get_target_cell_rows): table [n_cells], ids [rows, k] (sorted positions,
+        -1 padded), xyz [rows, k, 3], rho2 [rows], count [rows]."""
+        nc = self.target_index(slot, kind)["n_cells"]
+        n_rows, k = C.c_int(), C.c_int()
+        self._chk(self._L.lisreg_get_target_cell_rows(self._h, slot, kind, C.byref(n_rows), C.byref(k), None, 0, None, None, 0))
+        table = np.zeros(max(nc, 1), np.int32)
+        rows = np.zeros((max(n_rows.value, 1), k.value, 4), np.float32); meta = np.zeros((max(n_rows.value, 1), 2), np.float32)
+        self._chk(self._L.lisreg_get_target_cell_rows(self._h, slot, kind, C.byref(n_rows), C.byref(k), table.ctypes.data_as(C.POINTER(C.c_int)), nc,
+                                                      rows.ctypes.data_as(C.POINTER(C.c_float)), meta.ctypes.data_as(C.POINTER(C.c_float)), n_rows.value))
+        r = n_rows.value
+        return dict(k=k.value, n_rows=r, table=table[:nc], ids=rows[:r, :, 3].copy().view(np.int32), xyz=rows[:r, :, :3], rho2=meta[:r, 0],
+                    count=meta[:r, 1].copy().view(np.int32))
 
     def raw_counters(self):
         out = (C.c_ulonglong * 128)()

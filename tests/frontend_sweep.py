@@ -1,5 +1,5 @@
-"""Evidence run (not a test): with "canonical_ties" set, the three search front-ends of the PRODUCTION build — cell walk with eight lanes per
-query, cell walk with one, graph scan — must return the same five neighbours in the same order for every query of every iteration, hence
+"""Evidence run (not a test): with "canonical_ties" set, the search front-ends of the PRODUCTION build — cell walk with eight lanes per
+query, cell walk with one, graph scan, cell rows — must return the same five neighbours in the same order for every query of every iteration, hence
 bit-identical poses.  Random configurations of tests/test_exact.py::sweep_case.   python tests/frontend_sweep.py [first_seed] [n]"""
 import os, sys
 import numpy as np
@@ -18,7 +18,7 @@ for seed in range(first, first + n):
     p = copy_params(oc.default_params(variant), lisreg.Params)
     p.fixed_iters = fixed if fixed > 0 else 6
     runs = []
-    for mode, lanes in ((1, 8), (1, 1), (3, 1)):
+    for mode, lanes in ((1, 8), (1, 1), (3, 1), (5, 1)):
         c = lisreg.Context(0)
         c.set_option("canonical_ties", 1); c.set_option("search_mode", mode); c.set_option("lanes_per_query", lanes); c.set_option("dump_neighbors", 1)
         c.set_target(case["tgt_corner"], case["tgt_surf"])
@@ -30,6 +30,6 @@ for seed in range(first, first + n):
     if not ok:
         bad.append(seed)
         d = [int((runs[0][2][:5] != r[2][:5]).any(0).sum()) for r in runs[1:]]
-        print(f"seed {seed}: front-ends DIFFER — queries with other neighbours than the eight-lane walk: one-lane walk {d[0]}, graph scan {d[1]}")
-print(f"== {n - len(bad)} of {n} configurations: the three front-ends bit-identical (poses and traces of every iteration, neighbours and accept flags of the last); "
+        print(f"seed {seed}: front-ends DIFFER — queries with other neighbours than the eight-lane walk: one-lane walk {d[0]}, graph scan {d[1]}, cell rows {d[2]}")
+print(f"== {n - len(bad)} of {n} configurations: the four front-ends (walk x 8 lanes, walk, graph scan, cell rows) bit-identical (poses and traces of every iteration, neighbours and accept flags of the last); "
       f"{queries} queries; differing seeds: {bad}")

@@ -79,7 +79,17 @@ def test_cfg1_batch_vs_oracle(oracle, gpu_ctx):
     # batch == single calls, bit for bit, with the front-end left at auto: the batch qualifies for the graph scan, a single
     # registration takes the eight-lanes-per-query cell walk — equal distances are resolved by (distance, original index) in all of
     # them with the option "canonical_ties" (LISREG_CANONICAL_FIVE), so a frame's bits do not depend on the batch it sits in
-    assert gpu_ctx.get_option("front_end") == 3
+    assert gpu_ctx.get_option("front_end") == 3           # 12 scans: 69 query-iterations per target point — the graph scan (64 scans: the cell rows)
+    # the same batch through the cell rows (what auto picks for the 64 scans of bench.py): the same bits
+    gpu_ctx.set_option("search_mode", 5); gpu_ctx.set_option("rebuild_targets_each_run", 1)
+    try:
+        gpu_ctx.batch_prepare_device(items, T0, p)
+        assert gpu_ctx.get_option("front_end") == 5
+        gpu_ctx.batch_run()
+        T5, st5 = gpu_ctx.batch_fetch()
+    finally:
+        gpu_ctx.set_option("search_mode", 4); gpu_ctx.set_option("rebuild_targets_each_run", 0)
+    assert np.array_equal(T5, T) and st5 == st
     try:
         gpu_ctx.set_target(tc, ts)
         for i in (0, n - 1):
@@ -138,7 +148,7 @@ def test_cfg3_own_targets_256(oracle, gpu_ctx):
 
 def test_cfg4_dense_1m(oracle, gpu_ctx):
     """configs[4]: 128x2048 scans against a 1 M-point submap, 30 fixed iterations — one item against the oracle over all 30
-    iterations, an 8-item device batch against single calls, in both search front-ends."""
+    iterations, an 8-item device batch against single calls, in the three search front-ends (cell walk, graph scan, cell rows)."""
     import lisreg
     from lisreg import synth
     tc, ts = synth.make_submap(1_000_000, 42)
@@ -151,7 +161,7 @@ def test_cfg4_dense_1m(oracle, gpu_ctx):
     recs = [(_dev(s["corner"]), _dev(s["surf"])) for s in scans]
     items = [dict(corner_ptr=a.ptr, n_corner=a.shape[0], surf_ptr=b.ptr, n_surf=b.shape[0]) for a, b in recs]
     results = {}
-    for mode in (1, 3):
+    for mode in (1, 3, 5):
         ctx = lisreg.Context(0)
         ctx.set_option("search_mode", mode)
         ctx.set_option("canonical_ties", 1)
@@ -173,3 +183,4 @@ def test_cfg4_dense_1m(oracle, gpu_ctx):
     # float distance; with "canonical_ties" both front-ends resolve them by (distance, original index)
     assert np.array_equal(results[1][0], results[3][0])
     assert results[1][1] == results[3][1]
+    assert np.array_equal(results[1][0], results[5][0]) and results[1][1] == results[5][1]

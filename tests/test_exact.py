@@ -140,7 +140,7 @@ def test_exact_build_equals_oracle_on_the_goldens(oracle, path):
     print(f"[exact] golden {os.path.basename(path)}: worst pose difference {worst:.2e}, {n} accept flags equal")
 
 
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode", [1, 3, 5])
 def test_exact_build_front_ends_bit_identical(mode):
     """the exact arithmetic runs under every search front-end and lanes-per-query variant with identical bits"""
     import lisreg
@@ -195,10 +195,10 @@ def test_production_build_deviations_are_threshold_straddlers(oracle, seed):
 def test_exact_build_equals_oracle_at_full_size(oracle):
     """BASELINE configs[0] shape: one 64x1800 scan (every valid pixel a feature) vs a 50 k-point submap, 10 fixed iterations —
     115 k queries per iteration through the eight-lanes-per-query walk; and the same scan vs the 200 k submap of configs[1] through the
-    graph front-end (forced).  Integer outputs equal, poses to the last bit or two."""
+    graph front-end and through the cell rows (forced).  Integer outputs equal, poses to the last bit or two."""
     import lisreg
     from lisreg import synth
-    for m_points, mode in ((50000, 4), (200000, 3)):
+    for m_points, mode in ((50000, 4), (200000, 3), (200000, 5)):
         case = synth.make_case(h=64, w=1800, m_points=m_points, scan_seed=1000)
         p_o = oracle.default_params(1)
         p_o.fixed_iters = 10

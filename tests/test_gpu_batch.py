@@ -93,7 +93,7 @@ def test_device_resident_batch_and_rerun_is_idempotent(gpu_ctx):
     assert all(s["iters"] == 6 for s in s1)
 
 
-@pytest.mark.parametrize("mode,sort", [(0, 0), (0, 1), (1, 0), (1, 1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("mode,sort", [(0, 0), (0, 1), (1, 0), (1, 1), (3, 0), (3, 1), (5, 0), (5, 1)])
 def test_search_front_ends_agree(oracle, gpu_ctx, mode, sort):
     """LDS-staged workgroup box search and per-lane grid walk are both exact: same correspondence counts."""
     import lisreg
@@ -123,16 +123,19 @@ def test_graph_scan_equals_cell_walk_bitwise(gpu_ctx, variant, labelled, seed, m
     case = synth.make_case(h=16, w=450, m_points=m_points, scan_seed=seed, labelled=labelled, trans=0.4, rot_deg=2.5)
     p = lisreg.default_params(variant)
     out = {}
-    for mode in (1, 3):
+    for mode in (1, 3, 5):
         c2 = lisreg.Context(0)
         c2.set_option("search_mode", mode)
         c2.set_target(case["tgt_corner"], case["tgt_surf"])
         out[mode] = c2.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        assert c2.front_end() == mode
         c2.close()
     (T1, s1, tr1), (T3, s3, tr3) = out[1], out[3]
     assert s1 == s3 and s1["status"] == 0
     assert np.array_equal(T1, T3)
     assert np.array_equal(tr1, tr3)
+    T5, s5, tr5 = out[5]                                   # search_mode 5 (cell rows): the same list scan anchored at cell / octant centres
+    assert s1 == s5 and np.array_equal(T1, T5) and np.array_equal(tr1, tr5)
 
 
 def test_xcd_dispatch_order_does_not_change_results(gpu_ctx):
@@ -154,6 +157,14 @@ def test_xcd_dispatch_order_does_not_change_results(gpu_ctx):
             c2.close()
         assert np.array_equal(out[0][0], out[1][0])
         assert out[0][1] == out[1][1]
+        for xo in (0, 1):                                  # the cell-row front-end under both orders: the graph scan's bits
+            c2 = lisreg.Context(0)
+            c2.set_option("search_mode", 5); c2.set_option("xcd_order", xo); c2.set_option("sort_sources", sort)
+            c2.set_target(tc, ts)
+            o5 = c2.align_batch(cases, T0, p)
+            assert c2.get_option("xcd_order_now") == xo and c2.front_end() == 5
+            c2.close()
+            assert np.array_equal(out[0][0], o5[0]) and out[0][1] == o5[1]
 
 
 def test_edge_cases(oracle, gpu_ctx):

@@ -142,3 +142,75 @@ def test_graph_rows_cover_their_radius(gpu_ctx, m_points, kind):
         have = set(g["ids"][s][:g["count"][s]].tolist())
         assert len(have) == g["count"][s]                                      # each once
         assert want <= have, (s, rho, sorted(want - have)[:4])                 # (3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m_points,kind", [(60000, 1), (8000, 1), (60000, 0), (400000, 1)])
+def test_cell_rows_cover_their_radius(gpu_ctx, m_points, kind):
+    """The cell rows behind search front-end 5 (lisreg_get_target_cell_rows).  Table: -2 only where no target point lies in the 5 x 5 x 5 cell
+    block, every other cell has a centre row and one row per octant of its mask, rows laid end to end.  For every row, about its centre
+    (cell centre, or octant centre = cell corner + 0.25 / 0.75 of the edge): (1) the entries are target points, each once, ascending in
+    distance to 2^-16 relative (the build sorts quantised keys), (2) the stored coordinates are the listed points' own, bit for bit,
+    (3) EVERY target point closer than rho is listed — the guarantee the certificate rests on — against a float64 kd-tree, (4) padded
+    entries carry the centre's coordinates and id -1, (5) an octant with a target point inside its box has a row."""
+    from scipy.spatial import cKDTree
+    from lisreg import synth
+    tc, ts = synth.make_submap(m_points, 78)
+    gpu_ctx.set_target(tc, ts)
+    idx = gpu_ctx.target_index(0, kind); g = gpu_ctx.target_cell_rows(0, kind)
+    n, k, R = idx["n"], g["k"], g["n_rows"]
+    nx, ny, nz, cell, org = idx["nx"], idx["ny"], idx["nz"], np.float32(idx["cell"]), idx["origin"].astype(np.float32)
+    pts32 = idx["sorted"][:, :3]; pts = pts32.astype(np.float64)
+    tab = g["table"]
+    assert tab.shape == (nx * ny * nz,) and ((tab >= 0) | (tab == -2)).all()      # (-1 only when the buffers are too small: not here)
+    # occupancy -> which cells may be -2
+    cs = idx["cell_start"]; occ = (np.diff(cs) > 0).reshape(nx, ny, nz)
+    from scipy.ndimage import maximum_filter
+    near = maximum_filter(occ.astype(np.uint8), size=5, mode="constant", cval=0).astype(bool).reshape(-1)
+    assert np.array_equal(tab >= 0, near)
+    have = np.flatnonzero(tab >= 0)
+    base = tab[have] >> 8; mask = tab[have] & 255
+    cnt = 1 + np.array([bin(int(m)).count("1") for m in mask])
+    order = np.argsort(base)
+    assert base[order][0] == 0 and np.array_equal(base[order][1:], np.cumsum(cnt[order])[:-1]) and base[order][-1] + cnt[order][-1] == R
+    # (5): cells that hold a point have the octant that point is in
+    pc = np.floor((pts32 - org) / cell).astype(np.int64)
+    pc = np.minimum(np.maximum(pc, 0), np.array([nx - 1, ny - 1, nz - 1]))
+    frac = (pts32 - org) / cell - pc
+    inner = ((frac > 0.01) & (frac < 0.49)) | ((frac > 0.51) & (frac < 0.99))   # clear of the octant faces (float rounding)
+    ok = inner.all(1)
+    octv = (frac[:, 0] >= 0.5).astype(int) + 2 * (frac[:, 1] >= 0.5) + 4 * (frac[:, 2] >= 0.5)
+    cid = (pc[:, 0] * ny + pc[:, 1]) * nz + pc[:, 2]
+    assert ((tab[cid[ok]] >> octv[ok]) & 1).all()
+    # rows -> centres
+    centre = np.zeros((R, 3), np.float32)
+    for c_, b_, m_ in zip(have, base, mask):
+        iz = c_ % nz; iy = (c_ // nz) % ny; ix = c_ // (nz * ny)
+        h = np.array([ix, iy, iz], np.float32)
+        centre[b_] = (org.astype(np.float64) + (h.astype(np.float64) + 0.5) * np.float64(cell)).astype(np.float32)
+        slot = 1
+        for o in range(8):
+            if (m_ >> o) & 1:
+                f = np.array([0.75 if o & 1 else 0.25, 0.75 if o & 2 else 0.25, 0.75 if o & 4 else 0.25], np.float32)
+                centre[b_ + slot] = (org.astype(np.float64) + (h.astype(np.float64) + f.astype(np.float64)) * np.float64(cell)).astype(np.float32)
+                slot += 1
+    col = np.arange(k)[None, :]
+    listed = col < g["count"][:, None]
+    assert (g["count"] >= 0).all() and (g["count"] <= k).all() and ((g["ids"] >= 0) == listed).all()
+    # (4) (the device forms a centre with one fused multiply-add; float64 here, rounded once: the same value up to double rounding)
+    assert np.abs(g["xyz"][~listed] - np.broadcast_to(centre[:, None, :], g["xyz"].shape)[~listed]).max(initial=0) <= 4e-6
+    safe = np.where(listed, g["ids"], 0)
+    assert np.array_equal(g["xyz"][listed], pts32[safe][listed])               # (2)
+    d = np.linalg.norm(g["xyz"].astype(np.float64) - centre.astype(np.float64)[:, None, :], axis=2)
+    dd = np.where(listed, d, np.inf)
+    with np.errstate(invalid="ignore"):
+        ratio = dd[:, 1:] / np.maximum(dd[:, :-1], 1e-12)
+    assert (ratio[listed[:, 1:]] >= 1 - 2.0 ** -15).all()                      # (1) ascending up to the key quantisation
+    tree = cKDTree(pts)
+    rng = np.random.default_rng(2)
+    for r in rng.choice(R, min(R, 4000), replace=False):
+        rho = float(np.sqrt(g["rho2"][r]))
+        want = set(tree.query_ball_point(centre[r].astype(np.float64), rho * (1 - 1e-5)))
+        got = g["ids"][r][:g["count"][r]].tolist()
+        assert len(set(got)) == len(got)                                       # each once
+        assert want <= set(got), (r, rho, sorted(want - set(got))[:4])         # (3)

@@ -110,7 +110,7 @@ def test_front_end_0_refuses_canonical_ties_and_exact(gpu_ctx):
 
 
 def test_search_mode_environment_override_is_validated():
-    """LISREG_SEARCH_MODE outside {0, 1, 3, 4} is ignored with a message (it used to select the graph kernel without a graph)."""
+    """LISREG_SEARCH_MODE outside {0, 1, 3, 4, 5} is ignored with a message (it used to select the graph kernel without a graph)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = f"""
 import sys
