@@ -700,26 +700,6 @@ __device__ __forceinline__ void row_build_wave(const GridIndex& g, const float4 
     if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
 }
 
-// target points in the (2 R + 1)^3 block around a cell (one wave)
-template <int R>
-__device__ __forceinline__ int block_population(const GridIndex& g, int hx, int hy, int hz)
-{
-    constexpr int W = 2 * R + 1, NR = W * W;
-    const int lane = threadIdx.x & 63;
-    const int z0 = max(hz - R, 0), z1 = min(hz + R, g.nz - 1);
-    int len = 0;
-    if (lane < NR) {
-        const int ix = hx + lane / W - R, iy = hy + lane % W - R;
-        if (ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny) {
-            const int base = (ix * g.ny + iy) * g.nz;
-            len = g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) len += __shfl_xor(len, d);
-    return len;
-}
-
 __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int (*s_off)[64], int (*s_js)[64])
 {
     const float4 q = g.pts[s];
@@ -759,28 +739,15 @@ __global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __
 // ---- cell rows (search_mode 5) -------------------------------------------------------------------------------------------
 // Which cells get rows.  A cell with no target point in the 5 x 5 x 5 block around it gets none (need 0: a query in it has nothing within
 // two cells); every other cell a row at its centre; and each of its eight octants whose box has a point within `oct_margin` its own row
-// behind that (omask bit: the octants the surface runs through or next to — where the queries are once the pose has settled, at most 0.43
-// of a half cell from the octant's centre).  need = 1 + the number of such octants.
-__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells, float oct_margin, int* __restrict__ need, int* __restrict__ omask)
+// behind that (omask bits 0..7: the octants the surface runs through or next to — where the queries are once the pose has settled, at most
+// 0.43 of a half cell from the octant's centre).  need = 1 + the number of such octants; omask >> 8 = the block's population (capped).
+// One workgroup per tile of kCtX x kCtY columns over the whole z-range: the cell_start rows of the tile and its two-column rim are staged
+// in LDS once (two global reads per cell instead of fifty), every thread sums its cells' 5 x 5 columns from there; the cells that have a
+// point in their 3 x 3 x 3 neighbourhood are collected into an LDS list and dealt out evenly for the octant distances (a floor touches two
+// of the 29 cells of a column: without the list a wavefront had three lanes at work).
+constexpr int kCtX = 8, kCtY = 8, kCtRim = 2;
+__device__ __forceinline__ int crow_octant_mask(const GridIndex& g, int ix, int iy, int iz, float oct_margin)
 {
-    const int cid = blockIdx.x * 256 + threadIdx.x;
-    if (cid >= n_cells) return;
-    const int iz = cid % g.nz, t = cid / g.nz, iy = t % g.ny, ix = t / g.ny;
-    const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1);
-    int any = 0;
-#pragma unroll 1
-    for (int dx = -2; dx <= 2; ++dx) {
-        const int x = ix + dx;
-        if (x < 0 || x >= g.nx) continue;
-#pragma unroll
-        for (int dy = -2; dy <= 2; ++dy) {
-            const int y = iy + dy;
-            if (y < 0 || y >= g.ny) continue;
-            const int base = (x * g.ny + y) * g.nz;
-            any += g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
-        }
-    }
-    if (!any) { need[cid] = 0; omask[cid] = 0; return; }
     const float h = 0.5f * g.cell;
     const float lx = g.ox + (float)ix * g.cell, ly = g.oy + (float)iy * g.cell, lz = g.oz + (float)iz * g.cell;
     const int zz0 = max(iz - 1, 0), zz1 = min(iz + 1, g.nz - 1);
@@ -813,8 +780,83 @@ __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int n_cells,
     int m = 0;
 #pragma unroll
     for (int o = 0; o < 8; ++o) if (best[o] <= oct_margin * oct_margin) m |= 1 << o;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, float oct_margin, int tiles_y, int* __restrict__ need, int* __restrict__ omask)
+{
+    extern __shared__ int s_cs[];                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows, then the list
+    __shared__ int s_n;
+    constexpr int WX = kCtX + 2 * kCtRim, WY = kCtY + 2 * kCtRim;
+    const int nz1 = g.nz + 1;
+    int* s_list = s_cs + WX * WY * nz1;
+    const int tx0 = (int)(blockIdx.x / tiles_y) * kCtX, ty0 = (int)(blockIdx.x % tiles_y) * kCtY;
+    if (threadIdx.x == 0) s_n = 0;
+    for (int i = threadIdx.x; i < WX * WY * nz1; i += 256) {
+        const int c = i / nz1, z = i - c * nz1;
+        const int x = tx0 - kCtRim + c / WY, y = ty0 - kCtRim + c % WY;
+        // a column outside the grid holds nothing: any constant row will do
+        s_cs[i] = (x >= 0 && x < g.nx && y >= 0 && y < g.ny) ? g.cell_start[(x * g.ny + y) * g.nz + z] : 0;
+    }
+    __syncthreads();
+    const int ncell = kCtX * kCtY * g.nz;
+    for (int i = threadIdx.x; i < ncell; i += 256) {
+        const int col = i / g.nz, iz = i - col * g.nz;
+        const int lx = col / kCtY, ly = col % kCtY;
+        const int ix = tx0 + lx, iy = ty0 + ly;
+        if (ix >= g.nx || iy >= g.ny) continue;
+        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1), zz0 = max(iz - 1, 0), zz1 = min(iz + 1, g.nz - 1);
+        int cnt5 = 0, cnt3 = 0;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx)
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int* row = s_cs + ((lx + kCtRim + dx) * WY + (ly + kCtRim + dy)) * nz1;
+                cnt5 += row[z1 + 1] - row[z0];
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) cnt3 += row[zz1 + 1] - row[zz0];
+            }
+        const int cid = (ix * g.ny + iy) * g.nz + iz;
+        if (cnt5 == 0) { need[cid] = 0; omask[cid] = 0; }
+        else if (cnt3 == 0) { need[cid] = 1; omask[cid] = min(cnt5, 0xffff) << 8; }
+        else s_list[atomicAdd(&s_n, 1)] = (i << 16) | min(cnt5, 0xffff);
+    }
+    __syncthreads();
+    const int nl = s_n;
+    for (int j = threadIdx.x; j < nl; j += 256) {
+        const int e = s_list[j], i = e >> 16, cnt5 = e & 0xffff;
+        const int col = i / g.nz, iz = i - col * g.nz;
+        const int ix = tx0 + col / kCtY, iy = ty0 + col % kCtY;
+        const int m = crow_octant_mask(g, ix, iy, iz, oct_margin);
+        const int cid = (ix * g.ny + iy) * g.nz + iz;
+        need[cid] = 1 + __popc(m);
+        omask[cid] = m | (cnt5 << 8);
+    }
+}
+
+// the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~250 cells)
+__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, float oct_margin, int* __restrict__ need, int* __restrict__ omask)
+{
+    const int cid = blockIdx.x * 256 + threadIdx.x;
+    if (cid >= n_cells) return;
+    const int iz = cid % g.nz, t = cid / g.nz, iy = t % g.ny, ix = t / g.ny;
+    const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1);
+    int any = 0;
+#pragma unroll 1
+    for (int dx = -2; dx <= 2; ++dx) {
+        const int x = ix + dx;
+        if (x < 0 || x >= g.nx) continue;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int y = iy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const int base = (x * g.ny + y) * g.nz;
+            any += g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
+        }
+    }
+    if (!any) { need[cid] = 0; omask[cid] = 0; return; }
+    const int m = crow_octant_mask(g, ix, iy, iz, oct_margin);
     need[cid] = 1 + __popc(m);
-    omask[cid] = m;
+    omask[cid] = m | (min(any, 0xffff) << 8);
 }
 
 // The sorts of the cell-row build work on 32-bit keys: the squared distance's float bits with the low 7 bits replaced by a payload (the
@@ -1020,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, co
         if (n == 0) { if (lane == 0) tab[cid] = -2; continue; }
         const int b = scan[cid];
         if (b + n > cap || b >= (1 << 23)) { if (lane == 0) tab[cid] = -1; continue; }
-        const unsigned mask = (unsigned)omask[cid];
+        const unsigned om = (unsigned)omask[cid], mask = om & 255u;
         if (lane == 0) tab[cid] = (b << 8) | (int)mask;
         const int hz = cid % g.nz, t = cid / g.nz, hy = t % g.ny, hx = t / g.ny;
         const float4 q = make_float4(crow_centre(g.ox, g.cell, hx, 0.5f), crow_centre(g.oy, g.cell, hy, 0.5f), crow_centre(g.oz, g.cell, hz, 0.5f), 0.f);
@@ -1029,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, co
         // a centre row serves queries up to 0.87 cells from the centre wherever they are relative to the surface; one with fewer than five
         // points inside sqrt(tau) is certified by the coverage radius alone, which then has to reach sqrt(tau) + 0.87 cells: where the
         // 5 x 5 x 5 block does not fill the row (2.5 cells of coverage), the 7 x 7 x 7 block is searched (3.5 cells; few candidates there)
-        if (mask != 0u || !use_r3 || block_population<2>(g, hx, hy, hz) >= kGraphK) crow_build_wave<2>(g, q, hx, hy, hz, mask, row, meta, s_off, s_js);
+        if (mask != 0u || !use_r3 || (int)(om >> 8) >= kGraphK) crow_build_wave<2>(g, q, hx, hy, hz, mask, row, meta, s_off, s_js);
         else crow_build_wave<3>(g, q, hx, hy, hz, 0u, row, meta, s_off, s_js);
     }
 }
@@ -1417,7 +1459,16 @@ void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t 
 {
     if (g.n <= 0 || n_cells <= 0) return;
     static const float margin = getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.25f;      // in cells
-    k_crow_classify<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, margin * g.cell, cb.need, cb.omask);
+    const size_t lds = sizeof(int) * ((size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g.nz + 1) + (size_t)kCtX * kCtY * (size_t)g.nz);
+    if (lds <= 96 * 1024) {
+        const int tiles_x = (g.nx + kCtX - 1) / kCtX, tiles_y = (g.ny + kCtY - 1) / kCtY;
+        if (lds > 48 * 1024) {
+            static bool raised = false;                     // (idempotent; the attribute belongs to the kernel, not to a context)
+            if (!raised) { (void)hipFuncSetAttribute((const void*)k_crow_classify, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); raised = true; }
+        }
+        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, margin * g.cell, tiles_y, cb.need, cb.omask);
+    } else
+        k_crow_classify_plain<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, margin * g.cell, cb.need, cb.omask);
     exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
 }
 
