@@ -43,12 +43,6 @@ float env_float(const char* name, float dflt)
     return s ? (float)atof(s) : dflt;
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* s = getenv(name);
-    return s ? atoi(s) : dflt;
-}
-
 void pose_to_matrix_host(const float T[6], float M[12])
 {
     // pcl::getTransformation via trans2Affine3f (src/core/common.cpp:54-57)
@@ -160,6 +154,8 @@ void make_grid(const float bb_in[6], int n, GridIndex* g, int* n_cells, int marg
 }  // namespace lisreg
 namespace {
 
+constexpr int kCrowGridMargin = 2;
+
 int build_target_kind(lisreg_ctx* c, Target& t, int k)
 {
     const int n = t.n[k];
@@ -205,6 +201,16 @@ lisreg::CrowBuffers crow_buffers(Target& t, int k)
 int ensure_crows(lisreg_ctx* c, Target& t, int k)
 {
     if (t.crow_valid[k] && t.g[k].crow_tab) return LISREG_OK;
+    if (t.n[k] > 0 && t.grid_margin[k] < kCrowGridMargin) {
+        // a wall that bounds the cloud has half of a not-yet-registered scan's points OUTSIDE the cloud's bounding box: the grid is
+        // re-made two cells wider on every side (empty cells: four bytes of table each) and the index rebuilt on it, once per target
+        t.grid_margin[k] = kCrowGridMargin;
+        make_grid(t.bbox[k], t.n[k], &t.g[k], &t.n_cells[k], t.grid_margin[k]);
+        int rc = build_target_kind(c, t, k);
+        if (rc) return rc;
+        t.graph_valid[k] = false;
+        t.g[k].nbr = nullptr; t.g[k].nbr_meta = nullptr;
+    }
     const size_t nc = (size_t)std::max(t.n_cells[k], 1);
     HIPCHK(c, t.crow_need[k].ensure(sizeof(int) * (nc + 8)));
     HIPCHK(c, t.crow_omask[k].ensure(sizeof(int) * (nc + 8)));
@@ -482,7 +488,11 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
             if (n > 0 && !std::isfinite(bb[d])) return fail(c, LISREG_ERR_ARG, "set_target: the cloud has infinite coordinates (NaN points are ignored, Inf is not indexable)");
         if (n > 0 && !(bb[0] <= bb[3] && bb[1] <= bb[4] && bb[2] <= bb[5]))
             return fail(c, LISREG_ERR_ARG, "set_target: the cloud has no finite point (every coordinate is NaN)");
-        make_grid(bb, n, &t.g[k], &t.n_cells[k], env_int("LISREG_GRID_MARGIN", 2));
+        // the cell rows (search front-end 5) want a grid that reaches two cells past the cloud; when the front-end is left to the batch
+        // (auto), a target gets that margin only once a batch has chosen the cell rows for it (ensure_crow_margin)
+        memcpy(t.bbox[k], bb, sizeof bb);
+        t.grid_margin[k] = c->search_mode == 5 ? kCrowGridMargin : 0;
+        make_grid(bb, n, &t.g[k], &t.n_cells[k], t.grid_margin[k]);
         prof_mark(c, 2);
         int rc = build_target_kind(c, t, k);
         t.graph_valid[k] = false;
@@ -590,6 +600,13 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         }
         // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
         c->lanes_q = (c->mode_now == 1 && c->lanes_per_query_auto && total_src > 0 && total_src <= 131072) ? 8 : 1;
+        // the cell rows re-make a target's grid with a margin the first time they are chosen for it: before anything below reads the geometry
+        if (c->mode_now == 5)
+            for (int sl : seen)
+                for (int k = 0; k < 2; ++k) {
+                    Target& t = c->targets[(size_t)sl];
+                    if (t.valid && (!t.crow_valid[k] || !t.g[k].crow_tab)) { int rc = ensure_crows(c, t, k); if (rc) return rc; c->grids_dirty = true; }
+                }
     }
     const int qpb = kBlockQ / c->lanes_q;                  // queries per workgroup of the kQ-lane search (h_blocks_q)
     c->h_blocks_q.clear();

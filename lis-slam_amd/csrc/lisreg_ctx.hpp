@@ -42,6 +42,8 @@ struct Target {
     lisreg::DevBuf    nbr[2], nbr_meta[2];                // k-NN graph of the sorted points (search_mode 3)
     bool      graph_valid[2] = { false, false };
     lisreg::DevBuf    crow[2], crow_meta[2], crow_tab[2], crow_need[2], crow_omask[2], crow_scan[2], crow_scan_tmp[2];   // cell rows (search_mode 5)
+    float     bbox[2][6] = { { 0 }, { 0 } };           // the cloud's bounding box (the grid is made from it, with or without a margin)
+    int       grid_margin[2] = { 0, 0 };               // cells the grid reaches past the cloud on every side (the cell rows want two)
     int       crow_cap[2] = { 0, 0 };                  // rows allocated (= rows the classified index asked for when it was last sized)
     bool      crow_valid[2] = { false, false };
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours

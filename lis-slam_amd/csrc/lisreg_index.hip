@@ -738,60 +738,51 @@ __global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __
 
 // ---- cell rows (search_mode 5) -------------------------------------------------------------------------------------------
 // Which cells get rows.  A cell with no target point in the 5 x 5 x 5 block around it gets none (need 0: a query in it has nothing within
-// two cells); every other cell a row at its centre; and each of its eight octants whose box has a point within `oct_margin` its own row
-// behind that (omask bits 0..7: the octants the surface runs through or next to — where the queries are once the pose has settled, at most
-// 0.43 of a half cell from the octant's centre).  need = 1 + the number of such octants; omask >> 8 = the block's population (capped).
-// One workgroup per tile of kCtX x kCtY columns over the whole z-range: the cell_start rows of the tile and its two-column rim are staged
-// in LDS once (two global reads per cell instead of fifty), every thread sums its cells' 5 x 5 columns from there; the cells that have a
-// point in their 3 x 3 x 3 neighbourhood are collected into an LDS list and dealt out evenly for the octant distances (a floor touches two
-// of the 29 cells of a column: without the list a wavefront had three lanes at work).
-constexpr int kCtX = 8, kCtY = 8, kCtRim = 2;
-__device__ __forceinline__ int crow_octant_mask(const GridIndex& g, int ix, int iy, int iz, float oct_margin)
+// two cells); every other cell a row at its centre; and each of its eight octants that has a target point within `oct_margin` of its box
+// (per axis) its own row behind that (omask bits 0..7: the octants the surface runs through or next to — where the queries are once the
+// pose has settled, at most 0.43 of a half cell from the octant's centre).  need = 1 + the number of such octants; omask >> 8 = the
+// population of the cell's 5 x 5 x 5 block (capped).
+// k_crow_mark: one thread per target point ORs the octants it is near into the cells' masks (at most 2 x 2 x 2 octants: the margin is under
+// half an octant's edge) — a point-driven pass costs one or two atomics per point, where a cell-driven pass read every point of a 3 x 3 x 3
+// block per cell (7 ms of vector work per million cells).
+__global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin, int* __restrict__ omask)
 {
-    const float h = 0.5f * g.cell;
-    const float lx = g.ox + (float)ix * g.cell, ly = g.oy + (float)iy * g.cell, lz = g.oz + (float)iz * g.cell;
-    const int zz0 = max(iz - 1, 0), zz1 = min(iz + 1, g.nz - 1);
-    float best[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const float4 p = g.pts[i];
+    if (!(p.x == p.x && p.y == p.y && p.z == p.z)) return;
+    const float inv_h = 2.f * g.inv_cell;
+    // octant coordinates (half cells) of p -/+ the margin, clamped to the grid
+    const int ax0 = min(max((int)floorf((p.x - oct_margin - g.ox) * inv_h), 0), 2 * g.nx - 1), ax1 = min(max((int)floorf((p.x + oct_margin - g.ox) * inv_h), 0), 2 * g.nx - 1);
+    const int ay0 = min(max((int)floorf((p.y - oct_margin - g.oy) * inv_h), 0), 2 * g.ny - 1), ay1 = min(max((int)floorf((p.y + oct_margin - g.oy) * inv_h), 0), 2 * g.ny - 1);
+    const int az0 = min(max((int)floorf((p.z - oct_margin - g.oz) * inv_h), 0), 2 * g.nz - 1), az1 = min(max((int)floorf((p.z + oct_margin - g.oz) * inv_h), 0), 2 * g.nz - 1);
+#pragma unroll 1
+    for (int cx = ax0 >> 1; cx <= ax1 >> 1; ++cx) {
+        const int bx = (ax0 <= 2 * cx && 2 * cx <= ax1 ? 1 : 0) | (ax0 <= 2 * cx + 1 && 2 * cx + 1 <= ax1 ? 2 : 0);        // lower / upper half in range
+#pragma unroll 1
+        for (int cy = ay0 >> 1; cy <= ay1 >> 1; ++cy) {
+            const int by = (ay0 <= 2 * cy && 2 * cy <= ay1 ? 1 : 0) | (ay0 <= 2 * cy + 1 && 2 * cy + 1 <= ay1 ? 2 : 0);
+#pragma unroll 1
+            for (int cz = az0 >> 1; cz <= az1 >> 1; ++cz) {
+                const int bz = (az0 <= 2 * cz && 2 * cz <= az1 ? 1 : 0) | (az0 <= 2 * cz + 1 && 2 * cz + 1 <= az1 ? 2 : 0);
+                int m = 0;
 #pragma unroll
-    for (int o = 0; o < 8; ++o) best[o] = 3.0e38f;
-#pragma unroll 1
-    for (int dx = -1; dx <= 1; ++dx) {
-        const int x = ix + dx;
-        if (x < 0 || x >= g.nx) continue;
-#pragma unroll 1
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int y = iy + dy;
-            if (y < 0 || y >= g.ny) continue;
-            const int base = (x * g.ny + y) * g.nz;
-            const int js = g.cell_start[base + zz0], je = g.cell_start[base + zz1 + 1];
-#pragma unroll 1
-            for (int j = js; j < je; ++j) {
-                const float4 p = g.pts[j];
-                // squared distance of p from the lower / upper half of the cell, per axis
-                const float x0 = fmaxf(fmaxf(lx - p.x, p.x - (lx + h)), 0.f), x1 = fmaxf(fmaxf(lx + h - p.x, p.x - (lx + g.cell)), 0.f);
-                const float y0 = fmaxf(fmaxf(ly - p.y, p.y - (ly + h)), 0.f), y1 = fmaxf(fmaxf(ly + h - p.y, p.y - (ly + g.cell)), 0.f);
-                const float w0 = fmaxf(fmaxf(lz - p.z, p.z - (lz + h)), 0.f), w1 = fmaxf(fmaxf(lz + h - p.z, p.z - (lz + g.cell)), 0.f);
-                const float xx[2] = { x0 * x0, x1 * x1 }, yy[2] = { y0 * y0, y1 * y1 }, zz[2] = { w0 * w0, w1 * w1 };
-#pragma unroll
-                for (int o = 0; o < 8; ++o) best[o] = fminf(best[o], xx[o & 1] + yy[(o >> 1) & 1] + zz[(o >> 2) & 1]);
+                for (int o = 0; o < 8; ++o) if (((bx >> (o & 1)) & 1) && ((by >> ((o >> 1) & 1)) & 1) && ((bz >> ((o >> 2) & 1)) & 1)) m |= 1 << o;
+                atomicOr(&omask[(cx * g.ny + cy) * g.nz + cz], m);
             }
         }
     }
-    int m = 0;
-#pragma unroll
-    for (int o = 0; o < 8; ++o) if (best[o] <= oct_margin * oct_margin) m |= 1 << o;
-    return m;
 }
 
-__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, float oct_margin, int tiles_y, int* __restrict__ need, int* __restrict__ omask)
+// k_crow_classify: one workgroup per tile of kCtX x kCtY columns over the whole z-range: the cell_start rows of the tile and its
+// two-column rim are staged in LDS once (two global reads per cell instead of fifty), every thread sums its cells' 5 x 5 columns from there.
+constexpr int kCtX = 8, kCtY = 8, kCtRim = 2;
+__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask)
 {
-    extern __shared__ int s_cs[];                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows, then the list
-    __shared__ int s_n;
+    extern __shared__ int s_cs[];                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows
     constexpr int WX = kCtX + 2 * kCtRim, WY = kCtY + 2 * kCtRim;
     const int nz1 = g.nz + 1;
-    int* s_list = s_cs + WX * WY * nz1;
     const int tx0 = (int)(blockIdx.x / tiles_y) * kCtX, ty0 = (int)(blockIdx.x % tiles_y) * kCtY;
-    if (threadIdx.x == 0) s_n = 0;
     for (int i = threadIdx.x; i < WX * WY * nz1; i += 256) {
         const int c = i / nz1, z = i - c * nz1;
         const int x = tx0 - kCtRim + c / WY, y = ty0 - kCtRim + c % WY;
@@ -805,42 +796,30 @@ __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, float oct_ma
         const int lx = col / kCtY, ly = col % kCtY;
         const int ix = tx0 + lx, iy = ty0 + ly;
         if (ix >= g.nx || iy >= g.ny) continue;
-        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1), zz0 = max(iz - 1, 0), zz1 = min(iz + 1, g.nz - 1);
-        int cnt5 = 0, cnt3 = 0;
+        const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1);
+        int cnt5 = 0;
 #pragma unroll
         for (int dx = -2; dx <= 2; ++dx)
 #pragma unroll
             for (int dy = -2; dy <= 2; ++dy) {
                 const int* row = s_cs + ((lx + kCtRim + dx) * WY + (ly + kCtRim + dy)) * nz1;
                 cnt5 += row[z1 + 1] - row[z0];
-                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) cnt3 += row[zz1 + 1] - row[zz0];
             }
         const int cid = (ix * g.ny + iy) * g.nz + iz;
-        if (cnt5 == 0) { need[cid] = 0; omask[cid] = 0; }
-        else if (cnt3 == 0) { need[cid] = 1; omask[cid] = min(cnt5, 0xffff) << 8; }
-        else s_list[atomicAdd(&s_n, 1)] = (i << 16) | min(cnt5, 0xffff);
-    }
-    __syncthreads();
-    const int nl = s_n;
-    for (int j = threadIdx.x; j < nl; j += 256) {
-        const int e = s_list[j], i = e >> 16, cnt5 = e & 0xffff;
-        const int col = i / g.nz, iz = i - col * g.nz;
-        const int ix = tx0 + col / kCtY, iy = ty0 + col % kCtY;
-        const int m = crow_octant_mask(g, ix, iy, iz, oct_margin);
-        const int cid = (ix * g.ny + iy) * g.nz + iz;
-        need[cid] = 1 + __popc(m);
-        omask[cid] = m | (cnt5 << 8);
+        const int m = omask[cid] & 255;
+        need[cid] = cnt5 ? 1 + __popc(m) : 0;
+        omask[cid] = cnt5 ? (m | (min(cnt5, 0xffff) << 8)) : 0;
     }
 }
 
-// the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~250 cells)
-__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, float oct_margin, int* __restrict__ need, int* __restrict__ omask)
+// the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~120 cells)
+__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, int* __restrict__ need, int* __restrict__ omask)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;
     if (cid >= n_cells) return;
     const int iz = cid % g.nz, t = cid / g.nz, iy = t % g.ny, ix = t / g.ny;
     const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1);
-    int any = 0;
+    int cnt5 = 0;
 #pragma unroll 1
     for (int dx = -2; dx <= 2; ++dx) {
         const int x = ix + dx;
@@ -850,13 +829,12 @@ __global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_
             const int y = iy + dy;
             if (y < 0 || y >= g.ny) continue;
             const int base = (x * g.ny + y) * g.nz;
-            any += g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
+            cnt5 += g.cell_start[base + z1 + 1] - g.cell_start[base + z0];
         }
     }
-    if (!any) { need[cid] = 0; omask[cid] = 0; return; }
-    const int m = crow_octant_mask(g, ix, iy, iz, oct_margin);
-    need[cid] = 1 + __popc(m);
-    omask[cid] = m | (min(any, 0xffff) << 8);
+    const int m = omask[cid] & 255;
+    need[cid] = cnt5 ? 1 + __popc(m) : 0;
+    omask[cid] = cnt5 ? (m | (min(cnt5, 0xffff) << 8)) : 0;
 }
 
 // The sorts of the cell-row build work on 32-bit keys: the squared distance's float bits with the low 7 bits replaced by a payload (the
@@ -1458,17 +1436,16 @@ void launch_build_graph_one(GridIndex g, hipStream_t st)
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
 {
     if (g.n <= 0 || n_cells <= 0) return;
-    static const float margin = getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.25f;      // in cells
-    const size_t lds = sizeof(int) * ((size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g.nz + 1) + (size_t)kCtX * kCtY * (size_t)g.nz);
-    if (lds <= 96 * 1024) {
+    // octant margin in cells: under a quarter cell (half an octant's edge), so that a point is near at most two octants per axis
+    static const float margin = std::min(0.249f, std::max(0.f, getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.249f));
+    (void)hipMemsetAsync(cb.omask, 0, sizeof(int) * (size_t)n_cells, st);
+    k_crow_mark<<<(g.n + 255) / 256, 256, 0, st>>>(g, margin * g.cell, cb.omask);
+    const size_t lds = sizeof(int) * (size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g.nz + 1);
+    if (lds <= 64 * 1024) {
         const int tiles_x = (g.nx + kCtX - 1) / kCtX, tiles_y = (g.ny + kCtY - 1) / kCtY;
-        if (lds > 48 * 1024) {
-            static bool raised = false;                     // (idempotent; the attribute belongs to the kernel, not to a context)
-            if (!raised) { (void)hipFuncSetAttribute((const void*)k_crow_classify, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); raised = true; }
-        }
-        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, margin * g.cell, tiles_y, cb.need, cb.omask);
+        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, tiles_y, cb.need, cb.omask);
     } else
-        k_crow_classify_plain<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, margin * g.cell, cb.need, cb.omask);
+        k_crow_classify_plain<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, cb.need, cb.omask);
     exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
 }
 

@@ -536,9 +536,10 @@ class Context:
     def target_cell_rows(self, slot: int = 0, kind: int = 1) -> dict:
         """Diagnostics: the cell rows of a target (see lisreg_get_target_cell_rows): table [n_cells], ids [rows, k] (sorted positions,
         -1 padded), xyz [rows, k, 3], rho2 [rows], count [rows]."""
-        nc = self.target_index(slot, kind)["n_cells"]
         n_rows, k = C.c_int(), C.c_int()
+        # (the first call builds the rows if need be — which re-makes the target's grid with its two-cell margin: read the geometry after it)
         self._chk(self._L.lisreg_get_target_cell_rows(self._h, slot, kind, C.byref(n_rows), C.byref(k), None, 0, None, None, 0))
+        nc = self.target_index(slot, kind)["n_cells"]
         table = np.zeros(max(nc, 1), np.int32)
         rows = np.zeros((max(n_rows.value, 1), k.value, 4), np.float32); meta = np.zeros((max(n_rows.value, 1), 2), np.float32)
         self._chk(self._L.lisreg_get_target_cell_rows(self._h, slot, kind, C.byref(n_rows), C.byref(k), table.ctypes.data_as(C.POINTER(C.c_int)), nc,

@@ -157,7 +157,7 @@ def test_cell_rows_cover_their_radius(gpu_ctx, m_points, kind):
     from lisreg import synth
     tc, ts = synth.make_submap(m_points, 78)
     gpu_ctx.set_target(tc, ts)
-    idx = gpu_ctx.target_index(0, kind); g = gpu_ctx.target_cell_rows(0, kind)
+    g = gpu_ctx.target_cell_rows(0, kind); idx = gpu_ctx.target_index(0, kind)      # (building the rows gives the grid its two-cell margin)
     n, k, R = idx["n"], g["k"], g["n_rows"]
     nx, ny, nz, cell, org = idx["nx"], idx["ny"], idx["nz"], np.float32(idx["cell"]), idx["origin"].astype(np.float32)
     pts32 = idx["sorted"][:, :3]; pts = pts32.astype(np.float64)
