@@ -225,6 +225,8 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     t.crow_cap[k] = std::max(rows, 1);
+    if (const char* e = getenv("LISREG_CROW_CAP_PERCENT"))      // tests: under-size the row buffers (cells past the capacity get no row: their queries walk)
+        t.crow_cap[k] = std::max(1, (int)((long long)t.crow_cap[k] * std::max(0, atoi(e)) / 100));
     if (getenv("LISREG_CROW_DEBUG")) fprintf(stderr, "[lisreg] cell rows of kind %d: %d rows for %d points in %d cells (%d x %d x %d of %.3f m)\n", k, rows, t.n[k], t.n_cells[k], t.g[k].nx, t.g[k].ny, t.g[k].nz, t.g[k].cell);
     HIPCHK(c, t.crow[k].ensure(sizeof(float4) * kGraphK * (size_t)t.crow_cap[k]));
     HIPCHK(c, t.crow_meta[k].ensure(sizeof(float2) * (size_t)t.crow_cap[k]));

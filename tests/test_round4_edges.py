@@ -130,3 +130,48 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr
     assert "LISREG_SEARCH_MODE=2 ignored" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cell_rows_that_do_not_fit_their_buffers_fall_back_to_the_walk():
+    """search_mode 5 sizes its row buffers from the first classification of a target; a later rebuild inside a run (rebuild_targets_each_run)
+    whose cloud asks for more rows gives the cells past the capacity no row (table entry -1) and their queries take the cell walk.  Forced
+    here by under-sizing the buffers (LISREG_CROW_CAP_PERCENT=40): same neighbours, same bits as the cell walk; and an empty / a tiny target."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+import numpy as np
+sys.path.insert(0, {os.path.join(root, 'lis-slam_amd')!r})
+import lisreg
+from lisreg import synth
+case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=4600, trans=0.4, rot_deg=2.5)
+p = lisreg.default_params(1)
+out = {{}}
+for mode in (1, 5):
+    ctx = lisreg.Context(0)
+    ctx.set_option("search_mode", mode); ctx.set_option("canonical_ties", 1)
+    ctx.set_target(case["tgt_corner"], case["tgt_surf"])
+    out[mode] = ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+    if mode == 5:
+        g = ctx.target_cell_rows(0, 1)
+        assert (g["table"] == -1).sum() > 1000 and (g["table"] >= 0).sum() > 1000, ((g["table"] == -1).sum(), (g["table"] >= 0).sum())
+        # a target of four points (fewer than five: no correspondences at all) and an empty corner cloud
+        ctx.set_target(case["tgt_corner"][:0], case["tgt_surf"][:4])
+        T, st, _ = ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        assert st["status"] != 0 and np.array_equal(T, case["T_init"])
+        # forty points: rows exist, almost every query finds fewer than five neighbours inside tau
+        ctx.set_target(case["tgt_corner"][:5], case["tgt_surf"][:40])
+        T5, st5, tr5 = ctx.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        c1 = lisreg.Context(0); c1.set_option("search_mode", 1); c1.set_option("canonical_ties", 1)
+        c1.set_target(case["tgt_corner"][:5], case["tgt_surf"][:40])
+        T1, st1, tr1 = c1.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        assert st1 == st5 and np.array_equal(T1, T5) and np.array_equal(tr1, tr5)
+        c1.close()
+    ctx.close()
+(T1, s1, tr1), (T5, s5, tr5) = out[1], out[5]
+assert s1 == s5 and s1["status"] == 0 and np.array_equal(T1, T5) and np.array_equal(tr1, tr5)
+print("OK")
+"""
+    env = dict(os.environ, LISREG_CROW_CAP_PERCENT="40")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
