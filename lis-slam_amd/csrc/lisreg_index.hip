@@ -1021,10 +1021,11 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
     }
 }
 
-// One wave per cell (kCrowCPW of them in a row): the table entry and the cell's rows.
+// One wave per kCrowCPW consecutive cells: their table entries written lane-parallel (most cells of a grid have no row: one coalesced
+// load and store for all of them), then the cells that have rows one after the other, the whole wave on each.
 // crow_tab[cell] = -2: nothing within two cells; -1: no row (its rows did not fit the capacity the buffers were sized for); else
 // (first row << 8) | octant mask, rows = [centre, the octants of the mask in ascending order].
-constexpr int kCrowCPW = 2;
+constexpr int kCrowCPW = 8;
 __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
                                                     const int* __restrict__ scan, int cap, int use_r3)
 {
@@ -1032,16 +1033,22 @@ __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, co
     const int lane = threadIdx.x & 63;
     const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kCrowCPW);
     int* tab = const_cast<int*>(g.crow_tab);
+    int n_l = 0, b_l = 0, om_l = 0;
+    if (lane < kCrowCPW && first + lane < n_cells) {
+        n_l = need[first + lane];
+        if (n_l) { b_l = scan[first + lane]; om_l = omask[first + lane]; }
+        const bool fits = n_l != 0 && !(b_l + n_l > cap || b_l >= (1 << 23));
+        tab[first + lane] = n_l == 0 ? -2 : (fits ? (b_l << 8) | (om_l & 255) : -1);
+        if (!fits) n_l = 0;
+    }
+    unsigned long long live = __ballot(n_l != 0);
 #pragma unroll 1
-    for (int i = 0; i < kCrowCPW; ++i) {
+    while (live) {
+        const int i = __ffsll((long long)live) - 1;
+        live &= live - 1;
         const int cid = first + i;
-        if (cid >= n_cells) break;
-        const int n = need[cid];
-        if (n == 0) { if (lane == 0) tab[cid] = -2; continue; }
-        const int b = scan[cid];
-        if (b + n > cap || b >= (1 << 23)) { if (lane == 0) tab[cid] = -1; continue; }
-        const unsigned om = (unsigned)omask[cid], mask = om & 255u;
-        if (lane == 0) tab[cid] = (b << 8) | (int)mask;
+        const int b = __shfl(b_l, i);
+        const unsigned om = (unsigned)__shfl(om_l, i), mask = om & 255u;
         const int hz = cid % g.nz, t = cid / g.nz, hy = t % g.ny, hx = t / g.ny;
         const float4 q = make_float4(crow_centre(g.ox, g.cell, hx, 0.5f), crow_centre(g.oy, g.cell, hy, 0.5f), crow_centre(g.oz, g.cell, hz, 0.5f), 0.f);
         float4* row = const_cast<float4*>(g.crow) + (size_t)b * kGraphK;
