@@ -198,9 +198,13 @@ lisreg::CrowBuffers crow_buffers(Target& t, int k)
     return cb;
 }
 
-int ensure_crows(lisreg_ctx* c, Target& t, int k)
+// may_decline (front-end chosen by auto): a target whose rows would not fit "cell_rows_max_mb" is left without them (crow_too_big) and the
+// batch takes another front-end; with search_mode 5 set by the caller the buffers are capped there instead and the cells past them walk.
+int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false)
 {
     if (t.crow_valid[k] && t.g[k].crow_tab) return LISREG_OK;
+    if (may_decline && t.crow_too_big[k]) return LISREG_OK;       // found too big before (the note is cleared when the target is set again)
+    t.crow_too_big[k] = false;
     if (t.n[k] > 0 && t.grid_margin[k] < kCrowGridMargin) {
         // a wall that bounds the cloud has half of a not-yet-registered scan's points OUTSIDE the cloud's bounding box: the grid is
         // re-made two cells wider on every side (empty cells: four bytes of table each) and the index rebuilt on it, once per target
@@ -225,6 +229,14 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     t.crow_cap[k] = std::max(rows, 1);
+    {
+        // (a cloud scattered through space instead of lying on surfaces — vegetation, rain — asks for up to 125 centre rows per point)
+        const long long budget = (long long)std::max(c->cell_rows_max_mb, 1) * 1048576LL / (long long)(sizeof(float4) * kGraphK + sizeof(float2));
+        if ((long long)rows > budget) {
+            if (may_decline) { t.crow_too_big[k] = true; t.g[k].crow_tab = nullptr; return LISREG_OK; }
+            t.crow_cap[k] = (int)std::max(1LL, budget);
+        }
+    }
     if (const char* e = getenv("LISREG_CROW_CAP_PERCENT"))      // tests: under-size the row buffers (cells past the capacity get no row: their queries walk)
         t.crow_cap[k] = std::max(1, (int)((long long)t.crow_cap[k] * std::max(0, atoi(e)) / 100));
     if (getenv("LISREG_CROW_DEBUG")) fprintf(stderr, "[lisreg] cell rows of kind %d: %d rows for %d points in %d cells (%d x %d x %d of %.3f m)\n", k, rows, t.n[k], t.n_cells[k], t.g[k].nx, t.g[k].ny, t.g[k].nz, t.g[k].cell);
@@ -498,7 +510,7 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
         prof_mark(c, 2);
         int rc = build_target_kind(c, t, k);
         t.graph_valid[k] = false;
-        t.crow_valid[k] = false;
+        t.crow_valid[k] = false; t.crow_too_big[k] = false;
         t.g[k].crow = nullptr; t.g[k].crow_meta = nullptr; t.g[k].crow_tab = nullptr;
         if (!rc && c->search_mode == 3) rc = ensure_graph(c, t, k, true);
         if (!rc && c->search_mode == 5) rc = ensure_crows(c, t, k);
@@ -603,12 +615,20 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
         c->lanes_q = (c->mode_now == 1 && c->lanes_per_query_auto && total_src > 0 && total_src <= 131072) ? 8 : 1;
         // the cell rows re-make a target's grid with a margin the first time they are chosen for it: before anything below reads the geometry
-        if (c->mode_now == 5)
+        if (c->mode_now == 5) {
+            bool declined = false;
             for (int sl : seen)
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 2 && !declined; ++k) {
                     Target& t = c->targets[(size_t)sl];
-                    if (t.valid && (!t.crow_valid[k] || !t.g[k].crow_tab)) { int rc = ensure_crows(c, t, k); if (rc) return rc; c->grids_dirty = true; }
+                    if (t.valid && (!t.crow_valid[k] || !t.g[k].crow_tab)) {
+                        int rc = ensure_crows(c, t, k, c->search_mode == 4);
+                        if (rc) return rc;
+                        c->grids_dirty = true;
+                        declined = c->search_mode == 4 && t.crow_too_big[k];
+                    }
                 }
+            if (declined) c->mode_now = 3;                     // (auto only) the rows of a target would not fit "cell_rows_max_mb": the graph scan
+        }
     }
     const int qpb = kBlockQ / c->lanes_q;                  // queries per workgroup of the kQ-lane search (h_blocks_q)
     c->h_blocks_q.clear();

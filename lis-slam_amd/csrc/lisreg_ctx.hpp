@@ -46,6 +46,7 @@ struct Target {
     int       grid_margin[2] = { 0, 0 };               // cells the grid reaches past the cloud on every side (the cell rows want two)
     int       crow_cap[2] = { 0, 0 };                  // rows allocated (= rows the classified index asked for when it was last sized)
     bool      crow_valid[2] = { false, false };
+    bool      crow_too_big[2] = { false, false };      // the rows this target asks for exceed "cell_rows_max_mb" (auto: the batch takes the graph instead)
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
     const float4* raw_ptr[2] = { nullptr, nullptr };
     unsigned long long gen = 0;                        // bumped by every set_target of this slot (who built what is in here?)

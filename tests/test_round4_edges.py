@@ -175,3 +175,32 @@ print("OK")
     env = dict(os.environ, LISREG_CROW_CAP_PERCENT="40")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_auto_declines_cell_rows_that_exceed_their_memory_bound(gpu_ctx):
+    """search_mode auto picks the cell rows from 120 query-iterations per target point on — unless the rows a target asks for exceed
+    "cell_rows_max_mb" (a cloud scattered through space instead of lying on surfaces asks for up to 125 centre rows per point): then the
+    batch takes the graph scan, with the same result.  With search_mode 5 set by the caller the buffers are capped instead (the cells past
+    them walk): same result again."""
+    import lisreg
+    from lisreg import synth
+    tc, ts = synth.make_submap(20000, 42)
+    scans = [synth.make_scan(32, 900, 1000 + i) for i in range(10)]       # 10 x 27 k points x 10 iterations / 20 k target points = 135
+    cases = [dict(src_corner=s["corner"], src_surf=s["surf"]) for s in scans]
+    T0 = np.array([synth.perturb_pose(s["T_true"], np.random.default_rng(9 + i)) for i, s in enumerate(scans)], np.float32)
+    p = lisreg.default_params(1); p.fixed_iters = 10
+    out = {}
+    for name, mode, mb in (("auto", 4, 16384), ("auto_small", 4, 8), ("forced_small", 5, 8), ("walk", 1, 16384)):
+        c = lisreg.Context(0)
+        c.set_option("search_mode", mode); c.set_option("cell_rows_max_mb", mb); c.set_option("canonical_ties", 1); c.set_option("lanes_per_query", 1)
+        c.set_target(tc, ts)
+        out[name] = c.align_batch(cases, T0, p)
+        fe = c.front_end()
+        assert fe == {"auto": 5, "auto_small": 3, "forced_small": 5, "walk": 1}[name], (name, fe)
+        if name == "forced_small":
+            g = c.target_cell_rows(0, 1)
+            assert g["n_rows"] <= 8 * 1048576 // 1032 and (g["table"] == -1).any()
+        c.close()
+    for name in ("auto_small", "forced_small", "walk"):
+        assert np.array_equal(out["auto"][0], out[name][0]) and out["auto"][1] == out[name][1], name
