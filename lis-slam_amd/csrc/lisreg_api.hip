@@ -873,14 +873,29 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         if (c->mode_now == 3)
             launch_build_graph(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
                                c->grids_dev.as<GridIndex>(), st);
-        if (c->mode_now == 5)
-            for (int slot : c->batch_slots)
-                for (int k = 0; k < 2; ++k) {
+        if (c->mode_now == 5) {
+            // the rows of the corner targets (a few ten thousand rows: launches that leave most of the chip idle) are built on the side stream,
+            // underneath the surf targets' — separate buffers per target kind, joined before the first correspondence launch
+            if (!c->side_stream) {
+                if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+                if (c->side_stream && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                                       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+                    (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr;
+                }
+            }
+            const bool fork = c->side_stream && hipEventRecord(c->ev_fork, st) == hipSuccess &&
+                              hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) == hipSuccess;
+            for (int k = 0; k < 2; ++k) {
+                hipStream_t sk = (k == 0 && fork) ? c->side_stream : st;
+                for (int slot : c->batch_slots) {
                     Target& t = c->targets[(size_t)slot];
                     if (t.n[k] <= 0) continue;
-                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), st);
-                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), st);
+                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), sk);
+                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), sk);
                 }
+            }
+            if (fork) { (void)hipEventRecord(c->ev_join, c->side_stream); (void)hipStreamWaitEvent(st, c->ev_join, 0); }
+        }
         prof_mark(c, -1);
     }
     launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
