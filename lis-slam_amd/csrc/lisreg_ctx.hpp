@@ -180,6 +180,7 @@ struct lisreg_ctx {
     bool      exact = false;             // "exact_arithmetic": the correspondence launches and the pose cache run the reference's arithmetic (lisreg_assoc.hip)
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
     bool      sort_now = false;          // decision for the prepared batch
+    int       probe_items = -1, probe_elems = -1, probe_age = 0; bool probe_verdict = false;   // the batch shape the order was last probed on (auto): batches of a stream are alike
     float     first_pass_r = 0.45f;
     int       last_launches = 0;         // Gauss-Newton iterations the last fetched batch ran (its slowest item): where run_impl looks first
     int       wide_from = 0;
