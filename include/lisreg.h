@@ -209,7 +209,7 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * falls into instead of to last iteration's nearest neighbour, so nothing is carried between Gauss-Newton iterations and the first
  * iterations of a batch — queries a pose error away from every surface — cost the same scan as the last ones; ~3-5 KB of device memory
  * per target point, built in ~3 ns per target point —, 4 auto [default]: 5 when the prepared batch asks at least "cell_min_ratio"
- * [default 120] query-iterations per target point and its targets' rows fit "cell_rows_max_mb" [default 16384], else 3 from
+ * [default 170] query-iterations per target point and its targets' rows fit "cell_rows_max_mb" [default 16384], else 3 from
  * "graph_min_ratio" [default 60] query-iterations per target point on, else 1 — all return the same neighbours; the one exception is two candidates at exactly equal float distance from a query
  * competing for the fifth place: the first one met wins, and the front-ends meet them in different orders),
  * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),

@@ -165,8 +165,8 @@ struct lisreg_ctx {
     int       mode_now = 1;              // front-end of the prepared batch
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
     bool      lanes_per_query_auto = true;
-    int       cell_min_ratio = 120;      // auto: query-iterations per target point from which the cell rows pay (they cost ~3x the graph to build and
-                                         // halve the first iterations of a batch; measured break-even ~100)
+    int       cell_min_ratio = 170;      // auto: query-iterations per target point from which the cell rows pay (they cost ~3x the graph to build and
+                                         // halve the first iterations of a batch; measured break-even ~170: 24 scans against 200 k points lose 4 %, 32 win 2 %)
     int       cell_rows_max_mb = 16384;  // auto: cell rows only while the targets' rows are expected to fit this (about 5 KB per target point)
     int       graph_min_ratio = 60;      // auto: query-iterations per target point from which the graph build pays (measured break-even ~55)
     int       xcd_order = 2;             // XCD-aware dispatch order of the correspondence launches: 0 off, 1 on (graph front-end), 2 auto (graph front-end, >= 32 registrations, >= 2048 blocks)

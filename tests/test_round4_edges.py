@@ -179,14 +179,14 @@ print("OK")
 
 @pytest.mark.gpu
 def test_auto_declines_cell_rows_that_exceed_their_memory_bound(gpu_ctx):
-    """search_mode auto picks the cell rows from 120 query-iterations per target point on — unless the rows a target asks for exceed
+    """search_mode auto picks the cell rows from 170 query-iterations per target point on — unless the rows a target asks for exceed
     "cell_rows_max_mb" (a cloud scattered through space instead of lying on surfaces asks for up to 125 centre rows per point): then the
     batch takes the graph scan, with the same result.  With search_mode 5 set by the caller the buffers are capped instead (the cells past
     them walk): same result again."""
     import lisreg
     from lisreg import synth
     tc, ts = synth.make_submap(20000, 42)
-    scans = [synth.make_scan(32, 900, 1000 + i) for i in range(10)]       # 10 x 27 k points x 10 iterations / 20 k target points = 135
+    scans = [synth.make_scan(32, 900, 1000 + i) for i in range(14)]       # 14 x 27 k points x 10 iterations / 20 k target points = 190
     cases = [dict(src_corner=s["corner"], src_surf=s["surf"]) for s in scans]
     T0 = np.array([synth.perturb_pose(s["T_true"], np.random.default_rng(9 + i)) for i, s in enumerate(scans)], np.float32)
     p = lisreg.default_params(1); p.fixed_iters = 10
