@@ -212,7 +212,9 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * [default 170] query-iterations per target point and its targets' rows fit "cell_rows_max_mb" [default 16384], else 3 from
  * "graph_min_ratio" [default 60] query-iterations per target point on, else 1 — all return the same neighbours; the one exception is two candidates at exactly equal float distance from a query
  * competing for the fifth place: the first one met wins, and the front-ends meet them in different orders),
- * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared),
+ * "sort_sources" (0 caller order, 1 column sort, 2 auto [default]: probe the order when a batch is prepared — one pass over the sources
+ * and a 4-byte read-back, skipped for batches of the same shape (items, points) as the one last probed, whose verdict is reused; every 32nd
+ * such batch is probed again; the verdict decides speed only, the search is exact on any order),
  * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
  * point, 1 strip form — LDS histograms, one workgroup per strip of cells; an error if a grid does not fit its LDS tables —,
  * 2 [default] strip form whenever the grids fit; both produce the same index bit for bit), "index_strip_cells", "index_strip_cap",
