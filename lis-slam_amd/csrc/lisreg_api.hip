@@ -260,9 +260,27 @@ int upload_grids(lisreg_ctx* c)
             else memset(&h[s * 2 + k], 0, sizeof(GridIndex));
         }
     HIPCHK(c, c->grids_dev.ensure(sizeof(GridIndex) * std::max<size_t>(h.size(), 1)));
-    if (!h.empty())
-        HIPCHK(c, hipMemcpyAsync(c->grids_dev.p, h.data(), sizeof(GridIndex) * h.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));     // h is a local
+    const size_t bytes = sizeof(GridIndex) * h.size();
+    // through a pinned buffer of the context, guarded by an event: the copy is asynchronous and the host goes on building the batch's
+    // tables while the stream still works on the target index it has just been given (a frame loop sets a target per frame: waiting
+    // here meant an idle device for the rest of lisreg_batch_prepare)
+    if (bytes > c->grids_host_cap) {
+        if (c->grids_done) (void)hipEventSynchronize(c->grids_done);
+        if (c->grids_host) (void)hipHostFree(c->grids_host);
+        c->grids_host = nullptr; c->grids_host_cap = 0;
+        if (hipHostMalloc((void**)&c->grids_host, 2 * bytes + 1024, hipHostMallocDefault) == hipSuccess) c->grids_host_cap = 2 * bytes + 1024;
+        else { (void)hipGetLastError(); c->grids_host = nullptr; }
+    }
+    if (!c->grids_done && hipEventCreateWithFlags(&c->grids_done, hipEventDisableTiming) != hipSuccess) c->grids_done = nullptr;
+    if (bytes && c->grids_host && c->grids_done) {
+        HIPCHK(c, hipEventSynchronize(c->grids_done));          // (recorded by the previous upload: long past)
+        memcpy(c->grids_host, h.data(), bytes);
+        HIPCHK(c, hipMemcpyAsync(c->grids_dev.p, c->grids_host, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->grids_done, c->stream));
+    } else if (bytes) {
+        HIPCHK(c, hipMemcpyAsync(c->grids_dev.p, h.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // h is a local
+    }
     c->grids_dirty = false;
     return LISREG_OK;
 }
@@ -379,6 +397,8 @@ void lisreg_destroy(lisreg_ctx* c)
     if (c->fetch_host) (void)hipHostFree(c->fetch_host);
     if (c->stage_done) (void)hipEventDestroy(c->stage_done);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->grids_done) { (void)hipEventSynchronize(c->grids_done); (void)hipEventDestroy(c->grids_done); }
+    if (c->grids_host) (void)hipHostFree(c->grids_host);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

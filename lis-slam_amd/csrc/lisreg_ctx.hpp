@@ -109,6 +109,9 @@ struct lisreg_ctx {
     unsigned long long   target_gen = 0;
     lisreg::DevBuf       grids_dev;
     bool         grids_dirty = true;
+    unsigned char* grids_host = nullptr;    // pinned staging of the GridIndex table (upload_grids does not wait for the stream)
+    size_t       grids_host_cap = 0;
+    hipEvent_t   grids_done = nullptr;      // the last upload has left the staging buffer
     // sort scratch (shared by target build and source sort; stream-ordered so reuse is safe)
     lisreg::DevBuf hist, bucket_start, scan_tmp, elem_bucket, elem_sub, tmp_bucket, tmp_sub, tmp_idx, tmp_pts, bbox_dev, bbox_scratch;
     // batch
