@@ -21,7 +21,7 @@ for k in range(n):
             if len(arr): arr[f][rng.integers(0, len(arr), m)] = rng.choice([np.nan, np.inf, -np.inf], m)
     T0 = case["T_init"].copy()
     if k % 10 == 9: T0[int(rng.integers(0, 6))] = np.nan                      # a non-finite pose guess
-    for mode, lanes in ((1, 8), (1, 1), (3, 1)):
+    for mode, lanes in ((1, 8), (1, 1), (3, 1), (5, 1)):
         ctx.set_option("search_mode", mode); ctx.set_option("lanes_per_query", lanes)
         ctx.set_target(case["tgt_corner"], tgt)
         p = lisreg.default_params(1)
@@ -31,5 +31,5 @@ for k in range(n):
         finite = bool(np.all(np.isfinite(T))) or k % 10 == 9
         if not finite or dt > 2.0:
             bad.append((k, mode, lanes)); print(f"case {k} mode {mode} lanes {lanes}: finite {finite}, {dt:.2f} s, status {st['status']}")
-print(f"== {n} cases x 3 front-ends: {3 * n - len(bad)} finished with a finite pose (a NaN guess excepted: it stays NaN, status reported); offenders: {bad}")
+print(f"== {n} cases x 4 front-ends (walk x 8 lanes, walk, graph scan, cell rows): {4 * n - len(bad)} finished with a finite pose (a NaN guess excepted: it stays NaN, status reported); offenders: {bad}")
 ctx.close()
