@@ -204,3 +204,38 @@ def test_auto_declines_cell_rows_that_exceed_their_memory_bound(gpu_ctx):
         c.close()
     for name in ("auto_small", "forced_small", "walk"):
         assert np.array_equal(out["auto"][0], out[name][0]) and out["auto"][1] == out[name][1], name
+
+
+@pytest.mark.gpu
+def test_cell_rows_on_a_tall_grid_take_the_plain_classification(gpu_ctx):
+    """A target 100 m tall (200+ cells in z) does not fit the LDS tile of the cell-row classification: the per-cell kernel takes over.
+    Same neighbours as the cell walk (bit-identical registration with canonical ties); the rows cover their radius."""
+    import lisreg
+    from lisreg import synth
+    from scipy.spatial import cKDTree
+    case = synth.make_case(h=16, w=450, m_points=20000, scan_seed=4700, trans=0.3, rot_deg=2.0)
+    rng = np.random.default_rng(5)
+    tower = synth.to_pcl(np.stack([rng.uniform(-1, 1, 3000), rng.uniform(-1, 1, 3000), rng.uniform(0, 100, 3000)], 1).astype(np.float32))
+    ts = synth.concat_clouds([case["tgt_surf"], tower])
+    p = lisreg.default_params(1); p.fixed_iters = 5
+    out = {}
+    for mode in (1, 5):
+        c = lisreg.Context(0)
+        c.set_option("search_mode", mode); c.set_option("canonical_ties", 1); c.set_option("lanes_per_query", 1)
+        c.set_target(case["tgt_corner"], ts)
+        out[mode] = c.align(case["src_corner"], case["src_surf"], case["T_init"], p)
+        if mode == 5:
+            g = c.target_cell_rows(0, 1); idx = c.target_index(0, 1)
+            assert idx["nz"] > 150
+            pts = idx["sorted"][:, :3].astype(np.float64); tree = cKDTree(pts)
+            nz, ny = idx["nz"], idx["ny"]
+            have = np.flatnonzero(g["table"] >= 0)
+            for cid in np.random.default_rng(1).choice(have, 300, replace=False):
+                r = int(g["table"][cid]) >> 8                  # the cell's centre row
+                h = np.array([cid // (nz * ny), (cid // nz) % ny, cid % nz], np.float64)
+                m = idx["origin"].astype(np.float64) + (h + 0.5) * idx["cell"]
+                want = set(tree.query_ball_point(m, float(np.sqrt(g["rho2"][r])) * (1 - 1e-5)))
+                assert want <= set(g["ids"][r][:g["count"][r]].tolist())
+        c.close()
+    (T1, s1, tr1), (T5, s5, tr5) = out[1], out[5]
+    assert s1 == s5 and s1["status"] == 0 and np.array_equal(T1, T5) and np.array_equal(tr1, tr5)
