@@ -1057,7 +1057,7 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
 // (first row << 8) | octant mask, rows = [centre, the octants of the mask in ascending order].
 constexpr int kCrowCPW = 8;
 __global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
-                                                    const int* __restrict__ scan, int cap, int use_r3)
+                                                    const int* __restrict__ scan, int cap, int use_r3 /* 0: never the 7^3 block (experiments) */)
 {
     __shared__ int s_off[4][64], s_js[4][64];
     const int lane = threadIdx.x & 63;
