@@ -168,9 +168,25 @@ __device__ __forceinline__ double wave_sum(double v)
 // query index: inside a wavefront by an ascending butterfly, across the four wavefronts of a workgroup as (w0 + w1) + (w2 + w3); a
 // workgroup row covers 256 / Q queries, and the summing kernels first fold Q consecutive rows the same way (icp_row256) — from there
 // on both forms hold one value per 256 queries.
+// (the partner's value for the masks 1, 2 and 8 comes through DPP moves — quad permutes and a row rotation, vector-ALU work — instead of the
+// LDS crossbar: a launch of the ICP correspondence kernel made 204 ds_bpermute per wavefront for its 17 double sums, half of its
+// instructions and the busiest pipe; the masks 4, 16 and 32 stay there.  Same pairs, same order: the same bits.)
+template <int M> __device__ __forceinline__ double lane_xor_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (M == 1)      { lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }    // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) { lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);  hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }    // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) { lo = __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, true); }   // row_ror:8
+    else if constexpr (M == 4) {                                                                                  // row_half_mirror (xor 7), then quad_perm [3,2,1,0] (xor 3)
+        lo = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true); }
+    else                       { lo = __shfl_xor(lo, M, 64); hi = __shfl_xor(hi, M, 64); }
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_up(double v)
 {
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    v += lane_xor_d<1>(v); v += lane_xor_d<2>(v); v += lane_xor_d<4>(v);
+    v += lane_xor_d<8>(v); v += lane_xor_d<16>(v); v += lane_xor_d<32>(v);
     return v;
 }
 
