@@ -1041,7 +1041,14 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cell_min_ratio")) { c->cell_min_ratio = value; c->prepared = false; return LISREG_OK; }
-    if (!strcmp(name, "cell_rows_max_mb")) { c->cell_rows_max_mb = value; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "cell_rows_max_mb")) {
+        c->cell_rows_max_mb = value; c->prepared = false;
+        for (auto& t : c->targets) for (int k = 0; k < 2; ++k) {        // a new bound: what was too big may fit now, what fitted may have to be capped
+            t.crow_too_big[k] = false;
+            if (t.crow_valid[k]) { t.crow_valid[k] = false; c->grids_dirty = true; }
+        }
+        return LISREG_OK;
+    }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; return LISREG_OK; }
     if (!strcmp(name, "index_build")) {
