@@ -176,6 +176,10 @@ def main():
         from lisreg import replay
         fn = replay.bench_sequence if args.workload == "cfg3" else replay.bench_odometry
         out = fn(dev_index, steps=args.steps, warmup=args.warmup) if rank == 0 else None
+        if out is not None:
+            frames, recs = out.pop("_frames"), out.pop("_recs")
+            out["cpu_baseline"] = chain_cpu_baseline(args.workload, frames, recs, np) if args.cpu_regs > 0 else None
+            out["pcl_reference"] = pcl_reference_note()
         if use_dist:
             dist.barrier(); dist.destroy_process_group()
         if out is not None:
@@ -318,8 +322,21 @@ def main():
             except Exception:
                 traffic = None
         prof_steps = min(repeats, prof_repeats) * args.steps
+        # BASELINE.md section 3 / SURVEY.md section 8(d): the WHOLE step against the roofline — A_reg = 96 I N_s + 40 M / B_t bytes per
+        # registration (B_t = registrations sharing a target) x registrations/s of ONE GPU / 8 TB/s.  Everything of a step counts against it
+        # (index build, solves, launch gaps), so it is below the dominant kernel's own fraction `frac`.
+        n_tgt_pts = ctx.get_option("index_target_points")
+        a_reg = (ALG_BYTES_PER_POINT_ITER * ITERS * n_src + 40.0 * n_tgt_pts) / batch
+        step_achieved = a_reg * (batch / (ms_per_step * 1e-3)) / 1e9
+        fe_kib, grid_kib = ctx.get_option("index_kib_front_end"), ctx.get_option("index_kib_grid")
         roof = dict(bound="hbm", kernel="k_assoc_walk", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    step_frac=round(step_achieved / HBM_PEAK_GBS, 5), step_achieved=round(step_achieved, 2),
+                    algorithmic_bytes_per_registration=int(a_reg),
+                    step_frac_note="A_reg x registrations/s per GPU / 8 TB/s (BASELINE.md section 3): the whole step incl. index build and solves",
+                    index_bytes_per_target_point=round(1024.0 * (fe_kib + grid_kib) / max(n_tgt_pts, 1), 1),
+                    index_bytes_per_target_point_parts=dict(grid=round(1024.0 * grid_kib / max(n_tgt_pts, 1), 1),
+                                                            front_end=round(1024.0 * fe_kib / max(n_tgt_pts, 1), 1)),
                     avg_launch_ms=round(avg_ms, 4), launches=timing["assoc_launches"],
                     algorithmic_bytes_per_launch=alg_bytes, search_front_end=ctx.front_end(),
                     per_step_ms=dict(assoc=round(timing["assoc_ms"] / prof_steps, 4), solve=round(timing["solve_ms"] / prof_steps, 4),
@@ -331,7 +348,8 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and n_gpus == 1 and args.cpu_regs > 0:
+    # (rank 0 only; at N > 1 the other ranks wait at the barrier below — the leg is ~10-25 s of host work, after the timed region)
+    if rank == 0 and args.cpu_regs > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_ctypes as oc                                       # checker + timed CPU baseline only
         oc.build()
@@ -360,7 +378,7 @@ def main():
         kk = len(T_cpu)
         d = np.abs(T_gpu[:kk].astype(np.float64) - T_cpu.astype(np.float64))
         parity = dict(items=kk, max_rot_err_rad=float(d[:, :3].max()), max_trans_err_m=float(d[:, 3:].max()))
-        if not own_targets:
+        if not own_targets and n_gpus == 1:
             # the same registrations through the exact-arithmetic build (lisreg_assoc.hip compiled with the reference's arithmetic): its
             # poses are expected to BE the oracle's (tests/test_exact.py); reported, not timed
             cx = lisreg.Context(dev_index)
@@ -372,7 +390,7 @@ def main():
             parity["exact_build_poses_bit_identical"] = int(sum(np.array_equal(np.asarray(Tx[i], np.float32), np.asarray(T_cpu[i], np.float32))
                                                                 for i in range(kk)))
             parity["exact_build_max_diff"] = float(np.abs(np.asarray(Tx, np.float64) - T_cpu.astype(np.float64)).max())
-        cpu = dict(value=legs[1]["value"], unit="registrations/s", cores=1, kind="port",
+        cpu = dict(value=legs[1]["value"], unit="registrations/s", cores=1, kind="port", pcl_reference=pcl_reference_note(),
                    sample=f"{kk} of the {batch} registrations of this batch ({H}x{W} vs {M_SUBMAP // 1000}k submap, {ITERS} GN iters, "
                           f"kd-tree leaf 15, two tree builds per registration) per leg; OpenMP over the feature points like the "
                           f"reference's numberOfCores loops, kd-tree build single-threaded as in PCL; {ncores} host cores usable "
@@ -405,10 +423,27 @@ def main():
                               "sines / cosines from the host's libm: one host round trip per GN iteration) on the same device-resident batch")
 
     # ---- PCIe-inclusive leg: pinned host clouds in the reference's 32-byte layout through lisreg_align_batch ------
+    # At N > 1 EVERY rank runs it at the same time (between two barriers): the ranks' feeder threads and uploads then compete for the host's
+    # cores, memory and PCIe root ports — the contention SURVEY.md section 8(e) names as the multi-GPU limit — and rank 0 reports the
+    # whole-job rate (sum over ranks / the slowest rank's time) next to every rank's own figure.
     pcie = None
-    if rank == 0 and n_gpus == 1 and not args.no_pcie and not own_targets:
+    if not args.no_pcie and not own_targets:
+        if use_dist:
+            dist.barrier()
         pcie = pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_dev, T_init, params, T_gpu,
-                                  steps=max(3, min(args.steps, 20)))
+                                  steps=max(3, min(args.steps, 20)), feeder_threads=max(2, min(8, host_cores() // max(n_gpus, 1))) if n_gpus > 1 else 0)
+        if use_dist:
+            allp = [None] * world
+            dist.all_gather_object(allp, dict(rank=rank, value=pcie["value"], ms_per_step=pcie["ms_per_step"], stage_ms=pcie["stage_ms"],
+                                              feeder=pcie["feeder"], in_series=pcie["in_series"]["value"]))
+            if rank == 0:
+                slowest = max(p_["ms_per_step"] for p_ in allp)
+                pcie["all_ranks_concurrently"] = dict(
+                    value=round(n_gpus * batch / (slowest * 1e-3), 2), unit="registrations/s",
+                    note="every rank staged, ran and fetched its own batch at the same time; value = registrations of all ranks per step / the slowest rank's step time",
+                    per_rank=allp)
+            else:
+                pcie = None
 
     if os.environ.get("LISREG_COUNT"):
         cnt = ctx.counters()
@@ -434,7 +469,7 @@ def main():
                        "process_group": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                    "pose_gather": "lisreg_comm_init / lisreg_gather_results (the library's own RCCL all-gather)" if native_gather else "torch.distributed " + dist.get_backend(),
                                                                    "comm_nranks": comm_nranks, "ranks": rank_devices}},
-            "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie, "exact_build": exact_leg,
+            "roofline": roof, "cpu_baseline": cpu, "pcl_reference": pcl_reference_note(), "pcie_inclusive": pcie, "exact_build": exact_leg,
             "accuracy": {"max_rot_err_vs_truth_rad": float(err_truth[:, :3].max()),
                          "max_trans_err_vs_truth_m": float(err_truth[:, 3:].max()),
                          "vs_cpu_oracle": parity,
@@ -562,7 +597,7 @@ def bench_icp(args, lisreg, torch, np, synth, synth_torch, dev, dev_index, rank,
     err_t = max(float(np.abs(res[k]["T"][:3, 3] - T_fix[k % n_distinct][:3, 3]).max()) for k in range(batch))
     n_conv = int(sum(1 for r in res if r["converged"]))
     cpu = parity = None
-    if rank == 0 and world == 1 and args.cpu_regs > 0:
+    if rank == 0 and args.cpu_regs > 0:            # (at N > 1 the other ranks wait at the caller's barrier)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_ctypes as oc
         oc.build()
@@ -575,7 +610,7 @@ def bench_icp(args, lisreg, torch, np, synth, synth_torch, dev, dev_index, rank,
             ro_ = oc.icp_align(host_tgt[k], src_h, po)
             ros.append(ro_); po.prev_mse = ro_["prev_mse"]
         tcpu = time.perf_counter() - tc0
-        cpu = dict(value=round(kk / tcpu, 4), unit="candidates/s", cores=1, kind="port", seconds=round(tcpu, 2),
+        cpu = dict(value=round(kk / tcpu, 4), unit="candidates/s", cores=1, kind="port", seconds=round(tcpu, 2), pcl_reference=pcl_reference_note(),
                    sample=f"{kk} of the {batch} candidates ({H}x{W} key frame vs its 200k-point target, <= {ITERS} ICP iterations, kd-tree build "
                           "included) through the CPU restatement of pcl::IterativeClosestPoint, 1 thread (PCL's ICP is single-threaded)")
         dT = max(float(np.abs(res[k]["T"].astype(np.float64) - ros[k]["T"].astype(np.float64)).max()) for k in range(kk))
@@ -603,6 +638,53 @@ def bench_icp(args, lisreg, torch, np, synth, synth_torch, dev, dev_index, rank,
                          "iterations_min_max": [int(min(r["iters"] for r in res)), int(max(r["iters"] for r in res))]}}
 
 
+def pcl_reference_note():
+    """'if find_package(PCL QUIET) succeeds on the box, additionally time the verbatim KdTreeFLANN path; otherwise say
+    that it was unavailable'.  Looked for here the way CMake's find_package would find it (a PCLConfig.cmake / pcl_common pkg-config file /
+    the kdtree_flann header) — the image carries no PCL, FLANN, Eigen or OpenCV, so the verbatim path cannot be built and the timed CPU path
+    is the oracle port (`kind: port`)."""
+    import glob
+    hits = []
+    for pat in ("/usr/lib/*/cmake/pcl/PCLConfig.cmake", "/usr/share/pcl*/PCLConfig.cmake", "/usr/local/share/pcl*/PCLConfig.cmake",
+                "/usr/lib/*/pkgconfig/pcl_common*.pc", "/usr/include/pcl*/pcl/kdtree/kdtree_flann.h", "/usr/local/include/pcl*/pcl/kdtree/kdtree_flann.h",
+                "/opt/ros/*/include/pcl*/pcl/kdtree/kdtree_flann.h"):
+        hits += glob.glob(pat)
+    if hits:
+        return "found (" + hits[0] + ") but not wired: the verbatim leg needs Eigen, FLANN and OpenCV as well"
+    return "unavailable (find_package(PCL) would fail: no PCLConfig.cmake, pcl_common.pc or kdtree_flann.h on this box)"
+
+
+def chain_cpu_baseline(workload, frames, recs, np):
+    """cfg3 / odom: the CPU restatement's own frame loop (oracle/replay_oracle.py) on the first frames of the same drive — at ONE thread (faithful:
+    -fopenmp never reaches the reference's compiler, CMakeLists.txt:5-6, and params.yaml:127 asks for numberOfCores 2) and at min(16, usable
+    cores); never at the affinity mask's size (256 on the pool's hosts, which give the process 16 CPUs: oversubscribed, slower than 1 thread)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_ctypes as oc
+        import replay_oracle as ro
+        kk = min(len(frames), 8)
+        legs, dmax = {}, None
+        for nthreads in sorted({1, max(1, min(16, host_cores()))}):
+            tc0 = time.perf_counter()
+            if workload == "cfg3":
+                ref = ro.replay(list(frames[:kk]), n_threads=nthreads)
+            else:
+                ref = ro.replay_odom(list(frames[:kk]), oc.default_feature_params(), n_threads=nthreads)
+            tcpu = time.perf_counter() - tc0
+            legs[str(nthreads)] = dict(value=round(kk / tcpu, 3), seconds=round(tcpu, 2), frames=kk)
+            if nthreads == 1:
+                dmax = max(float(np.abs(np.asarray(a["T"], np.float64) - np.asarray(b["T"], np.float64)).max()) for a, b in zip(recs[:kk], ref))
+        what = ("semantic split, per-class voxel grids, sliding local map, copy #2 registration with its two kd-tree builds per frame" if workload == "cfg3"
+                else "range image + LOAM features, key-frame target with its voxel grids, copy #1 registration, key-frame gate")
+        return dict(value=legs["1"]["value"], unit="frames/s", cores=1, kind="port", seconds=legs["1"]["seconds"], by_threads=legs,
+                    pcl_reference=pcl_reference_note(),
+                    sample=f"the first {kk} frames of the same drive through the CPU restatement's frame loop ({what}); headline = 1 thread, "
+                           f"by_threads also has min(16, usable cores) OpenMP threads over the feature points ({host_cores()} cores usable here)",
+                    max_pose_diff_vs_hip_chain=dmax)
+    except Exception as e:                                      # the baseline is a report, never a reason to lose the line
+        return dict(error=repr(e))
+
+
 def host_cores():
     """cores this process may actually run on: scheduler affinity, capped by the cgroup CPU quota if there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -622,7 +704,7 @@ def host_cores():
     return max(1, n)
 
 
-def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_dev, T_init, params, T_ref, steps):
+def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_dev, T_init, params, T_ref, steps, feeder_threads=0):
     """The same batch with the sources living in pinned HOST memory as PCL PointXYZI structs (32 B per point): every timed
     step uploads them (hipMemcpyAsync on the context's stream), packs them on the device, runs the registration and
     copies poses + stats back — SURVEY.md §8(d)'s "incl. H2D of sources and D2H of poses".  Measured twice: one context (copy and
@@ -680,6 +762,8 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
 
     a = Lane()
     a.ctx.set_option("rebuild_targets_each_run", 1)
+    if feeder_threads > 0:                    # several ranks on one host share its cores: each takes its share
+        a.ctx.set_option("feeder_threads", feeder_threads)
     for kv in filter(None, os.environ.get("LISREG_OPTS", "").split(",")):        # tuning experiments, as for the main context
         k_, v_ = kv.split("=")
         a.ctx.set_option(k_, int(v_))

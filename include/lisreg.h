@@ -281,7 +281,9 @@ int  lisreg_get_target_graph(lisreg_ctx* ctx, int slot, int kind, int* k, float*
  * (x, y, z, sorted position as int bits) of the j-th nearest target point of the row's centre, ascending (to 2^-16 relative), padded with
  * (the centre's coordinates, -1); meta_out[r] = (rho^2, count as int bits): every point closer to the centre than rho is in the row.
  * Outputs may be NULL; capacity_rows >= *n_rows when rows_out / meta_out are given (call once with NULLs to learn it).  Building the rows
- * re-makes the target's grid two cells wider than the cloud on every side (once per target): read lisreg_get_target_index after this. */
+ * re-makes the target's grid two cells wider than the cloud on every side (once per target): read lisreg_get_target_index after this.
+ * When that happens a batch prepared on this context (lisreg_batch_prepare) is no longer valid — its copy of the grid geometry is stale —
+ * and lisreg_batch_run refuses it (LISREG_ERR_ARG, "no prepared batch") until it is prepared again. */
 int  lisreg_get_target_cell_rows(lisreg_ctx* ctx, int slot, int kind, int* n_rows, int* k, int* table_out, int capacity_cells,
                                  float* rows_out, float* meta_out, int capacity_rows);
 

@@ -214,6 +214,11 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false)
         if (rc) return rc;
         t.graph_valid[k] = false;
         t.g[k].nbr = nullptr; t.g[k].nbr_meta = nullptr;
+        // the geometry (origin, dims) and possibly the cell table's address have changed: a batch prepared against the old grid holds stale
+        // copies of both (the device GridIndex table, the rebuild table h_tsegs) — it has to be prepared again (lisreg_batch_prepare calls
+        // this before it reads any geometry; lisreg_get_target_cell_rows on a slot a prepared batch uses lands here too)
+        c->prepared = false;
+        c->grids_dirty = true;
     }
     const size_t nc = (size_t)std::max(t.n_cells[k], 1);
     HIPCHK(c, t.crow_need[k].ensure(sizeof(int) * (nc + 8)));
@@ -351,7 +356,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_SEARCH_MODE")) {            // the same values lisreg_set_option("search_mode") takes
         const int v = atoi(m);
         if (v == 0 || v == 1 || v == 3 || v == 4 || v == 5) c->search_mode = v;
-        else fprintf(stderr, "[lisreg] LISREG_SEARCH_MODE=%s ignored (0, 1, 3 or 4)\n", m);
+        else fprintf(stderr, "[lisreg] LISREG_SEARCH_MODE=%s ignored (0, 1, 3, 4 or 5)\n", m);
     }
     if (const char* m = getenv("LISREG_SORT_SOURCES")) c->sort_sources = atoi(m);
     if (const char* m = getenv("LISREG_EXACT")) c->exact = atoi(m) != 0;
@@ -587,6 +592,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->prm = make_dev_params(*params);
     c->prm.exact = c->exact ? 1 : 0;
     c->prm.ties = (c->canonical_ties || c->exact) ? 1 : 0;
+    c->prm.freeze_pose = getenv("LISREG_XP_FREEZE_POSE") ? 1 : 0;          // timing experiments only (tests/ab.sh): see DevParams
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
@@ -1100,6 +1106,26 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "cell_rows_max_mb")) { *value = c->cell_rows_max_mb; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { *value = c->xcd_order; return LISREG_OK; }
     if (!strcmp(name, "xcd_order_now")) { *value = c->xcd_now ? 1 : 0; return LISREG_OK; }
+    // size of the search index of the prepared batch's targets, in KiB (what the front-end in use reads), and their points:
+    //   index_kib_grid: sorted records + cell table; index_kib_front_end: k-NN graph rows (front-end 3) or cell rows + their table (front-end 5)
+    if (!strcmp(name, "index_kib_grid") || !strcmp(name, "index_kib_front_end") || !strcmp(name, "index_target_points")) {
+        unsigned long long grid = 0, fe = 0, pts = 0;
+        for (int slot : c->batch_slots) {
+            if (slot < 0 || (size_t)slot >= c->targets.size()) continue;
+            const lisreg::Target& t = c->targets[(size_t)slot];
+            for (int k = 0; k < 2; ++k) {
+                if (t.n[k] <= 0) continue;
+                pts += (unsigned long long)t.n[k];
+                grid += (unsigned long long)t.n[k] * sizeof(float4) + ((unsigned long long)t.n_cells[k] + 1) * sizeof(int);
+                if (c->mode_now == 3) fe += (unsigned long long)t.n[k] * (sizeof(float4) * lisreg::kGraphK + sizeof(float2));
+                if (c->mode_now == 5) fe += (unsigned long long)t.crow_cap[k] * (sizeof(float4) * lisreg::kGraphK + sizeof(float2)) +
+                                            (unsigned long long)t.n_cells[k] * sizeof(int);
+            }
+        }
+        const unsigned long long v = !strcmp(name, "index_target_points") ? pts : ((!strcmp(name, "index_kib_grid") ? grid : fe) + 1023) / 1024;
+        *value = (int)std::min<unsigned long long>(v, 0x7fffffffULL);
+        return LISREG_OK;
+    }
     return LISREG_ERR_ARG;
 }
 

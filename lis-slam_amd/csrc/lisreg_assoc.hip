@@ -52,6 +52,20 @@ namespace {
 namespace LISREG_ASSOC_NS {
 
 constexpr bool kExactArith = LISREG_EXACT != 0;
+// Wave sums of the 28 normal-equation terms on the matrix pipe (production build; LISREG_MFMA_REDUCE=0 keeps the lane-swap butterfly):
+// see row_and_reduce.
+#ifndef LISREG_MFMA_REDUCE
+#define LISREG_MFMA_REDUCE (!LISREG_EXACT)
+#endif
+// LDS of the reduction: one private region per wavefront (kRedWaveFloats floats) inside one array of the kernel.
+//   butterfly / exact build: the region starts with the wave's 28 sums (doubles);
+//   MFMA form: [0, 544) the 64 rows x 8 columns of the wave's Jacobian block as two half-waves of 32 rows (the second half 32 floats further
+//              on, so that both halves of a transposed read fall into different banks), [576, 704) the two 8 x 8 products of the halves
+constexpr int kRedWaveFloats = 1024;
+#if LISREG_MFMA_REDUCE
+constexpr int kRedHalfStride = 32 * 8 + 32;     // floats between the two half-wave blocks of rows
+constexpr int kRedOut        = 576;             // the 2 x 64 products
+#endif
 // the reference's `/` and sqrt(): IEEE in the exact build, one v_rcp_f32 / v_sqrt_f32 (1 ulp) in the production build
 __device__ __forceinline__ float fdiv(float a, float b) { return kExactArith ? a / b : a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float fsqrt(float x) { return kExactArith ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
@@ -466,7 +480,7 @@ __device__ __forceinline__ float label_weight(const DevParams& P, float payload)
 // Jacobian row + fixed-order fp64 reduction of the 28 normal-equation terms: wave halving butterfly -> LDS ->
 // one partial row per workgroup.  `ok` = this lane contributes a correspondence with coefficients cf.
 __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* jk,
-                                               const DevParams& P, double (*s_acc)[kNumAcc], double* __restrict__ out);
+                                               const DevParams& P, float* s_red, double* __restrict__ out);
 
 // Residual model shared by the search front-ends that re-fit every iteration.
 // (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
@@ -480,13 +494,26 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
     if (found) {
         float4 nb[5];
         const gptr_f4 gp = (gptr_f4)g.pts;
+#ifdef LISREG_XP_NOGATHER      /* timing experiment (wrong results): five synthetic neighbours on a plane through the query, no memory access */
+        (void)gp;
+        v4f n0, n1, n2, n3, n4;
+        n0.x = qx + 0.11f; n0.y = qy + 0.02f; n0.z = qz; n0.w = 0.f;  n1.x = qx - 0.07f; n1.y = qy + 0.13f; n1.z = qz; n1.w = 0.f;
+        n2.x = qx - 0.12f; n2.y = qy - 0.09f; n2.z = qz; n2.w = 0.f;  n3.x = qx + 0.05f; n3.y = qy - 0.14f; n3.z = qz; n3.w = 0.f;
+        n4.x = qx + 0.01f * (float)(i4 & 7); n4.y = qy + 0.21f; n4.z = qz; n4.w = 0.f;
+#else
         const v4f n0 = LISREG_LD4(gp, i0), n1 = LISREG_LD4(gp, i1), n2 = LISREG_LD4(gp, i2), n3 = LISREG_LD4(gp, i3), n4 = LISREG_LD4(gp, i4);
+#endif
         nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
         nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
         nb[4] = make_float4(n4.x, n4.y, n4.z, n4.w);
         float w = 1.f;
         if (P.use_label) w = label_weight(P, q4.w);
+#ifdef LISREG_XP_NOFIT          /* timing experiment (wrong results): no line / plane fit, the gathered points stay live */
+        cf[0] = nb[0].x + nb[1].y + w; cf[1] = nb[2].z + nb[3].x; cf[2] = nb[4].y + nb[0].z; cf[3] = (nb[1].x + nb[2].y + nb[3].z + nb[4].x) * 1e-3f;
+        ok = cf[3] < 1.0e30f;
+#else
         ok = (kind == 0) ? corner_coeff(nb, qx, qy, qz, w, P, cf) : surf_coeff(nb, qx, qy, qz, w, P, cf);
+#endif
     }
     return ok;
 }
@@ -494,18 +521,24 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
                                                     const float* jk, const DevParams& P, int kind,
-                                                    double (*s_acc)[kNumAcc], double* __restrict__ out, int* dbg_ok = nullptr)
+                                                    float* s_red, double* __restrict__ out, int* dbg_ok = nullptr)
 {
     float cf[4];
     const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
-    row_and_reduce(ok, cf, q4, jk, P, s_acc, out);
+    row_and_reduce(ok, cf, q4, jk, P, s_red, out);
 }
 
 __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const float4 q4, const float* jk,
-                                               const DevParams& P, double (*s_acc)[kNumAcc], double* __restrict__ out)
+                                               const DevParams& P, float* s_red, double* __restrict__ out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef LISREG_XP_NOREDUCE       /* timing experiment (wrong results): no Jacobian row, no sums */
+    if (ok && tid < kNumAcc) out[tid] = (double)(cf[0] + cf[1] + cf[2] + cf[3] + q4.x);
+    return;
+#endif
+    double (*s_acc)[kRedWaveFloats / 2] = reinterpret_cast<double (*)[kRedWaveFloats / 2]>(s_red);     // s_acc[wave][k]: the wave's region as doubles
+    (void)s_acc;
     float row[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rb = 0.f, one = 0.f;
     if (ok) { jacobian_row(jk, q4.x, q4.y, q4.z, cf, row, rb); one = 1.f; }
 #if LISREG_EXACT
@@ -549,6 +582,57 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
         const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         if ((lane & 1) == 0 && idx < kNumAcc) s_acc[wave][idx] = v1;
     }
+#elif LISREG_MFMA_REDUCE
+    // ---- wave sums on the matrix pipe (round 5) -------------------------------------------------------------------------------------
+    // The 28 sums are the upper triangle of E^T E for the 64 x 8 block E = [row0 .. row5 | b | 1] of the wavefront's rows (row^T row: 21,
+    // row * b: 6, 1 * 1: the count).  gfx950 has an exact-f32 MFMA (v_mfma_f32_16x16x4_f32: D += A(16x4) B(4x16), bitwise a chain of
+    // fmaf; MI355X_MICROARCH.md, "Matrix cores"), and for E^T E both operands are the SAME register: lane l supplies E[k = l >> 4][l & 15]
+    // of a 4-row slice.  Two half-waves ride side by side — columns 0-7 the rows of lanes 0-31, columns 8-15 those of lanes 32-63 — so
+    // the two diagonal 8 x 8 blocks of the 16 x 16 product are the half-wave sums after 8 instructions (32 rows each, a 32-term fmaf chain
+    // in lane order); the off-diagonal blocks are never read.  The transposition lanes-hold-rows -> lanes-hold-columns goes through the
+    // wave's private LDS region: 2 ds_write_b128 + 8 ds_read_b32 per lane.  Replaces 28 products + a 31-step lane-swap butterfly
+    // (~115 vector-ALU instructions and 24 lane swaps per wavefront, on a launch that is bound by vector-ALU issue).  Fixed order, no
+    // atomics: a registration gives the same bits alone and in any batch; above the half-wave everything stays fp64 in index order.
+    {
+        float* s_w = s_red + wave * kRedWaveFloats;
+        // (a lane without a correspondence contributes a zero row)
+        float4* dst = reinterpret_cast<float4*>(s_w + (lane >> 5) * kRedHalfStride + (lane & 31) * 8);
+        dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+        dst[1] = make_float4(row[4], row[5], rb, one);
+        // slice s: lane l reads E_half[4 s + (l >> 4)][l & 7], half = bit 3 of l
+        const float* src = s_w + ((lane >> 3) & 1) * kRedHalfStride + (lane >> 4) * 8 + (lane & 7);
+        typedef float v4acc __attribute__((ext_vector_type(4)));
+        v4acc acc = { 0.f, 0.f, 0.f, 0.f };
+        float e[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) e[s] = src[s * 32];                        // all eight slices asked for before the first product
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], e[s], acc, 0, 0, 0);
+        // D[i][j]: lane = j + 16 * (i >> 2), register i & 3.  Lower half-wave: i, j < 8 (lanes 0-7, 16-23); upper: i, j >= 8 (lanes 40-47, 56-63).
+        const int half = lane >> 5;
+        if (((lane >> 3) & 1) == half) {
+            float* o = s_w + kRedOut + half * 64 + ((lane >> 4) & 1) * 32 + (lane & 7);       // [i = 4 * ((l >> 4) & 1) + r][j = l & 7]
+            o[0] = acc[0]; o[8] = acc[1]; o[16] = acc[2]; o[24] = acc[3];
+        }
+    }
+    __syncthreads();
+    if (tid < kNumAcc) {
+        // tid -> (i, j) of the 8 x 8 product: 0..20 the upper triangle of the 6 x 6 corner (row-major), 21..26 column 6 (b), 27 = [7][7] (count)
+        int i = 0, j = tid;
+        if (tid >= 27) { i = 7; j = 7; }
+        else if (tid >= 21) { i = tid - 21; j = 6; }
+        else {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) if (j >= 6 - i) { j -= 6 - i; ++i; }
+            j += i;
+        }
+        double v = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2 * (kBlockQ / 64); ++h)                           // fixed order: half-waves 0 .. 7
+            v += (double)s_red[(h >> 1) * kRedWaveFloats + kRedOut + (h & 1) * 64 + i * 8 + j];
+        out[tid] = v;
+    }
+    return;
 #else
     // the 28 normal-equation terms of this row, produced on demand:
     //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
@@ -627,7 +711,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
     __shared__ int    s_run_off[kBlockQ + 1];
     __shared__ int    s_wave[4];
     __shared__ float  s_bb[4][6];
-    __shared__ double s_acc[4][kNumAcc];
+    __shared__ __attribute__((aligned(16))) float s_red[4 * kRedWaveFloats];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const BlockDesc bd = blocks[blockIdx.x];
@@ -746,7 +830,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
         }
     }
 
-    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_acc, out);
+    residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out);
 }
 
 // sorted top-5 insertion (ascending); `id` must not already be in the list
@@ -854,7 +938,7 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
                 if (!covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
                     const int base_ = (ix_ * g.ny + iy_) * g.nz; \
                     const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
-                    if (js_ < je_) { s_runs[cnt_][tid] = make_int2(js_, je_); ++cnt_; } \
+                    if (js_ < je_) { s_runs_at(cnt_, tid) = make_int2(js_, je_); ++cnt_; } \
                 } \
                 if (kQ == 1) { if (++iy_ > cy1_) { iy_ = cy0_; ++ix_; } } \
                 else { iy_ += kQ; while (iy_ > cy1_) { iy_ -= nyb_; ++ix_; } } \
@@ -863,7 +947,7 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
             if (kQ == 1 || !kShare) { \
                 int r_ = 0, j_ = 0, e_ = 0; \
                 for (;;) { \
-                    if (j_ >= e_) { if (r_ >= cnt_) break; const int2 t_ = s_runs[r_][tid]; j_ = t_.x; e_ = t_.y; ++r_; } \
+                    if (j_ >= e_) { if (r_ >= cnt_) break; const int2 t_ = s_runs_at(r_, tid); j_ = t_.x; e_ = t_.y; ++r_; } \
                     LISREG_WALK_FOUR(j_, e_ - 1); \
                     j_ += 4; \
                 } \
@@ -876,7 +960,7 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
                     for (;;) { \
                         if (j_ >= e_) { \
                             if (r_ >= cnt_) break; \
-                            const int2 t_ = s_runs[r_][tid]; ++r_; \
+                            const int2 t_ = s_runs_at(r_, tid); ++r_; \
                             if (t_.y - t_.x >= kShareRun) { long_ = true; continue; } \
                             j_ = t_.x; e_ = t_.y; \
                         } \
@@ -890,7 +974,7 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
                         const int peer_ = (tid & ~(kQ - 1)) + s_; \
                         const int pc_ = __shfl(long_ ? cnt_ : 0, ((tid & 63) & ~(kQ - 1)) + s_); \
                         _Pragma("unroll 1") for (int r_ = 0; r_ < pc_; ++r_) { \
-                            const int2 t_ = s_runs[r_][peer_]; \
+                            const int2 t_ = s_runs_at(r_, peer_); \
                             if (t_.y - t_.x >= kShareRun) \
                                 _Pragma("unroll 1") for (int j_ = t_.x + 4 * sub_q; j_ < t_.y; j_ += 4 * kQ) LISREG_WALK_FOUR(j_, t_.y - 1); \
                         } \
@@ -1093,13 +1177,20 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
                 const float thr_ = __builtin_amdgcn_sqrtf(b4) * 1.0001f + da_; thr2_ = thr_ * thr_; \
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY_ND); \
             } \
-            _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_; ++g_) { \
+            _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_ && LISREG_XP_SCAN_GROUPS(g_); ++g_) { \
                 const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
                 LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); \
             } \
             if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
-            certified = stop_; } while (0)
+            certified = stop_ || LISREG_XP_ALWAYS_CERTIFIED; } while (0)
 
+#ifdef LISREG_XP_NOSCAN         /* timing experiment (wrong results): two groups of the row, no stop test, never a walk */
+#define LISREG_XP_SCAN_GROUPS(g_) ((g_) < 2)
+#define LISREG_XP_ALWAYS_CERTIFIED true
+#else
+#define LISREG_XP_SCAN_GROUPS(g_) true
+#define LISREG_XP_ALWAYS_CERTIFIED false
+#endif
 #define LISREG_CE5(a, b) do { const bool sw_ = sd[b] < sd[a]; const float ta_ = sd[a]; const int ia_ = sid[a]; \
                               sd[a] = sw_ ? sd[b] : ta_; sd[b] = sw_ ? ta_ : sd[b]; sid[a] = sw_ ? sid[b] : ia_; sid[b] = sw_ ? ia_ : sid[b]; } while (0)
 
@@ -1162,8 +1253,12 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
                                                         int* __restrict__ dbg_nn, float4* __restrict__ coef, int* __restrict__ coef_ok,
                                                         double* __restrict__ partials, const int* __restrict__ xcd_order)
 {
-    __shared__ double s_acc[4][kNumAcc];
-    __shared__ int2   s_runs[kWalkCap][kBlockQ];          // per-lane list of candidate runs for the flattened walk
+    // per-lane lists of candidate runs for the flattened walk, one 4-KB region per wavefront (s_runs[wave][entry][lane]); the same memory
+    // serves the reduction once a wavefront's search is over (row_and_reduce: every wavefront works in its own region until the barrier)
+    __shared__ __attribute__((aligned(16))) int2 s_runs_w[kBlockQ / 64][kWalkCap][64];
+    static_assert(sizeof(int2) * kWalkCap * 64 == sizeof(float) * kRedWaveFloats, "one region per wavefront");
+    float* s_red = reinterpret_cast<float*>(&s_runs_w[0][0][0]);
+#define s_runs_at(r_, t_) s_runs_w[(t_) >> 6][(r_)][(t_) & 63]
     constexpr float kEps = 1e-3f;
 
     const int tid = threadIdx.x;
@@ -1378,9 +1473,13 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     }
     // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef LISREG_XP_NOSRC2         /* timing experiment (wrong results): no second read of the source record */
+    q4 = make_float4(qx, qy, qz, 0.f);
+#else
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
+#endif
     if (kQ == 1) {
-        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_acc, out,
+        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out,
                             dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
     } else {
         // kQ lanes per query: the coefficients go to memory and k_rows_reduce builds the partial rows with the SAME 256-query
@@ -1404,7 +1503,7 @@ __global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __rest
                                                          const float4* __restrict__ coef, const int* __restrict__ coef_ok,
                                                          double* __restrict__ partials)
 {
-    __shared__ double s_acc[4][kNumAcc];
+    __shared__ __attribute__((aligned(16))) float s_red[4 * kRedWaveFloats];
     const int tid = threadIdx.x;
     const BlockDesc bd = blocks[blockIdx.x];
     const ItemState* it = &items[bd.item];
@@ -1426,7 +1525,7 @@ __global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __rest
         ok = coef_ok[qflat] != 0;
     }
     const float cf[4] = { c4.x, c4.y, c4.z, c4.w };
-    row_and_reduce(ok, cf, q4, it->jk, P, s_acc, out);
+    row_and_reduce(ok, cf, q4, it->jk, P, s_red, out);
 }
 
 }  // namespace LISREG_ASSOC_NS

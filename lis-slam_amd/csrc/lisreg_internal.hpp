@@ -91,6 +91,8 @@ struct DevParams {
     int   exact;               // "exact_arithmetic" (the launches pick launch_assoc_exact; the host supplies the pose caches' sin / cos)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
     int   cell_anchor_until;   // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
+    int   freeze_pose;         // timing experiments only (env LISREG_XP_FREEZE_POSE): the solve leaves T as it is, so that every launch of a run
+                               // sees the same queries whatever a variant under test writes into the normal equations
 };
 
 // Mutable per-registration state (device resident for the whole GN loop — no host sync per iteration).

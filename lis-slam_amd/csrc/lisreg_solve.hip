@@ -353,8 +353,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
                 s_X[r] = (float)s;
             }
         }
-        for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];          // :955-960
-        write_pose_cache(it);
+        if (!P.freeze_pose) {
+            for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];      // :955-960
+            write_pose_cache(it);
+        }
         const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
         const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
         const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);

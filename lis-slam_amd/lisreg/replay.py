@@ -450,7 +450,8 @@ def _chain_roofline(ctx, make_replayer, frames, src_points_of):
 
 def bench_sequence(device: int, steps: int = 20, warmup: int = 2) -> dict:
     """bench.py --workload cfg3: frames/s of the synthetic drive on the HIP chain (host-inclusive: every frame's sweep crosses
-    PCIe, as in the reference's node), with the CPU oracle chain timed on the first frames as the baseline."""
+    PCIe, as in the reference's node).  Returns the bench line plus `_frames` / `_recs` (the inputs and the HIP chain's records)
+    for bench.py's CPU-baseline leg."""
     import lisreg
     n = max(steps, 2) + warmup
     frames = [c for c, _ in synthetic_drive(n)]
@@ -472,23 +473,8 @@ def bench_sequence(device: int, steps: int = 20, warmup: int = 2) -> dict:
     err = max(float(np.abs(np.asarray(rec["T"], np.float64)[3:5] - truth[rec["frame"]][3:5]).max()) for rec in recs)
     roof = _chain_roofline(ctx, lambda: DeviceReplayer(ctx, 2), frames, lambda rec: int(rec["n_src_corner"]) + int(rec["n_src_surf"]))
     ctx.close()
-    # CPU baseline: the oracle chain (the restatement's own frame loop) on the first frames of the same drive
+    # (the CPU baseline of this line — the oracle chain on the first frames — is timed by bench.py: this package never touches oracle/)
     cpu = None
-    try:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
-        import replay_oracle as ro
-        kk = min(len(frames), 8)
-        nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        tc0 = time.perf_counter()
-        ref = ro.replay(frames[:kk], n_threads=nthreads)
-        tcpu = time.perf_counter() - tc0
-        dmax = max(float(np.abs(np.asarray(a["T"], np.float64) - np.asarray(b["T"], np.float64)).max()) for a, b in zip(recs[:kk], ref))
-        cpu = dict(value=round(kk / tcpu, 3), unit="frames/s", cores=nthreads, kind="port", seconds=round(tcpu, 2),
-                   sample=f"the first {kk} frames of the same drive through the CPU restatement's frame loop (semantic split, per-class voxel grids, "
-                          f"sliding local map, copy #2 registration with its two kd-tree builds per frame), OpenMP over the feature points with {nthreads} threads",
-                   max_pose_diff_vs_hip_chain=dmax)
-    except Exception as e:                                      # the baseline is a report, never a reason to lose the line
-        cpu = dict(error=repr(e))
     return {"metric": "sequential scan-to-local-map registrations/sec (synthetic drive, semantic mask on)",
             "value": round((n - warmup) / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt / (n - warmup), 3), "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
@@ -496,7 +482,8 @@ def bench_sequence(device: int, steps: int = 20, warmup: int = 2) -> dict:
                                                         "device-resident sliding local map, copy #2 parameters, early exit"},
             "roofline": roof, "cpu_baseline": cpu,
             "accuracy": {"max_xy_err_vs_truth_m": err, "frames": n,
-                         "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]}}
+                         "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]},
+            "_frames": list(frames), "_recs": recs}
 
 
 def bench_odometry(device: int, steps: int = 20, warmup: int = 2) -> dict:
@@ -519,24 +506,7 @@ def bench_odometry(device: int, steps: int = 20, warmup: int = 2) -> dict:
     err = max(float(np.abs(np.asarray(rec["T"], np.float64)[3:5] - truth[rec["frame"]][3:5]).max()) for rec in recs)
     roof = _chain_roofline(ctx, lambda: DeviceOdomReplayer(ctx), frames, lambda rec: int(rec.get("n_src_corner", 0)) + int(rec.get("n_src_surf", 0)))
     ctx.close()
-    cpu = None
-    try:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
-        import oracle_ctypes as oc
-        import replay_oracle as ro
-        kk = min(len(frames), 8)
-        nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        fp_o = oc.default_feature_params()
-        tc0 = time.perf_counter()
-        ref = ro.replay_odom(list(frames[:kk]), fp_o, n_threads=nthreads)
-        tcpu = time.perf_counter() - tc0
-        dmax = max(float(np.abs(np.asarray(a["T"], np.float64) - np.asarray(b["T"], np.float64)).max()) for a, b in zip(recs[:kk], ref))
-        cpu = dict(value=round(kk / tcpu, 3), unit="frames/s", cores=nthreads, kind="port", seconds=round(tcpu, 2),
-                   sample=f"the first {kk} sweeps of the same drive through the CPU restatement's odometry loop (range image + LOAM features, key-frame "
-                          f"target with its voxel grids, copy #1 registration, key-frame gate), OpenMP over the feature points with {nthreads} threads",
-                   max_pose_diff_vs_hip_chain=dmax)
-    except Exception as e:
-        cpu = dict(error=repr(e))
+    cpu = None                                  # timed by bench.py (see bench_sequence)
     return {"metric": "sequential scan-to-map odometry frames/sec (synthetic raw drive, no labels)",
             "value": round((n - warmup) / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt / (n - warmup), 3), "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
@@ -544,4 +514,5 @@ def bench_odometry(device: int, steps: int = 20, warmup: int = 2) -> dict:
                                                         "voxel grids, copy #1 registration against <= 19 keyframes, early exit"},
             "roofline": roof, "cpu_baseline": cpu,
             "accuracy": {"max_xy_err_vs_truth_m": err, "frames": n, "keyframes": int(sum(rec["keyframe"] for rec in recs)),
-                         "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]}}
+                         "iters": [rec["stats"]["iters"] for rec in recs if rec["stats"]]},
+            "_frames": list(frames), "_recs": recs}
