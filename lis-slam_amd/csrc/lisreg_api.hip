@@ -638,6 +638,13 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             c->mode_now = (t_pts > 0 && qi >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
             if (t_pts > 0 && qi >= (double)c->cell_min_ratio * t_pts && t_pts * 5120.0 <= (double)c->cell_rows_max_mb * 1048576.0) c->mode_now = 5;
         }
+        // cell-row entries keep six bits next to the id (lisreg_internal.hpp, kCrowTagShift): targets of 2^26 points or more take the graph
+        if (c->mode_now == 5)
+            for (int sl : seen)
+                if (std::max(c->targets[(size_t)sl].n[0], c->targets[(size_t)sl].n[1]) > lisreg::kCrowIdMask) {
+                    if (c->search_mode == 5) return fail(c, LISREG_ERR_ARG, "batch_prepare: search_mode 5 (cell rows) takes targets of fewer than 2^26 points");
+                    c->mode_now = 3;
+                }
         // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
         c->lanes_q = (c->mode_now == 1 && c->lanes_per_query_auto && total_src > 0 && total_src <= 131072) ? 8 : 1;
         // the cell rows re-make a target's grid with a margin the first time they are chosen for it: before anything below reads the geometry
@@ -1333,7 +1340,14 @@ int lisreg_get_target_cell_rows(lisreg_ctx* c, int slot, int kind, int* n_rows, 
         HIPCHK(c, hipMemcpy(table_out, t.crow_tab[kind].p, sizeof(int) * (size_t)t.n_cells[kind], hipMemcpyDeviceToHost));
     }
     if ((rows_out || meta_out) && capacity_rows < rows) return fail(c, LISREG_ERR_ARG, "get_target_cell_rows: capacity_rows too small");
-    if (rows_out && rows) HIPCHK(c, hipMemcpy(rows_out, t.crow[kind].p, sizeof(float4) * kGraphK * (size_t)rows, hipMemcpyDeviceToHost));
+    if (rows_out && rows) {
+        HIPCHK(c, hipMemcpy(rows_out, t.crow[kind].p, sizeof(float4) * kGraphK * (size_t)rows, hipMemcpyDeviceToHost));
+        // the device rows carry the entry's position next to the id (lisreg_internal.hpp, kCrowTagShift): the diagnostic view is the plain id
+        for (size_t e = 0; e < (size_t)rows * kGraphK; ++e) {
+            int w; memcpy(&w, rows_out + 4 * e + 3, 4);
+            w = lisreg::crow_id(w); memcpy(rows_out + 4 * e + 3, &w, 4);
+        }
+    }
     if (meta_out && rows) HIPCHK(c, hipMemcpy(meta_out, t.crow_meta[kind].p, sizeof(float2) * (size_t)rows, hipMemcpyDeviceToHost));
     return LISREG_OK;
 }

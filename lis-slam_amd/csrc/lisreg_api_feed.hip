@@ -306,12 +306,15 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         int next_copy = 0, lowest_stolen = n_chunks;
         size_t raw_off = 0;
         unsigned char* raw_dev = nullptr;
+        bool force_one = job && c->feeder_engine >= 3;           // tests: one chunk goes to the engine whatever the packing threads' speed
         for (int i = 0; i < lowest_stolen; ++i) {
             if (want > 0) {
-                while (!c->pack_done[(size_t)i].load(std::memory_order_acquire)) {
+                while (force_one || !c->pack_done[(size_t)i].load(std::memory_order_acquire)) {
                     bool stole = false;
+                    const bool forced = force_one;
+                    force_one = false;
                     if (job && c->feeder_engine > 0 && chunks[(size_t)lowest_stolen - 1].pinned &&
-                        (c->feeder_engine > 1 || hipStreamQuery(c->copy_stream) == hipSuccess)) {
+                        (forced || c->feeder_engine > 1 || hipStreamQuery(c->copy_stream) == hipSuccess)) {
                         const int k = job->take_back();
                         if (k >= 0) {
                             const PackChunk& ck = chunks[(size_t)k];

@@ -52,10 +52,12 @@ namespace {
 namespace LISREG_ASSOC_NS {
 
 constexpr bool kExactArith = LISREG_EXACT != 0;
-// Wave sums of the 28 normal-equation terms on the matrix pipe (production build; LISREG_MFMA_REDUCE=0 keeps the lane-swap butterfly):
-// see row_and_reduce.
+// Wave sums of the 28 normal-equation terms on the matrix pipe (-DLISREG_MFMA_REDUCE=1; see row_and_reduce).  Built, tested (all GPU
+// parity tests green) and measured in round 5: 188-190 us per steady-state launch against 186-188 for the lane-swap butterfly — gfx950's
+// f32 MFMA runs at the f32 VECTOR rate (MI355X_MICROARCH.md), so eight of them cost what the ~115 vector instructions they replace cost.
+// Off by default; kept as the record of that measurement (profiles/r05_kernel_experiments.md).
 #ifndef LISREG_MFMA_REDUCE
-#define LISREG_MFMA_REDUCE (!LISREG_EXACT)
+#define LISREG_MFMA_REDUCE 0
 #endif
 // LDS of the reduction: one private region per wavefront (kRedWaveFloats floats) inside one array of the kernel.
 //   butterfly / exact build: the region starts with the wave's 28 sums (doubles);
@@ -484,9 +486,12 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
 
 // Residual model shared by the search front-ends that re-fit every iteration.
 // (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
+// kTagged: the ids come out of cell rows and carry the entry's position in its row (crow_tagged); `stage` / `stage_en` = this lane's row as
+// staged in LDS and the number of entries of it there (null / 0: nothing staged) — a neighbour among them is read from LDS.
+template <bool kTagged = false>
 __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int i2, int i3, int i4, const GridIndex& g,
                                                 const float4 q4, float qx, float qy, float qz, const DevParams& P, int kind,
-                                                float cf[4])
+                                                float cf[4], const v4f* stage = nullptr, int stage_en = 0)
 {
     cf[0] = cf[1] = cf[2] = cf[3] = 0.f;
     bool ok = false;
@@ -501,7 +506,21 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
         n2.x = qx - 0.12f; n2.y = qy - 0.09f; n2.z = qz; n2.w = 0.f;  n3.x = qx + 0.05f; n3.y = qy - 0.14f; n3.z = qz; n3.w = 0.f;
         n4.x = qx + 0.01f * (float)(i4 & 7); n4.y = qy + 0.21f; n4.z = qz; n4.w = 0.f;
 #else
-        const v4f n0 = LISREG_LD4(gp, i0), n1 = LISREG_LD4(gp, i1), n2 = LISREG_LD4(gp, i2), n3 = LISREG_LD4(gp, i3), n4 = LISREG_LD4(gp, i4);
+        v4f n0, n1, n2, n3, n4;
+        if (kTagged) {
+            // tag - 1 = position in the row; unsigned: tag 0 (an id that did not come out of a row) wraps past every bound
+            const unsigned t0 = ((unsigned)i0 >> kCrowTagShift) - 1u, t1 = ((unsigned)i1 >> kCrowTagShift) - 1u, t2 = ((unsigned)i2 >> kCrowTagShift) - 1u,
+                           t3 = ((unsigned)i3 >> kCrowTagShift) - 1u, t4 = ((unsigned)i4 >> kCrowTagShift) - 1u;
+            const unsigned en = (unsigned)stage_en;
+            const bool l0 = t0 < en, l1 = t1 < en, l2 = t2 < en, l3 = t3 < en, l4 = t4 < en;
+            if (l0) n0 = stage[t0]; else n0 = LISREG_LD4(gp, i0 & kCrowIdMask);
+            if (l1) n1 = stage[t1]; else n1 = LISREG_LD4(gp, i1 & kCrowIdMask);
+            if (l2) n2 = stage[t2]; else n2 = LISREG_LD4(gp, i2 & kCrowIdMask);
+            if (l3) n3 = stage[t3]; else n3 = LISREG_LD4(gp, i3 & kCrowIdMask);
+            if (l4) n4 = stage[t4]; else n4 = LISREG_LD4(gp, i4 & kCrowIdMask);
+        } else {
+            n0 = LISREG_LD4(gp, i0); n1 = LISREG_LD4(gp, i1); n2 = LISREG_LD4(gp, i2); n3 = LISREG_LD4(gp, i3); n4 = LISREG_LD4(gp, i4);
+        }
 #endif
         nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
         nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
@@ -518,13 +537,15 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
     return ok;
 }
 
+template <bool kTagged = false>
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
                                                     const float* jk, const DevParams& P, int kind,
-                                                    float* s_red, double* __restrict__ out, int* dbg_ok = nullptr)
+                                                    float* s_red, double* __restrict__ out, int* dbg_ok = nullptr,
+                                                    const v4f* stage = nullptr, int stage_en = 0)
 {
     float cf[4];
-    const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
+    const bool ok = residual_coeffs<kTagged>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf, stage, stage_en);
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
     row_and_reduce(ok, cf, q4, jk, P, s_red, out);
 }
@@ -884,6 +905,17 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 // per-column maxima.  Lists are flushed whenever a lane's list is full, which also re-prunes against the shrinking bound
 // during the wide early-iteration walks.  Same columns, same candidate order, same inserts: the result is identical.
 constexpr int kWalkCap = 8;
+// cell rows staged in LDS (k_assoc_walk<.., 2, 1>): a wavefront's 4-KB region holds a row-id table and the first 16 entries of up to
+// kStageS16 rows, or the first 8 entries of up to kStageS8 rows (one pad record per row)
+// Built, exact to every GPU test and measured in round 5 (profiles/r05_kernel_experiments.md, section 3): 188-194 us per steady-state launch
+// against 188-192 without — the launch is bound by vector-ALU issue, not by its loads.  Off by default; -DLISREG_STAGE_ROWS=1 builds it.
+#ifndef LISREG_STAGE_ROWS
+#define LISREG_STAGE_ROWS 0
+#endif
+constexpr bool kStageRows = LISREG_STAGE_ROWS != 0;
+constexpr int kStageBase = 128;                    // bytes: the row-id table (<= 32 ints) comes first
+constexpr int kStageS16 = 14, kStageS8 = 27;
+static_assert(kStageBase + kStageS16 * (16 * 16 + 16) <= 4096 && kStageBase + kStageS8 * (8 * 16 + 16) <= 4096 && kStageS8 <= 32, "a wavefront's LDS region is 4 KB");
 constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of this length or more are shared by the kQ lanes
 // INNER: restrict this pass to the 3 x 3 columns around the query's own column and remember that box (sx0..sy1);
 // SKIP: leave out the columns of the remembered box (a preceding INNER pass covered them with a z-range at least as wide).
@@ -1139,10 +1171,13 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
 // falls into (lisreg_index.hip, k_crow_build), so d_m = |q - m| is bounded by the cell size whatever the query's distance from the surface:
 // the same certificate as the graph scan (stop at the first entry farther from m than c5 + d_m; an exhausted list certifies through
 // rho(m) > c5 + d_m), no anchor carried between iterations, no anchor point to fetch, no hop.  No certificate -> the cell walk, seeded.
-#define LISREG_CELL_SCAN() do { \
+// Where the head of the row is staged in LDS (ST_: wave-uniform; SP_ = the lane's staged row, EN_ entries of it), the first EN_ / 4 groups
+// come from there — no memory round trip between them — and the rest of the row from memory as before.  Same entries, same order: same five.
+#define LISREG_CELL_SCAN(ST_, EN_, SP_) do { \
             const gptr_f4 R_ = (gptr_f4)(crow + (size_t)row_ * kGraphK); \
-            const v4f r0_ = R_[0], r1_ = R_[1], r2_ = R_[2], r3_ = R_[3]; \
-            const v2f am_ = cmeta[row_]; \
+            v4f r0_, r1_, r2_, r3_; \
+            if (ST_) { r0_ = (SP_)[0]; r1_ = (SP_)[1]; r2_ = (SP_)[2]; r3_ = (SP_)[3]; } \
+            else { r0_ = R_[0]; r1_ = R_[1]; r2_ = R_[2]; r3_ = R_[3]; } \
             const float rho2_ = am_.x; \
             const int cnt_ = __float_as_int(am_.y); \
             v4f ap_; ap_.x = mx_; ap_.y = my_; ap_.z = mz_; ap_.w = 0.f; \
@@ -1178,7 +1213,9 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY_ND); \
             } \
             _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_ && LISREG_XP_SCAN_GROUPS(g_); ++g_) { \
-                const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
+                v4f e0g_, e1g_, e2g_, e3g_; \
+                if ((ST_) && 4 * g_ < (EN_)) { e0g_ = (SP_)[4 * g_]; e1g_ = (SP_)[4 * g_ + 1]; e2g_ = (SP_)[4 * g_ + 2]; e3g_ = (SP_)[4 * g_ + 3]; } \
+                else { e0g_ = R_[4 * g_]; e1g_ = R_[4 * g_ + 1]; e2g_ = R_[4 * g_ + 2]; e3g_ = R_[4 * g_ + 3]; } \
                 LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); \
             } \
             if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
@@ -1306,12 +1343,16 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     float b0, b1, b2, b3, b4;
     int   i0, i1, i2, i3, i4;
     bool  tie = false;                                     // kTies: an equal-distance pair that can matter was met
+    int   stage_en = 0;                                    // cell rows: entries per row staged in this wavefront's LDS region (0: none)
+    const v4f* stage_sp = nullptr;                         //            this lane's staged row
 #define LISREG_LIST_INIT() do { b0 = b1 = b2 = b3 = b4 = P.tau; i0 = i1 = i2 = i3 = i4 = -1; } while (0)
     if (kGraph) {
         // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
         bool need_walk = valid, scanned = false;
         if (kGraph == 2) {
             // search_mode 5: the row of the cell (or octant) the query is in — nothing carried between iterations
+            int row_ = -1;
+            float mx_ = 0.f, my_ = 0.f, mz_ = 0.f;
             if (valid && g.crow_tab) {
                 // a query outside the grid (the target's bounding box: a wall seen from a pose that is still off puts half of its points
                 // there) takes the row of the nearest boundary cell — any row is valid for any query, the certificate works with the
@@ -1320,31 +1361,75 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
                 const float tx = (qx - g.ox) * g.inv_cell, ty = (qy - g.oy) * g.inv_cell, tz = (qz - g.oz) * g.inv_cell;
                 const int gx = (int)floorf(tx), gy = (int)floorf(ty), gz = (int)floorf(tz);
                 const int hx = min(max(gx, 0), g.nx - 1), hy = min(max(gy, 0), g.ny - 1), hz = min(max(gz, 0), g.nz - 1);
-                {
-                    const int v = ((gptr_i32)g.crow_tab)[(hx * g.ny + hy) * g.nz + hz];
-                    if (v >= 0) {
-                        float fx = 0.5f, fy = 0.5f, fz = 0.5f;
-                        int row_ = v >> 8;
-                        {
-                            const bool ux = tx - (float)hx >= 0.5f, uy = ty - (float)hy >= 0.5f, uz = tz - (float)hz >= 0.5f;
-                            const int oct = (int)ux + 2 * (int)uy + 4 * (int)uz, bit = 1 << oct;
-                            if (v & bit) {                     // the octant has a row of its own
-                                fx = ux ? 0.75f : 0.25f; fy = uy ? 0.75f : 0.25f; fz = uz ? 0.75f : 0.25f;
-                                row_ += 1 + __popc(v & (bit - 1));
-                            }
+                const int v = ((gptr_i32)g.crow_tab)[(hx * g.ny + hy) * g.nz + hz];
+                if (v >= 0) {
+                    float fx = 0.5f, fy = 0.5f, fz = 0.5f;
+                    row_ = v >> 8;
+                    {
+                        const bool ux = tx - (float)hx >= 0.5f, uy = ty - (float)hy >= 0.5f, uz = tz - (float)hz >= 0.5f;
+                        const int oct = (int)ux + 2 * (int)uy + 4 * (int)uz, bit = 1 << oct;
+                        if (v & bit) {                     // the octant has a row of its own
+                            fx = ux ? 0.75f : 0.25f; fy = uy ? 0.75f : 0.25f; fz = uz ? 0.75f : 0.25f;
+                            row_ += 1 + __popc(v & (bit - 1));
                         }
-                        const float mx_ = crow_centre(g.ox, g.cell, hx, fx), my_ = crow_centre(g.oy, g.cell, hy, fy), mz_ = crow_centre(g.oz, g.cell, hz, fz);
-                        const gptr_f4 crow = (gptr_f4)g.crow;
-                        const gptr_f2 cmeta = (gptr_f2)g.crow_meta;
-                        bool certified = false;
-                        scanned = true;
-                        LISREG_CELL_SCAN();
-                        need_walk = !certified;
-                    } else if (v == -2 && hx == gx && hy == gy && hz == gz && P.tau <= (2.f * g.cell - 2.f * kEps) * (2.f * g.cell - 2.f * kEps)) {
-                        need_walk = false;                     // nothing within two cells of this one: no neighbour inside sqrt(tau)
                     }
+                    mx_ = crow_centre(g.ox, g.cell, hx, fx); my_ = crow_centre(g.oy, g.cell, hy, fy); mz_ = crow_centre(g.oz, g.cell, hz, fz);
+                } else if (v == -2 && hx == gx && hy == gy && hz == gz && P.tau <= (2.f * g.cell - 2.f * kEps) * (2.f * g.cell - 2.f * kEps)) {
+                    need_walk = false;                     // nothing within two cells of this one: no neighbour inside sqrt(tau)
                 }
             }
+            const gptr_f4 crow = (gptr_f4)g.crow;
+            const gptr_f2 cmeta = (gptr_f2)g.crow_meta;
+            const bool scan_ = row_ >= 0;
+            v2f am_; am_.x = 0.f; am_.y = 0.f;
+            if (scan_) am_ = cmeta[row_];                  // (rho^2, count): asked for before the staging round trip
+            // ---- the heads of the rows this wavefront needs, staged in LDS once (round 5) ---------------------------------------------
+            // Consecutive queries of a scan fall into the same octant (0.25 m) a few at a time: a wavefront of 64 needs ~18 distinct rows
+            // (median 14).  Each lane fetching its own 64 bytes per group of four entries means four gather instructions per group over those
+            // ~18 lines, a dependent round trip between groups, and five more gathers for the kept neighbours at the end.  Here the leaders
+            // of the runs of equal rows post their row ids, the wavefront loads the first 16 entries (up to kStageS16 rows) or 8 entries (up
+            // to kStageS8 rows) of every posted row with one fully coalesced 16-byte-per-lane load per 4 / 8 rows into its private LDS
+            // region, and every lane scans its row out of LDS.  Entries carry their position in the row (crow_tagged), so a kept neighbour
+            // that came out of the staged part is read back from LDS by the fit (residual_coeffs) instead of being gathered again.
+            if (kQ == 1 && kStageRows) {
+                const int lane_ = tid & 63;
+                const int prev_ = __shfl_up(row_, 1);
+                const bool lead_ = scan_ && (lane_ == 0 || prev_ != row_);
+                const unsigned long long lm_ = __builtin_amdgcn_ballot_w64(lead_);
+                const int L_ = __popcll(lm_);
+                stage_en = (L_ >= 1 && L_ <= kStageS16) ? 16 : ((L_ >= 1 && L_ <= kStageS8) ? 8 : 0);
+                if (stage_en) {
+                    const int below_ = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm_, 0u));
+                    const int slot_ = lead_ ? below_ : below_ - 1;
+                    char* sw_ = reinterpret_cast<char*>(s_red) + (tid >> 6) * (kRedWaveFloats * 4);
+                    int* s_rowid_ = reinterpret_cast<int*>(sw_);
+                    if (lead_) s_rowid_[slot_] = row_;
+                    const int stride_ = stage_en * 16 + 16;                    // one 16-byte pad per row: rows start in different banks
+                    const int sub_ = stage_en == 16 ? (lane_ >> 4) : (lane_ >> 3), ent_ = lane_ & (stage_en - 1), spp_ = stage_en == 16 ? 4 : 8;
+                    v4f t_[4];
+#pragma unroll
+                    for (int p_ = 0; p_ < 4; ++p_) {
+                        const int sl_ = p_ * spp_ + sub_;
+                        t_[p_].x = t_[p_].y = t_[p_].z = t_[p_].w = 0.f;
+                        if (sl_ < L_) t_[p_] = crow[(size_t)s_rowid_[sl_] * kGraphK + ent_];
+                    }
+#pragma unroll
+                    for (int p_ = 0; p_ < 4; ++p_) {
+                        const int sl_ = p_ * spp_ + sub_;
+                        if (sl_ < L_) *reinterpret_cast<v4f*>(sw_ + kStageBase + sl_ * stride_ + ent_ * 16) = t_[p_];
+                    }
+                    stage_sp = reinterpret_cast<const v4f*>(sw_ + kStageBase + (scan_ ? slot_ : 0) * stride_);
+                }
+            }
+            if (scan_) {
+                bool certified = false;
+                scanned = true;
+                LISREG_CELL_SCAN(stage_en != 0, stage_en, stage_sp);
+                need_walk = !certified;
+            }
+            // a walking lane's run lists overwrite the staged rows of its wavefront (the same LDS): such a wavefront gathers the kept
+            // neighbours from memory again (rare: no lane walks once the pose has settled)
+            if (__builtin_amdgcn_ballot_w64(need_walk) != 0ull) stage_en = 0;
         } else
         if (valid && it->iter > 0 && g.nbr) {
             int anchor = nn[qflat];
@@ -1375,6 +1460,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
             }
         }
         if (need_walk) {
+            if (kGraph == 2 && scanned) { i0 = crow_id(i0); i1 = crow_id(i1); i2 = crow_id(i2); i3 = crow_id(i3); i4 = crow_id(i4); }   // the walk compares plain ids
             int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;
             if (kWide) {
                 LISREG_WALK_LIST(3.0e38f, true, false);
@@ -1461,7 +1547,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
         bool same = true;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const int o = ids[k] >= 0 ? __float_as_int(pts[ids[k]].w) : -1;
+            const int o = ids[k] >= 0 ? __float_as_int(pts[kGraph == 2 ? crow_id(ids[k]) : ids[k]].w) : -1;
             same = same && dbg_nn[(size_t)k * n_elems + qflat] == o;
             dbg_nn[(size_t)k * n_elems + qflat] = o;
         }
@@ -1479,8 +1565,8 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
 #endif
     if (kQ == 1) {
-        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out,
-                            dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
+        residual_and_reduce<kGraph == 2>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out,
+                                         dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr, stage_sp, stage_en);
     } else {
         // kQ lanes per query: the coefficients go to memory and k_rows_reduce builds the partial rows with the SAME 256-query
         // workgroups and the SAME reduction tree as the kQ = 1 kernel, so the normal equations — hence every pose — are

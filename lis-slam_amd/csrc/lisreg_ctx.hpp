@@ -125,7 +125,7 @@ struct lisreg_ctx {
     unsigned char* pack_host[2] = { nullptr, nullptr };
     size_t       pack_cap[2] = { 0, 0 };
     lisreg::DevBuf pack_dev[2];
-    int            feeder_engine = 1;                    // 0: the copy engine takes no chunks; 1: when idle (default); 2: whenever a packed chunk is not ready (tests)
+    int            feeder_engine = 1;                    // 0: the copy engine takes no chunks; 1: when idle (default); 2: whenever a packed chunk is not ready; 3: the same and one chunk up front, ready or not (tests)
     int            pack_stolen = 0, pack_chunks_n = 0;   // last lisreg_stage_host_items: chunks the copy engine took / all chunks
     lisreg::DevBuf pack_raw[2];                // structs that crossed the link as they are (chunks the copy engine took over), packed on the device
     unsigned char* up_host = nullptr;          // pinned staging of lisreg_upload_cloud

@@ -944,24 +944,31 @@ __device__ __forceinline__ float crow_inscribed(const GridIndex& g, const CrowBl
 
 constexpr unsigned kInfQ = 0x7f800000u;                     // +inf, payload bits clear
 
+// topc (x, y, z of the listed point, per lane) is filled where it costs no memory access: a block of at most 64 candidates is ONE chunk,
+// every candidate's record is in some lane's registers, and three lane permutes put it next to its key — the row is then written without
+// gathering the points a second time (have_c; a multi-chunk list leaves it to crow_emit's gather).
 template <int R>
 __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>& b, float qx, float qy, float qz,
-                                          int (*s_off)[64], int (*s_js)[64], unsigned& topk, int& topi)
+                                          int (*s_off)[64], int (*s_js)[64], unsigned& topk, int& topi, float4& topc, bool& have_c)
 {
     constexpr int W = 2 * R + 1, NR = W * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     topk = kInfQ; topi = -1;                                // running kGraphK best, ascending: quantised key and id per lane
+    topc = make_float4(0.f, 0.f, 0.f, 0.f);
+    have_c = b.total <= 64;
 #pragma unroll 1
     for (int c0 = 0; c0 < b.total; c0 += 64) {
         const int t = c0 + lane;
         unsigned k = kInfQ | (unsigned)lane;
         int cj = -1;
+        float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < b.total) {
             int lo = 0, hi = NR - 1;                        // last run whose offset is <= t
 #pragma unroll
             for (int it = 0; it < (NR > 32 ? 6 : 5); ++it) { const int mid = (lo + hi + 1) >> 1; if (s_off[wave][mid] <= t) lo = mid; else hi = mid - 1; }
             const int j = s_js[wave][lo] + (t - s_off[wave][lo]);
             const float4 c = g.pts[j];
+            cc = c;
             const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
             const float d2 = ex * ex + ey * ey + ez * ez;
             if (d2 < 3.0e38f) { k = (__float_as_uint(d2) & ~0x7Fu) | (unsigned)lane; cj = j; }     // NaN / Inf points are never listed
@@ -969,6 +976,7 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
         k = sort64x32(k, lane);
         const int cs = __shfl(cj, (int)(k & 63u));
         const unsigned ck = k & ~0x7Fu;
+        if (have_c) { const int sl = (int)(k & 63u); topc = make_float4(__shfl(cc.x, sl), __shfl(cc.y, sl), __shfl(cc.z, sl), 0.f); }
         if (c0 == 0) { topk = ck; topi = cs; }
         else {
             // the lane-wise minimum of the running list and the reversed chunk is the 64 smallest of both as one bitonic sequence
@@ -985,7 +993,8 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
 
 // one row: the entries of the list inside rho (the block's inscribed radius, or the first point left out), padded with (q, -1)
 __device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float qy, float qz, float rc, unsigned topk, int topi,
-                                           float4* __restrict__ row_out, float2* __restrict__ meta_out, bool& keep, float4& e)
+                                           float4* __restrict__ row_out, float2* __restrict__ meta_out, bool& keep, float4& e,
+                                           const float4 topc = make_float4(0.f, 0.f, 0.f, 0.f), bool have_c = false)
 {
     const int lane = threadIdx.x & 63;
     const float tk = __uint_as_float(topk);
@@ -994,7 +1003,11 @@ __device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float q
     keep = topi >= 0 && tk <= rho2;
     const int cnt = __popcll(__ballot(keep));
     e = make_float4(qx, qy, qz, __int_as_float(-1));
-    if (keep) { const float4 c = g.pts[topi]; e = make_float4(c.x, c.y, c.z, __int_as_float(topi)); }
+    if (keep) {
+        float4 c = topc;
+        if (!have_c) c = g.pts[topi];
+        e = make_float4(c.x, c.y, c.z, __int_as_float(crow_tagged(topi, lane)));
+    }
     row_out[lane] = e;
     if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
     return rho2;
@@ -1012,10 +1025,10 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
     const int lane = threadIdx.x & 63;
     constexpr float kEps = 1e-3f;
     const CrowBlock<R> b = crow_runs<R>(g, hx, hy, hz, s_off, s_js);
-    unsigned topk; int topi;
-    crow_list<R>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi);
+    unsigned topk; int topi; float4 topc; bool have_c;
+    crow_list<R>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c);
     bool keep; float4 e;
-    const float rho2 = crow_emit(g, q.x, q.y, q.z, crow_inscribed<R>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e);
+    const float rho2 = crow_emit(g, q.x, q.y, q.z, crow_inscribed<R>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e, topc, have_c);
     if (mask) {
         const float off = 0.25f * g.cell * 1.7320508f;                         // |octant centre - cell centre|
         const float rho_o = fmaxf(sqrtf(rho2) - off - 2.f * kEps, 0.f), rho_o2 = rho_o * rho_o;
@@ -1034,17 +1047,20 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
                     k = (__float_as_uint(ex * ex + ey * ey + ez * ez) & ~0x7Fu) | (unsigned)lane;
                 }
                 k = sort64x32(k, lane);
-                const int oi = __shfl(keep ? topi : -1, (int)(k & 63u));
+                const int sl = (int)(k & 63u);
+                const int oi = __shfl(keep ? topi : -1, sl);
+                // the coordinates travel with the id: they are the centre row's entries, in some lane's registers (no second gather)
+                const float ox = __shfl(e.x, sl), oy = __shfl(e.y, sl), oz = __shfl(e.z, sl);
                 const bool okeep = oi >= 0 && __uint_as_float(k & ~0x7Fu) <= rho_o2;
                 const int ocnt = __popcll(__ballot(okeep));
                 float4 oe = make_float4(mx, my, mz, __int_as_float(-1));
-                if (okeep) { const float4 c = g.pts[oi]; oe = make_float4(c.x, c.y, c.z, __int_as_float(oi)); }
+                if (okeep) oe = make_float4(ox, oy, oz, __int_as_float(crow_tagged(oi, lane)));
                 orow[lane] = oe;
                 if (lane == 0) meta_out[slot] = make_float2(rho_o2, __int_as_float(ocnt));
             } else {
-                unsigned ok; int oi; bool okeep; float4 oe;
-                crow_list<R>(g, b, mx, my, mz, s_off, s_js, ok, oi);
-                (void)crow_emit(g, mx, my, mz, crow_inscribed<R>(g, b, mx, my, mz), ok, oi, orow, meta_out + slot, okeep, oe);
+                unsigned ok; int oi; bool okeep; float4 oe, oc; bool ohave;
+                crow_list<R>(g, b, mx, my, mz, s_off, s_js, ok, oi, oc, ohave);
+                (void)crow_emit(g, mx, my, mz, crow_inscribed<R>(g, b, mx, my, mz), ok, oi, orow, meta_out + slot, okeep, oe, oc, ohave);
             }
             ++slot;
         }
@@ -1056,7 +1072,17 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
 // crow_tab[cell] = -2: nothing within two cells; -1: no row (its rows did not fit the capacity the buffers were sized for); else
 // (first row << 8) | octant mask, rows = [centre, the octants of the mask in ascending order].
 constexpr int kCrowCPW = 8;
-__global__ __launch_bounds__(256) void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
+#ifndef LISREG_CROW_WAVES
+#define LISREG_CROW_WAVES 6          // waves per SIMD the row build is compiled for (0: the compiler's choice = 86 registers, 5 waves).  The build is a
+                                     // chain of dependent loads per cell: measured (profiles/r05_kernel_experiments.md) 6 waves with 3 spilled registers beat 5
+                                     // without by 2-3 % of a configs[1] step; 7 and 8 waves (10 / 18 spilled) lose it again
+#endif
+#if LISREG_CROW_WAVES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LISREG_CROW_WAVES, LISREG_CROW_WAVES)))
+#else
+__global__ __launch_bounds__(256)
+#endif
+void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
                                                     const int* __restrict__ scan, int cap, int use_r3 /* 0: never the 7^3 block (experiments) */)
 {
     __shared__ int s_off[4][64], s_js[4][64];

@@ -40,6 +40,15 @@ struct GridIndex {
     const int*    crow_tab;
 };
 
+// Cell-row entries carry their position in the row next to the point's sorted position: w = id | tag << kCrowTagShift, tag = min(j + 1, 31)
+// for entry j (padded entries stay -1).  The scan stages the head of every row a wavefront needs in LDS once (lisreg_assoc.hip); a kept
+// neighbour whose tag says "among the staged entries" is then read back from LDS instead of being gathered from the point array.  Ids of
+// cell-row targets are therefore limited to 2^26 points (a bigger target takes another front-end).
+constexpr int kCrowTagShift = 26;
+constexpr int kCrowIdMask   = (1 << kCrowTagShift) - 1;
+__host__ __device__ __forceinline__ int crow_tagged(int id, int j) { return id | ((j + 1 < 31 ? j + 1 : 31) << kCrowTagShift); }
+__host__ __device__ __forceinline__ int crow_id(int w) { return w < 0 ? w : (w & kCrowIdMask); }
+
 // centre coordinate of cell h (off = 0.5f) or of one of its halves (0.25f / 0.75f) along one axis: the build and the scan must agree to
 // the bit (the scan re-derives the list distances of a row from this centre) although their translation units are compiled with different
 // contraction settings: ONE fused multiply-add, whatever the flags (hipcc's __fmul_rn / __fadd_rn are plain operators and do get contracted)

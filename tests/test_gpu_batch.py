@@ -462,7 +462,7 @@ def test_staged_items_through_the_copy_engine_equal_the_packed_ones(labelled):
             else: arr[i].src_surf = C.c_void_p(t.ptr); arr[i].n_surf = len(a)
         arr[i].stride_bytes = cases[i]["src_surf"].dtype.itemsize; arr[i].fmt = lisreg.FMT_XYZIL if labelled else lisreg.FMT_XYZI
     taken = []
-    for engine in (2, 0, 1):
+    for engine in (3, 0, 1):          # 3 = mode 2 plus one chunk handed to the engine up front (mode 2 alone takes none when the packing threads keep ahead)
         ctx.set_option("feeder_copy_engine", engine)
         staged = (lisreg.Item * n)()
         assert ctx._L.lisreg_stage_host_items(ctx._h, n, arr, staged) == 0
@@ -472,7 +472,7 @@ def test_staged_items_through_the_copy_engine_equal_the_packed_ones(labelled):
         ctx._n_items = n
         T, st = ctx.batch_fetch()
         assert np.array_equal(T, T_ref) and st == st_ref, engine
-        if engine == 2:
+        if engine == 3:
             # "the caller's clouds are not referenced after the call returns" holds for pinned clouds too: overwrite them right after
             # staging (before the batch is even prepared) and the staged records must still be the original ones
             staged2 = (lisreg.Item * n)()
