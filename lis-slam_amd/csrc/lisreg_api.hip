@@ -947,11 +947,19 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     // XCD-aware dispatch order (lisreg_assoc.hip, launch_xcd_order): two small launches per run, at the initial poses.  Auto: the graph
     // front-end with >= 32 registrations (measured: +2.5 % at 64 scans, +4.9 % at 256; with 8 big scans the sectors are unevenly loaded
     // and it costs 2 %; the walk front-end gains nothing)
-    c->xcd_now = (c->mode_now == 3 || c->mode_now == 5) && c->lanes_q != 8 && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32));
+    // Round 5: a batch whose registrations bring targets of their own (configs[3]: 256 candidate pairs, 256 x 6 MB of index) takes the order
+    // by TARGET whatever the front-end — whole targets per XCD, so that an L2 holds the one or two targets its CUs are working on instead of
+    // a slice of all eight-plus in flight.
+    // (measured on configs[3], 256 own-target registrations through the cell walk: 13 539 reg/s against 13 716 in plain order — no gain, the walk
+    //  is not bound by L2 misses either; the order by target is taken only with xcd_order = 1, profiles/r05_kernel_experiments.md)
+    const bool many_targets = c->batch_slots.size() >= 8 && c->xcd_order == 1;
+    c->xcd_now = c->lanes_q != 8 && c->mode_now != 0 &&
+                 (((c->mode_now == 3 || c->mode_now == 5) && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32))) ||
+                  (many_targets && c->xcd_order != 0 && c->n_blocks >= 2048));
     if (c->xcd_now) {
         HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
         launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
-                         c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, st);
+                         c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, st);
     }
     const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk != 0;
     // how often the host looks at the "registrations finished" counter: a skipped launch of a big batch still dispatches tens of

@@ -1629,12 +1629,20 @@ __global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __rest
 constexpr int kSectorBins = 1024;
 __global__ __launch_bounds__(256) void k_xcd_keys(const BlockDesc* __restrict__ blocks, int n_blocks, const Segment* __restrict__ segs,
                                                   const GridIndex* __restrict__ grids, const ItemState* __restrict__ items,
-                                                  const float4* __restrict__ sorted_all, int* __restrict__ keys)
+                                                  const float4* __restrict__ sorted_all, int by_target, int* __restrict__ keys)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= n_blocks) return;
     const BlockDesc bd = blocks[b];
     const Segment sg = segs[bd.seg];
+    if (by_target) {
+        // a batch whose registrations have targets of their own (loop-closure candidate pairs): the blocks are ranked by target slot, slots
+        // x, x + 8, ... first for x = 0 .. 7, so that the x-th eighth of the ranking — XCD x's share — holds whole targets: each L2 then
+        // serves one target (3-6 MB with its cell table) at a time instead of a slice of every target in flight
+        const int slot = sg.target >> 1;
+        keys[b] = ((slot & 7) << 7) | min(slot >> 3, 127);
+        return;
+    }
     const GridIndex g = grids[sg.target];
     const float* M = items[bd.item].M;
     const int e = bd.start + bd.count / 2;
@@ -1699,10 +1707,10 @@ __global__ __launch_bounds__(1024) void k_xcd_order(int n_blocks, const int* __r
 
 #if !LISREG_EXACT
 void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,
-                      const float4* sorted_all, int* keys, int* order, hipStream_t st)
+                      const float4* sorted_all, bool by_target, int* keys, int* order, hipStream_t st)
 {
     if (n_blocks <= 0) return;
-    k_xcd_keys<<<(n_blocks + 255) / 256, 256, 0, st>>>(blocks, n_blocks, segs, grids, items, sorted_all, keys);
+    k_xcd_keys<<<(n_blocks + 255) / 256, 256, 0, st>>>(blocks, n_blocks, segs, grids, items, sorted_all, by_target ? 1 : 0, keys);
     k_xcd_order<<<1, 1024, 0, st>>>(n_blocks, keys, order);
 }
 #endif
@@ -1739,10 +1747,10 @@ static void launch_assoc_impl(const BlockDesc* blocks, int n_blocks, const Segme
     else if (mode == 1) {
         if (wide)
             k_assoc_walk<true, 0, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                              first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+                                                                              first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
         else
             k_assoc_walk<false, 0, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
-                                                                               first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, nullptr);
+                                                                               first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
     } else if (mode == 5) {
         if (wide)
             k_assoc_walk<true, 2, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,

@@ -1071,7 +1071,10 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
 // load and store for all of them), then the cells that have rows one after the other, the whole wave on each.
 // crow_tab[cell] = -2: nothing within two cells; -1: no row (its rows did not fit the capacity the buffers were sized for); else
 // (first row << 8) | octant mask, rows = [centre, the octants of the mask in ascending order].
-constexpr int kCrowCPW = 8;
+#ifndef LISREG_CROW_CPW
+#define LISREG_CROW_CPW 8
+#endif
+constexpr int kCrowCPW = LISREG_CROW_CPW;
 #ifndef LISREG_CROW_WAVES
 #define LISREG_CROW_WAVES 6          // waves per SIMD the row build is compiled for (0: the compiler's choice = 86 registers, 5 waves).  The build is a
                                      // chain of dependent loads per cell: measured (profiles/r05_kernel_experiments.md) 6 waves with 3 spilled registers beat 5

@@ -97,6 +97,35 @@ __device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const Gr
     return bi;
 }
 
+// A seed for a query that has none (the first ICP iteration): the nearest of up to four points out of the z-window [hz - 1, hz + 1] of the
+// query's own (x, y) column of the grid — one contiguous run of the cell-sorted array, two table reads and four records.  Any point will do
+// (nn1_search treats the seed as an ordinary candidate); a near one makes the first pass's radius the distance to it instead of a 0.5 m box
+// that doubles until something is inside.  -1: the column has nothing there.
+__device__ __forceinline__ int nn1_cell_seed(float qx, float qy, float qz, const GridIndex& g)
+{
+    if (g.n <= 0) return -1;
+    const int hx = gcoord(qx, g.ox, g.inv_cell), hy = gcoord(qy, g.oy, g.inv_cell), hz = gcoord(qz, g.oz, g.inv_cell);
+    if (hx < 0 || hx >= g.nx || hy < 0 || hy >= g.ny || hz < -1 || hz > g.nz) return -1;          // (a non-finite query saturates: out)
+    const int z0 = min(max(hz - 1, 0), g.nz - 1), z1 = min(max(hz + 1, 0), g.nz - 1);
+    const gptr_i32 cells = (gptr_i32)g.cell_start;
+    const gptr_f4 pts = (gptr_f4)g.pts;
+    const int base = (hx * g.ny + hy) * g.nz;
+    const int js = cells[base + z0], je = cells[base + z1 + 1];
+    if (js >= je) return -1;
+    const int n = je - js;
+    const int p1 = js + (n >> 2), p2 = js + (n >> 1), p3 = je - 1;
+    const v4f c0 = pts[js], c1 = pts[p1], c2 = pts[p2], c3 = pts[p3];
+    const float ax = qx - c0.x, ay = qy - c0.y, az = qz - c0.z, bx = qx - c1.x, by = qy - c1.y, bz = qz - c1.z;
+    const float ex = qx - c2.x, ey = qy - c2.y, ez = qz - c2.z, fx = qx - c3.x, fy = qy - c3.y, fz = qz - c3.z;
+    const float d0 = ax * ax + ay * ay + az * az, d1 = bx * bx + by * by + bz * bz;
+    const float d2 = ex * ex + ey * ey + ez * ez, d3 = fx * fx + fy * fy + fz * fz;
+    int a = js; float d = d0;
+    if (d1 < d) { d = d1; a = p1; }
+    if (d2 < d) { d = d2; a = p2; }
+    if (d3 < d) { a = p3; }
+    return a;
+}
+
 // map_scan_feature_pts_distance_removal (subMap.h:1076-1087).  The reference's unbounded search is cut at `cap2`, the largest
 // FINITE threshold (thresholds default to FLT_MAX, whose square is +inf): beyond it the predicate no longer depends on the
 // distance and its value is `keep_far`.
@@ -201,6 +230,31 @@ __device__ __forceinline__ int icp_find_item(const IcpItem* __restrict__ items, 
     return lo;
 }
 
+// Which alignment, and which of its blocks, a workgroup of a batch launch works on.  Plain launch: workgroup p = block p of the batch.
+// XCD-aware launch (round 5): MI355X hands workgroup p to XCD p & 7, and a batch of loop-closure candidates brings a target of its own per
+// alignment (3 MB of points + 2.5 MB of cell table each): in plain order the ~2 000 resident workgroups belong to four or five alignments
+// and every XCD's 4-MB L2 sees a slice of all of them.  Here XCD x works through the alignments x, x + 8, ... one after the other (workgroup
+// p = block p >> 3 of that sequence), so an L2 holds the one target its CUs are searching.  Results do not depend on the order: the
+// partial rows stay addressed by the batch-wide block number.  Returns -1 for a workgroup past its XCD's share.
+__device__ __forceinline__ int icp_locate(const IcpItem* __restrict__ items, int n_items, int xcd_mode, int* b)
+{
+    if (!xcd_mode) {
+        const int item = icp_find_item(items, n_items, blockIdx.x);
+        *b = (int)blockIdx.x - items[item].blk0;
+        return item;
+    }
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    if (k >= items[n_items + 1 + x].blk0) return -1;
+    int lo = 0, hi = ((n_items - x + 7) >> 3) - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[x + 8 * mid].xblk0 <= k) lo = mid; else hi = mid - 1;
+    }
+    const int item = x + 8 * lo;
+    *b = k - items[item].xblk0;
+    return item;
+}
+
 // value `k` of the b-th 256-query row of an item (rows of 256 / Q queries are folded pairwise: Q = 4 -> (r0 + r1) + (r2 + r3))
 template <int kAcc>
 __device__ __forceinline__ double icp_row256(const double* __restrict__ rows, int n_rows, int q, int b, int k)
@@ -225,48 +279,77 @@ __device__ __forceinline__ void apply4(const float* F, float x, float y, float z
 // iteration — kept that way rather than re-deriving the points from the cumulative transform), then determineCorrespondences
 // and the sums TransformationEstimationSVD needs.
 template <int Q>
-__global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ items, int n_items, const IcpState* __restrict__ states,
+__global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ items, int n_items, int xcd_mode, const IcpState* __restrict__ states,
                                                    float cap2, double* __restrict__ partials)
 {
+    const bool getenv_icp_seed0 = (xcd_mode & 2) == 0;       // bit 1 of xcd_mode: experiments switch the first iteration's seed off (LISREG_ICP_NO_SEED0)
     __shared__ double red[4][kIcpAcc];
-    const int item = icp_find_item(items, n_items, blockIdx.x);
+    int blk;
+    const int item = icp_locate(items, n_items, xcd_mode & 1, &blk);
+    if (item < 0) return;
     const IcpState* stp = &states[item];
     if (stp->done) return;
     const IcpItem I = items[item];
-    const int i = (int)((((long long)blockIdx.x - I.blk0) * 256 + threadIdx.x) / Q);
+    const int i = (int)(((long long)blk * 256 + threadIdx.x) / Q);
     const bool lead = (threadIdx.x & (Q - 1)) == 0;
-    double acc[kIcpAcc];
-#pragma unroll
-    for (int k = 0; k < kIcpAcc; ++k) acc[k] = 0.0;
+    // The 16 sums other than the squared distance are the 4 x 4 outer product (1, q) x (1, p) summed over the correspondences: count = 1*1,
+    // sum p = 1*p, sum q = q*1, sum q_r p_c.  They are reduced by a HALVING butterfly — 8 + 4 + 2 + 1 (+ 2) additions per lane instead of
+    // 16 x 6 — over exactly the pairs, and in exactly the order (lane ^ 1, 2, 4, 8, 16, 32), of wave_sum_up: the same tree, the same bits as
+    // the full butterflies this replaces (each addition has the same two operands; a + b = b + a to the bit).  What makes a halving
+    // butterfly cheap here is the placement: lane l keeps value (s ^ (l & 15)) in slot s, so at every level the value a lane keeps and the
+    // value its partner sends are the same slots for every lane — no selects; the placement itself is two conditional swaps per factor
+    // vector, made on the float factors before the products are formed.
+    float fa[4] = { 0.f, 0.f, 0.f, 0.f }, fb[4] = { 0.f, 0.f, 0.f, 0.f };
+    double dsum = 0.0;
     if (i < I.n) {
         const GridIndex g = *I.grid;
         // the first pass reads the source itself (and moves it by the guess), later ones the working copy: no copy up front
         const float4 s = stp->iters == 0 ? I.src[i] : I.cur[i];
         float px, py, pz, d2;
         apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
-        const int seed = stp->iters == 0 ? -1 : I.nn[i];              // last iteration's neighbour (position in the sorted target)
+        // last iteration's neighbour (position in the sorted target); the first iteration takes a point out of the query's own grid column
+        const int seed = stp->iters == 0 ? (getenv_icp_seed0 ? nn1_cell_seed(px, py, pz, g) : -1) : I.nn[i];
         const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2, seed);      // (all Q lanes have read their record before the lead lane writes)
         if (lead) { I.cur[i] = make_float4(px, py, pz, s.w); I.nn[i] = bi; }
         if (bi >= 0 && lead) {
             const float4 q = g.pts[bi];
-            acc[0] = 1.0;
-            acc[1] = px; acc[2] = py; acc[3] = pz;
-            acc[4] = q.x; acc[5] = q.y; acc[6] = q.z;
-            acc[7] = (double)q.x * px;  acc[8] = (double)q.x * py;  acc[9] = (double)q.x * pz;
-            acc[10] = (double)q.y * px; acc[11] = (double)q.y * py; acc[12] = (double)q.y * pz;
-            acc[13] = (double)q.z * px; acc[14] = (double)q.z * py; acc[15] = (double)q.z * pz;
-            acc[16] = d2;
+            fa[0] = 1.f; fa[1] = q.x; fa[2] = q.y; fa[3] = q.z;
+            fb[0] = 1.f; fb[1] = px;  fb[2] = py;  fb[3] = pz;
+            dsum = d2;
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kIcpAcc; ++k) {
-        const double v = wave_sum_up(acc[k]);
-        if (lane == 0) red[wave][k] = v;
+    {
+        // slot s <- value s ^ (lane & 15): value index = 4 * (row of fa) + (column of fb)
+#define LISREG_CSWAP(c_, x_, y_) do { const float tx_ = (x_), ty_ = (y_); (x_) = (c_) ? ty_ : tx_; (y_) = (c_) ? tx_ : ty_; } while (0)
+        const bool a1 = (lane & 4) != 0, a2 = (lane & 8) != 0, b1 = (lane & 1) != 0, b2 = (lane & 2) != 0;
+        LISREG_CSWAP(a1, fa[0], fa[1]); LISREG_CSWAP(a1, fa[2], fa[3]); LISREG_CSWAP(a2, fa[0], fa[2]); LISREG_CSWAP(a2, fa[1], fa[3]);
+        LISREG_CSWAP(b1, fb[0], fb[1]); LISREG_CSWAP(b1, fb[2], fb[3]); LISREG_CSWAP(b2, fb[0], fb[2]); LISREG_CSWAP(b2, fb[1], fb[3]);
+#undef LISREG_CSWAP
     }
+    double v16[16];
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) v16[sl] = (double)fa[sl >> 2] * (double)fb[sl & 3];
+    double v8[8], v4[4], v2[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v8[k] = v16[2 * k] + lane_xor_d<1>(v16[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v4[k] = v8[2 * k] + lane_xor_d<2>(v8[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v2[k] = v4[2 * k] + lane_xor_d<4>(v4[2 * k + 1]);
+    double v1 = v2[0] + lane_xor_d<8>(v2[1]);
+    v1 += lane_xor_d<16>(v1); v1 += lane_xor_d<32>(v1);              // lane l now holds the wavefront's total of value l & 15
+    dsum = wave_sum_up(dsum);
+    if (lane < 16) {
+        // back to the row layout the summing kernels read: 0 count, 1-3 sum p, 4-6 sum q, 7-15 sum q_r p_c (row-major), 16 sum d2
+        const int ra = lane >> 2, cb = lane & 3;
+        const int k = ra == 0 ? cb : (cb == 0 ? 3 + ra : 7 + 3 * (ra - 1) + (cb - 1));
+        red[wave][k] = v1;
+    }
+    if (lane == 0) red[wave][16] = dsum;
     __syncthreads();
     if (threadIdx.x < kIcpAcc)
-        partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        partials[(size_t)(I.blk0 + blk) * kIcpAcc + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // 3x3 SVD by one-sided Jacobi (double); U S V^T = A, singular values descending, U completed to an orthogonal matrix
@@ -431,13 +514,15 @@ __global__ __launch_bounds__(256) void k_icp_fitness(const float4* __restrict__ 
 
 // the batch forms of the two kernels above: block -> item table, rows of 256 / Q queries summed by the Q-independent tree
 template <int Q>
-__global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict__ items, int n_items, const IcpState* __restrict__ states,
+__global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict__ items, int n_items, int xcd_mode, const IcpState* __restrict__ states,
                                                        double* __restrict__ partials)
 {
     __shared__ double red[4][2];
-    const int item = icp_find_item(items, n_items, blockIdx.x);
+    int blk;
+    const int item = icp_locate(items, n_items, xcd_mode, &blk);
+    if (item < 0) return;
     const IcpItem I = items[item];
-    const int i = (int)((((long long)blockIdx.x - I.blk0) * 256 + threadIdx.x) / Q);
+    const int i = (int)(((long long)blk * 256 + threadIdx.x) / Q);
     double sum = 0, cnt = 0;
     if (i < I.n) {
         const GridIndex g = *I.grid;
@@ -451,7 +536,7 @@ __global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave][0] = sum; red[wave][1] = cnt; }
     __syncthreads();
-    if (threadIdx.x < 2) partials[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 2) partials[(size_t)(I.blk0 + blk) * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void k_icp_fit_reduce_b(const double* __restrict__ all_partials, const IcpItem* __restrict__ items,
@@ -650,13 +735,15 @@ int icp_blocks(int n) { return (int)(((long long)n * icp_lanes(n) + 255) / 256);
 int icp_batch_lanes(long long total) { return icp_lanes((int)std::min<long long>(total, 0x7fffffff)); }
 int icp_batch_blocks(int n, int q) { return (int)(((long long)n * q + 255) / 256); }
 
-void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
+void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int xcd_blocks, int q, IcpState* states, float cap2, double* partials,
                       hipStream_t stream)
 {
     if (n_items <= 0) return;
     if (total_blocks > 0) {
-        if (q == 1) k_icp_assoc<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
-        else        k_icp_assoc<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
+        static const int no_seed0 = getenv("LISREG_ICP_NO_SEED0") ? 2 : 0;
+        const int grid = xcd_blocks > 0 ? 8 * xcd_blocks : total_blocks, xm = (xcd_blocks > 0 ? 1 : 0) | no_seed0;
+        if (q == 1) k_icp_assoc<1><<<grid, 256, 0, stream>>>(items, n_items, xm, states, cap2, partials);
+        else        k_icp_assoc<4><<<grid, 256, 0, stream>>>(items, n_items, xm, states, cap2, partials);
     }
 }
 
@@ -666,12 +753,13 @@ void launch_icp_solve(const IcpItem* items, int n_items, int q, IcpState* states
     if (n_items > 0) k_icp_solve<<<n_items, 1024, 0, stream>>>(partials, items, states, q, max_iters, eps_t, eps_mse, n_done);
 }
 
-void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream)
+void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int xcd_blocks, int q, IcpState* states, double* partials, hipStream_t stream)
 {
     if (n_items <= 0) return;
     if (total_blocks > 0) {
-        if (q == 1) k_icp_fitness_b<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, partials);
-        else        k_icp_fitness_b<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, partials);
+        const int grid = xcd_blocks > 0 ? 8 * xcd_blocks : total_blocks, xm = xcd_blocks > 0 ? 1 : 0;
+        if (q == 1) k_icp_fitness_b<1><<<grid, 256, 0, stream>>>(items, n_items, xm, states, partials);
+        else        k_icp_fitness_b<4><<<grid, 256, 0, stream>>>(items, n_items, xm, states, partials);
     }
     k_icp_fit_reduce_b<<<n_items, 256, 0, stream>>>(partials, items, states, q);
 }
