@@ -889,6 +889,30 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     if (!c->prepared) return fail(c, LISREG_ERR_ARG, "batch_run: no prepared batch");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    // XCD-aware dispatch order (lisreg_assoc.hip, launch_xcd_order): two small launches per run, at the initial poses.  Auto: the graph
+    // front-end with >= 32 registrations (measured: +2.5 % at 64 scans, +4.9 % at 256; with 8 big scans the sectors are unevenly loaded
+    // and it costs 2 %; the walk front-end gains nothing)
+    // Round 5: a batch whose registrations bring targets of their own (configs[3]: 256 candidate pairs, 256 x 6 MB of index) takes the order
+    // by TARGET whatever the front-end — whole targets per XCD, so that an L2 holds the one or two targets its CUs are working on instead of
+    // a slice of all eight-plus in flight.
+    // (measured on configs[3], 256 own-target registrations through the cell walk: 13 539 reg/s against 13 716 in plain order — no gain, the walk
+    //  is not bound by L2 misses either; the order by target is taken only with xcd_order = 1, profiles/r05_kernel_experiments.md)
+    const bool many_targets = c->batch_slots.size() >= 8 && c->xcd_order == 1;
+    c->xcd_now = c->lanes_q != 8 && c->mode_now != 0 &&
+                 (((c->mode_now == 3 || c->mode_now == 5) && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32))) ||
+                  (many_targets && c->xcd_order != 0 && c->n_blocks >= 2048));
+    if (c->xcd_now) HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
+    // per-run reset of the registrations and the dispatch order: both depend on the batch only (items, initial poses, grid geometry), not on
+    // the rebuilt index — with the cell rows they ride on the side stream behind the corner target's rows, underneath the surf target's
+    // (25-30 us of two small launches and a single-workgroup counting sort off the critical path of a configs[1] step)
+    bool reset_done = false;
+    auto reset_and_order = [&](hipStream_t s_) {
+        launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), s_);
+        if (c->xcd_now)
+            launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
+                             c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, s_);
+        reset_done = true;
+    };
     if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
         prof_mark(c, 2);
         if (c->strip_now) {
@@ -934,33 +958,21 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                     launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), sk);
                 }
             }
+            if (fork && !c->sort_now && !c->exact) reset_and_order(c->side_stream);
             if (fork) { (void)hipEventRecord(c->ev_join, c->side_stream); (void)hipStreamWaitEvent(st, c->ev_join, 0); }
         }
         prof_mark(c, -1);
     }
-    launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
+    const bool early = reset_done;
+    if (!early) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
     if (c->exact) { int rc = exact_pose_caches(c); if (rc) return rc; }
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
-    // XCD-aware dispatch order (lisreg_assoc.hip, launch_xcd_order): two small launches per run, at the initial poses.  Auto: the graph
-    // front-end with >= 32 registrations (measured: +2.5 % at 64 scans, +4.9 % at 256; with 8 big scans the sectors are unevenly loaded
-    // and it costs 2 %; the walk front-end gains nothing)
-    // Round 5: a batch whose registrations bring targets of their own (configs[3]: 256 candidate pairs, 256 x 6 MB of index) takes the order
-    // by TARGET whatever the front-end — whole targets per XCD, so that an L2 holds the one or two targets its CUs are working on instead of
-    // a slice of all eight-plus in flight.
-    // (measured on configs[3], 256 own-target registrations through the cell walk: 13 539 reg/s against 13 716 in plain order — no gain, the walk
-    //  is not bound by L2 misses either; the order by target is taken only with xcd_order = 1, profiles/r05_kernel_experiments.md)
-    const bool many_targets = c->batch_slots.size() >= 8 && c->xcd_order == 1;
-    c->xcd_now = c->lanes_q != 8 && c->mode_now != 0 &&
-                 (((c->mode_now == 3 || c->mode_now == 5) && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32))) ||
-                  (many_targets && c->xcd_order != 0 && c->n_blocks >= 2048));
-    if (c->xcd_now) {
-        HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
+    if (!early && c->xcd_now)
         launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
                          c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, st);
-    }
     const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk != 0;
     // how often the host looks at the "registrations finished" counter: a skipped launch of a big batch still dispatches tens of
     // thousands of workgroups (check every 3 iterations), a skipped launch of a single frame costs ~2 us (check every 6: one
