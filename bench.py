@@ -422,6 +422,40 @@ def main():
                          note="option exact_arithmetic = 1 (the reference's arithmetic operation for operation, canonical ties, the pose's "
                               "sines / cosines from the host's libm: one host round trip per GN iteration) on the same device-resident batch")
 
+    # ---- two independent batches in flight: two contexts, two HIP streams, the same device-resident inputs ---------------------------
+    # `value` above is ONE stream running step after step.  A step has stretches that leave most of the chip idle (the 6x6 solves: one
+    # workgroup per registration; launch gaps) or half busy (the index / row build: latency- and LDS-bound); a second, independent batch on
+    # another stream fills them.  Reported next to `value`, never as `value`; poses must equal the single-stream ones.
+    overlap_leg = None
+    if rank == 0 and n_gpus == 1 and not own_targets and not os.environ.get("LISREG_BENCH_NO_OVERLAP"):
+        lanes = []
+        for _ in range(2):
+            cx = lisreg.Context(dev_index)
+            sx = torch.cuda.Stream(device=dev)
+            cx.set_stream(sx.cuda_stream)
+            cx.set_option("rebuild_targets_each_run", 1)
+            cx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
+            cx.batch_prepare_device(items, T_init, params)
+            lanes.append((cx, sx))
+        for cx, _ in lanes:
+            cx.batch_run()
+        torch.cuda.synchronize()
+        osteps = 2 * max(5, min(args.steps, 20))
+        to0 = time.perf_counter()
+        for k in range(osteps):
+            lanes[k & 1][0].batch_run()
+        torch.cuda.synchronize()
+        dto = time.perf_counter() - to0
+        same = True
+        for cx, _ in lanes:
+            To, _ = cx.batch_fetch()
+            same = same and bool(np.array_equal(np.asarray(To), T_gpu))
+            cx.close()
+        overlap_leg = dict(value=round(batch * osteps / dto, 2), unit="registrations/s", ms_per_step=round(1e3 * dto / osteps, 3), steps=osteps,
+                           poses_equal_single_stream_run=same,
+                           note="two contexts on two HIP streams, each running the same device-resident batch step after step (index build inside every "
+                                "step); the streams' kernels share the chip, so per-kernel durations of this leg are not comparable with `roofline`")
+
     # ---- PCIe-inclusive leg: pinned host clouds in the reference's 32-byte layout through lisreg_align_batch ------
     # At N > 1 EVERY rank runs it at the same time (between two barriers): the ranks' feeder threads and uploads then compete for the host's
     # cores, memory and PCIe root ports — the contention SURVEY.md section 8(e) names as the multi-GPU limit — and rank 0 reports the
@@ -469,7 +503,7 @@ def main():
                        "process_group": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                    "pose_gather": "lisreg_comm_init / lisreg_gather_results (the library's own RCCL all-gather)" if native_gather else "torch.distributed " + dist.get_backend(),
                                                                    "comm_nranks": comm_nranks, "ranks": rank_devices}},
-            "roofline": roof, "cpu_baseline": cpu, "pcl_reference": pcl_reference_note(), "pcie_inclusive": pcie, "exact_build": exact_leg,
+            "roofline": roof, "cpu_baseline": cpu, "pcl_reference": pcl_reference_note(), "pcie_inclusive": pcie, "two_batches_in_flight": overlap_leg, "exact_build": exact_leg,
             "accuracy": {"max_rot_err_vs_truth_rad": float(err_truth[:, :3].max()),
                          "max_trans_err_vs_truth_m": float(err_truth[:, 3:].max()),
                          "vs_cpu_oracle": parity,
