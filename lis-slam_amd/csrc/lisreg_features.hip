@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
     __shared__ int   s_col[kMaxRingPts];
     __shared__ float s_val[6 * kMaxSector];          // the six sectors of the ring, each padded to SP entries, sorted together
     __shared__ int   s_ind[6 * kMaxSector];
+    __shared__ unsigned char s_run[kMaxRingPts];     // per position: how far a pick there suppresses (forward | backward << 4), see below
 
     const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves sort, wave 0 picks
     // the extracted cloud this ring belongs to: [base, size) — the whole cloud for one sweep, the sweep's own slice in a batch
@@ -144,6 +145,18 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
     const int lo = max(r0 - 6, base), hi = min(r1 + 6, size);
     for (int k = lo + tid; k < hi; k += 256) { s_picked[k - lo] = fb.picked[k]; s_curv[k - lo] = fb.curv[k]; s_col[k - lo] = fb.col[k]; }
     __syncthreads();
+    // How far a pick at position c suppresses (:647-659, :681-693): forward over c + 1 .. c + 5 and backward over c - 1 .. c - 5, each direction
+    // stopping at the cloud's end or at the first pair of neighbours more than 10 columns apart.  Both directions test the same pair
+    // predicate pair(a) = "a - 1 and a are both in the cloud and at most 10 columns apart": forward = the run of pair(c + 1), pair(c + 2), ...,
+    // backward = the run of pair(c), pair(c - 1), ....  The runs depend on the columns only, so they are formed here once, by all four
+    // wavefronts, instead of by ten lanes and an LDS round trip inside every pick of the sequential pass below.
+    for (int a = lo + tid; a < hi; a += 256) {
+        auto pair_ok = [&](int x) { return x - 1 >= lo && x < hi && x < size && x - 1 >= base && abs(s_col[x - lo] - s_col[x - 1 - lo]) <= 10; };
+        int nf = 0, nb = 0;
+        while (nf < 5 && pair_ok(a + nf + 1)) ++nf;
+        while (nb < 5 && pair_ok(a - nb)) ++nb;
+        s_run[a - lo] = (unsigned char)(nf | (nb << 4));
+    }
 
     // std::sort of every sector's curvatures (:620) — the six sorts are independent of the picking, so they run as ONE bitonic network
     // over the six sectors side by side (each padded to SP entries, the largest sector's power of two): 45 barriers for a 1800-column ring
@@ -187,17 +200,13 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
         // that lane marks itself and its +-5 neighbours in LDS, and candidates suppressed meanwhile are skipped for
         // free (cloudNeighborPicked only ever goes 0 -> 1, so "not eligible when reached" == "never eligible").
         if (wave == 0) {
-// the pick's +-5 neighbours (:647-659, :681-693): each direction stops at the cloud's end or at the first column gap > 10.  Ten lanes test
-// one offset each, a ballot turns the tests into the run lengths, the lanes inside the runs mark — one LDS round instead of ten
-#define LISREG_SUPPRESS(ind_) do { \
-            const int c_ = (ind_); \
-            bool ok_ = false; int a_ = 0; \
-            if (lane < 5) { a_ = c_ + lane + 1; ok_ = !(a_ >= size || a_ - 1 < base) && abs(s_col[a_ - lo] - s_col[a_ - 1 - lo]) <= 10; } \
-            else if (lane < 10) { a_ = c_ - (lane - 4); ok_ = !(a_ < base || a_ + 1 >= size) && abs(s_col[a_ - lo] - s_col[a_ + 1 - lo]) <= 10; } \
-            const unsigned okm_ = (unsigned)__ballot(ok_); \
-            const int nf_ = __ffs((int)((~okm_ & 0x1fu) | 0x20u)) - 1, nb_ = __ffs((int)(((~okm_ >> 5) & 0x1fu) | 0x20u)) - 1; \
-            if ((lane < 5 && lane < nf_) || (lane >= 5 && lane < 10 && lane - 5 < nb_)) s_picked[a_ - lo] = 1; \
-            __builtin_amdgcn_wave_barrier(); } while (0)
+// One batch = 64 candidates in sorted order, one per lane.  A lane reads its candidate's picked flag and suppression runs ONCE per batch; a
+// pick then costs a ballot, three lane reads and a range test — every lane whose candidate lies inside the pick's run marks itself in a
+// register, the run's positions are marked in LDS for the batches and sectors still to come (nothing in the loop waits for LDS).
+#define LISREG_PICK_MARK(c_, run_) do { \
+            const int nf_ = (run_) & 15, nb_ = (run_) >> 4; \
+            if (ind >= (c_) - nb_ && ind <= (c_) + nf_) mypicked = true; \
+            if (lane <= nf_ + nb_) s_picked[(c_) - nb_ + lane - lo] = 1; } while (0)
         {   // edge features: largest curvature first (:626-661), at most 20 per sector, the first 4 are "sharp"
             int largest = 0;
             bool stop = false;
@@ -206,10 +215,11 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
                 const bool inr = k >= sp;
                 const int ind = inr ? ((k == ep) ? ep : s_sorted[k - sp]) : lo;   // element ep lies outside the sorted range
                 const bool stat = inr && s_curv[ind - lo] > P.edge_threshold;
+                bool mypicked = !stat || s_picked[ind - lo] != 0;
+                const int myrun = s_run[ind - lo];
                 unsigned long long todo = __ballot(stat);
                 while (todo) {
-                    const bool elig = stat && s_picked[ind - lo] == 0;
-                    const unsigned long long m = __ballot(elig) & todo;
+                    const unsigned long long m = __ballot(!mypicked) & todo;
                     if (!m) break;
                     const int f = __ffsll((long long)m) - 1;
                     todo &= ~((2ull << f) - 1ull);                             // lanes up to f have had their turn
@@ -219,12 +229,13 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
                         fb.label[ind] = 1;
                         lists[0 * kListCap + n_corner] = ind;
                         if (largest <= 4) lists[1 * kListCap + n_csharp] = ind;
-                        s_picked[ind - lo] = 1;
                     }
-                    LISREG_SUPPRESS(__shfl(ind, f));
+                    const int c = __builtin_amdgcn_readlane(ind, f), run = __builtin_amdgcn_readlane(myrun, f);
+                    LISREG_PICK_MARK(c, run);
                     n_corner++;
                     if (largest <= 4) n_csharp++;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         {   // planar features: smallest curvature first (:663-695), the first 10 per sector are "sharp"
@@ -234,25 +245,27 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
                 const bool inr = k <= ep;
                 const int ind = inr ? ((k == ep) ? ep : s_sorted[k - sp]) : lo;
                 const bool stat = inr && s_curv[ind - lo] < P.surf_threshold;
+                bool mypicked = !stat || s_picked[ind - lo] != 0;
+                const int myrun = s_run[ind - lo];
                 unsigned long long todo = __ballot(stat);
                 while (todo) {
-                    const bool elig = stat && s_picked[ind - lo] == 0;
-                    const unsigned long long m = __ballot(elig) & todo;
+                    const unsigned long long m = __ballot(!mypicked) & todo;
                     if (!m) break;
                     const int f = __ffsll((long long)m) - 1;
                     todo &= ~((2ull << f) - 1ull);
                     largest++;
                     if (lane == f) {
                         fb.label[ind] = -1;
-                        s_picked[ind - lo] = 1;
                         if (largest <= 10) lists[2 * kListCap + n_ssharp] = ind;
                     }
-                    LISREG_SUPPRESS(__shfl(ind, f));
+                    const int c = __builtin_amdgcn_readlane(ind, f), run = __builtin_amdgcn_readlane(myrun, f);
+                    LISREG_PICK_MARK(c, run);
                     if (largest <= 10) n_ssharp++;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-#undef LISREG_SUPPRESS
+#undef LISREG_PICK_MARK
         }   // wave 0
     }
     if (tid == 0) {
