@@ -312,7 +312,10 @@ def main():
     roof = None
     if timing and timing["assoc_launches"] > 0:
         avg_ms = timing["assoc_ms"] / timing["assoc_launches"]
-        alg_bytes = ALG_BYTES_PER_POINT_ITER * n_src                     # one launch = one GN iteration of the batch
+        prof_steps_ = min(repeats, prof_repeats) * args.steps
+        # one launch = one GN iteration of the batch — or of HALF the batch when the run is interleaved (option "interleave": the two halves
+        # iterate on two streams, each half's solves underneath the other half's correspondence launch): bytes per launch follow the launch count
+        alg_bytes = int(ALG_BYTES_PER_POINT_ITER * n_src * (prof_steps_ * ITERS) / timing["assoc_launches"])
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes/launch
@@ -339,6 +342,7 @@ def main():
                                                             front_end=round(1024.0 * fe_kib / max(n_tgt_pts, 1), 1)),
                     avg_launch_ms=round(avg_ms, 4), launches=timing["assoc_launches"],
                     algorithmic_bytes_per_launch=alg_bytes, search_front_end=ctx.front_end(),
+                    launches_per_iteration=round(timing["assoc_launches"] / (prof_steps_ * ITERS), 3), interleaved=bool(ctx.get_option("interleaved_now")),
                     per_step_ms=dict(assoc=round(timing["assoc_ms"] / prof_steps, 4), solve=round(timing["solve_ms"] / prof_steps, 4),
                                      index=round(timing["index_ms"] / prof_steps, 4), wall=round(ms_per_step, 4)))
 

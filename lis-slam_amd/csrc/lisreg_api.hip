@@ -290,14 +290,17 @@ int upload_grids(lisreg_ctx* c)
     return LISREG_OK;
 }
 
-void prof_mark(lisreg_ctx* c, int kind_of_next_interval)
+// (sidx 1: the mark goes on the side stream — the second half of an interleaved run, run_impl; an interval runs from a mark to the next mark
+//  on the SAME stream)
+void prof_mark(lisreg_ctx* c, int kind_of_next_interval, int sidx = 0)
 {
     if (!c->profiling) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
-    (void)hipEventRecord(e, c->stream);
+    (void)hipEventRecord(e, sidx ? c->side_stream : c->stream);
     c->ev.push_back(e);
     c->ev_kind.push_back(kind_of_next_interval);
+    c->ev_sidx.push_back(sidx);
 }
 
 void prof_collect(lisreg_ctx* c)
@@ -306,7 +309,10 @@ void prof_collect(lisreg_ctx* c)
     const bool dump = getenv("LISREG_PROF_DUMP") != nullptr;
     for (size_t i = 0; i + 1 < c->ev.size(); ++i) {
         float ms = 0;
-        if (c->ev_kind[i] >= 0 && hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+        size_t j = i + 1;
+        while (j < c->ev.size() && c->ev_sidx[j] != c->ev_sidx[i]) ++j;          // the next mark on the same stream
+        if (j >= c->ev.size()) continue;
+        if (c->ev_kind[i] >= 0 && hipEventElapsedTime(&ms, c->ev[i], c->ev[j]) == hipSuccess) {
             if (dump) fprintf(stderr, "[lisreg prof] interval %zu kind %d: %.4f ms\n", i, c->ev_kind[i], ms);
             if (c->ev_kind[i] == 0) { c->timing[0] += ms; c->timing[1] += 1; }
             else if (c->ev_kind[i] == 1) { c->timing[2] += ms; c->timing[3] += 1; }
@@ -314,7 +320,7 @@ void prof_collect(lisreg_ctx* c)
         }
     }
     for (auto e : c->ev) (void)hipEventDestroy(e);
-    c->ev.clear(); c->ev_kind.clear();
+    c->ev.clear(); c->ev_kind.clear(); c->ev_sidx.clear();
 }
 
 }  // namespace
@@ -406,6 +412,8 @@ void lisreg_destroy(lisreg_ctx* c)
     if (c->grids_host) (void)hipHostFree(c->grids_host);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_ab) (void)hipEventDestroy(c->ev_ab);
+    if (c->ev_ba) (void)hipEventDestroy(c->ev_ba);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -905,12 +913,46 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     // per-run reset of the registrations and the dispatch order: both depend on the batch only (items, initial poses, grid geometry), not on
     // the rebuilt index — with the cell rows they ride on the side stream behind the corner target's rows, underneath the surf target's
     // (25-30 us of two small launches and a single-workgroup counting sort off the critical path of a configs[1] step)
+    // Two halves of the batch on two streams (round 5).  The 6x6 solves are one workgroup per registration and ~13 us of dependent latency
+    // between two correspondence launches: the chip idles through ten of them per step.  Registrations are independent, so the batch is cut
+    // in two at an item boundary near the middle of the workgroups: the first half iterates on the context's stream, the second on the side
+    // stream, and each half's solve (and launch gaps, and the thinning tail of its correspondence launch) runs underneath the other half's
+    // correspondence launch.  Same kernels on the same data in the same order per registration: same results to the bit.  Only for runs
+    // that do not stop early from the host (fixed iteration counts, lisreg_batch_run) and are big enough to fill the chip twice.
+    const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk != 0;
+    int split_item = 0, split_blk = 0;
+    if (c->interleave != 0 && !c->exact && !can_stop && c->lanes_q == 1 && c->mode_now != 0 && c->n_items >= 2 && c->n_blocks >= c->interleave_min_blocks) {
+        if (!c->side_stream) {
+            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+            if (c->side_stream && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                                   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+                (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr;
+            }
+        }
+        if (c->side_stream && !c->ev_ab && (hipEventCreateWithFlags(&c->ev_ab, hipEventDisableTiming) != hipSuccess ||
+                                            hipEventCreateWithFlags(&c->ev_ba, hipEventDisableTiming) != hipSuccess)) { c->ev_ab = nullptr; c->ev_ba = nullptr; }
+        if (c->side_stream) {
+            for (int i = 1; i < c->n_items; ++i)
+                if (c->h_items[(size_t)i].blk_begin * 2 >= c->n_blocks) { split_item = i; split_blk = c->h_items[(size_t)i].blk_begin; break; }
+            if (split_blk * 4 < c->n_blocks || (c->n_blocks - split_blk) * 4 < c->n_blocks) { split_item = 0; split_blk = 0; }     // (a lop-sided cut hides nothing)
+        }
+    }
     bool reset_done = false;
+    auto dispatch_order = [&](hipStream_t s_) {
+        if (c->xcd_now) {
+            // (an interleaved run dispatches its halves separately: one table per half, positions and ids relative to the half)
+            const int nb0 = split_blk ? split_blk : c->n_blocks;
+            launch_xcd_order(c->blocks.as<BlockDesc>(), nb0, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
+                             c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, s_);
+            if (split_blk)
+                launch_xcd_order(c->blocks.as<BlockDesc>() + split_blk, c->n_blocks - split_blk, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
+                                 c->items.as<ItemState>(), c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets,
+                                 c->xcd_tab.as<int>() + split_blk, c->xcd_tab.as<int>() + c->n_blocks + split_blk, s_);
+        }
+    };
     auto reset_and_order = [&](hipStream_t s_) {
         launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), s_);
-        if (c->xcd_now)
-            launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
-                             c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, s_);
+        dispatch_order(s_);
         reset_done = true;
     };
     if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
@@ -970,10 +1012,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
-    if (!early && c->xcd_now)
-        launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
-                         c->sort_now ? c->sorted_all.as<float4>() : nullptr, many_targets, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, st);
-    const bool can_stop = early_stop && c->prm.fixed_iters <= 0 && c->done_host && c->early_stop_chunk != 0;
+    if (!early) dispatch_order(st);                        // (after the source sort: the keys read the sorted records)
     // how often the host looks at the "registrations finished" counter: a skipped launch of a big batch still dispatches tens of
     // thousands of workgroups (check every 3 iterations), a skipped launch of a single frame costs ~2 us (check every 6: one
     // round trip for the typical 3-6 iteration registration)
@@ -983,21 +1022,46 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     int next_check = chunk;
     if (c->early_stop_chunk <= 0 && c->last_launches > 0) next_check = std::max(2, std::min(c->last_launches, chunk));
     c->prm.cell_anchor_until = c->cell_anchor_until;
-    for (int it = 0; it < c->prm.bound; ++it) {
-        prof_mark(c, 0);
+    // one Gauss-Newton iteration of the items [i0, i0 + ni) = the workgroups [b0, b0 + nb) on stream s_ (sidx: which stream the profiling marks go on)
+    // (after_assoc: an event recorded right behind the correspondence launch, for the alternation of an interleaved run)
+    auto iteration = [&](int it, int i0, int ni, int b0, int nb, hipStream_t s_, int sidx, hipEvent_t after_assoc) {
+        if (!after_assoc) prof_mark(c, 0, sidx);          // (an alternating run marks behind its wait for the other half)
         (c->exact ? launch_assoc_exact : launch_assoc)(
-                     c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
-                     c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>(),
+                     c->blocks.as<BlockDesc>() + b0, nb, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
+                     c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>() + (size_t)b0 * kNumAcc,
                      c->mode_now, c->nn.as<int>(), c->n_elems, c->first_pass_r * c->first_pass_r,
                      it >= (c->lanes_q == 8 ? c->wide_from_small : c->wide_from) && it <= (c->mode_now == 3 || c->mode_now == 5 ? c->graph_wide_until : c->wide_until), c->graph_hops,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
                      c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, c->lanes_q,
                      c->blocks_q.as<BlockDesc>(), (int)c->h_blocks_q.size(), c->coef.as<float4>(), c->coef_ok.as<int>(),
-                     c->xcd_now ? c->xcd_tab.as<int>() + c->n_blocks : nullptr, st);
-        prof_mark(c, 1);
-        launch_solve(c->items.as<ItemState>(), c->n_items, c->prm, c->partials.as<double>(),
-                     c->trace_cap > 0 ? c->trace.as<float>() : nullptr, c->trace_cap, c->done_dev.as<int>(), st);
-        prof_mark(c, -1);
+                     c->xcd_now ? c->xcd_tab.as<int>() + c->n_blocks + b0 : nullptr, s_);
+        if (after_assoc) (void)hipEventRecord(after_assoc, s_);
+        prof_mark(c, 1, sidx);
+        launch_solve(c->items.as<ItemState>() + i0, ni, c->prm, c->partials.as<double>(),
+                     c->trace_cap > 0 ? c->trace.as<float>() + (size_t)i0 * (size_t)c->trace_cap * kTraceStride : nullptr, c->trace_cap, c->done_dev.as<int>(), s_);
+        prof_mark(c, -1, sidx);
+    };
+    c->interleaved_now = false;
+    if (split_blk > 0 && hipEventRecord(c->ev_fork, st) == hipSuccess && hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) == hipSuccess) {
+        c->interleaved_now = true;
+        // interleave 1: the two correspondence launches ALTERNATE (each waits for the other half's previous one through an event), so that
+        // every launch has the chip to itself apart from the other half's solve — per-launch durations stay what they are for a launch
+        // alone, which is what the roofline figures of bench.py and the profiler tables are made of; 2: free-running (the launches of the
+        // two streams share the chip whenever both are ready: same throughput, launch durations no longer comparable)
+        const bool alternate = c->interleave == 1 && c->ev_ab && c->ev_ba;
+        for (int it = 0; it < c->prm.bound; ++it) {
+            if (alternate && it > 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ba, 0));            // B's launch of the iteration before is through
+            if (alternate) prof_mark(c, 0, 0);
+            iteration(it, 0, split_item, 0, split_blk, st, 0, alternate ? c->ev_ab : nullptr);
+            if (alternate) HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_ab, 0));          // A's launch of this iteration is through
+            if (alternate) prof_mark(c, 0, 1);
+            iteration(it, split_item, c->n_items - split_item, split_blk, c->n_blocks - split_blk, c->side_stream, 1, alternate ? c->ev_ba : nullptr);
+        }
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    } else
+    for (int it = 0; it < c->prm.bound; ++it) {
+        iteration(it, 0, c->n_items, 0, c->n_blocks, st, 0, nullptr);
         if (c->exact && it + 1 < c->prm.bound) { int rc = exact_pose_caches(c); if (rc) return rc; }
         if (can_stop && it + 1 == next_check && it + 1 < c->prm.bound) {
             HIPCHK(c, hipMemcpyAsync(c->done_host, c->done_dev.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1105,6 +1169,8 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     if (!strcmp(name, "trace_cap")) { c->trace_cap = std::max(0, value); c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "feeder_threads")) { c->feeder_threads = std::min(std::max(value, 0), 64); return LISREG_OK; }
     if (!strcmp(name, "feeder_numa")) { c->feeder_numa = value != 0; return LISREG_OK; }       // takes effect when the thread pool is created
+    if (!strcmp(name, "interleave_min_blocks")) { c->interleave_min_blocks = std::max(value, 2); return LISREG_OK; }
+    if (!strcmp(name, "interleave")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "interleave: 0 off, 1 alternating halves, 2 free-running halves"); c->interleave = value; return LISREG_OK; }
     return fail(c, LISREG_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
 
@@ -1133,6 +1199,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "cell_rows_max_mb")) { *value = c->cell_rows_max_mb; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { *value = c->xcd_order; return LISREG_OK; }
     if (!strcmp(name, "xcd_order_now")) { *value = c->xcd_now ? 1 : 0; return LISREG_OK; }
+    if (!strcmp(name, "interleave")) { *value = c->interleave; return LISREG_OK; }
+    if (!strcmp(name, "interleaved_now")) { *value = c->interleaved_now ? 1 : 0; return LISREG_OK; }
     // size of the search index of the prepared batch's targets, in KiB (what the front-end in use reads), and their points:
     //   index_kib_grid: sorted records + cell table; index_kib_front_end: k-NN graph rows (front-end 3) or cell rows + their table (front-end 5)
     if (!strcmp(name, "index_kib_grid") || !strcmp(name, "index_kib_front_end") || !strcmp(name, "index_target_points")) {

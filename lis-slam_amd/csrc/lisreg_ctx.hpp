@@ -160,6 +160,7 @@ struct lisreg_ctx {
     bool      strip_now = false;
     hipStream_t side_stream = nullptr;                  // strip build: the big-strip kernel runs here, forked from / joined to `stream`
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t  ev_ab = nullptr, ev_ba = nullptr;       // interleaved runs: "half A's / half B's correspondence launch is through"
     int       t_elems = 0, t_buckets = 0;
     bool      count_searches = false;
     bool      dump_neighbors = false;   // tests: keep the five neighbour ids of every query of the last iteration run
@@ -172,6 +173,14 @@ struct lisreg_ctx {
                                          // halve the first iterations of a batch; measured break-even ~170: 24 scans against 200 k points lose 4 %, 32 win 2 %)
     int       cell_rows_max_mb = 16384;  // auto: cell rows only while the targets' rows are expected to fit this (about 5 KB per target point)
     int       graph_min_ratio = 60;      // auto: query-iterations per target point from which the graph build pays (measured break-even ~55)
+    int       interleave = 0;            // "interleave": big batches that run a fixed number of iterations are cut in two halves iterating on two
+                                         // streams, each half's solves underneath the other half's correspondence launch (run_impl).  0 off (default),
+                                         // 1 the halves' launches alternate through events, 2 free-running.  Measured on configs[1] (round 5):
+                                         // 24.09 k reg/s off, 21.7 k alternating (a cross-stream hand-off costs more than the solve it hides),
+                                         // 24.5 k free-running (+1.7 %, but two launches then share the chip and their durations stop being a
+                                         // launch's own: 122 us per half against 98) — bit-identical results either way (tests)
+    bool      interleaved_now = false;   // what the last run did
+    int       interleave_min_blocks = 8192;   // workgroups from which a run is interleaved (each half should still fill the chip; tests lower it)
     int       xcd_order = 2;             // XCD-aware dispatch order of the correspondence launches: 0 off, 1 on (graph front-end), 2 auto (graph front-end, >= 32 registrations, >= 2048 blocks)
     bool      xcd_now = false;           // what the last run used
     int       feeder_numa = 1;           // packing threads bound to the CPUs of the device's NUMA node (those this process owns)
@@ -208,6 +217,7 @@ struct lisreg_ctx {
     bool      profiling = false;
     std::vector<hipEvent_t> ev;
     std::vector<int>        ev_kind;        // kind of the interval STARTING at event i: 0 assoc, 1 solve, 2 index, -1 none
+    std::vector<int>        ev_sidx;        // stream the event was recorded on: 0 the context's, 1 the side stream (interleaved runs)
     double    timing[5] = { 0, 0, 0, 0, 0 };
     // last align trace (host copy)
     std::vector<float> last_trace;

@@ -168,6 +168,32 @@ def test_xcd_dispatch_order_does_not_change_results(gpu_ctx):
         assert np.array_equal(o5[0][0], o5[1][0]) and o5[0][1] == o5[1][1]
 
 
+def test_interleaved_halves_do_not_change_results(gpu_ctx):
+    """Option "interleave" (round 5): a run with a fixed iteration count is cut in two at an item boundary, the halves iterate on two streams
+    (1: their correspondence launches alternate through events; 2: free-running), each half's solves underneath the other half's launch.
+    Every registration sees the same kernels on the same data in the same order: poses and stats are bit-identical with it off, for every
+    front-end, with and without the XCD dispatch tables (one per half).  Checks that the option really engaged (interleaved_now)."""
+    import lisreg
+    tc, ts, cases = _cases(9)
+    p = lisreg.default_params(1)
+    p.fixed_iters = 5                                      # (a run that stops early from the host is never interleaved)
+    T0 = np.array([c["T_init"] for c in cases])
+    for mode, xo in ((1, 0), (3, 0), (3, 1), (5, 0), (5, 1)):
+        out = {}
+        for il in (0, 1, 2):
+            c2 = lisreg.Context(0)
+            c2.set_option("search_mode", mode); c2.set_option("xcd_order", xo)
+            c2.set_option("lanes_per_query", 1)            # (small test batches would take eight lanes per query: those are not interleaved)
+            c2.set_option("interleave", il); c2.set_option("interleave_min_blocks", 4)
+            c2.set_target(tc, ts)
+            out[il] = c2.align_batch(cases, T0, p)
+            assert c2.get_option("interleaved_now") == (1 if il else 0), (mode, xo, il)
+            c2.close()
+        for il in (1, 2):
+            assert np.array_equal(out[0][0], out[il][0]), (mode, xo, il)
+            assert out[0][1] == out[il][1], (mode, xo, il)
+
+
 def test_edge_cases(oracle, gpu_ctx):
     import lisreg
     from lisreg import synth
