@@ -636,7 +636,7 @@ template <int H> __device__ __forceinline__ unsigned long long merge_blocks(unsi
     return half_cleaners<(H >> 1)>(k, lane);
 }
 // ascending sort of one key per lane across the wave
-__device__ __forceinline__ unsigned long long sort64(unsigned long long k, int lane)
+__attribute__((unused)) __device__ __forceinline__ unsigned long long sort64(unsigned long long k, int lane)
 {
     k = merge_blocks<1>(k, lane); k = merge_blocks<2>(k, lane); k = merge_blocks<4>(k, lane);
     k = merge_blocks<8>(k, lane); k = merge_blocks<16>(k, lane); k = merge_blocks<32>(k, lane);
@@ -730,11 +730,26 @@ __device__ __forceinline__ void row_build_wave(const GridIndex& g, const float4 
     if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
 }
 
+// Round 5: the graph's rows through the sort of the cell rows (32-bit keys: the squared distance's float bits with the low 7 bits replaced by
+// the lane, one min / max per network stage instead of a 64-bit compare and four selects; defined with the cell rows below).  The order of a
+// row is then exact to 2^-16 relative — far inside the millimetre of slack the scan's stop test carries for exactly this (kEps in
+// LISREG_GRAPH_GROUP) — and rho comes from the quantised key of the first point left out, a floor: "closer than rho => listed" holds as before.
+// -DLISREG_GRAPH_KEYS64=1 keeps the 64-bit (distance, id) keys of rounds 2-4.
+#ifndef LISREG_GRAPH_KEYS64
+#define LISREG_GRAPH_KEYS64 0
+#endif
+__attribute__((unused)) __device__ __forceinline__ void graph_row_q32(const GridIndex& g, const float4 q, int hx, int hy, int hz, int s,
+                                              float4* __restrict__ row_out, float2* __restrict__ meta_out, int (*s_off)[64], int (*s_js)[64]);
+
 __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int (*s_off)[64], int (*s_js)[64])
 {
     const float4 q = g.pts[s];
     const int hx = cell_coord(q.x, g.ox, g.inv_cell, g.nx), hy = cell_coord(q.y, g.oy, g.inv_cell, g.ny), hz = cell_coord(q.z, g.oz, g.inv_cell, g.nz);
+#if LISREG_GRAPH_KEYS64
     row_build_wave<2>(g, q, hx, hy, hz, s, const_cast<float4*>(g.nbr) + (size_t)s * kGraphK, const_cast<float2*>(g.nbr_meta) + s, s_off, s_js);
+#else
+    graph_row_q32(g, q, hx, hy, hz, s, const_cast<float4*>(g.nbr) + (size_t)s * kGraphK, const_cast<float2*>(g.nbr_meta) + s, s_off, s_js);
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_graph_build_one(GridIndex g)
@@ -949,7 +964,8 @@ constexpr unsigned kInfQ = 0x7f800000u;                     // +inf, payload bit
 // gathering the points a second time (have_c; a multi-chunk list leaves it to crow_emit's gather).
 template <int R>
 __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>& b, float qx, float qy, float qz,
-                                          int (*s_off)[64], int (*s_js)[64], unsigned& topk, int& topi, float4& topc, bool& have_c)
+                                          int (*s_off)[64], int (*s_js)[64], unsigned& topk, int& topi, float4& topc, bool& have_c,
+                                          int exclude = -1 /* a sorted position to leave out: the point itself, for the k-NN graph's rows */)
 {
     constexpr int W = 2 * R + 1, NR = W * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -971,7 +987,7 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
             cc = c;
             const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
             const float d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 < 3.0e38f) { k = (__float_as_uint(d2) & ~0x7Fu) | (unsigned)lane; cj = j; }     // NaN / Inf points are never listed
+            if (j != exclude && d2 < 3.0e38f) { k = (__float_as_uint(d2) & ~0x7Fu) | (unsigned)lane; cj = j; }     // NaN / Inf points are never listed
         }
         k = sort64x32(k, lane);
         const int cs = __shfl(cj, (int)(k & 63u));
@@ -992,6 +1008,7 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
 }
 
 // one row: the entries of the list inside rho (the block's inscribed radius, or the first point left out), padded with (q, -1)
+template <bool kTag = true>
 __device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float qy, float qz, float rc, unsigned topk, int topi,
                                            float4* __restrict__ row_out, float2* __restrict__ meta_out, bool& keep, float4& e,
                                            const float4 topc = make_float4(0.f, 0.f, 0.f, 0.f), bool have_c = false)
@@ -1006,11 +1023,21 @@ __device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float q
     if (keep) {
         float4 c = topc;
         if (!have_c) c = g.pts[topi];
-        e = make_float4(c.x, c.y, c.z, __int_as_float(crow_tagged(topi, lane)));
+        e = make_float4(c.x, c.y, c.z, __int_as_float(kTag ? crow_tagged(topi, lane) : topi));      // (the k-NN graph's rows carry plain ids)
     }
     row_out[lane] = e;
     if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
     return rho2;
+}
+
+__device__ __forceinline__ void graph_row_q32(const GridIndex& g, const float4 q, int hx, int hy, int hz, int s,
+                                              float4* __restrict__ row_out, float2* __restrict__ meta_out, int (*s_off)[64], int (*s_js)[64])
+{
+    const CrowBlock<2> b = crow_runs<2>(g, hx, hy, hz, s_off, s_js);
+    unsigned topk; int topi; float4 topc; bool have_c;
+    crow_list<2>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c, s);
+    bool keep; float4 e;
+    (void)crow_emit<false>(g, q.x, q.y, q.z, crow_inscribed<2>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e, topc, have_c);
 }
 
 // The row at the cell's centre q and, behind it, one row per octant in `mask`.  An octant row is derived from the centre row where that
