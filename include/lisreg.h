@@ -270,7 +270,7 @@ int  lisreg_get_target_index(lisreg_ctx* ctx, int slot, int kind, int* dims, flo
 
 /* Diagnostics: the k-NN graph of a target's search index (search front-end 3; built now if it was not yet).  *k = entries per
  * row; rows_out[p * k + j] = (x, y, z, sorted position as int bits) of the j-th nearest other point of sorted point p, ascending
- * by distance, padded with (p's own coordinates, -1); meta_out[p] = (rho^2, count as int bits): every point closer to p than rho
+ * by distance (to 2^-16 relative: the build sorts quantised keys, the scan's stop test carries a millimetre of slack for it), padded with (p's own coordinates, -1); meta_out[p] = (rho^2, count as int bits): every point closer to p than rho
  * is in its row.  Either output may be NULL.  capacity_points >= the target's point count. */
 int  lisreg_get_target_graph(lisreg_ctx* ctx, int slot, int kind, int* k, float* rows_out, float* meta_out, int capacity_points);
 
