@@ -200,9 +200,10 @@ lisreg::CrowBuffers crow_buffers(Target& t, int k)
 
 // may_decline (front-end chosen by auto): a target whose rows would not fit "cell_rows_max_mb" is left without them (crow_too_big) and the
 // batch takes another front-end; with search_mode 5 set by the caller the buffers are capped there instead and the cells past them walk.
-int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false)
+// rows_left (auto): rows the batch may still take under "cell_rows_max_mb" — the bound is on the batch's targets together, not on each
+int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false, long long* rows_left = nullptr)
 {
-    if (t.crow_valid[k] && t.g[k].crow_tab) return LISREG_OK;
+    if (t.crow_valid[k] && t.g[k].crow_tab) { if (rows_left) *rows_left -= t.crow_cap[k]; return LISREG_OK; }
     if (may_decline && t.crow_too_big[k]) return LISREG_OK;       // found too big before (the note is cleared when the target is set again)
     t.crow_too_big[k] = false;
     if (t.n[k] > 0 && t.grid_margin[k] < kCrowGridMargin) {
@@ -236,7 +237,8 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false)
     t.crow_cap[k] = std::max(rows, 1);
     {
         // (a cloud scattered through space instead of lying on surfaces — vegetation, rain — asks for up to 125 centre rows per point)
-        const long long budget = (long long)std::max(c->cell_rows_max_mb, 1) * 1048576LL / (long long)(sizeof(float4) * kGraphK + sizeof(float2));
+        long long budget = (long long)std::max(c->cell_rows_max_mb, 1) * 1048576LL / (long long)(sizeof(float4) * kGraphK + sizeof(float2));
+        if (rows_left) budget = std::min(budget, std::max(*rows_left, 0LL));
         if ((long long)rows > budget) {
             if (may_decline) { t.crow_too_big[k] = true; t.g[k].crow_tab = nullptr; return LISREG_OK; }
             t.crow_cap[k] = (int)std::max(1LL, budget);
@@ -245,8 +247,19 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false)
     if (const char* e = getenv("LISREG_CROW_CAP_PERCENT"))      // tests: under-size the row buffers (cells past the capacity get no row: their queries walk)
         t.crow_cap[k] = std::max(1, (int)((long long)t.crow_cap[k] * std::max(0, atoi(e)) / 100));
     if (getenv("LISREG_CROW_DEBUG")) fprintf(stderr, "[lisreg] cell rows of kind %d: %d rows for %d points in %d cells (%d x %d x %d of %.3f m)\n", k, rows, t.n[k], t.n_cells[k], t.g[k].nx, t.g[k].ny, t.g[k].nz, t.g[k].cell);
-    HIPCHK(c, t.crow[k].ensure(sizeof(float4) * kGraphK * (size_t)t.crow_cap[k]));
-    HIPCHK(c, t.crow_meta[k].ensure(sizeof(float2) * (size_t)t.crow_cap[k]));
+    {
+        // (auto: a refused allocation — many own-target items, each under the bound — is a reason to take another front-end, not an error)
+        const hipError_t e1 = t.crow[k].ensure(sizeof(float4) * kGraphK * (size_t)t.crow_cap[k]);
+        const hipError_t e2 = e1 == hipSuccess ? t.crow_meta[k].ensure(sizeof(float2) * (size_t)t.crow_cap[k]) : e1;
+        if (e2 != hipSuccess) {
+            (void)hipGetLastError();
+            t.crow[k].release(); t.crow_meta[k].release();
+            if (may_decline) { t.crow_too_big[k] = true; t.g[k].crow_tab = nullptr; return LISREG_OK; }
+            return lisreg::ctx_fail(c, LISREG_ERR_HIP, std::string("cell rows: ") + hipGetErrorString(e2));
+        }
+    }
+    if (rows_left) *rows_left -= t.crow_cap[k];
+    t.crow_chosen[k] = true;
     t.g[k].crow = t.crow[k].as<float4>();
     t.g[k].crow_meta = t.crow_meta[k].as<float2>();
     if (t.n[k] > 0) launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream);
@@ -400,7 +413,7 @@ void lisreg_destroy(lisreg_ctx* c)
     for (auto& kv : c->maps) { auto& m = kv.second; m.raw.release(); m.sorted.release(); m.cell_start.release(); m.g_dev.release(); }
     for (auto& m : c->localmaps) { for (auto& b : m.cls) b.release(); m.tgt[0].release(); m.tgt[1].release(); }
     for (auto& r : c->keyrings) { for (auto& f : r.frames) { f.cloud[0].release(); f.cloud[1].release(); } r.cat[0].release(); r.cat[1].release(); r.tgt[0].release(); r.tgt[1].release(); }
-    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->exact_trig, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur, &c->icp_items, &c->map_tab, &c->map_tsegs, &c->map_tblocks };
+    DevBuf* mbufs[] = { &c->lm_in, &c->lm_tmp, &c->lm_bbox, &c->exact_trig, &c->mp_pts, &c->mp_flag, &c->mp_pos, &c->mp_idx, &c->mp_cnt, &c->mp_d2, &c->mp_out, &c->icp_state, &c->icp_partials, &c->icp_cur, &c->icp_items, &c->map_tab, &c->map_tsegs, &c->map_tblocks, &c->map_stage };
     for (auto b : mbufs) b->release();
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->done_host) (void)hipHostFree(c->done_host);
@@ -537,8 +550,10 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
             return fail(c, LISREG_ERR_ARG, "set_target: the cloud has no finite point (every coordinate is NaN)");
         // the cell rows (search front-end 5) want a grid that reaches two cells past the cloud; when the front-end is left to the batch
         // (auto), a target gets that margin only once a batch has chosen the cell rows for it (ensure_crow_margin)
+        // — and keeps it from then on: a slot whose targets went through the cell rows last time (a frame stream re-sets its slot
+        // every frame) is indexed with the margin straight away, instead of being built twice per set
         memcpy(t.bbox[k], bb, sizeof bb);
-        t.grid_margin[k] = c->search_mode == 5 ? kCrowGridMargin : 0;
+        t.grid_margin[k] = (c->search_mode == 5 || (c->search_mode == 4 && t.crow_chosen[k])) ? kCrowGridMargin : 0;
         make_grid(bb, n, &t.g[k], &t.n_cells[k], t.grid_margin[k]);
         prof_mark(c, 2);
         int rc = build_target_kind(c, t, k);
@@ -604,22 +619,6 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
-    // 2-D sort columns of the (optional) source sort: 0.25 m tiles over every item's target footprint.  The bucket count is kept
-    // in 64 bits and the tile grows until the whole batch fits 2^26 buckets (km-scale submaps x large batches would otherwise
-    // overflow the int32 bucket numbering and ask for gigabytes of histogram).
-    float tile = env_float("LISREG_TILE", 0.25f);
-    for (;;) {
-        long long total = 0;
-        for (int i = 0; i < n_items; ++i) {
-            if (items[i].target < 0 || (size_t)items[i].target >= c->targets.size()) continue;
-            for (int k = 0; k < 2; ++k) {
-                const GridIndex& g = c->targets[(size_t)items[i].target].g[k];
-                total += (long long)std::max(1.0, std::ceil((double)g.nx * g.cell / tile)) * (long long)std::max(1.0, std::ceil((double)g.ny * g.cell / tile));
-            }
-        }
-        if (total <= (1LL << 26)) break;
-        tile *= 1.5f;
-    }
     // front-end of this batch.  The k-NN graph costs ~1 ns per target point and saves ~0.015 ns per query-iteration
     // (MI355X): it pays for shared / long-lived targets (a batch of scans against one submap), not for
     // one-shot targets (a loop-closure candidate pair, a single odometry frame).
@@ -658,18 +657,45 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         // the cell rows re-make a target's grid with a margin the first time they are chosen for it: before anything below reads the geometry
         if (c->mode_now == 5) {
             bool declined = false;
+            long long rows_left = (long long)std::max(c->cell_rows_max_mb, 1) * 1048576LL / (long long)(sizeof(float4) * kGraphK + sizeof(float2));
             for (int sl : seen)
                 for (int k = 0; k < 2 && !declined; ++k) {
                     Target& t = c->targets[(size_t)sl];
-                    if (t.valid && (!t.crow_valid[k] || !t.g[k].crow_tab)) {
-                        int rc = ensure_crows(c, t, k, c->search_mode == 4);
-                        if (rc) return rc;
-                        c->grids_dirty = true;
-                        declined = c->search_mode == 4 && t.crow_too_big[k];
-                    }
+                    if (!t.valid) continue;
+                    const bool had = t.crow_valid[k] && t.g[k].crow_tab;
+                    int rc = ensure_crows(c, t, k, c->search_mode == 4, c->search_mode == 4 ? &rows_left : nullptr);
+                    if (rc) return rc;
+                    if (!had) c->grids_dirty = true;
+                    declined = c->search_mode == 4 && t.crow_too_big[k];
                 }
-            if (declined) c->mode_now = 3;                     // (auto only) the rows of a target would not fit "cell_rows_max_mb": the graph scan
+            if (declined) {
+                // (auto only) the rows of the batch's targets would not fit "cell_rows_max_mb" together: the graph scan — and the rows already
+                // made for the batch's other targets go back (they would only hold memory)
+                c->mode_now = 3;
+                for (int sl : seen)
+                    for (int k = 0; k < 2; ++k) {
+                        Target& t = c->targets[(size_t)sl];
+                        if (t.crow_valid[k]) { t.crow[k].release(); t.crow_meta[k].release(); t.crow_valid[k] = false; t.g[k].crow = nullptr; t.g[k].crow_meta = nullptr; t.g[k].crow_tab = nullptr; c->grids_dirty = true; }
+                    }
+            }
         }
+    }
+    // (after the front-end choice: the cell rows re-make a target's grid with a margin, and the tile count follows the grids)
+    // 2-D sort columns of the (optional) source sort: 0.25 m tiles over every item's target footprint.  The bucket count is kept
+    // in 64 bits and the tile grows until the whole batch fits 2^26 buckets (km-scale submaps x large batches would otherwise
+    // overflow the int32 bucket numbering and ask for gigabytes of histogram).
+    float tile = env_float("LISREG_TILE", 0.25f);
+    for (;;) {
+        long long total = 0;
+        for (int i = 0; i < n_items; ++i) {
+            if (items[i].target < 0 || (size_t)items[i].target >= c->targets.size()) continue;
+            for (int k = 0; k < 2; ++k) {
+                const GridIndex& g = c->targets[(size_t)items[i].target].g[k];
+                total += (long long)std::max(1.0, std::ceil((double)g.nx * g.cell / tile)) * (long long)std::max(1.0, std::ceil((double)g.ny * g.cell / tile));
+            }
+        }
+        if (total <= (1LL << 26)) break;
+        tile *= 1.5f;
     }
     const int qpb = kBlockQ / c->lanes_q;                  // queries per workgroup of the kQ-lane search (h_blocks_q)
     c->h_blocks_q.clear();

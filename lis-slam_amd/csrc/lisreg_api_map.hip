@@ -152,23 +152,23 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
     if (total > 0x7fffffffLL / 2) return bad(c, "map_index_set_batch: more than 2^30 points in one batch");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    std::vector<MapIndex*> ms((size_t)n_maps);
-    for (int k = 0; k < n_maps; ++k) { ms[(size_t)k] = &c->maps[slots[k]]; ms[(size_t)k]->valid = false; ms[(size_t)k]->n = counts[k]; }
+    // The clouds in device memory: the caller's own records, or — host clouds — packed into ONE staging buffer of the context and uploaded
+    // with one copy (the build below is the only reader; it is through when this call returns).
+    std::vector<const float4*> src((size_t)n_maps, nullptr);
     if (fmt == LISREG_FMT_DEVICE) {
-        for (int k = 0; k < n_maps; ++k) ms[(size_t)k]->raw_ptr = static_cast<const float4*>(clouds[k]);
+        for (int k = 0; k < n_maps; ++k) src[(size_t)k] = static_cast<const float4*>(clouds[k]);
     } else {
-        for (int k = 0; k < n_maps; ++k) {
-            MapIndex& m = *ms[(size_t)k];
-            std::vector<lisreg_dpoint> h((size_t)std::max(counts[k], 1));
-            pack_cloud(clouds[k], counts[k], stride, fmt, h.data());
-            HIPCHK(c, m.raw.ensure(sizeof(float4) * (size_t)std::max(counts[k], 1)));
-            if (counts[k] > 0) HIPCHK(c, hipMemcpy(m.raw.p, h.data(), sizeof(float4) * (size_t)counts[k], hipMemcpyHostToDevice));
-            m.raw_ptr = m.raw.as<float4>();
-        }
+        std::vector<lisreg_dpoint> h((size_t)std::max<long long>(total, 1));
+        long long off = 0;
+        for (int k = 0; k < n_maps; ++k) { pack_cloud(clouds[k], counts[k], stride, fmt, h.data() + off); off += counts[k]; }
+        HIPCHK(c, c->map_stage.ensure(sizeof(float4) * (size_t)std::max<long long>(total, 1)));
+        if (total > 0) HIPCHK(c, hipMemcpy(c->map_stage.p, h.data(), sizeof(float4) * (size_t)total, hipMemcpyHostToDevice));
+        off = 0;
+        for (int k = 0; k < n_maps; ++k) { src[(size_t)k] = c->map_stage.as<float4>() + off; off += counts[k]; }
     }
     // bounding boxes of all clouds: one launch pair, one read-back
     std::vector<CloudRef> refs((size_t)n_maps);
-    for (int k = 0; k < n_maps; ++k) refs[(size_t)k] = CloudRef{ ms[(size_t)k]->raw_ptr, counts[k], 0 };
+    for (int k = 0; k < n_maps; ++k) refs[(size_t)k] = CloudRef{ src[(size_t)k], counts[k], 0 };
     HIPCHK(c, c->map_tab.ensure(sizeof(CloudRef) * (size_t)n_maps));
     HIPCHK(c, c->bbox_dev.ensure(sizeof(float) * 6 * (size_t)n_maps + 64));
     HIPCHK(c, c->bbox_scratch.ensure(sizeof(float) * 6 * 64 * (size_t)n_maps + 6 * 256 * sizeof(float)));
@@ -178,12 +178,11 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
     std::vector<float> bbs((size_t)n_maps * 6);
     HIPCHK(c, hipMemcpyAsync(bbs.data(), c->bbox_dev.p, sizeof(float) * 6 * (size_t)n_maps, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));            // (also: refs is a local)
-    // grid geometry per map, then one table for the batched build
-    std::vector<TargetSeg> tsegs((size_t)n_maps);
-    std::vector<BlockDesc> tblocks;
-    int tflat = 0;
+    // Every cloud is checked and every grid laid out BEFORE any map of the batch is touched: an unusable cloud (infinite coordinates, no
+    // finite point, too many cells) fails the call with every named slot — those that held an index before — as it was.
+    std::vector<GridIndex> grids((size_t)n_maps);
+    std::vector<int> ncells((size_t)n_maps, 1);
     for (int k = 0; k < n_maps; ++k) {
-        MapIndex& m = *ms[(size_t)k];
         const float* bb = &bbs[(size_t)k * 6];
         const int n = counts[k];
         float zero[6] = { 0, 0, 0, 0, 0, 0 };
@@ -191,7 +190,22 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
             for (int d = 0; d < 6; ++d) if (!std::isfinite(bb[d])) return bad(c, "map_index_set_batch: a cloud has infinite coordinates");
             if (!(bb[0] <= bb[3] && bb[1] <= bb[4] && bb[2] <= bb[5])) return bad(c, "map_index_set_batch: a cloud has no finite point (every coordinate is NaN)");
         }
-        make_grid(n > 0 ? bb : zero, n, &m.g, &m.n_cells);
+        memset(&grids[(size_t)k], 0, sizeof(GridIndex));
+        make_grid(n > 0 ? bb : zero, n, &grids[(size_t)k], &ncells[(size_t)k]);
+        total_cells += ncells[(size_t)k];
+        if (total_cells > 0x7fffffffLL / 2) return bad(c, "map_index_set_batch: the grids of this batch have more than 2^30 cells in all — set them in smaller groups");
+    }
+    total_cells = 0;
+    std::vector<MapIndex*> ms((size_t)n_maps);
+    for (int k = 0; k < n_maps; ++k) { ms[(size_t)k] = &c->maps[slots[k]]; ms[(size_t)k]->valid = false; ms[(size_t)k]->n = counts[k]; ms[(size_t)k]->raw_ptr = src[(size_t)k]; }
+    // one table for the batched build
+    std::vector<TargetSeg> tsegs((size_t)n_maps);
+    std::vector<BlockDesc> tblocks;
+    int tflat = 0;
+    for (int k = 0; k < n_maps; ++k) {
+        MapIndex& m = *ms[(size_t)k];
+        const int n = counts[k];
+        m.g = grids[(size_t)k]; m.n_cells = ncells[(size_t)k];
         HIPCHK(c, m.cell_start.ensure(sizeof(int) * ((size_t)m.n_cells + 2)));
         HIPCHK(c, m.sorted.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
         HIPCHK(c, m.g_dev.ensure(sizeof(GridIndex)));
@@ -207,7 +221,6 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
         ts.grid_id = k;
         for (int s0 = 0; s0 < n; s0 += kBlockQ) tblocks.push_back(BlockDesc{ k, s0, std::min(kBlockQ, n - s0), 0 });
         tflat += n; total_cells += m.n_cells;
-        if (total_cells > 0x7fffffffLL / 2) return bad(c, "map_index_set_batch: the grids of this batch have more than 2^30 cells in all — set them in smaller groups");
     }
     int rc = ensure_sort_scratch(c, (size_t)std::max(tflat, 1), (size_t)std::max<long long>(total_cells, 1));
     if (rc) return rc;

@@ -46,6 +46,7 @@ struct Target {
     int       grid_margin[2] = { 0, 0 };               // cells the grid reaches past the cloud on every side (the cell rows want two)
     int       crow_cap[2] = { 0, 0 };                  // rows allocated (= rows the classified index asked for when it was last sized)
     bool      crow_valid[2] = { false, false };
+    bool      crow_chosen[2] = { false, false };       // a batch took the cell rows for this slot before: its next target is indexed with the margin at once
     bool      crow_too_big[2] = { false, false };      // the rows this target asks for exceed "cell_rows_max_mb" (auto: the batch takes the graph instead)
     bool      raw_external[2] = { false, false };     // LISREG_FMT_DEVICE: caller's memory, not ours
     const float4* raw_ptr[2] = { nullptr, nullptr };
@@ -142,6 +143,7 @@ struct lisreg_ctx {
     std::vector<lisreg::LocalMap> localmaps;
     std::vector<lisreg::KeyframeRing> keyrings;
     lisreg::DevBuf lm_in, lm_tmp, lm_bbox, exact_trig;
+    lisreg::DevBuf map_stage;                          // lisreg_map_index_set_batch: host clouds of a batch, packed, in one upload
     lisreg::DevBuf mp_pts, mp_flag, mp_pos, mp_idx, mp_cnt, mp_d2, mp_out, icp_state, icp_partials, icp_cur, icp_items, map_tab, map_tsegs, map_tblocks;
     int*      done_host = nullptr;          // pinned
     unsigned char* stage_host = nullptr;    // pinned staging of the per-batch tables

@@ -307,10 +307,13 @@ class InitialGuess:
         """initial_guess = (x, y, z, roll, pitch, yaw) of cloudInfo.initialGuess*"""
         inp = GuessInput(1 if odom_available else 0, 1 if imu_available else 0, *[float(v) for v in imu_rpy], *[float(v) for v in initial_guess])
         T = np.array(T, np.float32)
-        pred = np.full(6, np.nan, np.float32)
+        # "not assigned" is told by a bit pattern the library cannot produce (a NaN with a payload of its own), not by NaN-ness: a prediction
+        # that really IS NaN (a NaN pose propagated through the increment) comes back as what it is
+        sentinel = np.uint32(0x7FC0DEAD)
+        pred = np.full(6, sentinel, np.uint32).view(np.float32)
         f = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
         lib().lisreg_update_initial_guess(self.variant, 1 if self.heading else 0, C.byref(inp), C.byref(self.state), f(T), f(pred))
-        return T, (None if np.isnan(pred).any() else pred)
+        return T, (None if (pred.view(np.uint32) == sentinel).all() else pred)
 
 
 def _info_dict(info: LocalMapInfo) -> dict:

@@ -135,7 +135,8 @@ def test_graph_rows_cover_their_radius(gpu_ctx, m_points, kind):
     # (1) ascending up to the key quantisation: since round 5 the graph's rows go through the 32-bit-key sort of the cell rows (the squared
     # distance's float bits with the low 7 bits replaced by the lane), exact to 2^-16 relative — inside the scan's millimetre of slack
     assert (ratio[listed[:, 1:]] >= 1 - 2.0 ** -15).all()
-    assert (dd[listed] <= np.sqrt(g["rho2"].astype(np.float64))[:, None].repeat(k, 1)[listed] * (1 + 1e-6)).all()
+    # (a listed entry is inside rho up to the key quantisation: keys are compared with their low 7 mantissa bits cleared)
+    assert (dd[listed] <= np.sqrt(g["rho2"].astype(np.float64))[:, None].repeat(k, 1)[listed] * (1 + 2.0 ** -15)).all()
     tree = cKDTree(pts)
     rng = np.random.default_rng(1)
     for s in rng.choice(n, min(n, 4000), replace=False):
