@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment helper (GPU box): tests/ab_env.sh "label:VAR=val VAR2=val2" ... — per-GN-iteration k_assoc_* durations of bench.py under each
 # environment (rocprofv3 --kernel-trace), interleaved twice.  AB_ITERS = GN iterations per step (10), BENCH_ARGS = extra bench.py arguments.
-R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; export LISREG_BENCH_NO_EXACT=1      # (the exact-arithmetic leg of the bench line would put its own launches into the table)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; export LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1      # (the exact-arithmetic leg of the bench line would put its own launches into the table)
 for rep in 1 2; do
 for spec in "$@"; do
   v=${spec%%:*}; envs=${spec#*:}

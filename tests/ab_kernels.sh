@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment helper (GPU box): AB_PAT="crow|solve" tests/ab_kernels.sh <variant> ... — per-step time of the kernels whose names match AB_PAT
 # (and of all lisreg kernels) for each variant library (base = the regular build), rocprofv3 --kernel-trace of bench.py, interleaved twice.
-R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; export LISREG_BENCH_NO_EXACT=1
+R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; export LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1
 cp $R/lis-slam_amd/lib/liblisreg.so /tmp/liblisreg_keep.so
 for rep in 1 2; do
 for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # experiment helper (GPU box): tests/kstat.sh "VAR=val ..." [bench args] — rocprofv3 kernel stats (mean us per kernel) of bench.py --steps 3
-R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; export LISREG_BENCH_NO_EXACT=1; envs=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; export LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1; envs=$1; shift
 rm -rf /tmp/kstat; cd /tmp
 env $envs rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/kstat -o t -- python $R/bench.py --steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 "$@" > /tmp/kstat.log 2>&1
 python - <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment helper (GPU box): tests/pmc_kernel.sh <kernel-name-substring> "VAR=val ..." — per-wave instruction counters of one kernel (rocprofv3 --pmc, no tracing)
 set -u
-K=$1; envs=$2; REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=/tmp/pmc_kernel; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1; cd /tmp
+K=$1; envs=$2; REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=/tmp/pmc_kernel; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1; cd /tmp
 env $envs rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES -d $OUT -o pmc -- python $REPO/bench.py --steps 2 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 > $OUT/log.txt 2>&1
 python - "$K" <<'PY'
 import csv,glob,collections,sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-GN-iteration instruction counts of k_assoc_walk (one rocprofv3 --pmc pass, no tracing): tests/pmc_periter.sh [bench args]
 set -u
-REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_periter; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_periter; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1; cd /tmp
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES -d $OUT -o pmc -- python $REPO/bench.py --steps 2 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 "$@" > $OUT/log.txt 2>&1
 cd $REPO
 python - <<'PY'
