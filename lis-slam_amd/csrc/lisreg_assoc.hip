@@ -59,6 +59,12 @@ constexpr bool kExactArith = LISREG_EXACT != 0;
 #ifndef LISREG_MFMA_REDUCE
 #define LISREG_MFMA_REDUCE 0
 #endif
+#ifndef LISREG_SELECT_SWAP
+#define LISREG_SELECT_SWAP 0
+#endif
+#ifndef LISREG_MED3_INSERT
+#define LISREG_MED3_INSERT 0
+#endif
 // LDS of the reduction: one private region per wavefront (kRedWaveFloats floats) inside one array of the kernel.
 //   butterfly / exact build: the region starts with the wave's 28 sums (doubles);
 //   MFMA form: [0, 544) the 64 rows x 8 columns of the wave's Jacobian block as two half-waves of 32 rows (the second half 32 floats further
@@ -313,8 +319,19 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
 
     // k = 0
     {
+#if LISREG_SELECT_SWAP
+        // the same swaps as selects (the compiler turns the conditional swaps into divergent branches with a register copy per value and path)
+        const bool s1_ = n1 > n0 && n1 >= n2, s2_ = !s1_ && n2 > n0 && n2 > n1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float a0_ = a[i][0], a1_ = a[i][1], a2_ = a[i][2];
+            a[i][0] = s1_ ? a1_ : (s2_ ? a2_ : a0_); a[i][1] = s1_ ? a0_ : a1_; a[i][2] = s2_ ? a0_ : a2_;
+        }
+        p0 = s1_ ? 1 : (s2_ ? 2 : 0); p1 = s1_ ? 0 : 1; p2 = s2_ ? 0 : 2;
+#else
         if (n1 > n0 && n1 >= n2) LISREG_SWAPCOL(0, 1, p0, p1);
         else if (n2 > n0 && n2 > n1) LISREG_SWAPCOL(0, 2, p0, p2);
+#endif
         const float big = fmaxf(n0, fmaxf(n1, n2));
         if (big < thr * 5.f) rank = 0;
         else LISREG_HOUSEHOLDER(0);
@@ -323,7 +340,16 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         float m1 = 0, m2 = 0;
 #pragma unroll
         for (int i = 1; i < 5; ++i) { m1 += a[i][1] * a[i][1]; m2 += a[i][2] * a[i][2]; }
+#if LISREG_SELECT_SWAP
+        {
+            const bool s_ = m2 > m1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { const float a1_ = a[i][1], a2_ = a[i][2]; a[i][1] = s_ ? a2_ : a1_; a[i][2] = s_ ? a1_ : a2_; }
+            const int q1_ = p1, q2_ = p2; p1 = s_ ? q2_ : q1_; p2 = s_ ? q1_ : q2_;
+        }
+#else
         if (m2 > m1) LISREG_SWAPCOL(1, 2, p1, p2);
+#endif
         if (fmaxf(m1, m2) < thr * 4.f) rank = 1;
         else LISREG_HOUSEHOLDER(1);
     }
@@ -855,6 +881,21 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 }
 
 // sorted top-5 insertion (ascending); `id` must not already be in the list
+#if LISREG_MED3_INSERT
+// the inner distances of the new list are medians of three (the list ascends and d2 < b4 here): three v_med3_f32 instead of six selects,
+// same values (d2 equal to an entry: both forms keep the entry in front)
+#define LISREG_INSERT(d2, id) do { \
+        const bool c3_ = (d2) < b3, c2_ = (d2) < b2, c1_ = (d2) < b1, c0_ = (d2) < b0; \
+        const float n4_ = c3_ ? b3 : (d2), n3_ = __builtin_amdgcn_fmed3f(b2, b3, (d2)); \
+        const float n2_ = __builtin_amdgcn_fmed3f(b1, b2, (d2)), n1_ = __builtin_amdgcn_fmed3f(b0, b1, (d2)); \
+        const float n0_ = c0_ ? (d2) : b0; \
+        i4 = c3_ ? i3 : (id); \
+        i3 = c3_ ? (c2_ ? i2 : (id)) : i3; \
+        i2 = c2_ ? (c1_ ? i1 : (id)) : i2; \
+        i1 = c1_ ? (c0_ ? i0 : (id)) : i1; \
+        i0 = c0_ ? (id) : i0; \
+        b4 = n4_; b3 = n3_; b2 = n2_; b1 = n1_; b0 = n0_; } while (0)
+#else
 #define LISREG_INSERT(d2, id) do { \
         const bool c3_ = (d2) < b3, c2_ = (d2) < b2, c1_ = (d2) < b1, c0_ = (d2) < b0; \
         b4 = c3_ ? b3 : (d2);               i4 = c3_ ? i3 : (id); \
@@ -862,6 +903,7 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
         b2 = c2_ ? (c1_ ? b1 : (d2)) : b2;  i2 = c2_ ? (c1_ ? i1 : (id)) : i2; \
         b1 = c1_ ? (c0_ ? b0 : (d2)) : b1;  i1 = c1_ ? (c0_ ? i0 : (id)) : i1; \
         b0 = c0_ ? (d2) : b0;               i0 = c0_ ? (id) : i0; } while (0)
+#endif
 
 // Per-lane grid walk: every lane visits only the cells that can hold a point closer than its current 5th-best
 // distance (pruned per x-slab, per (x,y) column and per z-range), reading candidates straight from the

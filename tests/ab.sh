@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment helper: tests/ab.sh <variant> [<variant> ...]  (on the GPU box) — per-GN-iteration k_assoc durations of each variant library
 # (rocprofv3 --kernel-trace of bench.py), interleaved twice so that box-to-box and warm-up differences show.
-R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp LISREG_BENCH_NO_OVERLAP=1
+R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp LISREG_BENCH_NO_OVERLAP=1 LISREG_BENCH_NO_EXACT=1
 cp $R/lis-slam_amd/lib/liblisreg.so /tmp/liblisreg_keep.so
 for rep in 1 2; do
 for v in "$@"; do

@@ -19,4 +19,24 @@ timeout 120 python tests/replay_probe.py 2>/dev/null > $O/${TAG}_replay_stage_ti
 ( timeout 120 tests/ktrace.sh cfg3 30; timeout 120 tests/ktrace.sh odom 30 ) 2>&1 | grep -v "^W2026" > $O/${TAG}_replay_kernel_times.txt
 timeout 900 bash tests/prof.sh $TAG > $O/prof.log 2>&1
 cp gpurun_out/prof_$TAG/summary.txt $O/${TAG}_rocprofv3_summary.txt 2>/dev/null
+cp gpurun_out/prof_$TAG/kernel_stats.csv $O/${TAG}_kernel_stats.csv 2>/dev/null
+cp gpurun_out/prof_$TAG/traffic.json $O/traffic.json 2>/dev/null
+# per-GN-iteration k_assoc durations (rocprofv3 --kernel-trace) of configs[1], configs[3] (own targets) and configs[4] (30 iterations)
+{ echo "configs[1]:"; AB_ITERS=10 timeout 400 bash tests/ab.sh base 2>/dev/null | tail -2
+  echo "configs[3] (cfg4):"; AB_ITERS=10 BENCH_ARGS="--workload cfg4" timeout 400 bash tests/ab.sh base 2>/dev/null | tail -2
+  echo "configs[4] (cfg5):"; AB_ITERS=30 BENCH_ARGS="--workload cfg5" timeout 400 bash tests/ab.sh base 2>/dev/null | tail -2; } > $O/${TAG}_per_iteration.txt
+for w in cfg4 cfg5; do
+  ( cd /tmp; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1; rocprofv3 --output-format csv --kernel-trace --stats -d $O/tr_$w -o trace -- python $R/bench.py --workload $w --steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 > $O/tr_$w.log 2>&1 )
+  python - "$O" "$TAG" "$w" <<'PY'
+import csv, glob, sys
+O, TAG, W = sys.argv[1:4]
+f = glob.glob(f"{O}/tr_{W}/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = [r for r in csv.DictReader(open(f[0])) if "lisreg" in r["Name"]]
+    with open(f"{O}/{TAG}_{W}_kernel_stats.csv", "w") as o:
+        w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+PY
+  rm -rf $O/tr_$w
+done
+LISREG_BENCH_OVERSUBSCRIBE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/${TAG}_bench_2ranks_one_gpu.json
 ls $O

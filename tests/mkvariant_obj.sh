@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../lis-slam_amd/csrc"
 make -s
 mkdir -p ../lib/variants
 FLAGS=""; case $STEM in lisreg_solve|lisreg_nn1|lisreg_features) FLAGS="-ffp-contract=off";; esac
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $FLAGS "$@" -c $STEM.hip -o ../lib/variants/${STEM}_$N.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -fno-slp-vectorize $FLAGS "$@" -c $STEM.hip -o ../lib/variants/${STEM}_$N.o
 OBJS=$(ls ../lib/*.o | grep -v "$STEM.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/liblisreg_$N.so $OBJS ../lib/variants/${STEM}_$N.o -ldl
 rm ../lib/variants/${STEM}_$N.o

@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-export LISREG_BENCH_NO_EXACT=1      # the exact-arithmetic leg of the bench line would add its own kernel rows to the tables
+export LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1      # the exact-arithmetic leg and the two-contexts leg of the bench line would add their own kernel rows to the tables
 ARGS="--steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 $*"
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py $ARGS > $OUT/trace.log 2>&1

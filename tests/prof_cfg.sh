@@ -2,7 +2,7 @@
 # rocprofv3 summaries of one bench workload (kernel-trace stats pass + separate PMC passes): tests/prof_cfg.sh <workload> [iters]
 set -u
 W=${1:-cfg5}; IT=${2:-30}
-REPO=$(pwd); OUT=$REPO/gpurun_out/prof_$W; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
+REPO=$(pwd); OUT=$REPO/gpurun_out/prof_$W; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1
 ARGS="--workload $W --steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0"
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
