@@ -63,7 +63,7 @@ constexpr bool kExactArith = LISREG_EXACT != 0;
 #define LISREG_SELECT_SWAP 0
 #endif
 #ifndef LISREG_MED3_INSERT
-#define LISREG_MED3_INSERT 0
+#define LISREG_MED3_INSERT 1
 #endif
 // LDS of the reduction: one private region per wavefront (kRedWaveFloats floats) inside one array of the kernel.
 //   butterfly / exact build: the region starts with the wave's 28 sums (doubles);
