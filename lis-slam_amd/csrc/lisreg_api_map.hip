@@ -200,8 +200,9 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
     for (int k = 0; k < n_maps; ++k) { ms[(size_t)k] = &c->maps[slots[k]]; ms[(size_t)k]->valid = false; ms[(size_t)k]->n = counts[k]; ms[(size_t)k]->raw_ptr = src[(size_t)k]; }
     // one table for the batched build
     std::vector<TargetSeg> tsegs((size_t)n_maps);
-    std::vector<BlockDesc> tblocks;
-    int tflat = 0;
+    std::vector<BlockDesc> tblocks, tchunks;
+    int tflat = 0, tstrip = 0, max_units = 0, max_ucells = 0;
+    bool strips_fit = true;
     for (int k = 0; k < n_maps; ++k) {
         MapIndex& m = *ms[(size_t)k];
         const int n = counts[k];
@@ -219,19 +220,59 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
         ts.ox = m.g.ox; ts.oy = m.g.oy; ts.oz = m.g.oz; ts.inv_cell = m.g.inv_cell;
         ts.nx = m.g.nx; ts.ny = m.g.ny; ts.nz = m.g.nz;
         ts.grid_id = k;
+        // strip form of the build (the one a prepared batch's targets take, lisreg_batch_prepare): same layout rule
+        ts.strip_base = tstrip;
+        ts.ystrip = std::max(1, std::min(ts.ny, (c->strip_cells + ts.nz / 2) / std::max(ts.nz, 1)));
+        if (ts.nx > 0 && ts.nx <= kMaxStrips) {
+            const int max_nstrips = std::max(1, kMaxStrips / ts.nx);
+            ts.ystrip = std::max(ts.ystrip, (ts.ny + max_nstrips - 1) / max_nstrips);
+        }
+        ts.nstrips = (ts.ny + ts.ystrip - 1) / ts.ystrip;
+        if (n > 0) {
+            const int units = ts.nx * ts.nstrips;
+            tstrip += units; max_units = std::max(max_units, units); max_ucells = std::max(max_ucells, ts.ystrip * ts.nz);
+            strips_fit = strips_fit && units <= kMaxStrips;
+        }
         for (int s0 = 0; s0 < n; s0 += kBlockQ) tblocks.push_back(BlockDesc{ k, s0, std::min(kBlockQ, n - s0), 0 });
+        for (int s0 = 0; s0 < n; s0 += kPartChunkHost) tchunks.push_back(BlockDesc{ k, s0, std::min(kPartChunkHost, n - s0), 0 });
         tflat += n; total_cells += m.n_cells;
     }
-    int rc = ensure_sort_scratch(c, (size_t)std::max(tflat, 1), (size_t)std::max<long long>(total_cells, 1));
+    // Two or more maps whose grids fit it take the strip form (4.9 -> 1.2 ms for the 256 targets of 200 k points of bench.py --workload
+    // cfg4_icp: LDS histograms instead of one random global atomic per point, profiles/r05_kernel_experiments.md section 12); same records,
+    // same tables (tests/test_index_build.py, tests/test_mapfilter.py).  index_build 0 keeps the bucket sort.
+    strips_fit = strips_fit && ((size_t)max_ucells + 1) * 4 + (size_t)c->strip_cap * 6 + 8192 <= kStripLdsLarge;
+    const bool strips = strips_fit && c->index_build != 0 && n_maps >= 2 && tstrip > 0;
+    int rc = ensure_sort_scratch(c, (size_t)std::max(tflat, 1), strips ? 1 : (size_t)std::max<long long>(total_cells, 1));
     if (rc) return rc;
+    const std::vector<BlockDesc>& tb = strips ? tchunks : tblocks;
     HIPCHK(c, c->map_tsegs.ensure(sizeof(TargetSeg) * (size_t)n_maps));
-    HIPCHK(c, c->map_tblocks.ensure(sizeof(BlockDesc) * std::max<size_t>(tblocks.size(), 1)));
+    HIPCHK(c, c->map_tblocks.ensure(sizeof(BlockDesc) * std::max<size_t>(tb.size(), 1)));
+    if (strips) HIPCHK(c, c->strip_tab.ensure(sizeof(int) * (3 * ((size_t)tstrip + 4) + (size_t)tstrip / 2048 + 8)));
     HIPCHK(c, hipMemcpyAsync(c->map_tsegs.p, tsegs.data(), sizeof(TargetSeg) * (size_t)n_maps, hipMemcpyHostToDevice, st));
-    if (!tblocks.empty()) HIPCHK(c, hipMemcpyAsync(c->map_tblocks.p, tblocks.data(), sizeof(BlockDesc) * tblocks.size(), hipMemcpyHostToDevice, st));
+    if (!tb.empty()) HIPCHK(c, hipMemcpyAsync(c->map_tblocks.p, tb.data(), sizeof(BlockDesc) * tb.size(), hipMemcpyHostToDevice, st));
     for (int k = 0; k < n_maps; ++k)
         HIPCHK(c, hipMemcpyAsync(ms[(size_t)k]->g_dev.p, &ms[(size_t)k]->g, sizeof(GridIndex), hipMemcpyHostToDevice, st));
-    launch_build_targets_batched(c->map_tblocks.as<BlockDesc>(), (int)tblocks.size(), c->map_tsegs.as<TargetSeg>(), n_maps, tflat,
-                                 (int)std::max<long long>(total_cells, 1), sort_buffers(c), st);
+    if (strips) {
+        StripBuffers sl;
+        sl.cnt = c->strip_tab.as<int>(); sl.fill = sl.cnt + (tstrip + 1); sl.start = sl.fill + (tstrip + 1);
+        sl.scan_tmp = sl.start + (tstrip + 2);
+        sl.tmp_pts = c->tmp_pts.as<float4>(); sl.slot_idx = c->elem_bucket.as<uint32_t>(); sl.slot_pos = c->elem_sub.as<uint32_t>();
+        if (!c->side_stream) {                    // created once; failure just means the two strip variants run back to back
+            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+            if (c->side_stream && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                                   hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+                (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr;
+            }
+        }
+        sl.side = c->side_stream; sl.ev_fork = c->ev_fork; sl.ev_join = c->ev_join;
+        for (int k = 0; k < n_maps; ++k)          // an empty cloud has no strip: its one-cell table is [0, 0]
+            if (counts[k] <= 0) HIPCHK(c, hipMemsetAsync(ms[(size_t)k]->cell_start.p, 0, sizeof(int) * ((size_t)ms[(size_t)k]->n_cells + 1), st));
+        if (launch_build_targets_strips(c->map_tblocks.as<BlockDesc>(), (int)tchunks.size(), c->map_tsegs.as<TargetSeg>(), n_maps, tstrip,
+                                        max_units, max_ucells, c->strip_cap, sl, st))
+            return ctx_fail(c, LISREG_ERR_HIP, "map_index_set_batch: strip index build: LDS configuration refused");
+    } else
+        launch_build_targets_batched(c->map_tblocks.as<BlockDesc>(), (int)tblocks.size(), c->map_tsegs.as<TargetSeg>(), n_maps, tflat,
+                                     (int)std::max<long long>(total_cells, 1), sort_buffers(c), st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));            // the tables are locals
     for (int k = 0; k < n_maps; ++k) ms[(size_t)k]->valid = true;
@@ -402,7 +443,7 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
         for (int x = 0; x < 8; ++x) { hi[(size_t)n_items + 1 + (size_t)x].blk0 = per_xcd[x]; xcd_blocks = std::max(xcd_blocks, per_xcd[x]); }
     }
     HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)n_items + 64));
-    HIPCHK(c, c->icp_items.ensure(sizeof(IcpItem) * ((size_t)n_items + 9)));
+    HIPCHK(c, c->icp_items.ensure(sizeof(IcpItem) * 2 * ((size_t)n_items + 9)));      // the batch's table + its compacted form (below)
     HIPCHK(c, c->icp_partials.ensure(sizeof(double) * 17 * (size_t)std::max(total_blocks, 1)));
     IcpState* sd = c->icp_state.as<IcpState>();
     int* n_done_dev = reinterpret_cast<int*>(reinterpret_cast<char*>(c->icp_state.p) + sizeof(IcpState) * (size_t)n_items);
@@ -414,14 +455,25 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     float cap2 = max_d2 >= 3.0e38 ? 3.0e38f : (float)max_d2;
     if ((double)cap2 > max_d2) cap2 = std::nextafterf(cap2, 0.f);
     const IcpItem* di = c->icp_items.as<IcpItem>();
-    int n_done = 0;
+    // Alignments end at different iterations (configs[3]: between the 8th and the 19th of at most 30), and a workgroup of a finished one
+    // costs its launch slot (460 k empty wavefronts = 0.10 ms per launch).  Whenever the finished-counter read at the end of a chunk has
+    // moved, the blocks of the alignments still iterating are renumbered end to end (finished ones get no block; same order, same blocks per
+    // alignment, so the same partial rows in the same order: same sums) and the next launches shrink to them.  The fitness pass takes the
+    // full table again.  Not with the XCD-aware order (its per-XCD numbering is not rebuilt).
+    IcpItem* dc = c->icp_items.as<IcpItem>() + ((size_t)n_items + 9);
+    const IcpItem* dcur = di;
+    int cur_blocks = total_blocks;
+    std::vector<IcpItem> hc;
+    int n_done = 0, n_done_seen = 0;
     for (int it = 0; it < P->max_iters && n_done < n_items;) {
-        const int chunk = std::min(4, P->max_iters - it);
+        // four iterations between two looks at the counter; two once alignments have begun to finish (a look costs ~30 us, a launch of
+        // nothing but finished alignments 100)
+        const int chunk = std::min(n_done > 0 ? 2 : 4, P->max_iters - it);
         for (int k = 0; k < chunk; ++k) {
             ctx_prof_mark(c, 0);
-            launch_icp_assoc(di, n_items, total_blocks, xcd_blocks, q, sd, cap2, c->icp_partials.as<double>(), st);
+            launch_icp_assoc(dcur, n_items, cur_blocks, dcur == di ? xcd_blocks : 0, q, sd, cap2, c->icp_partials.as<double>(), st);
             ctx_prof_mark(c, 1);
-            launch_icp_solve(di, n_items, q, sd, c->icp_partials.as<double>(), P->max_iters, P->transformation_epsilon,
+            launch_icp_solve(dcur, n_items, q, sd, c->icp_partials.as<double>(), P->max_iters, P->transformation_epsilon,
                              P->euclidean_fitness_epsilon, n_done_dev, st);
             ctx_prof_mark(c, -1);
         }
@@ -429,6 +481,22 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
         it += chunk;
         HIPCHK(c, hipMemcpyAsync(&n_done, n_done_dev, sizeof n_done, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        if (n_done > n_done_seen && n_done < n_items && xcd_blocks == 0 && it < P->max_iters) {
+            n_done_seen = n_done;
+            HIPCHK(c, hipMemcpyAsync(hs.data(), sd, sizeof(IcpState) * (size_t)n_items, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            hc = hi;
+            int b = 0;
+            for (int k = 0; k < n_items; ++k) {
+                hc[(size_t)k].blk0 = b;
+                if (hs[(size_t)k].done) hc[(size_t)k].nblk = 0;
+                b += hc[(size_t)k].nblk;
+            }
+            hc[(size_t)n_items].blk0 = b;
+            HIPCHK(c, hipMemcpyAsync(dc, hc.data(), sizeof(IcpItem) * ((size_t)n_items + 9), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));      // (hc is pageable: the copy has left it when this returns)
+            dcur = dc; cur_blocks = b;
+        }
     }
     launch_icp_fitness_batch(di, n_items, total_blocks, xcd_blocks, q, sd, c->icp_partials.as<double>(), st);
     HIPCHK(c, hipGetLastError());

@@ -6,7 +6,7 @@ rocprofv3 --output-format csv --kernel-trace -d /tmp/kt_$W -o t -- python $R/ben
 tail -1 /tmp/kt_$W.log | cut -c1-200
 python - $W $S <<'PY'
 import csv,glob,collections,sys
-w=sys.argv[1]; steps=int(sys.argv[2])+2
+w=sys.argv[1]; steps=2*(int(sys.argv[2])+2)      # the bench line walks the frames twice: the timed pass and the untimed pass with events around the correspondence launches
 f=glob.glob(f'/tmp/kt_{w}/**/*kernel_trace.csv',recursive=True)[0]
 d=collections.defaultdict(lambda:[0,0.0])
 tot=0

@@ -295,6 +295,16 @@ def test_map_index_set_batch_equals_single_sets(gpu_ctx):
         assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), k
     with pytest.raises(lisreg.LisregError):
         gpu_ctx.map_index_set_batch([90, 90], clouds[:2])
+    # the batch takes the strip form of the index build where the grids fit it (round 5); index_build 0 keeps the batched bucket sort: same maps
+    gpu_ctx.set_option("index_build", 0)
+    try:
+        gpu_ctx.map_index_set_batch([100 + k for k in range(len(clouds))], clouds)
+    finally:
+        gpu_ctx.set_option("index_build", 2)
+    for k in range(len(clouds)):
+        i1, d1 = gpu_ctx.nearest(60 + k, q, 5.0)
+        i2, d2 = gpu_ctx.nearest(100 + k, q, 5.0)
+        assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), k
 
 
 @pytest.mark.gpu
