@@ -413,6 +413,8 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     long long total = 0;
     for (const IcpHostItem& it : its) total += it.n;
     if (total > 0x7fffffffLL / 4) return bad(c, "icp: more than 2^29 source points in one batch");
+    for (const IcpHostItem& it : its)
+        if (c->maps[it.slot].n >= (1 << 28)) return bad(c, "icp: a target of 2^28 points or more (the search addresses its records by 32-bit byte offsets)");
     const int q = icp_batch_lanes(total);
     std::vector<IcpItem> hi((size_t)n_items + 1 + 8);      // + the end sentinel + the eight XCDs' block counts (icp_locate)
     HIPCHK(c, c->icp_cur.ensure((sizeof(float4) + sizeof(int)) * (size_t)std::max<long long>(total, 1)));

@@ -97,6 +97,108 @@ __device__ __forceinline__ int nn1_search(float qx, float qy, float qz, const Gr
     return bi;
 }
 
+// The same search for ONE lane per query with the candidate loop flattened (round 5; the ICP kernels' batches).  nn1_search above costs a
+// wavefront, per pass, the SUM over column steps of the longest run any lane has at that step, and every candidate the full tie rule
+// (lane use 0.41-0.50, ~1 200 vector instructions per wavefront in the seeded iterations of configs[3]).  Here a lane first collects the
+// non-empty runs of its columns (LDS, kNn1Cap per lane), then streams through them in ONE loop four candidates at a time — a wavefront pays
+// its longest TOTAL — and the common case of a group (a unique closest candidate, not at the distance of the best so far) is a strict
+// insertion of that one candidate; a group whose minimum EQUALS the best so far, or is attained twice, takes the full rule
+// (distance, then original index) for its four.  The result is the lexicographic minimum over the same candidates either way.
+// The seed enters one ulp ABOVE its distance: the walk meets the seed point itself (its cell is inside the final box) and inserts it at
+// its true distance by the strict rule — so a real tie with it is an equality like any other, and meeting it is not.
+constexpr int kNn1Cap = 8;
+#ifndef LISREG_ICP_FLAT
+#define LISREG_ICP_FLAT 1
+#endif
+constexpr bool kIcpFlat = LISREG_ICP_FLAT != 0;
+__device__ __forceinline__ int nn1_search_flat(float qx, float qy, float qz, const GridIndex& g, float max_d2, float* d2_out, int seed,
+                                               int2 (*s_runs)[256])
+{
+    constexpr float kEps = 1e-3f;
+    // records and table entries are addressed base (scalar registers) + 32-bit byte offset: a target of the ICP kernels has fewer than 2^28
+    // points (icp_run checks) and a grid at most 2^24 cells (make_grid)
+    typedef __attribute__((address_space(1))) const char* gptr_c;
+    const unsigned long long pa_ = (unsigned long long)g.pts, ca_ = (unsigned long long)g.cell_start;
+    // (the builtin returns a signed int: each half goes through `unsigned` before it is widened)
+    const gptr_c pts_b = (gptr_c)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pa_ >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa_));
+    const gptr_c cells_b = (gptr_c)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ca_ >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ca_));
+#define LISREG_NN1_PT(i_) (*(gptr_f4)(pts_b + ((unsigned)(i_) << 4)))
+#define LISREG_NN1_CELL(i_) (*(gptr_i32)(cells_b + ((unsigned)(i_) << 2)))
+    float best = __uint_as_float(__float_as_uint(max_d2) + 1u);      // strictly-less test below must admit d2 == max_d2
+    int bi = -1;
+    if (g.n <= 0) { *d2_out = best; return -1; }
+    const int tid = threadIdx.x;
+    float seed_d2 = 0.f;
+    int seed_i = -2;
+    if (seed >= 0 && seed < g.n) {
+        const v4f c = LISREG_NN1_PT(seed);
+        const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        if (d2 < best) { seed_d2 = d2; seed_i = seed; best = __uint_as_float(__float_as_uint(d2) + 1u); bi = seed; }
+    }
+    for (float r = 0.5f;; r *= 2.f) {
+        const float lim = fminf(r * r, best);
+        const float rad = __builtin_amdgcn_sqrtf(lim) * 1.0001f + kEps;
+        const int cx0 = max(gcoord(qx - rad, g.ox, g.inv_cell), 0), cx1 = min(gcoord(qx + rad, g.ox, g.inv_cell), g.nx - 1);
+        const int cy0 = max(gcoord(qy - rad, g.oy, g.inv_cell), 0), cy1 = min(gcoord(qy + rad, g.oy, g.inv_cell), g.ny - 1);
+        const int cz0 = max(gcoord(qz - rad, g.oz, g.inv_cell), 0), cz1 = min(gcoord(qz + rad, g.oz, g.inv_cell), g.nz - 1);
+        int ix = cx0, iy = cy0;
+        if (cz0 > cz1 || cx0 > cx1 || cy0 > cy1) ix = cx1 + 1;          // an empty box (a non-finite query has one): nothing to step through
+        while (ix <= cx1) {
+            int cnt = 0;
+            // phase 1: up to kNn1Cap non-empty runs
+            while (cnt < kNn1Cap && ix <= cx1) {
+                const float xl = g.ox + (float)ix * g.cell, yl = g.oy + (float)iy * g.cell;
+                const float dx = fmaxf(fmaxf(xl - qx, qx - (xl + g.cell)) - kEps, 0.f);
+                const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.cell)) - kEps, 0.f);
+                if (dx * dx + dy * dy < fminf(best, lim)) {
+                    const int base = (ix * g.ny + iy) * g.nz;
+                    const int js = LISREG_NN1_CELL(base + cz0), je = LISREG_NN1_CELL(base + cz1 + 1);
+                    if (js < je) { s_runs[cnt][tid] = make_int2(js, je); ++cnt; }
+                }
+                if (++iy > cy1) { iy = cy0; ++ix; }
+            }
+            // phase 2: one loop over the collected candidates
+            int rr = 0, j = 0, e = 0;
+            for (;;) {
+                if (j >= e) { if (rr >= cnt) break; const int2 t = s_runs[rr][tid]; j = t.x; e = t.y; ++rr; }
+                const int l = e - 1;
+                const int j1 = min(j + 1, l), j2 = min(j + 2, l), j3 = min(j + 3, l);
+                const v4f c0 = LISREG_NN1_PT(j), c1 = LISREG_NN1_PT(j1), c2 = LISREG_NN1_PT(j2), c3 = LISREG_NN1_PT(j3);      // (a clamped tail repeats the run's last point)
+                const float ax = qx - c0.x, ay = qy - c0.y, az = qz - c0.z, bx = qx - c1.x, by = qy - c1.y, bz = qz - c1.z;
+                const float ux = qx - c2.x, uy = qy - c2.y, uz = qz - c2.z, vx = qx - c3.x, vy = qy - c3.y, vz = qz - c3.z;
+                const float e0 = ax * ax + ay * ay + az * az, e1 = bx * bx + by * by + bz * bz;        // flann::L2_Simple order
+                const float e2 = ux * ux + uy * uy + uz * uz, e3 = vx * vx + vy * vy + vz * vz;
+                const float m = fminf(fminf(e0, e1), fminf(e2, e3));
+                if (m <= best) {
+                    const bool q0 = e0 == m, q1 = e1 == m, q2 = e2 == m, q3 = e3 == m;
+                    const bool twice = (q0 && q1) || (q0 && q2) || (q0 && q3) || (q1 && q2) || (q1 && q3) || (q2 && q3);     // (lane masks: scalar work)
+                    if (m == best || twice) {
+                        // the full rule for the four: closer, or as close with the smaller original index
+                        int bw = bi >= 0 ? __float_as_int(LISREG_NN1_PT(bi).w) : (int)0x80000000;     // (nothing held yet: equality with the cap's bound must not insert)
+#define LISREG_NN1_FULL(e_, c_, j_) do { const int w_ = __float_as_int((c_).w); \
+                            if ((e_) < best || ((e_) == best && w_ < bw)) { best = (e_); bi = (j_); bw = w_; } } while (0)
+                        LISREG_NN1_FULL(e0, c0, j); LISREG_NN1_FULL(e1, c1, j1); LISREG_NN1_FULL(e2, c2, j2); LISREG_NN1_FULL(e3, c3, j3);
+#undef LISREG_NN1_FULL
+                    } else {
+                        best = m;
+                        bi = q0 ? j : (q1 ? j1 : (q2 ? j2 : j3));
+                    }
+                }
+                j += 4;
+            }
+        }
+        if (best <= r * r || !(r * r < max_d2)) break;     // exact: everything within min(best, r) was visited (a NaN cap ends the search too)
+    }
+    if (bi == seed_i && best > seed_d2) best = seed_d2;    // (cannot happen — the seed's cell is inside the last box — but the distance returned must be the point's)
+    *d2_out = best;
+    return bi;
+#undef LISREG_NN1_PT
+#undef LISREG_NN1_CELL
+}
+
 // A seed for a query that has none (the first ICP iteration): the nearest of up to four points out of the z-window [hz - 1, hz + 1] of the
 // query's own (x, y) column of the grid — one contiguous run of the cell-sorted array, two table reads and four records.  Any point will do
 // (nn1_search treats the seed as an ordinary candidate); a near one makes the first pass's radius the distance to it instead of a 0.5 m box
@@ -284,8 +386,11 @@ __global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ i
 {
     const bool getenv_icp_seed0 = (xcd_mode & 2) == 0;       // bit 1 of xcd_mode: experiments switch the first iteration's seed off (LISREG_ICP_NO_SEED0)
     __shared__ double red[4][kIcpAcc];
+    __shared__ int2 s_runs[Q == 1 ? kNn1Cap : 1][256];      // run lists of the flattened search (one lane per query)
     int blk;
-    const int item = icp_locate(items, n_items, xcd_mode & 1, &blk);
+    int item = icp_locate(items, n_items, xcd_mode & 1, &blk);
+    // (both are the same in every lane; said so, the item's table entry, its grid and the target's base pointers stay in scalar registers)
+    item = __builtin_amdgcn_readfirstlane(item); blk = __builtin_amdgcn_readfirstlane(blk);
     if (item < 0) return;
     const IcpState* stp = &states[item];
     if (stp->done) return;
@@ -309,7 +414,9 @@ __global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ i
         apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
         // last iteration's neighbour (position in the sorted target); the first iteration takes a point out of the query's own grid column
         const int seed = stp->iters == 0 ? (getenv_icp_seed0 ? nn1_cell_seed(px, py, pz, g) : -1) : I.nn[i];
-        const int bi = nn1_search<Q>(px, py, pz, g, cap2, &d2, seed);      // (all Q lanes have read their record before the lead lane writes)
+        int bi;
+        if (Q == 1 && kIcpFlat) bi = nn1_search_flat(px, py, pz, g, cap2, &d2, seed, s_runs);
+        else bi = nn1_search<Q>(px, py, pz, g, cap2, &d2, seed);          // (all Q lanes have read their record before the lead lane writes)
         if (lead) { I.cur[i] = make_float4(px, py, pz, s.w); I.nn[i] = bi; }
         if (bi >= 0 && lead) {
             const float4 q = g.pts[bi];
@@ -518,8 +625,10 @@ __global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict
                                                        double* __restrict__ partials)
 {
     __shared__ double red[4][2];
+    __shared__ int2 s_runs[Q == 1 ? kNn1Cap : 1][256];
     int blk;
-    const int item = icp_locate(items, n_items, xcd_mode, &blk);
+    int item = icp_locate(items, n_items, xcd_mode, &blk);
+    item = __builtin_amdgcn_readfirstlane(item); blk = __builtin_amdgcn_readfirstlane(blk);
     if (item < 0) return;
     const IcpItem I = items[item];
     const int i = (int)(((long long)blk * 256 + threadIdx.x) / Q);
@@ -530,7 +639,8 @@ __global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict
         float px, py, pz, d2;
         apply4(states[item].F, s.x, s.y, s.z, px, py, pz);
         // seed: the neighbour of the last ICP iteration (every item has run at least one; -1 where nothing was within reach)
-        if (nn1_search<Q>(px, py, pz, g, 3.0e38f, &d2, I.nn[i]) >= 0 && (threadIdx.x & (Q - 1)) == 0) { sum = d2; cnt = 1; }
+        const int bi = (Q == 1 && kIcpFlat) ? nn1_search_flat(px, py, pz, g, 3.0e38f, &d2, I.nn[i], s_runs) : nn1_search<Q>(px, py, pz, g, 3.0e38f, &d2, I.nn[i]);
+        if (bi >= 0 && (threadIdx.x & (Q - 1)) == 0) { sum = d2; cnt = 1; }
     }
     sum = wave_sum_up(sum); cnt = wave_sum_up(cnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
