@@ -268,6 +268,40 @@ def test_hip_icp_batch_equals_single_calls_bitwise_and_oracle(oracle, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_hip_icp_flat_search_resolves_exact_ties_like_the_column_walk(gpu_ctx, monkeypatch):
+    """The one-lane-per-query ICP kernels search with the flattened walk (nn1_search_flat: strict insertion of a group's unique minimum,
+    the full (distance, original index) rule only on equality), the four-lane ones with the column walk.  A target on a lattice and a
+    source on its cell centres make EVERY query's nearest neighbour an eight-way exact tie between different points, so the rule decides
+    every correspondence: both forms must give the same alignment to the bit (and the same again with the lattice's points listed twice)."""
+    import lisreg
+    g = np.arange(-6, 7, dtype=f32) * f32(0.25)
+    X, Y, Z = np.meshgrid(g, g, g[:5], indexing="ij")
+    lat = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(f32)
+    rng = np.random.default_rng(5)
+    lat = lat[rng.permutation(len(lat))]                                    # original indices in no spatial order
+    cases_dtype = _case(61, n_map=2000, hw=(16, 450))[0].dtype
+    def cloud(xyz):
+        c = np.zeros(len(xyz), dtype=cases_dtype)
+        c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+        return c
+    tgt = cloud(lat)
+    tgt2 = cloud(np.concatenate([lat, lat[::-1]]))
+    centres = (lat[np.all(lat < 1.4, axis=1) & (lat[:, 2] < 0.9)] + f32(0.125)).astype(f32)
+    src = cloud(centres[rng.permutation(len(centres))])
+    gpu_ctx.map_index_set(40, tgt); gpu_ctx.map_index_set(41, tgt2)
+    pg = lisreg.icp_default_params(0)
+    items = [(40, src, None), (41, src, None), (40, src[: len(src) // 2], None)]
+    out = {}
+    for q in ("1", "4"):
+        monkeypatch.setenv("LISREG_NN1_Q", q)
+        out[q] = gpu_ctx.icp_align_batch(items, pg)
+    monkeypatch.delenv("LISREG_NN1_Q")
+    for a, b in zip(out["1"], out["4"]):
+        assert _same(a, b), (a, b)
+        assert a["n_corr_last"] > 0
+
+
+@pytest.mark.gpu
 def test_map_index_set_batch_equals_single_sets(gpu_ctx):
     """setInputTarget of all candidates in one call (lisreg_map_index_set_batch): k = 1 queries and ICP alignments against the maps it
     builds equal those against maps built one by one — host clouds, device records, an empty and a one-point cloud among them."""
