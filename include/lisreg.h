@@ -240,12 +240,20 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * "feeder_numa" (1 [default]: the packing threads are bound to those CPUs of the device's NUMA node that the process may run on — the
  * pinned staging buffers are on that node already; read-only "feeder_numa_node" / "feeder_numa_cpus" say what was found),
  * "feeder_copy_engine" (1 [default]: while the next packed chunk is not ready and the copy engine is idle, the engine takes the last free
- * chunk of a pinned cloud as it is and a kernel packs it on the device; 0: never; 2: whenever a packed chunk is not ready — for tests),
+ * chunk of a pinned cloud as it is and a kernel packs it on the device; 0: never; 2: whenever a packed chunk is not ready — for tests;
+ * 3: the engine takes the FIRST chunk whatever the packing threads do — for tests),
+ * "interleave" (0 [default]: one launch per Gauss-Newton iteration for the whole batch; 1 / 2: a fixed-iteration run of at least
+ * "interleave_min_blocks" [8192] workgroups is cut at an item boundary near its middle and the halves iterate on two streams, so that each
+ * half's 6x6 solves run underneath the other half's correspondence launch — 1: the halves' launches alternate, 2: free-running; same
+ * kernels on the same data in the same order per registration, results identical to the bit; measured +1.7 % (mode 2) on
+ * BASELINE configs[1], +5.8 % on configs[4], at the price of per-kernel durations that are no longer a launch's own — off),
  * "graph_min_ratio", "cell_min_ratio", "cell_rows_max_mb", "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
  * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the
- * sector dispatch order. */
+ * sector dispatch order, "interleaved_now" = 1 if it ran as two halves; size of the prepared batch's search index: "index_kib_grid"
+ * (sorted records + cell tables of its targets), "index_kib_front_end" (k-NN graph rows or cell rows + their tables; 0 for the cell
+ * walk), "index_target_points" (points in those targets) — bench.py's roofline.index_bytes_per_target_point. */
 int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
 
 /* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):
@@ -407,7 +415,8 @@ int  lisreg_map_index_set(lisreg_ctx* ctx, int slot, const void* cloud, int n, i
 /* The same for n clouds at once — setInputTarget of every candidate of a loop-closure batch (subMapOptmizationNode.cpp:2793 inside the
  * candidate loop of :2776-2840): one bounding-box launch, one read-back and ONE sort launch sequence for all of them.  slots[k] receives
  * clouds[k] (counts[k] points; one stride / format for the batch; a slot may not be named twice).  Each index equals what
- * lisreg_map_index_set builds for that cloud, bit for bit. */
+ * lisreg_map_index_set builds for that cloud, bit for bit.  Two or more clouds whose grids fit it take the strip form of the build
+ * (option "index_build": 0 keeps the batched bucket sort; 256 clouds of 200 k points: 1.2 instead of 4.9 ms). */
 int  lisreg_map_index_set_batch(lisreg_ctx* ctx, int n_maps, const int* slots, const void* const* clouds, const int* counts,
                                 int stride_bytes, int fmt);
 /* nearestKSearch(query, k = 1) for a whole cloud: idx_out[i] = index into the map cloud of the nearest point, or -1 when it
