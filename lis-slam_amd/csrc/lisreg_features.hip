@@ -26,7 +26,6 @@ namespace lisreg {
 
 namespace {
 
-constexpr int kMaxSector = 1024;      // points per sector that the in-LDS sort handles (W/6 + 1 <= 1024 <=> W <= 6138)
 constexpr int kMaxRingPts = 4096 + 16;
 constexpr int kListCap = 128;         // per ring: <= 6*20 corners, <= 6*4 sharp corners, <= 6*10 sharp surfaces
 constexpr int kEmpty = 0x7f7f7f7f;   // pixel owner after a byte-wise 0x7f fill: larger than any input index
@@ -124,13 +123,13 @@ __global__ __launch_bounds__(256) void k_feat_occlude(const int* __restrict__ co
 
 // extractFeatures (:610-713): one wave per ring
 __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos, int H, int W, lisreg_feature_params P,
-                                                    FeatureBuffers fb, int rows_per_sweep)
+                                                    FeatureBuffers fb, int rows_per_sweep, int xp_stop)
 {
     __shared__ int   s_picked[kMaxRingPts];
     __shared__ float s_curv[kMaxRingPts];
     __shared__ int   s_col[kMaxRingPts];
-    __shared__ float s_val[6 * kMaxSector];          // the six sectors of the ring, each padded to SP entries, sorted together
-    __shared__ int   s_ind[6 * kMaxSector];
+    __shared__ unsigned long long s_key[kMaxRingPts];   // (curvature bits << 32 | position): the sort key of every point of the window
+    __shared__ int   s_sorted_all[kMaxRingPts];         // per sector, at the sector's own positions: its points ascending by (curvature, index)
     __shared__ unsigned char s_run[kMaxRingPts];     // per position: how far a pick there suppresses (forward | backward << 4), see below
 
     const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 4 waves sort, wave 0 picks
@@ -157,44 +156,54 @@ __global__ __launch_bounds__(256) void k_feat_select(const int* __restrict__ pos
         while (nb < 5 && pair_ok(a - nb)) ++nb;
         s_run[a - lo] = (unsigned char)(nf | (nb << 4));
     }
+    if (xp_stop == 1) return;                                          // timing experiments only (LISREG_XP_FEAT_STOP): wrong results
 
-    // std::sort of every sector's curvatures (:620) — the six sorts are independent of the picking, so they run as ONE bitonic network
-    // over the six sectors side by side (each padded to SP entries, the largest sector's power of two): 45 barriers for a 1800-column ring
-    // instead of 270, every thread busy in every stage
-    int SP = 1;
-    for (int j = 0; j < 6; ++j) {
-        const int sp = (startRing * (6 - j) + endRing * j) / 6, ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
-        while (SP < ep - sp) SP <<= 1;
-    }
-    for (int j = 0; j < 6; ++j) {
-        const int sp = (startRing * (6 - j) + endRing * j) / 6, ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
-        const int m = max(ep - sp, 0);                                 // std::sort range [sp, ep)
-        for (int t = tid; t < SP; t += 256) {
-            s_val[j * SP + t] = t < m ? s_curv[sp + t - lo] : 3.0e38f;
-            s_ind[j * SP + t] = t < m ? sp + t : 0x7fffffff;
+    // std::sort of every sector's curvatures (:620), ascending by (curvature, index) — by RANK COUNTING (round 5): a curvature is a square,
+    // so its float bits order like the value, and (bits << 32 | position) is one 64-bit key per point; a point's place in its sector's
+    // sorted order is the number of keys of the sector below its own.  1 800 points x 300 compares, one barrier, against the 45
+    // barrier-separated stages of the bitonic network this replaces; the same order, since the keys
+    // are distinct.  (A NaN curvature — there is none: ranges are finite — would sort behind every number.)
+    for (int k = lo + tid; k < hi; k += 256)
+        s_key[k - lo] = ((unsigned long long)__float_as_uint(s_curv[k - lo]) << 32) | (unsigned)k;
+    __syncthreads();
+    {
+        int sps[6], ms[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            sps[j] = (startRing * (6 - j) + endRing * j) / 6;
+            ms[j] = max((startRing * (5 - j) + endRing * (j + 1)) / 6 - 1 - sps[j], 0);      // std::sort range [sp, ep)
+        }
+        // 42 threads per sector, each with up to eight of its sector's points in registers per pass: one LDS read per compared key serves eight
+        // counts (the threads of a sector read the same address: a broadcast)
+        const int j = tid / 42, r = tid - j * 42;
+        if (j < 6) {
+            int sp = sps[0], m = ms[0];
+#pragma unroll
+            for (int jj = 1; jj < 6; ++jj) if (j == jj) { sp = sps[jj]; m = ms[jj]; }
+            const unsigned long long* keys = s_key + (sp - lo);
+            for (int t0 = r; t0 < m; t0 += 8 * 42) {
+                unsigned long long mine[8];
+                int below[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int t = t0 + 42 * q; mine[q] = t < m ? keys[t] : 0ull; below[q] = 0; }
+                for (int u = 0; u < m; ++u) {
+                    const unsigned long long ku = keys[u];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) below[q] += ku < mine[q] ? 1 : 0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int t = t0 + 42 * q; if (t < m) s_sorted_all[sp - lo + below[q]] = sp + t; }
+            }
         }
     }
     __syncthreads();
-    // bitonic sort ascending by (value, index), every sector inside its own aligned block of SP entries
-    for (int ksz = 2; ksz <= SP; ksz <<= 1)
-        for (int jj = ksz >> 1; jj > 0; jj >>= 1) {
-            for (int pr = tid; pr < 3 * SP; pr += 256) {                // 6 SP / 2 pairs
-                const int t = ((pr / jj) * 2 * jj) + (pr % jj), u = t + jj;
-                const float va = s_val[t], vb = s_val[u];
-                const int ia = s_ind[t], ib = s_ind[u];
-                const bool a_gt_b = va > vb || (va == vb && ia > ib);
-                const bool up = ((t & (SP - 1)) & ksz) == 0;           // the direction bit of the index INSIDE the sector (the last merge: all ascending)
-                if (a_gt_b == up) { s_val[t] = vb; s_val[u] = va; s_ind[t] = ib; s_ind[u] = ia; }
-            }
-            __syncthreads();
-        }
-    if (wave != 0) return;                                             // the picking below is one wavefront's work; no barrier follows
+    if (wave != 0 || xp_stop == 2) return;                             // the picking below is one wavefront's work; no barrier follows
 
     for (int j = 0; j < 6; ++j) {
         const int sp = (startRing * (6 - j) + endRing * j) / 6;
         const int ep = (startRing * (5 - j) + endRing * (j + 1)) / 6 - 1;
         if (sp >= ep) continue;                                        // wave-uniform
-        const int* s_sorted = s_ind + j * SP;                           // this sector's indices, ascending by (curvature, index)
+        const int* s_sorted = s_sorted_all + (sp - lo);                 // this sector's indices, ascending by (curvature, index)
         // The greedy passes are sequential in the SORTED order, but a candidate only costs time when it is picked:
         // every lane holds one sorted candidate, ballot + ffs finds the next one that qualifies and is still unpicked,
         // that lane marks itself and its +-5 neighbours in LDS, and candidates suppressed meanwhile are skipped for
@@ -523,7 +532,8 @@ void launch_extract_features(const float4* pts, const uint32_t* rings, int n, li
     k_feat_extract<<<(hw + 16 + 255) / 256, 256, 0, st>>>(pts, fb.owner, fb.pos, H, W, fb);
     k_feat_smooth<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.curv, fb.pos, hw_sweep, n_sweeps);
     k_feat_occlude<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.col, fb.picked, fb.pos, hw_sweep, n_sweeps);
-    k_feat_select<<<H, 256, 0, st>>>(fb.pos, H, W, P, fb, rows_per_sweep);            // grid = sweeps x rings
+    static const int xp_stop = getenv("LISREG_XP_FEAT_STOP") ? atoi(getenv("LISREG_XP_FEAT_STOP")) : 0;
+    k_feat_select<<<H, 256, 0, st>>>(fb.pos, H, W, P, fb, rows_per_sweep, xp_stop);   // grid = sweeps x rings
     k_feat_surface_flags<<<(hw + 16 + 255) / 256, 256, 0, st>>>(fb.pos, H, W, fb);
     // the second scan goes to the upper half of `pos`; the lower half (ring boundaries) stays valid
     launch_exclusive_scan(fb.flag, fb.pos + (hw + 17), fb.scan_tmp, hw + 16, st);
