@@ -507,6 +507,8 @@ static int set_target_impl(lisreg_ctx* c, int slot, const void* clouds[2], const
     if (slot < 0 || slot > 65535) return fail(c, LISREG_ERR_ARG, "set_target: bad slot");
     for (int k = 0; k < 2; ++k)
         if (counts[k] < 0 || (counts[k] > 0 && !clouds[k])) return fail(c, LISREG_ERR_ARG, "set_target: NULL cloud with n > 0");
+    for (int k = 0; k < 2; ++k)          // the kernels address a target's 16-byte records by 32-bit byte offsets from a scalar base
+        if (counts[k] >= (1 << 28)) return fail(c, LISREG_ERR_ARG, "set_target: a cloud of 2^28 points or more");
     if (fmt != LISREG_FMT_DEVICE && stride < 12) return fail(c, LISREG_ERR_ARG, "set_target: stride < 12");
     if (fmt == LISREG_FMT_XYZIL && stride < 22) return fail(c, LISREG_ERR_ARG, "set_target: XYZIL needs stride >= 22");
     HIPCHK(c, hipSetDevice(c->device));

@@ -968,7 +968,7 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
 #define LISREG_WALK_FOUR(j_, l_) do { \
         const int j1_ = min((j_) + 1, (l_)), j2_ = min((j_) + 2, (l_)), j3_ = min((j_) + 3, (l_)); \
         /* only x, y, z take part in the search: 12-byte loads (the original index in .w is read for the final five) */ \
-        const v3f c0_ = *(gptr_f3)(pts + (j_)), c1_ = *(gptr_f3)(pts + j1_), c2_ = *(gptr_f3)(pts + j2_), c3_ = *(gptr_f3)(pts + j3_); \
+        const v3f c0_ = LISREG_LD3(pts, (j_)), c1_ = LISREG_LD3(pts, j1_), c2_ = LISREG_LD3(pts, j2_), c3_ = LISREG_LD3(pts, j3_);     /* scalar base + 32-bit offset: with 64-bit lane addresses the counted loop below lost 6 % on configs[3] to the scheduler (a wait in front of the fourth load) */ \
         const float ax_ = qx - c0_.x, ay_ = qy - c0_.y, az_ = qz - c0_.z; \
         const float bx_ = qx - c1_.x, by_ = qy - c1_.y, bz_ = qz - c1_.z; \
         const float gx_ = qx - c2_.x, gy_ = qy - c2_.y, gz_ = qz - c2_.z; \
@@ -1002,8 +1002,9 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
             /* kQ lanes per query: the group goes on while any of its lanes has columns left (its lanes share the candidates below) */ \
             if (kQ == 1 || !kShare) { if (!(ix_ <= cx1_)) break; } \
             else if (((__builtin_amdgcn_ballot_w64(ix_ <= cx1_) >> ((tid & 63) & ~(kQ - 1))) & ((1ull << kQ) - 1ull)) == 0ull) break; \
-            int cnt_ = 0; \
-            /* phase 1: collect up to kWalkCap non-empty runs */ \
+            int cnt_ = 0, grp_ = 0; \
+            bool lng_ = false; \
+            /* phase 1: collect up to kWalkCap non-empty runs (grp_: their groups of four candidates) */ \
             while (cnt_ < kWalkCap && ix_ <= cx1_) { \
                 const float xl_ = g.ox + (float)ix_ * g.cell, yl_ = g.oy + (float)iy_ * g.cell; \
                 const float dx_ = fmaxf(fmaxf(xl_ - qx, qx - (xl_ + g.cell)) - kEps, 0.f); \
@@ -1012,30 +1013,34 @@ constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of 
                 if (!covered_ && dx_ * dx_ + dy_ * dy_ < fminf(b4, lim_)) { \
                     const int base_ = (ix_ * g.ny + iy_) * g.nz; \
                     const int js_ = cells[base_ + cz0_], je_ = cells[base_ + cz1_ + 1]; \
-                    if (js_ < je_) { s_runs_at(cnt_, tid) = make_int2(js_, je_); ++cnt_; } \
+                    if (js_ < je_) { \
+                        s_runs_at(cnt_, tid) = make_int2(js_, je_); ++cnt_; \
+                        if (kQ > 1 && kShare && je_ - js_ >= kShareRun) lng_ = true; else grp_ += (je_ - js_ + 3) >> 2; \
+                    } \
                 } \
                 if (kQ == 1) { if (++iy_ > cy1_) { iy_ = cy0_; ++ix_; } } \
                 else { iy_ += kQ; while (iy_ > cy1_) { iy_ -= nyb_; ++ix_; } } \
             } \
             /* phase 2: one loop over all collected candidates */ \
             if (kQ == 1 || !kShare) { \
+                /* the loop leaves at its head only (a counted loop over the groups): with the exit inside the run switch the compiler kept the \
+                   five-best list in two register sets and copied it twice per pass (19-29 v_mov per group of four, round 5) */ \
                 int r_ = 0, j_ = 0, e_ = 0; \
-                for (;;) { \
-                    if (j_ >= e_) { if (r_ >= cnt_) break; const int2 t_ = s_runs_at(r_, tid); j_ = t_.x; e_ = t_.y; ++r_; } \
+                _Pragma("unroll 1") for (int g2_ = 0; g2_ < grp_; ++g2_) { \
+                    if (j_ >= e_) { const int2 t_ = s_runs_at(r_, tid); j_ = t_.x; e_ = t_.y; ++r_; } \
                     LISREG_WALK_FOUR(j_, e_ - 1); \
                     j_ += 4; \
                 } \
             } else { \
                 /* every lane its own SHORT runs; a long run — a column that holds a pole or a stretch of wall, hundreds of points — is \
                    dealt out to all kQ lanes in groups of four candidates instead of keeping its lane busy alone */ \
-                bool long_ = false; \
+                const bool long_ = lng_; \
                 { \
                     int r_ = 0, j_ = 0, e_ = 0; \
-                    for (;;) { \
+                    _Pragma("unroll 1") for (int g2_ = 0; g2_ < grp_; ++g2_) {      /* (grp_ counts the groups of the SHORT runs here) */ \
                         if (j_ >= e_) { \
-                            if (r_ >= cnt_) break; \
-                            const int2 t_ = s_runs_at(r_, tid); ++r_; \
-                            if (t_.y - t_.x >= kShareRun) { long_ = true; continue; } \
+                            int2 t_; \
+                            do { t_ = s_runs_at(r_, tid); ++r_; } while (t_.y - t_.x >= kShareRun); \
                             j_ = t_.x; e_ = t_.y; \
                         } \
                         LISREG_WALK_FOUR(j_, e_ - 1); \

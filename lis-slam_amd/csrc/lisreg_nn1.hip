@@ -147,8 +147,8 @@ __device__ __forceinline__ int nn1_search_flat(float qx, float qy, float qz, con
         int ix = cx0, iy = cy0;
         if (cz0 > cz1 || cx0 > cx1 || cy0 > cy1) ix = cx1 + 1;          // an empty box (a non-finite query has one): nothing to step through
         while (ix <= cx1) {
-            int cnt = 0;
-            // phase 1: up to kNn1Cap non-empty runs
+            int cnt = 0, grp = 0;
+            // phase 1: up to kNn1Cap non-empty runs (grp: their groups of four candidates)
             while (cnt < kNn1Cap && ix <= cx1) {
                 const float xl = g.ox + (float)ix * g.cell, yl = g.oy + (float)iy * g.cell;
                 const float dx = fmaxf(fmaxf(xl - qx, qx - (xl + g.cell)) - kEps, 0.f);
@@ -156,14 +156,15 @@ __device__ __forceinline__ int nn1_search_flat(float qx, float qy, float qz, con
                 if (dx * dx + dy * dy < fminf(best, lim)) {
                     const int base = (ix * g.ny + iy) * g.nz;
                     const int js = LISREG_NN1_CELL(base + cz0), je = LISREG_NN1_CELL(base + cz1 + 1);
-                    if (js < je) { s_runs[cnt][tid] = make_int2(js, je); ++cnt; }
+                    if (js < je) { s_runs[cnt][tid] = make_int2(js, je); ++cnt; grp += (je - js + 3) >> 2; }
                 }
                 if (++iy > cy1) { iy = cy0; ++ix; }
             }
             // phase 2: one loop over the collected candidates
             int rr = 0, j = 0, e = 0;
-            for (;;) {
-                if (j >= e) { if (rr >= cnt) break; const int2 t = s_runs[rr][tid]; j = t.x; e = t.y; ++rr; }
+#pragma unroll 1
+            for (int gi = 0; gi < grp; ++gi) {       // (a counted loop that leaves at its head only: no copies of the loop-carried values)
+                if (j >= e) { const int2 t = s_runs[rr][tid]; j = t.x; e = t.y; ++rr; }
                 const int l = e - 1;
                 const int j1 = min(j + 1, l), j2 = min(j + 2, l), j3 = min(j + 3, l);
                 const v4f c0 = LISREG_NN1_PT(j), c1 = LISREG_NN1_PT(j1), c2 = LISREG_NN1_PT(j2), c3 = LISREG_NN1_PT(j3);      // (a clamped tail repeats the run's last point)
