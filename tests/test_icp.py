@@ -308,7 +308,9 @@ def test_map_index_set_batch_equals_single_sets(gpu_ctx):
     import lisreg
     from lisreg import synth
     cases = [_case(71 + k, n_map=int(15000 + 9000 * k), trans=0.3, rot_deg=1.5, hw=(16, 450)) for k in range(5)]
-    clouds = [c[0] for c in cases] + [cases[0][0][:0], cases[1][0][:1]]
+    holes = cases[3][0].copy()                                                  # a cloud with non-finite points in it (never anyone's neighbour)
+    holes["x"][5::97] = np.nan; holes["z"][11::131] = np.nan
+    clouds = [c[0] for c in cases] + [cases[0][0][:0], cases[1][0][:1], holes]
     for k, cl in enumerate(clouds):
         gpu_ctx.map_index_set(60 + k, cl)
     gpu_ctx.map_index_set_batch([80 + k for k in range(len(clouds))], clouds)
