@@ -138,7 +138,9 @@ int  lisreg_default_params(int variant, lisreg_params* p);
  * the caller's records must stay valid and unchanged until the slot is set again or the context is destroyed (with the
  * option "rebuild_targets_each_run" every lisreg_batch_run re-reads them).  The index persists until the next call for
  * that slot, so a target shared by many registrations is built once.  Slot 0 is what lisreg_align uses.  A cloud with an
- * infinite coordinate, or with no finite point at all, is refused (LISREG_ERR_ARG); NaN points are simply never neighbours. */
+ * infinite coordinate, or with no finite point at all, is refused (LISREG_ERR_ARG); NaN points are simply never neighbours.
+ * A cloud is limited to 2^28 - 1 points (the kernels address its 16-byte records by 32-bit byte offsets); with the cell rows
+ * (search_mode 5 / auto) to 2^26 - 1. */
 int  lisreg_set_target(lisreg_ctx* ctx, const void* corner, int n_corner,
                        const void* surf, int n_surf, int stride_bytes, int fmt);
 int  lisreg_set_target_slot(lisreg_ctx* ctx, int slot, const void* corner, int n_corner,
