@@ -52,28 +52,15 @@ namespace {
 namespace LISREG_ASSOC_NS {
 
 constexpr bool kExactArith = LISREG_EXACT != 0;
-// Wave sums of the 28 normal-equation terms on the matrix pipe (-DLISREG_MFMA_REDUCE=1; see row_and_reduce).  Built, tested (all GPU
-// parity tests green) and measured in round 5: 188-190 us per steady-state launch against 186-188 for the lane-swap butterfly — gfx950's
-// f32 MFMA runs at the f32 VECTOR rate (MI355X_MICROARCH.md), so eight of them cost what the ~115 vector instructions they replace cost.
-// Off by default; kept as the record of that measurement (profiles/r05_kernel_experiments.md).
-#ifndef LISREG_MFMA_REDUCE
-#define LISREG_MFMA_REDUCE 0
-#endif
-#ifndef LISREG_SELECT_SWAP
-#define LISREG_SELECT_SWAP 0
-#endif
+// (Round 5 built three variants of this file that measured no gain and were taken out again — the 28 wave sums on the matrix pipe
+// (v_mfma_f32_16x16x4_f32: gfx950's f32 MFMA runs at the f32 vector rate), the heads of the cell rows staged in LDS, the plane fit's pivot
+// swaps as selects: profiles/r05_kernel_experiments.md sections 1, 3, 11; the code is profiles/r05_xp_mfma_stage_select.patch.)
 #ifndef LISREG_MED3_INSERT
 #define LISREG_MED3_INSERT 1
 #endif
 // LDS of the reduction: one private region per wavefront (kRedWaveFloats floats) inside one array of the kernel.
-//   butterfly / exact build: the region starts with the wave's 28 sums (doubles);
-//   MFMA form: [0, 544) the 64 rows x 8 columns of the wave's Jacobian block as two half-waves of 32 rows (the second half 32 floats further
-//              on, so that both halves of a transposed read fall into different banks), [576, 704) the two 8 x 8 products of the halves
+//   the region starts with the wave's 28 sums (doubles)
 constexpr int kRedWaveFloats = 1024;
-#if LISREG_MFMA_REDUCE
-constexpr int kRedHalfStride = 32 * 8 + 32;     // floats between the two half-wave blocks of rows
-constexpr int kRedOut        = 576;             // the 2 x 64 products
-#endif
 // the reference's `/` and sqrt(): IEEE in the exact build, one v_rcp_f32 / v_sqrt_f32 (1 ulp) in the production build
 __device__ __forceinline__ float fdiv(float a, float b) { return kExactArith ? a / b : a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float fsqrt(float x) { return kExactArith ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
@@ -319,19 +306,8 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
 
     // k = 0
     {
-#if LISREG_SELECT_SWAP
-        // the same swaps as selects (the compiler turns the conditional swaps into divergent branches with a register copy per value and path)
-        const bool s1_ = n1 > n0 && n1 >= n2, s2_ = !s1_ && n2 > n0 && n2 > n1;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const float a0_ = a[i][0], a1_ = a[i][1], a2_ = a[i][2];
-            a[i][0] = s1_ ? a1_ : (s2_ ? a2_ : a0_); a[i][1] = s1_ ? a0_ : a1_; a[i][2] = s2_ ? a0_ : a2_;
-        }
-        p0 = s1_ ? 1 : (s2_ ? 2 : 0); p1 = s1_ ? 0 : 1; p2 = s2_ ? 0 : 2;
-#else
         if (n1 > n0 && n1 >= n2) LISREG_SWAPCOL(0, 1, p0, p1);
         else if (n2 > n0 && n2 > n1) LISREG_SWAPCOL(0, 2, p0, p2);
-#endif
         const float big = fmaxf(n0, fmaxf(n1, n2));
         if (big < thr * 5.f) rank = 0;
         else LISREG_HOUSEHOLDER(0);
@@ -340,16 +316,7 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
         float m1 = 0, m2 = 0;
 #pragma unroll
         for (int i = 1; i < 5; ++i) { m1 += a[i][1] * a[i][1]; m2 += a[i][2] * a[i][2]; }
-#if LISREG_SELECT_SWAP
-        {
-            const bool s_ = m2 > m1;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { const float a1_ = a[i][1], a2_ = a[i][2]; a[i][1] = s_ ? a2_ : a1_; a[i][2] = s_ ? a1_ : a2_; }
-            const int q1_ = p1, q2_ = p2; p1 = s_ ? q2_ : q1_; p2 = s_ ? q1_ : q2_;
-        }
-#else
         if (m2 > m1) LISREG_SWAPCOL(1, 2, p1, p2);
-#endif
         if (fmaxf(m1, m2) < thr * 4.f) rank = 1;
         else LISREG_HOUSEHOLDER(1);
     }
@@ -512,12 +479,11 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
 
 // Residual model shared by the search front-ends that re-fit every iteration.
 // (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
-// kTagged: the ids come out of cell rows and carry the entry's position in its row (crow_tagged); `stage` / `stage_en` = this lane's row as
-// staged in LDS and the number of entries of it there (null / 0: nothing staged) — a neighbour among them is read from LDS.
+// kTagged: the ids come out of cell rows and carry the entry's position in its row in their upper bits (crow_tagged): stripped here.
 template <bool kTagged = false>
 __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int i2, int i3, int i4, const GridIndex& g,
                                                 const float4 q4, float qx, float qy, float qz, const DevParams& P, int kind,
-                                                float cf[4], const v4f* stage = nullptr, int stage_en = 0)
+                                                float cf[4])
 {
     cf[0] = cf[1] = cf[2] = cf[3] = 0.f;
     bool ok = false;
@@ -534,16 +500,8 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
 #else
         v4f n0, n1, n2, n3, n4;
         if (kTagged) {
-            // tag - 1 = position in the row; unsigned: tag 0 (an id that did not come out of a row) wraps past every bound
-            const unsigned t0 = ((unsigned)i0 >> kCrowTagShift) - 1u, t1 = ((unsigned)i1 >> kCrowTagShift) - 1u, t2 = ((unsigned)i2 >> kCrowTagShift) - 1u,
-                           t3 = ((unsigned)i3 >> kCrowTagShift) - 1u, t4 = ((unsigned)i4 >> kCrowTagShift) - 1u;
-            const unsigned en = (unsigned)stage_en;
-            const bool l0 = t0 < en, l1 = t1 < en, l2 = t2 < en, l3 = t3 < en, l4 = t4 < en;
-            if (l0) n0 = stage[t0]; else n0 = LISREG_LD4(gp, i0 & kCrowIdMask);
-            if (l1) n1 = stage[t1]; else n1 = LISREG_LD4(gp, i1 & kCrowIdMask);
-            if (l2) n2 = stage[t2]; else n2 = LISREG_LD4(gp, i2 & kCrowIdMask);
-            if (l3) n3 = stage[t3]; else n3 = LISREG_LD4(gp, i3 & kCrowIdMask);
-            if (l4) n4 = stage[t4]; else n4 = LISREG_LD4(gp, i4 & kCrowIdMask);
+            n0 = LISREG_LD4(gp, i0 & kCrowIdMask); n1 = LISREG_LD4(gp, i1 & kCrowIdMask); n2 = LISREG_LD4(gp, i2 & kCrowIdMask);
+            n3 = LISREG_LD4(gp, i3 & kCrowIdMask); n4 = LISREG_LD4(gp, i4 & kCrowIdMask);
         } else {
             n0 = LISREG_LD4(gp, i0); n1 = LISREG_LD4(gp, i1); n2 = LISREG_LD4(gp, i2); n3 = LISREG_LD4(gp, i3); n4 = LISREG_LD4(gp, i4);
         }
@@ -567,11 +525,10 @@ template <bool kTagged = false>
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
                                                     const float* jk, const DevParams& P, int kind,
-                                                    float* s_red, double* __restrict__ out, int* dbg_ok = nullptr,
-                                                    const v4f* stage = nullptr, int stage_en = 0)
+                                                    float* s_red, double* __restrict__ out, int* dbg_ok = nullptr)
 {
     float cf[4];
-    const bool ok = residual_coeffs<kTagged>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf, stage, stage_en);
+    const bool ok = residual_coeffs<kTagged>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
     row_and_reduce(ok, cf, q4, jk, P, s_red, out);
 }
@@ -629,57 +586,6 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
         const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         if ((lane & 1) == 0 && idx < kNumAcc) s_acc[wave][idx] = v1;
     }
-#elif LISREG_MFMA_REDUCE
-    // ---- wave sums on the matrix pipe (round 5) -------------------------------------------------------------------------------------
-    // The 28 sums are the upper triangle of E^T E for the 64 x 8 block E = [row0 .. row5 | b | 1] of the wavefront's rows (row^T row: 21,
-    // row * b: 6, 1 * 1: the count).  gfx950 has an exact-f32 MFMA (v_mfma_f32_16x16x4_f32: D += A(16x4) B(4x16), bitwise a chain of
-    // fmaf; MI355X_MICROARCH.md, "Matrix cores"), and for E^T E both operands are the SAME register: lane l supplies E[k = l >> 4][l & 15]
-    // of a 4-row slice.  Two half-waves ride side by side — columns 0-7 the rows of lanes 0-31, columns 8-15 those of lanes 32-63 — so
-    // the two diagonal 8 x 8 blocks of the 16 x 16 product are the half-wave sums after 8 instructions (32 rows each, a 32-term fmaf chain
-    // in lane order); the off-diagonal blocks are never read.  The transposition lanes-hold-rows -> lanes-hold-columns goes through the
-    // wave's private LDS region: 2 ds_write_b128 + 8 ds_read_b32 per lane.  Replaces 28 products + a 31-step lane-swap butterfly
-    // (~115 vector-ALU instructions and 24 lane swaps per wavefront, on a launch that is bound by vector-ALU issue).  Fixed order, no
-    // atomics: a registration gives the same bits alone and in any batch; above the half-wave everything stays fp64 in index order.
-    {
-        float* s_w = s_red + wave * kRedWaveFloats;
-        // (a lane without a correspondence contributes a zero row)
-        float4* dst = reinterpret_cast<float4*>(s_w + (lane >> 5) * kRedHalfStride + (lane & 31) * 8);
-        dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-        dst[1] = make_float4(row[4], row[5], rb, one);
-        // slice s: lane l reads E_half[4 s + (l >> 4)][l & 7], half = bit 3 of l
-        const float* src = s_w + ((lane >> 3) & 1) * kRedHalfStride + (lane >> 4) * 8 + (lane & 7);
-        typedef float v4acc __attribute__((ext_vector_type(4)));
-        v4acc acc = { 0.f, 0.f, 0.f, 0.f };
-        float e[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) e[s] = src[s * 32];                        // all eight slices asked for before the first product
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], e[s], acc, 0, 0, 0);
-        // D[i][j]: lane = j + 16 * (i >> 2), register i & 3.  Lower half-wave: i, j < 8 (lanes 0-7, 16-23); upper: i, j >= 8 (lanes 40-47, 56-63).
-        const int half = lane >> 5;
-        if (((lane >> 3) & 1) == half) {
-            float* o = s_w + kRedOut + half * 64 + ((lane >> 4) & 1) * 32 + (lane & 7);       // [i = 4 * ((l >> 4) & 1) + r][j = l & 7]
-            o[0] = acc[0]; o[8] = acc[1]; o[16] = acc[2]; o[24] = acc[3];
-        }
-    }
-    __syncthreads();
-    if (tid < kNumAcc) {
-        // tid -> (i, j) of the 8 x 8 product: 0..20 the upper triangle of the 6 x 6 corner (row-major), 21..26 column 6 (b), 27 = [7][7] (count)
-        int i = 0, j = tid;
-        if (tid >= 27) { i = 7; j = 7; }
-        else if (tid >= 21) { i = tid - 21; j = 6; }
-        else {
-#pragma unroll
-            for (int r = 0; r < 5; ++r) if (j >= 6 - i) { j -= 6 - i; ++i; }
-            j += i;
-        }
-        double v = 0.0;
-#pragma unroll
-        for (int h = 0; h < 2 * (kBlockQ / 64); ++h)                           // fixed order: half-waves 0 .. 7
-            v += (double)s_red[(h >> 1) * kRedWaveFloats + kRedOut + (h & 1) * 64 + i * 8 + j];
-        out[tid] = v;
-    }
-    return;
 #else
     // the 28 normal-equation terms of this row, produced on demand:
     //   k = 0..20 upper triangle of row^T row (row-major), 21..26 row * b, 27 the correspondence count
@@ -947,17 +853,6 @@ __global__ __launch_bounds__(kBlockQ) void k_assoc_staged(const BlockDesc* __res
 // per-column maxima.  Lists are flushed whenever a lane's list is full, which also re-prunes against the shrinking bound
 // during the wide early-iteration walks.  Same columns, same candidate order, same inserts: the result is identical.
 constexpr int kWalkCap = 8;
-// cell rows staged in LDS (k_assoc_walk<.., 2, 1>): a wavefront's 4-KB region holds a row-id table and the first 16 entries of up to
-// kStageS16 rows, or the first 8 entries of up to kStageS8 rows (one pad record per row)
-// Built, exact to every GPU test and measured in round 5 (profiles/r05_kernel_experiments.md, section 3): 188-194 us per steady-state launch
-// against 188-192 without — the launch is bound by vector-ALU issue, not by its loads.  Off by default; -DLISREG_STAGE_ROWS=1 builds it.
-#ifndef LISREG_STAGE_ROWS
-#define LISREG_STAGE_ROWS 0
-#endif
-constexpr bool kStageRows = LISREG_STAGE_ROWS != 0;
-constexpr int kStageBase = 128;                    // bytes: the row-id table (<= 32 ints) comes first
-constexpr int kStageS16 = 14, kStageS8 = 27;
-static_assert(kStageBase + kStageS16 * (16 * 16 + 16) <= 4096 && kStageBase + kStageS8 * (8 * 16 + 16) <= 4096 && kStageS8 <= 32, "a wavefront's LDS region is 4 KB");
 constexpr int kShareRun = 32;          // kQ lanes per query: candidate runs of this length or more are shared by the kQ lanes
 // INNER: restrict this pass to the 3 x 3 columns around the query's own column and remember that box (sx0..sy1);
 // SKIP: leave out the columns of the remembered box (a preceding INNER pass covered them with a z-range at least as wide).
@@ -1218,13 +1113,9 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
 // falls into (lisreg_index.hip, k_crow_build), so d_m = |q - m| is bounded by the cell size whatever the query's distance from the surface:
 // the same certificate as the graph scan (stop at the first entry farther from m than c5 + d_m; an exhausted list certifies through
 // rho(m) > c5 + d_m), no anchor carried between iterations, no anchor point to fetch, no hop.  No certificate -> the cell walk, seeded.
-// Where the head of the row is staged in LDS (ST_: wave-uniform; SP_ = the lane's staged row, EN_ entries of it), the first EN_ / 4 groups
-// come from there — no memory round trip between them — and the rest of the row from memory as before.  Same entries, same order: same five.
-#define LISREG_CELL_SCAN(ST_, EN_, SP_) do { \
+#define LISREG_CELL_SCAN() do { \
             const gptr_f4 R_ = (gptr_f4)(crow + (size_t)row_ * kGraphK); \
-            v4f r0_, r1_, r2_, r3_; \
-            if (ST_) { r0_ = (SP_)[0]; r1_ = (SP_)[1]; r2_ = (SP_)[2]; r3_ = (SP_)[3]; } \
-            else { r0_ = R_[0]; r1_ = R_[1]; r2_ = R_[2]; r3_ = R_[3]; } \
+            const v4f r0_ = R_[0], r1_ = R_[1], r2_ = R_[2], r3_ = R_[3]; \
             const float rho2_ = am_.x; \
             const int cnt_ = __float_as_int(am_.y); \
             v4f ap_; ap_.x = mx_; ap_.y = my_; ap_.z = mz_; ap_.w = 0.f; \
@@ -1260,9 +1151,7 @@ __device__ __forceinline__ int cell_anchor(const GridIndex& g, gptr_i32 cells, g
                 if (cnt_ > 0) LISREG_GRAPH_GROUP(r0_, r1_, r2_, r3_, LISREG_TRY_ND); \
             } \
             _Pragma("unroll 1") for (int g_ = 1; !stop_ && 4 * g_ < cnt_ && LISREG_XP_SCAN_GROUPS(g_); ++g_) { \
-                v4f e0g_, e1g_, e2g_, e3g_; \
-                if ((ST_) && 4 * g_ < (EN_)) { e0g_ = (SP_)[4 * g_]; e1g_ = (SP_)[4 * g_ + 1]; e2g_ = (SP_)[4 * g_ + 2]; e3g_ = (SP_)[4 * g_ + 3]; } \
-                else { e0g_ = R_[4 * g_]; e1g_ = R_[4 * g_ + 1]; e2g_ = R_[4 * g_ + 2]; e3g_ = R_[4 * g_ + 3]; } \
+                const v4f e0g_ = R_[4 * g_], e1g_ = R_[4 * g_ + 1], e2g_ = R_[4 * g_ + 2], e3g_ = R_[4 * g_ + 3]; \
                 LISREG_GRAPH_GROUP(e0g_, e1g_, e2g_, e3g_, LISREG_TRY_ND); \
             } \
             if (!stop_) stop_ = rho2_ > thr2_;                 /* list exhausted: the coverage radius decides */ \
@@ -1390,8 +1279,6 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     float b0, b1, b2, b3, b4;
     int   i0, i1, i2, i3, i4;
     bool  tie = false;                                     // kTies: an equal-distance pair that can matter was met
-    int   stage_en = 0;                                    // cell rows: entries per row staged in this wavefront's LDS region (0: none)
-    const v4f* stage_sp = nullptr;                         //            this lane's staged row
 #define LISREG_LIST_INIT() do { b0 = b1 = b2 = b3 = b4 = P.tau; i0 = i1 = i2 = i3 = i4 = -1; } while (0)
     if (kGraph) {
         // search_mode 3: one anchor id per query instead of five seeds; graph scan first, cell walk only without a certificate
@@ -1429,54 +1316,13 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
             const gptr_f2 cmeta = (gptr_f2)g.crow_meta;
             const bool scan_ = row_ >= 0;
             v2f am_; am_.x = 0.f; am_.y = 0.f;
-            if (scan_) am_ = cmeta[row_];                  // (rho^2, count): asked for before the staging round trip
-            // ---- the heads of the rows this wavefront needs, staged in LDS once (round 5) ---------------------------------------------
-            // Consecutive queries of a scan fall into the same octant (0.25 m) a few at a time: a wavefront of 64 needs ~18 distinct rows
-            // (median 14).  Each lane fetching its own 64 bytes per group of four entries means four gather instructions per group over those
-            // ~18 lines, a dependent round trip between groups, and five more gathers for the kept neighbours at the end.  Here the leaders
-            // of the runs of equal rows post their row ids, the wavefront loads the first 16 entries (up to kStageS16 rows) or 8 entries (up
-            // to kStageS8 rows) of every posted row with one fully coalesced 16-byte-per-lane load per 4 / 8 rows into its private LDS
-            // region, and every lane scans its row out of LDS.  Entries carry their position in the row (crow_tagged), so a kept neighbour
-            // that came out of the staged part is read back from LDS by the fit (residual_coeffs) instead of being gathered again.
-            if (kQ == 1 && kStageRows) {
-                const int lane_ = tid & 63;
-                const int prev_ = __shfl_up(row_, 1);
-                const bool lead_ = scan_ && (lane_ == 0 || prev_ != row_);
-                const unsigned long long lm_ = __builtin_amdgcn_ballot_w64(lead_);
-                const int L_ = __popcll(lm_);
-                stage_en = (L_ >= 1 && L_ <= kStageS16) ? 16 : ((L_ >= 1 && L_ <= kStageS8) ? 8 : 0);
-                if (stage_en) {
-                    const int below_ = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm_, 0u));
-                    const int slot_ = lead_ ? below_ : below_ - 1;
-                    char* sw_ = reinterpret_cast<char*>(s_red) + (tid >> 6) * (kRedWaveFloats * 4);
-                    int* s_rowid_ = reinterpret_cast<int*>(sw_);
-                    if (lead_) s_rowid_[slot_] = row_;
-                    const int stride_ = stage_en * 16 + 16;                    // one 16-byte pad per row: rows start in different banks
-                    const int sub_ = stage_en == 16 ? (lane_ >> 4) : (lane_ >> 3), ent_ = lane_ & (stage_en - 1), spp_ = stage_en == 16 ? 4 : 8;
-                    v4f t_[4];
-#pragma unroll
-                    for (int p_ = 0; p_ < 4; ++p_) {
-                        const int sl_ = p_ * spp_ + sub_;
-                        t_[p_].x = t_[p_].y = t_[p_].z = t_[p_].w = 0.f;
-                        if (sl_ < L_) t_[p_] = crow[(size_t)s_rowid_[sl_] * kGraphK + ent_];
-                    }
-#pragma unroll
-                    for (int p_ = 0; p_ < 4; ++p_) {
-                        const int sl_ = p_ * spp_ + sub_;
-                        if (sl_ < L_) *reinterpret_cast<v4f*>(sw_ + kStageBase + sl_ * stride_ + ent_ * 16) = t_[p_];
-                    }
-                    stage_sp = reinterpret_cast<const v4f*>(sw_ + kStageBase + (scan_ ? slot_ : 0) * stride_);
-                }
-            }
+            if (scan_) am_ = cmeta[row_];                  // (rho^2, count)
             if (scan_) {
                 bool certified = false;
                 scanned = true;
-                LISREG_CELL_SCAN(stage_en != 0, stage_en, stage_sp);
+                LISREG_CELL_SCAN();
                 need_walk = !certified;
             }
-            // a walking lane's run lists overwrite the staged rows of its wavefront (the same LDS): such a wavefront gathers the kept
-            // neighbours from memory again (rare: no lane walks once the pose has settled)
-            if (__builtin_amdgcn_ballot_w64(need_walk) != 0ull) stage_en = 0;
         } else
         if (valid && it->iter > 0 && g.nbr) {
             int anchor = nn[qflat];
@@ -1613,7 +1459,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
 #endif
     if (kQ == 1) {
         residual_and_reduce<kGraph == 2>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out,
-                                         dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr, stage_sp, stage_en);
+                                         dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
     } else {
         // kQ lanes per query: the coefficients go to memory and k_rows_reduce builds the partial rows with the SAME 256-query
         // workgroups and the SAME reduction tree as the kQ = 1 kernel, so the normal equations — hence every pose — are
