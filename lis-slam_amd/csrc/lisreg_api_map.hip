@@ -416,7 +416,7 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     for (const IcpHostItem& it : its)
         if (c->maps[it.slot].n >= (1 << 28)) return bad(c, "icp: a target of 2^28 points or more (the search addresses its records by 32-bit byte offsets)");
     const int q = icp_batch_lanes(total);
-    std::vector<IcpItem> hi((size_t)n_items + 1 + 8);      // + the end sentinel + the eight XCDs' block counts (icp_locate)
+    std::vector<IcpItem> hi((size_t)n_items + 1);          // + the end sentinel
     HIPCHK(c, c->icp_cur.ensure((sizeof(float4) + sizeof(int)) * (size_t)std::max<long long>(total, 1)));
     int* nn_base = reinterpret_cast<int*>(c->icp_cur.as<float4>() + std::max<long long>(total, 1));
     long long off = 0; int blk = 0;
@@ -429,28 +429,19 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
         h.prev_mse = it.prev_mse; h.cur_mse = DBL_MAX; h.first_mse = -1.0; h.defer_first = it.defer;
         IcpItem& d = hi[(size_t)k];
         d.src = it.src; d.cur = c->icp_cur.as<float4>() + off; d.nn = nn_base + off; d.grid = c->maps[it.slot].g_dev.as<GridIndex>();
-        d.n = it.n; d.blk0 = blk; d.nblk = icp_batch_blocks(it.n, q); d.xblk0 = 0;
+        d.n = it.n; d.blk0 = blk; d.nblk = icp_batch_blocks(it.n, q); d.pad_ = 0;
         off += it.n; blk += d.nblk;
     }
-    memset(&hi[(size_t)n_items], 0, sizeof(IcpItem) * 9);
+    memset(&hi[(size_t)n_items], 0, sizeof(IcpItem));
     hi[(size_t)n_items].blk0 = blk;
     const int total_blocks = blk;
-    // XCD-aware launch order for batches of alignments with targets of their own (lisreg_nn1.hip, icp_locate): alignment k belongs to XCD k & 7.
-    // Measured in round 5 on configs[3] (256 candidates, own 200 k-point targets): 8 406 candidates/s against 8 760 in plain order — the
-    // search is not bound by L2 misses.  Off unless LISREG_ICP_XCD_ORDER is set (profiles/r05_kernel_experiments.md).
-    int xcd_blocks = 0;
-    if (n_items >= 8 && total_blocks >= 2048 && getenv("LISREG_ICP_XCD_ORDER")) {
-        int per_xcd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int k = 0; k < n_items; ++k) { hi[(size_t)k].xblk0 = per_xcd[k & 7]; per_xcd[k & 7] += hi[(size_t)k].nblk; }
-        for (int x = 0; x < 8; ++x) { hi[(size_t)n_items + 1 + (size_t)x].blk0 = per_xcd[x]; xcd_blocks = std::max(xcd_blocks, per_xcd[x]); }
-    }
     HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)n_items + 64));
-    HIPCHK(c, c->icp_items.ensure(sizeof(IcpItem) * 2 * ((size_t)n_items + 9)));      // the batch's table + its compacted form (below)
+    HIPCHK(c, c->icp_items.ensure(sizeof(IcpItem) * 2 * ((size_t)n_items + 1)));      // the batch's table + its compacted form (below)
     HIPCHK(c, c->icp_partials.ensure(sizeof(double) * 17 * (size_t)std::max(total_blocks, 1)));
     IcpState* sd = c->icp_state.as<IcpState>();
     int* n_done_dev = reinterpret_cast<int*>(reinterpret_cast<char*>(c->icp_state.p) + sizeof(IcpState) * (size_t)n_items);
     HIPCHK(c, hipMemcpyAsync(sd, hs.data(), sizeof(IcpState) * (size_t)n_items, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->icp_items.p, hi.data(), sizeof(IcpItem) * ((size_t)n_items + 9), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->icp_items.p, hi.data(), sizeof(IcpItem) * ((size_t)n_items + 1), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(n_done_dev, 0, sizeof(int), st));
     // (double) d2 > max_distance^2 rejects (correspondence_estimation.hpp): the largest float that still passes
     const double max_d2 = P->max_corr_dist * P->max_corr_dist;
@@ -461,8 +452,8 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
     // costs its launch slot (460 k empty wavefronts = 0.10 ms per launch).  Whenever the finished-counter read at the end of a chunk has
     // moved, the blocks of the alignments still iterating are renumbered end to end (finished ones get no block; same order, same blocks per
     // alignment, so the same partial rows in the same order: same sums) and the next launches shrink to them.  The fitness pass takes the
-    // full table again.  Not with the XCD-aware order (its per-XCD numbering is not rebuilt).
-    IcpItem* dc = c->icp_items.as<IcpItem>() + ((size_t)n_items + 9);
+    // full table again.
+    IcpItem* dc = c->icp_items.as<IcpItem>() + ((size_t)n_items + 1);
     const IcpItem* dcur = di;
     int cur_blocks = total_blocks;
     std::vector<IcpItem> hc;
@@ -473,7 +464,7 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
         const int chunk = std::min(n_done > 0 ? 2 : 4, P->max_iters - it);
         for (int k = 0; k < chunk; ++k) {
             ctx_prof_mark(c, 0);
-            launch_icp_assoc(dcur, n_items, cur_blocks, dcur == di ? xcd_blocks : 0, q, sd, cap2, c->icp_partials.as<double>(), st);
+            launch_icp_assoc(dcur, n_items, cur_blocks, q, sd, cap2, c->icp_partials.as<double>(), st);
             ctx_prof_mark(c, 1);
             launch_icp_solve(dcur, n_items, q, sd, c->icp_partials.as<double>(), P->max_iters, P->transformation_epsilon,
                              P->euclidean_fitness_epsilon, n_done_dev, st);
@@ -483,7 +474,7 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
         it += chunk;
         HIPCHK(c, hipMemcpyAsync(&n_done, n_done_dev, sizeof n_done, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        if (n_done > n_done_seen && n_done < n_items && xcd_blocks == 0 && it < P->max_iters) {
+        if (n_done > n_done_seen && n_done < n_items && it < P->max_iters) {
             n_done_seen = n_done;
             HIPCHK(c, hipMemcpyAsync(hs.data(), sd, sizeof(IcpState) * (size_t)n_items, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
@@ -495,12 +486,12 @@ int icp_run(lisreg_ctx* c, const std::vector<IcpHostItem>& its, const lisreg_icp
                 b += hc[(size_t)k].nblk;
             }
             hc[(size_t)n_items].blk0 = b;
-            HIPCHK(c, hipMemcpyAsync(dc, hc.data(), sizeof(IcpItem) * ((size_t)n_items + 9), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(dc, hc.data(), sizeof(IcpItem) * ((size_t)n_items + 1), hipMemcpyHostToDevice, st));
             HIPCHK(c, hipStreamSynchronize(st));      // (hc is pageable: the copy has left it when this returns)
             dcur = dc; cur_blocks = b;
         }
     }
-    launch_icp_fitness_batch(di, n_items, total_blocks, xcd_blocks, q, sd, c->icp_partials.as<double>(), st);
+    launch_icp_fitness_batch(di, n_items, total_blocks, q, sd, c->icp_partials.as<double>(), st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hs.data(), sd, sizeof(IcpState) * (size_t)n_items, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -307,20 +307,18 @@ struct IcpItem {
     int*             nn;     // last iteration's neighbour of every source point (position in the sorted target, -1 none): the next search's seed
     const GridIndex* grid;   // its target's k = 1 index
     int n, blk0, nblk;
-    int xblk0;               // XCD-aware launches: first block of this alignment among the blocks of ITS XCD (alignments k, k + 8, ... share XCD k & 7)
+    int pad_;
 };
 int  icp_batch_lanes(long long total_points);
 int  icp_batch_blocks(int n, int q);
 int  icp_blocks(int n);
 // one ICP iteration on the working copy `cur` (input_transformed): apply st->Tm in place, correspondences + sums
 // (partials: icp_blocks(n) * 17 doubles), then transform estimate + convergence (st->Tm = the new transformation_)
-// xcd_blocks > 0: the batch is launched XCD-aware — 8 * xcd_blocks workgroups, workgroup p works on block p >> 3 of XCD p & 7's alignments
-// (items[n_items + 1 + x].blk0 = the number of blocks of XCD x; lisreg_nn1.hip, icp_locate); 0: workgroup p = block p of the batch
-void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int xcd_blocks, int q, IcpState* states, float cap2, double* partials,
+void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
                       hipStream_t stream);
 void launch_icp_solve(const IcpItem* items, int n_items, int q, IcpState* states, const double* partials,
                       int max_iters, double eps_t, double eps_mse, int* n_done, hipStream_t stream);
-void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int xcd_blocks, int q, IcpState* states, double* partials, hipStream_t stream);
+void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream);
 // one OptimizedICPGN iteration (partials: icp_blocks(n) * 22 doubles); st->F is T, st->iters counts the applied steps
 void launch_icpgn_iteration(const float4* src, int n, const GridIndex* grid_dev, IcpState* st, float cap2, double* partials,
                             hipStream_t stream);

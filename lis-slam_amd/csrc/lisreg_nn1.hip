@@ -333,28 +333,13 @@ __device__ __forceinline__ int icp_find_item(const IcpItem* __restrict__ items, 
     return lo;
 }
 
-// Which alignment, and which of its blocks, a workgroup of a batch launch works on.  Plain launch: workgroup p = block p of the batch.
-// XCD-aware launch (round 5): MI355X hands workgroup p to XCD p & 7, and a batch of loop-closure candidates brings a target of its own per
-// alignment (3 MB of points + 2.5 MB of cell table each): in plain order the ~2 000 resident workgroups belong to four or five alignments
-// and every XCD's 4-MB L2 sees a slice of all of them.  Here XCD x works through the alignments x, x + 8, ... one after the other (workgroup
-// p = block p >> 3 of that sequence), so an L2 holds the one target its CUs are searching.  Results do not depend on the order: the
-// partial rows stay addressed by the batch-wide block number.  Returns -1 for a workgroup past its XCD's share.
-__device__ __forceinline__ int icp_locate(const IcpItem* __restrict__ items, int n_items, int xcd_mode, int* b)
+// Which alignment, and which of its blocks, a workgroup of a batch launch works on: workgroup p = block p of the batch.  (An XCD-aware order —
+// XCD x working through the alignments x, x + 8, ... so that an L2 holds the one target its CUs are searching — measured 4 % SLOWER on
+// configs[3] in round 5: the search is not bound by L2 misses; profiles/r05_kernel_experiments.md section 6, r05_xp_icp_xcd_order.patch.)
+__device__ __forceinline__ int icp_locate(const IcpItem* __restrict__ items, int n_items, int* b)
 {
-    if (!xcd_mode) {
-        const int item = icp_find_item(items, n_items, blockIdx.x);
-        *b = (int)blockIdx.x - items[item].blk0;
-        return item;
-    }
-    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-    if (k >= items[n_items + 1 + x].blk0) return -1;
-    int lo = 0, hi = ((n_items - x + 7) >> 3) - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[x + 8 * mid].xblk0 <= k) lo = mid; else hi = mid - 1;
-    }
-    const int item = x + 8 * lo;
-    *b = k - items[item].xblk0;
+    const int item = icp_find_item(items, n_items, blockIdx.x);
+    *b = (int)blockIdx.x - items[item].blk0;
     return item;
 }
 
@@ -382,14 +367,13 @@ __device__ __forceinline__ void apply4(const float* F, float x, float y, float z
 // iteration — kept that way rather than re-deriving the points from the cumulative transform), then determineCorrespondences
 // and the sums TransformationEstimationSVD needs.
 template <int Q>
-__global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ items, int n_items, int xcd_mode, const IcpState* __restrict__ states,
+__global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ items, int n_items, const IcpState* __restrict__ states,
                                                    float cap2, double* __restrict__ partials)
 {
-    const bool getenv_icp_seed0 = (xcd_mode & 2) == 0;       // bit 1 of xcd_mode: experiments switch the first iteration's seed off (LISREG_ICP_NO_SEED0)
     __shared__ double red[4][kIcpAcc];
     __shared__ int2 s_runs[Q == 1 ? kNn1Cap : 1][256];      // run lists of the flattened search (one lane per query)
     int blk;
-    int item = icp_locate(items, n_items, xcd_mode & 1, &blk);
+    int item = icp_locate(items, n_items, &blk);
     // (both are the same in every lane; said so, the item's table entry, its grid and the target's base pointers stay in scalar registers)
     item = __builtin_amdgcn_readfirstlane(item); blk = __builtin_amdgcn_readfirstlane(blk);
     if (item < 0) return;
@@ -414,7 +398,7 @@ __global__ __launch_bounds__(256) void k_icp_assoc(const IcpItem* __restrict__ i
         float px, py, pz, d2;
         apply4(stp->Tm, s.x, s.y, s.z, px, py, pz);
         // last iteration's neighbour (position in the sorted target); the first iteration takes a point out of the query's own grid column
-        const int seed = stp->iters == 0 ? (getenv_icp_seed0 ? nn1_cell_seed(px, py, pz, g) : -1) : I.nn[i];
+        const int seed = stp->iters == 0 ? nn1_cell_seed(px, py, pz, g) : I.nn[i];
         int bi;
         if (Q == 1 && kIcpFlat) bi = nn1_search_flat(px, py, pz, g, cap2, &d2, seed, s_runs);
         else bi = nn1_search<Q>(px, py, pz, g, cap2, &d2, seed);          // (all Q lanes have read their record before the lead lane writes)
@@ -622,13 +606,13 @@ __global__ __launch_bounds__(256) void k_icp_fitness(const float4* __restrict__ 
 
 // the batch forms of the two kernels above: block -> item table, rows of 256 / Q queries summed by the Q-independent tree
 template <int Q>
-__global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict__ items, int n_items, int xcd_mode, const IcpState* __restrict__ states,
+__global__ __launch_bounds__(256) void k_icp_fitness_b(const IcpItem* __restrict__ items, int n_items, const IcpState* __restrict__ states,
                                                        double* __restrict__ partials)
 {
     __shared__ double red[4][2];
     __shared__ int2 s_runs[Q == 1 ? kNn1Cap : 1][256];
     int blk;
-    int item = icp_locate(items, n_items, xcd_mode, &blk);
+    int item = icp_locate(items, n_items, &blk);
     item = __builtin_amdgcn_readfirstlane(item); blk = __builtin_amdgcn_readfirstlane(blk);
     if (item < 0) return;
     const IcpItem I = items[item];
@@ -846,16 +830,12 @@ int icp_blocks(int n) { return (int)(((long long)n * icp_lanes(n) + 255) / 256);
 int icp_batch_lanes(long long total) { return icp_lanes((int)std::min<long long>(total, 0x7fffffff)); }
 int icp_batch_blocks(int n, int q) { return (int)(((long long)n * q + 255) / 256); }
 
-void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int xcd_blocks, int q, IcpState* states, float cap2, double* partials,
+void launch_icp_assoc(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, float cap2, double* partials,
                       hipStream_t stream)
 {
-    if (n_items <= 0) return;
-    if (total_blocks > 0) {
-        static const int no_seed0 = getenv("LISREG_ICP_NO_SEED0") ? 2 : 0;
-        const int grid = xcd_blocks > 0 ? 8 * xcd_blocks : total_blocks, xm = (xcd_blocks > 0 ? 1 : 0) | no_seed0;
-        if (q == 1) k_icp_assoc<1><<<grid, 256, 0, stream>>>(items, n_items, xm, states, cap2, partials);
-        else        k_icp_assoc<4><<<grid, 256, 0, stream>>>(items, n_items, xm, states, cap2, partials);
-    }
+    if (n_items <= 0 || total_blocks <= 0) return;
+    if (q == 1) k_icp_assoc<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
+    else        k_icp_assoc<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, cap2, partials);
 }
 
 void launch_icp_solve(const IcpItem* items, int n_items, int q, IcpState* states, const double* partials,
@@ -864,13 +844,12 @@ void launch_icp_solve(const IcpItem* items, int n_items, int q, IcpState* states
     if (n_items > 0) k_icp_solve<<<n_items, 1024, 0, stream>>>(partials, items, states, q, max_iters, eps_t, eps_mse, n_done);
 }
 
-void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int xcd_blocks, int q, IcpState* states, double* partials, hipStream_t stream)
+void launch_icp_fitness_batch(const IcpItem* items, int n_items, int total_blocks, int q, IcpState* states, double* partials, hipStream_t stream)
 {
     if (n_items <= 0) return;
     if (total_blocks > 0) {
-        const int grid = xcd_blocks > 0 ? 8 * xcd_blocks : total_blocks, xm = xcd_blocks > 0 ? 1 : 0;
-        if (q == 1) k_icp_fitness_b<1><<<grid, 256, 0, stream>>>(items, n_items, xm, states, partials);
-        else        k_icp_fitness_b<4><<<grid, 256, 0, stream>>>(items, n_items, xm, states, partials);
+        if (q == 1) k_icp_fitness_b<1><<<total_blocks, 256, 0, stream>>>(items, n_items, states, partials);
+        else        k_icp_fitness_b<4><<<total_blocks, 256, 0, stream>>>(items, n_items, states, partials);
     }
     k_icp_fit_reduce_b<<<n_items, 256, 0, stream>>>(partials, items, states, q);
 }
