@@ -86,25 +86,24 @@ __device__ void eigen_sym6(float* A, float* W, float* V, int* indR, int* indC)
     }
 }
 
-// cv::solve(AtA, AtB, X, DECOMP_QR): Householder QR in float; x zeroed and false returned if singular.
-// Same algorithm with everything in registers (all loops fully unrolled, compile-time indices): the per-iteration
-// critical path of a single registration is this solve, and LDS round trips tripled its latency.
-__device__ __forceinline__ bool solve6_qr_reg(const float* __restrict__ Ain, const float* __restrict__ bin, float* x)
+// cv::solve(AtA, AtB, X, DECOMP_QR): Householder QR in float; x zeroed and false returned if singular.  Everything in registers (all
+// loops fully unrolled, compile-time indices): the per-iteration critical path of a single registration is this solve.
+// One COLUMN of [A | b] per lane (lanes 0..5 hold column j: a[i] = A[i][j]; lane 6 holds b; the other lanes idle
+// along): at step k lane k forms the Householder vector of its own column (tail sum in ascending row order, beta, v, tau as cv does), tau and v travel
+// by readlane, and every later column is updated by its own lane — the same operations in the same order as the one-lane form this replaces
+// (rounds 2-5: the same bits, checked by the exact build's sweeps against the oracle), a sixth of the instructions on the critical path of a
+// Gauss-Newton iteration (the step is one wavefront's serial latency between two correspondence launches).
+// The triangular solve runs on values read out of the lanes (uniform), so every lane ends with the same x.
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ bool solve6_qr_lanes(float a[6], int lane, float x[6])
 {
-    float A[6][6], c[6], v[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        c[i] = bin[i];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) A[i][j] = Ain[i * 6 + j];
-    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const float c0 = A[k][k];
+        const float c0 = a[k];
         float tail = 0.f;
 #pragma unroll
-        for (int i = k + 1; i < 6; ++i) tail += A[i][k] * A[i][k];
-        float beta, tau;
+        for (int i = k + 1; i < 6; ++i) tail += a[i] * a[i];
+        float beta, tau, v[6];
         if (tail <= 1.17549435e-38f) {
             tau = 0.f; beta = c0;
 #pragma unroll
@@ -113,40 +112,40 @@ __device__ __forceinline__ bool solve6_qr_reg(const float* __restrict__ Ain, con
             beta = sqrtf(c0 * c0 + tail);
             if (c0 >= 0.f) beta = -beta;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = (i > k) ? A[i][k] / (c0 - beta) : 0.f;
+            for (int i = 0; i < 6; ++i) v[i] = (i > k) ? a[i] / (c0 - beta) : 0.f;
             tau = (beta - c0) / beta;
         }
-        A[k][k] = beta;
-        if (tau != 0.f) {
+        if (lane == k) a[k] = beta;
+        tau = lane_value(tau, k);
 #pragma unroll
-            for (int j = k + 1; j < 6; ++j) {
-                float dot = A[k][j];
+        for (int i = k + 1; i < 6; ++i) v[i] = lane_value(v[i], k);
+        if (tau != 0.f && lane > k) {                            // columns k + 1 .. 5 and the right-hand side
+            float dot = a[k];
 #pragma unroll
-                for (int i = k + 1; i < 6; ++i) dot += v[i] * A[i][j];
-                dot *= tau;
-                A[k][j] -= dot;
-#pragma unroll
-                for (int i = k + 1; i < 6; ++i) A[i][j] -= dot * v[i];
-            }
-            float dot = c[k];
-#pragma unroll
-            for (int i = k + 1; i < 6; ++i) dot += v[i] * c[i];
+            for (int i = k + 1; i < 6; ++i) dot += v[i] * a[i];
             dot *= tau;
-            c[k] -= dot;
+            a[k] -= dot;
 #pragma unroll
-            for (int i = k + 1; i < 6; ++i) c[i] -= dot * v[i];
+            for (int i = k + 1; i < 6; ++i) a[i] -= dot * v[i];
         }
+    }
+    float R[6][6], c[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        c[i] = lane_value(a[i], 6);
+#pragma unroll
+        for (int j = i; j < 6; ++j) R[i][j] = lane_value(a[i], j);
     }
     bool singular = false;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) singular = singular || (fabsf(A[i][i]) <= 1.17549435e-38f);
+    for (int i = 0; i < 6; ++i) singular = singular || (fabsf(R[i][i]) <= 1.17549435e-38f);
     float y[6];
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
-        float s = c[i];
+        float s_ = c[i];
 #pragma unroll
-        for (int j = i + 1; j < 6; ++j) s -= A[i][j] * y[j];
-        y[i] = s / A[i][i];
+        for (int j = i + 1; j < 6; ++j) s_ -= R[i][j] * y[j];
+        y[i] = s_ / R[i][i];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = singular ? 0.f : y[i];
@@ -246,6 +245,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
     __shared__ int   s_ind[12];
     __shared__ double s_part[kSolveThreads / 32][32];
     __shared__ double s_sum[kNumAcc];
+    __shared__ double s_L[36];
 
     ItemState* it = &items[blockIdx.x];
     if (it->done) return;
@@ -257,25 +257,18 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
         if (col < kNumAcc) {
             const double* p = partials + (size_t)it->blk_begin * kNumAcc + col;
             const int nb = it->blk_count;
-            // the rows of a group are added in ascending order whatever the unrolling; sixteen loads in flight instead of four: a launch of
-            // this kernel is a chain of load round trips on one workgroup per registration (450 rows / 16 groups = 28 loads per thread)
-            int b = grp;
+            // the rows of a group are added in ascending order whatever the unrolling.  A launch of this kernel is a chain of load round
+            // trips on one workgroup per registration (450 rows / 16 groups = 28 loads per thread): up to 32 rows are asked for at once — rows
+            // past the end read as +0.0, which leaves a sum that started at +0.0 unchanged to the bit — so that the usual registration is ONE
+            // round trip (it was four: chunks of 16 + 4 + 4 + 4)
             constexpr int kG = kSolveThreads / 32;
-            for (; b + 15 * kG < nb; b += 16 * kG) {
-                double v[16];
+            for (int b = grp; b < nb; b += 32 * kG) {
+                double v[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(b + u * kG) * kNumAcc];
+                for (int u = 0; u < 32; ++u) v[u] = (b + u * kG < nb) ? p[(size_t)(b + u * kG) * kNumAcc] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) s += v[u];
+                for (int u = 0; u < 32; ++u) s += v[u];
             }
-            for (; b + 3 * kG < nb; b += 4 * kG) {
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(b + u * kG) * kNumAcc];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) s += v[u];
-            }
-            for (; b < nb; b += kG) s += p[(size_t)b * kNumAcc];
         }
         s_part[grp][col] = s;
     }
@@ -287,96 +280,133 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(ItemState* __restrict__
         s_sum[threadIdx.x] = s;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    // the rest is one wavefront: lane-parallel where the arithmetic allows (the matrix fill, the QR solve, the three sine / cosine pairs of
+    // the pose cache), lane 0 for the strictly sequential pieces
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const bool l0 = lane == 0;
 
     const int iter = it->iter;
     const int n_sel = (int)(s_sum[27] + 0.5);
-    it->n_corr = n_sel;
     float* tr = (trace && iter < trace_cap) ? trace + ((size_t)blockIdx.x * trace_cap + iter) * kTraceStride : nullptr;
-    if (tr) {
-        for (int k = 0; k < kTraceStride; ++k) tr[k] = 0.f;
-        tr[0] = (float)n_sel;
-        for (int k = 0; k < 6; ++k) tr[49 + k] = it->T[k];
+    if (l0) {
+        it->n_corr = n_sel;
+        if (tr) {
+            for (int k = 0; k < kTraceStride; ++k) tr[k] = 0.f;
+            tr[0] = (float)n_sel;
+            for (int k = 0; k < 6; ++k) tr[49 + k] = it->T[k];
+        }
     }
     bool finished = false;
-    if (n_sel >= P.min_corr) {                                   // :870-872
-        int k = 0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) { const float v = (float)s_sum[k++]; s_AtA[r * 6 + c] = v; s_AtA[c * 6 + r] = v; }
-        for (int r = 0; r < 6; ++r) s_AtB[r] = (float)s_sum[21 + r];
-        solve6_qr_reg(s_AtA, s_AtB, s_X);                        // :921
-        int isDeg = it->degenerate;
-        // Shortcut for the common, well-conditioned case: if AtA - shift * I is positive definite (6x6 Cholesky in double,
-        // < 1 us on one lane) every eigenvalue exceeds shift = eig_thresh + 2e-5 * trace, far enough above the threshold that
-        // cv::eigen's float Jacobi (absolute error ~ 1e-7 * norm) cannot report one below it: not degenerate, matP = V^-1 V = I.
-        // Anything closer to the threshold takes the full restatement of cv::eigen below (78 us at this size).
-        bool well_conditioned = false;
-        if (iter == 0) {
-            double L[36], trace = 0.0;
-            for (int i = 0; i < 6; ++i) trace += (double)s_AtA[i * 6 + i];
-            const double shift = (double)P.eig_thresh + 2e-5 * trace;
-            well_conditioned = trace > 0.0;
-            for (int r = 0; r < 6 && well_conditioned; ++r)
-                for (int c = 0; c <= r; ++c) {
-                    double v = (double)s_AtA[r * 6 + c] - (r == c ? shift : 0.0);
-                    for (int k = 0; k < c; ++k) v -= L[r * 6 + k] * L[c * 6 + k];
-                    if (r == c) { if (!(v > 0.0)) { well_conditioned = false; break; } L[r * 6 + r] = sqrt(v); }
-                    else L[r * 6 + c] = v / L[c * 6 + c];
+    if (n_sel >= P.min_corr) {                                   // :870-872 (uniform: n_sel comes out of LDS)
+        // packed upper triangle -> the symmetric matrix: entry (r, c) of the 36 by lane, the right-hand side by the next six
+        if (lane < 36) {
+            const int r_ = lane / 6, c_ = lane % 6, lo = min(r_, c_), hi = max(r_, c_);
+            s_AtA[lane] = (float)s_sum[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        } else if (lane < 42) s_AtB[lane - 36] = (float)s_sum[21 + lane - 36];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            float a[6], xs[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a[i] = lane < 6 ? s_AtA[i * 6 + lane] : (lane == 6 ? s_AtB[i] : 0.f);
+            solve6_qr_lanes(a, lane, xs);                        // :921
+            if (l0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s_X[i] = xs[i];
+            }
+        }
+        int isDeg = 0;
+        float Tn[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (l0) {
+            isDeg = it->degenerate;
+            // Shortcut for the common, well-conditioned case: if AtA - shift * I is positive definite (6x6 Cholesky in double,
+            // < 1 us on one lane) every eigenvalue exceeds shift = eig_thresh + 2e-5 * trace, far enough above the threshold that
+            // cv::eigen's float Jacobi (absolute error ~ 1e-7 * norm) cannot report one below it: not degenerate, matP = V^-1 V = I.
+            // Anything closer to the threshold takes the full restatement of cv::eigen below (78 us at this size).
+            // (the factor lives in LDS: as a private array under these data-dependent loops it went to scratch memory, and the first
+            //  iteration's step took 26 us instead of 10)
+            bool well_conditioned = false;
+            if (iter == 0) {
+                double* L = s_L;
+                double trace = 0.0;
+                for (int i = 0; i < 6; ++i) trace += (double)s_AtA[i * 6 + i];
+                const double shift = (double)P.eig_thresh + 2e-5 * trace;
+                well_conditioned = trace > 0.0;
+                for (int r = 0; r < 6 && well_conditioned; ++r)
+                    for (int c = 0; c <= r; ++c) {
+                        double v = (double)s_AtA[r * 6 + c] - (r == c ? shift : 0.0);
+                        for (int k = 0; k < c; ++k) v -= L[r * 6 + k] * L[c * 6 + k];
+                        if (r == c) { if (!(v > 0.0)) { well_conditioned = false; break; } L[r * 6 + r] = sqrt(v); }
+                        else L[r * 6 + c] = v / L[c * 6 + c];
+                    }
+            }
+            if (iter == 0 && well_conditioned) {
+                isDeg = 0;
+                for (int i = 0; i < 36; ++i) it->P[i] = (i % 7 == 0) ? 1.f : 0.f;
+            } else if (iter == 0) {                                  // :923-946
+                for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
+                eigen_sym6(s_A, s_E, s_V, s_ind, s_ind + 6);
+                for (int i = 0; i < 36; ++i) s_V2[i] = s_V[i];
+                isDeg = 0;
+                for (int i = 5; i >= 0; --i) {
+                    if (s_E[i] < P.eig_thresh) { for (int j = 0; j < 6; ++j) s_V2[i * 6 + j] = 0.f; isDeg = 1; }
+                    else break;
                 }
-        }
-        if (iter == 0 && well_conditioned) {
-            isDeg = 0;
-            for (int i = 0; i < 36; ++i) it->P[i] = (i % 7 == 0) ? 1.f : 0.f;
-        } else if (iter == 0) {                                  // :923-946
-            for (int i = 0; i < 36; ++i) s_A[i] = s_AtA[i];
-            eigen_sym6(s_A, s_E, s_V, s_ind, s_ind + 6);
-            for (int i = 0; i < 36; ++i) s_V2[i] = s_V[i];
-            isDeg = 0;
-            for (int i = 5; i >= 0; --i) {
-                if (s_E[i] < P.eig_thresh) { for (int j = 0; j < 6; ++j) s_V2[i * 6 + j] = 0.f; isDeg = 1; }
-                else break;
+                for (int i = 0; i < 36; ++i) s_A[i] = s_V[i];
+                inv6_lu(s_A, s_Vi);
+                for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+                    double s = 0; for (int m = 0; m < 6; ++m) s += (double)s_Vi[r * 6 + m] * (double)s_V2[m * 6 + c];
+                    it->P[r * 6 + c] = (float)s;
+                }
+            } else if (P.emulate_shadow) {
+                for (int i = 0; i < 36; ++i) it->P[i] = 0.f;         // local zero cv::Mat matP (:880)
             }
-            for (int i = 0; i < 36; ++i) s_A[i] = s_V[i];
-            inv6_lu(s_A, s_Vi);
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-                double s = 0; for (int m = 0; m < 6; ++m) s += (double)s_Vi[r * 6 + m] * (double)s_V2[m * 6 + c];
-                it->P[r * 6 + c] = (float)s;
+            if (isDeg) {                                             // :948-953
+                float X2[6];
+                for (int r = 0; r < 6; ++r) X2[r] = s_X[r];
+                for (int r = 0; r < 6; ++r) {
+                    double s = 0; for (int m = 0; m < 6; ++m) s += (double)it->P[r * 6 + m] * (double)X2[m];
+                    s_X[r] = (float)s;
+                }
             }
-        } else if (P.emulate_shadow) {
-            for (int i = 0; i < 36; ++i) it->P[i] = 0.f;         // local zero cv::Mat matP (:880)
-        }
-        if (isDeg) {                                             // :948-953
-            float X2[6];
-            for (int r = 0; r < 6; ++r) X2[r] = s_X[r];
-            for (int r = 0; r < 6; ++r) {
-                double s = 0; for (int m = 0; m < 6; ++m) s += (double)it->P[r * 6 + m] * (double)X2[m];
-                s_X[r] = (float)s;
+            if (!P.freeze_pose) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) { Tn[m] = it->T[m] + s_X[m]; it->T[m] = Tn[m]; }      // :955-960
             }
         }
         if (!P.freeze_pose) {
-            for (int m = 0; m < 6; ++m) it->T[m] += s_X[m];      // :955-960
-            write_pose_cache(it);
+            // the pose cache's three sine / cosine pairs (yaw, pitch, roll) on three lanes at once; lane 0 assembles the cache from them
+            const float ang = lane == 0 ? lane_value(Tn[2], 0) : (lane == 1 ? lane_value(Tn[1], 0) : lane_value(Tn[0], 0));
+            const float cs = cosf(ang), sn = sinf(ang);
+            const float trig[6] = { lane_value(cs, 0), lane_value(sn, 0), lane_value(cs, 1), lane_value(sn, 1), lane_value(cs, 2), lane_value(sn, 2) };
+            if (l0) write_pose_cache(it, trig);
         }
-        const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
-        const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
-        const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-        const float dT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
-        it->deltaR = dR; it->deltaT = dT;
-        it->degenerate = isDeg;
-        it->any_solved = 1;
-        if (tr) {
-            for (int i = 0; i < 36; ++i) tr[1 + i] = s_AtA[i];
-            for (int i = 0; i < 6; ++i) { tr[37 + i] = s_AtB[i]; tr[43 + i] = s_X[i]; tr[49 + i] = it->T[i]; }
-            tr[55] = 1.f;
-        }
-        if (dR < P.conv_deg && dT < P.conv_cm && P.fixed_iters <= 0) {   // :969-972 -> break at :617
-            it->iters_out = iter;
-            finished = true;
+        if (l0) {
+            const double r0 = (double)(s_X[0] * 57.29578f), r1 = (double)(s_X[1] * 57.29578f), r2 = (double)(s_X[2] * 57.29578f);
+            const double t0 = (double)(s_X[3] * 100.f), t1 = (double)(s_X[4] * 100.f), t2 = (double)(s_X[5] * 100.f);
+            const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            const float dT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+            it->deltaR = dR; it->deltaT = dT;
+            it->degenerate = isDeg;
+            it->any_solved = 1;
+            if (tr) {
+                for (int i = 0; i < 36; ++i) tr[1 + i] = s_AtA[i];
+                for (int i = 0; i < 6; ++i) { tr[37 + i] = s_AtB[i]; tr[43 + i] = s_X[i]; tr[49 + i] = it->T[i]; }
+                tr[55] = 1.f;
+            }
+            if (dR < P.conv_deg && dT < P.conv_cm && P.fixed_iters <= 0) {   // :969-972 -> break at :617
+                it->iters_out = iter;
+                finished = true;
+            }
         }
     }
-    it->iter = iter + 1;
-    if (!finished && iter + 1 >= P.bound) { it->iters_out = P.bound; finished = true; }
-    if (finished) { it->done = 1; atomicAdd(done_counter, 1); }     // host-side early stop of the launch loop
+    if (l0) {
+        it->iter = iter + 1;
+        if (!finished && iter + 1 >= P.bound) { it->iters_out = P.bound; finished = true; }
+        if (finished) { it->done = 1; atomicAdd(done_counter, 1); }     // host-side early stop of the launch loop
+    }
 }
 
 // tf::Quaternion / tf::Matrix3x3 pieces of transformUpdate (odomEstimationNode.cpp:976-1006), double like tf
