@@ -594,7 +594,16 @@ __global__ __launch_bounds__(kLarge ? 1024 : 256) void k_strip_build(const Targe
 // into the running 32 best.  rho = min(distance of the 32nd, distance to the nearest face of the block that has
 // cells beyond it), so nothing outside the block has to be looked at: sparse neighbourhoods simply get shorter
 // lists with rho = the block's inscribed radius (>= 2 cells).  No divergence, one coalesced 128-byte store per point.
-constexpr int kGraphPPW = 16;            // points per wave (sequential)
+// One wavefront per workgroup: the rows are wavefront-level work (no barrier), and a workgroup's slots come free only when its LAST
+// wavefront ends — with four wavefronts of unequal work per workgroup the build ran at 2.4 wavefronts per SIMD in flight (round 5,
+// profiles/r05_kernel_experiments.md section 19: graph build 947 -> 906 us per launch on configs[4] with 8 points per wavefront, row build below)
+#ifndef LISREG_GRAPH_WPB
+#define LISREG_GRAPH_WPB 1           // wavefronts per workgroup of the graph build
+#endif
+#ifndef LISREG_GRAPH_PPW
+#define LISREG_GRAPH_PPW 8
+#endif
+constexpr int kGraphPPW = LISREG_GRAPH_PPW;            // points per wave (sequential)
 
 // value of lane (l ^ M).  The sort below is bound by cross-lane traffic, and ds_bpermute (the LDS crossbar, 4 LDS cycles per
 // wave-instruction) was 40 % of the build's wave time; most masks of the network have a pure-VALU form on gfx950: quad
@@ -752,10 +761,10 @@ __device__ __forceinline__ void graph_build_wave(const GridIndex& g, int s, int 
 #endif
 }
 
-__global__ __launch_bounds__(256) void k_graph_build_one(GridIndex g)
+__global__ __launch_bounds__(64 * LISREG_GRAPH_WPB) void k_graph_build_one(GridIndex g)
 {
-    __shared__ int s_off[4][64], s_js[4][64];
-    const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kGraphPPW;
+    __shared__ int s_off[LISREG_GRAPH_WPB][64], s_js[LISREG_GRAPH_WPB][64];
+    const int first = (blockIdx.x * LISREG_GRAPH_WPB + (threadIdx.x >> 6)) * kGraphPPW;
 #pragma unroll 1
     for (int i = 0; i < kGraphPPW; ++i) {
         const int s = first + i;
@@ -764,14 +773,15 @@ __global__ __launch_bounds__(256) void k_graph_build_one(GridIndex g)
     }
 }
 
-__global__ __launch_bounds__(256) void k_graph_build_batched(const BlockDesc* __restrict__ blocks,
+__global__ __launch_bounds__(64 * LISREG_GRAPH_WPB) void k_graph_build_batched(const BlockDesc* __restrict__ blocks,
                                                              const TargetSeg* __restrict__ tsegs,
                                                              const GridIndex* __restrict__ grids)
 {
-    __shared__ int s_off[4][64], s_js[4][64];
-    constexpr int kSub = kBlockQ / (4 * kGraphPPW);         // workgroups per 256-point block descriptor
+    __shared__ int s_off[LISREG_GRAPH_WPB][64], s_js[LISREG_GRAPH_WPB][64];
+    constexpr int kSub = kBlockQ / (LISREG_GRAPH_WPB * kGraphPPW);         // workgroups per 256-point block descriptor
+    static_assert(kSub * LISREG_GRAPH_WPB * kGraphPPW == kBlockQ, "whole workgroups per block descriptor");
     const BlockDesc bd = blocks[blockIdx.x / kSub];
-    const int first = ((int)(blockIdx.x % kSub) * 4 + (int)(threadIdx.x >> 6)) * kGraphPPW;
+    const int first = ((int)(blockIdx.x % kSub) * LISREG_GRAPH_WPB + (int)(threadIdx.x >> 6)) * kGraphPPW;
     const GridIndex g = grids[tsegs[bd.seg].grid_id];
 #pragma unroll 1
     for (int i = 0; i < kGraphPPW; ++i) {
@@ -1098,6 +1108,11 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
 // load and store for all of them), then the cells that have rows one after the other, the whole wave on each.
 // crow_tab[cell] = -2: nothing within two cells; -1: no row (its rows did not fit the capacity the buffers were sized for); else
 // (first row << 8) | octant mask, rows = [centre, the octants of the mask in ascending order].
+#ifndef LISREG_CROW_WPB
+#define LISREG_CROW_WPB 1            // wavefronts per workgroup of the row build.  Measured (same box, interleaved): 1 -> 213-236 us per launch, 2 -> 222,
+                                     // 4 (rounds 4-5) -> 248-270, 16 -> 370: most cells of a grid have no row, a few have nine — a workgroup of four
+                                     // wavefronts holds its slots until the slowest of them is through
+#endif
 #ifndef LISREG_CROW_CPW
 #define LISREG_CROW_CPW 8
 #endif
@@ -1108,16 +1123,16 @@ constexpr int kCrowCPW = LISREG_CROW_CPW;
                                      // without by 2-3 % of a configs[1] step; 7 and 8 waves (10 / 18 spilled) lose it again
 #endif
 #if LISREG_CROW_WAVES
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LISREG_CROW_WAVES, LISREG_CROW_WAVES)))
+__global__ __launch_bounds__(64 * LISREG_CROW_WPB) __attribute__((amdgpu_waves_per_eu(LISREG_CROW_WAVES, LISREG_CROW_WAVES)))
 #else
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64 * LISREG_CROW_WPB)
 #endif
 void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
                                                     const int* __restrict__ scan, int cap, int use_r3 /* 0: never the 7^3 block (experiments) */)
 {
-    __shared__ int s_off[4][64], s_js[4][64];
+    __shared__ int s_off[LISREG_CROW_WPB][64], s_js[LISREG_CROW_WPB][64];
     const int lane = threadIdx.x & 63;
-    const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kCrowCPW);
+    const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * LISREG_CROW_WPB + (int)(threadIdx.x >> 6)) * kCrowCPW);
     int* tab = const_cast<int*>(g.crow_tab);
     int n_l = 0, b_l = 0, om_l = 0;
     if (lane < kCrowCPW && first + lane < n_cells) {
@@ -1517,13 +1532,13 @@ void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* 
                         hipStream_t st)
 {
     if (n_blocks <= 0) return;
-    k_graph_build_batched<<<n_blocks * (kBlockQ / (4 * kGraphPPW)), 256, 0, st>>>(blocks, tsegs, grids);
+    k_graph_build_batched<<<n_blocks * (kBlockQ / (LISREG_GRAPH_WPB * kGraphPPW)), 64 * LISREG_GRAPH_WPB, 0, st>>>(blocks, tsegs, grids);
 }
 
 void launch_build_graph_one(GridIndex g, hipStream_t st)
 {
     if (g.n <= 0 || !g.nbr) return;
-    k_graph_build_one<<<(g.n + 4 * kGraphPPW - 1) / (4 * kGraphPPW), 256, 0, st>>>(g);
+    k_graph_build_one<<<(g.n + LISREG_GRAPH_WPB * kGraphPPW - 1) / (LISREG_GRAPH_WPB * kGraphPPW), 64 * LISREG_GRAPH_WPB, 0, st>>>(g);
 }
 
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
@@ -1546,7 +1561,7 @@ void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
 {
     if (g.n <= 0 || n_cells <= 0 || cb.cap_rows <= 0 || !g.crow) return;
     static const int use_r3 = getenv("LISREG_CROW_R3") ? atoi(getenv("LISREG_CROW_R3")) : 1;
-    k_crow_build<<<(n_cells + 4 * kCrowCPW - 1) / (4 * kCrowCPW), 256, 0, st>>>(g, n_cells, cb.need, cb.omask, cb.scan, cb.cap_rows, use_r3);
+    k_crow_build<<<(n_cells + LISREG_CROW_WPB * kCrowCPW - 1) / (LISREG_CROW_WPB * kCrowCPW), 64 * LISREG_CROW_WPB, 0, st>>>(g, n_cells, cb.need, cb.omask, cb.scan, cb.cap_rows, use_r3);
 }
 
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
