@@ -223,14 +223,14 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false, long
     }
     const size_t nc = (size_t)std::max(t.n_cells[k], 1);
     HIPCHK(c, t.crow_need[k].ensure(sizeof(int) * (nc + 8)));
-    HIPCHK(c, t.crow_omask[k].ensure(sizeof(int) * (nc + 8)));
+    { const size_t before = t.crow_omask[k].cap; HIPCHK(c, t.crow_omask[k].ensure(sizeof(int) * (nc + 8))); if (t.crow_omask[k].cap != before) t.omask_zero[k] = 0; }     // (a new allocation: nothing known)
     HIPCHK(c, t.crow_scan[k].ensure(sizeof(int) * (nc + 8)));
     HIPCHK(c, t.crow_scan_tmp[k].ensure(sizeof(int) * (nc / 2048 + 8)));
     HIPCHK(c, t.crow_tab[k].ensure(sizeof(int) * (nc + 8)));
     t.g[k].crow_tab = t.crow_tab[k].as<int>();
     int rows = 0;
     if (t.n[k] > 0) {
-        launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream);
+        launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream, &t.omask_zero[k]);
         HIPCHK(c, hipMemcpyAsync(&rows, t.crow_scan[k].as<int>() + t.n_cells[k], sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -262,7 +262,7 @@ int ensure_crows(lisreg_ctx* c, Target& t, int k, bool may_decline = false, long
     t.crow_chosen[k] = true;
     t.g[k].crow = t.crow[k].as<float4>();
     t.g[k].crow_meta = t.crow_meta[k].as<float2>();
-    if (t.n[k] > 0) launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream);
+    if (t.n[k] > 0) launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), c->stream, &t.omask_zero[k]);
     else HIPCHK(c, hipMemsetAsync(t.crow_tab[k].p, 0xff, sizeof(int) * nc, c->stream));
     HIPCHK(c, hipGetLastError());
     t.crow_valid[k] = true;
@@ -1024,8 +1024,8 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                 for (int slot : c->batch_slots) {
                     Target& t = c->targets[(size_t)slot];
                     if (t.n[k] <= 0) continue;
-                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), sk);
-                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), sk);
+                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), sk, &t.omask_zero[k]);
+                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), sk, &t.omask_zero[k]);
                 }
             }
             if (fork && !c->sort_now && !c->exact) reset_and_order(c->side_stream);

@@ -44,6 +44,7 @@ struct Target {
     lisreg::DevBuf    crow[2], crow_meta[2], crow_tab[2], crow_need[2], crow_omask[2], crow_scan[2], crow_scan_tmp[2];   // cell rows (search_mode 5)
     float     bbox[2][6] = { { 0 }, { 0 } };           // the cloud's bounding box (the grid is made from it, with or without a margin)
     int       grid_margin[2] = { 0, 0 };               // cells the grid reaches past the cloud on every side (the cell rows want two)
+    int       omask_zero[2] = { 0, 0 };                // cells at the head of crow_omask known to be zero (launch_crow_classify / _build)
     int       crow_cap[2] = { 0, 0 };                  // rows allocated (= rows the classified index asked for when it was last sized)
     bool      crow_valid[2] = { false, false };
     bool      crow_chosen[2] = { false, false };       // a batch took the cell rows for this slot before: its next target is indexed with the margin at once

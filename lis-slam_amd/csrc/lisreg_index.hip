@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(64 * LISREG_CROW_WPB) __attribute__((amdgpu_waves_p
 #else
 __global__ __launch_bounds__(64 * LISREG_CROW_WPB)
 #endif
-void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const int* __restrict__ omask,
+void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, int* __restrict__ omask,
                                                     const int* __restrict__ scan, int cap, int use_r3 /* 0: never the 7^3 block (experiments) */)
 {
     __shared__ int s_off[LISREG_CROW_WPB][64], s_js[LISREG_CROW_WPB][64];
@@ -1137,7 +1137,9 @@ void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, const 
     int n_l = 0, b_l = 0, om_l = 0;
     if (lane < kCrowCPW && first + lane < n_cells) {
         n_l = need[first + lane];
-        if (n_l) { b_l = scan[first + lane]; om_l = omask[first + lane]; }
+        om_l = omask[first + lane];
+        omask[first + lane] = 0;                            // handed back clean: the next classification ORs into it without a memset
+        if (n_l) b_l = scan[first + lane];
         const bool fits = n_l != 0 && !(b_l + n_l > cap || b_l >= (1 << 23));
         tab[first + lane] = n_l == 0 ? -2 : (fits ? (b_l << 8) | (om_l & 255) : -1);
         if (!fits) n_l = 0;
@@ -1541,12 +1543,14 @@ void launch_build_graph_one(GridIndex g, hipStream_t st)
     k_graph_build_one<<<(g.n + LISREG_GRAPH_WPB * kGraphPPW - 1) / (LISREG_GRAPH_WPB * kGraphPPW), 64 * LISREG_GRAPH_WPB, 0, st>>>(g);
 }
 
-void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
+void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells)
 {
     if (g.n <= 0 || n_cells <= 0) return;
+    const bool zero_already = omask_zero_cells && *omask_zero_cells >= n_cells;
+    if (omask_zero_cells) *omask_zero_cells = 0;              // the marks go in now; launch_crow_build takes them out again
     // octant margin in cells: under a quarter cell (half an octant's edge), so that a point is near at most two octants per axis
     static const float margin = std::min(0.249f, std::max(0.f, getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.249f));
-    (void)hipMemsetAsync(cb.omask, 0, sizeof(int) * (size_t)n_cells, st);
+    if (!zero_already) (void)hipMemsetAsync(cb.omask, 0, sizeof(int) * (size_t)n_cells, st);
     k_crow_mark<<<(g.n + 255) / 256, 256, 0, st>>>(g, margin * g.cell, cb.omask);
     const size_t lds = sizeof(int) * (size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g.nz + 1);
     if (lds <= 64 * 1024) {
@@ -1557,9 +1561,10 @@ void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t 
     exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
 }
 
-void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st)
+void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells)
 {
     if (g.n <= 0 || n_cells <= 0 || cb.cap_rows <= 0 || !g.crow) return;
+    if (omask_zero_cells) *omask_zero_cells = n_cells;        // (k_crow_build zeroes the mask of every cell it is dealt, with or without rows)
     static const int use_r3 = getenv("LISREG_CROW_R3") ? atoi(getenv("LISREG_CROW_R3")) : 1;
     k_crow_build<<<(n_cells + LISREG_CROW_WPB * kCrowCPW - 1) / (LISREG_CROW_WPB * kCrowCPW), 64 * LISREG_CROW_WPB, 0, st>>>(g, n_cells, cb.need, cb.omask, cb.scan, cb.cap_rows, use_r3);
 }

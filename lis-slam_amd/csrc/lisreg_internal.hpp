@@ -189,8 +189,11 @@ void launch_build_graph_one(GridIndex g, hipStream_t st);
 // cell rows of one target (search_mode 5).  classify: need[cell] = rows the cell wants (0 / 1 / 8), scan[cell] = first row, scan[n_cells] = rows
 // in all; build: crow_tab, then one wave per row (at most cap_rows of them: cells past the capacity get no row and their queries walk)
 struct CrowBuffers { int* need; int* omask; int* scan; int* scan_tmp; int cap_rows; };
-void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st);
-void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st);
+// The octant masks (cb.omask) are accumulated by atomic ORs and must start at zero: launch_crow_build hands every cell's mask back as zero
+// once it has read it, so a classify that FOLLOWS a build on the same buffer needs no memset (two fill launches and their gaps on the
+// critical path of every step).  *omask_zero_cells = cells of the buffer's head known to be zero (0: unknown); both launchers keep it.
+void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells = nullptr);
+void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells = nullptr);
 // sources of a whole batch: tile-sort every segment under its item's initial pose
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,

@@ -6,7 +6,7 @@ rocprofv3 --output-format csv --kernel-trace -d /tmp/tl -o t -- python $R/bench.
 python - <<'PY'
 import csv,glob,re
 f=glob.glob('/tmp/tl/**/*kernel_trace.csv',recursive=True)[0]
-rows=sorted([r for r in csv.DictReader(open(f)) if 'lisreg' in r['Kernel_Name']], key=lambda r:int(r['Start_Timestamp']))
+rows=sorted([r for r in csv.DictReader(open(f)) if 'lisreg' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']], key=lambda r:int(r['Start_Timestamp']))
 # last step = from the last k_strip_partition<false> (or k_reset_items) on
 idx=[i for i,r in enumerate(rows) if 'k_strip_partition' in r['Kernel_Name']]
 start=idx[-2] if len(idx)>=2 else 0
