@@ -349,14 +349,59 @@ __device__ __forceinline__ void lstsq5x3(const float4 nb[5], float X[3])
 // surfOptimization body for one point (odomEstimationNode.cpp:776-821), split like the edge case:
 //   surf_model : plane (pa,pb,pc,pd) of the five neighbours + the |n.p+d| <= 0.2 validity test; pd = NaN if invalid;
 //   surf_eval  : point-to-plane residual, range-scaled robust weight, accept test for the transformed query.
+// The least-squares solution of [p_j] n = -1 in closed form (production arithmetic).  With c the centroid of the five points, d_j = p_j - c
+// and S = sum d_j d_j^T (the 3 x 3 scatter matrix; sum d_j = 0), the normal equations (S + 5 c c^T) n = -5 c give, by Sherman-Morrison,
+// n = -5 S^-1 c / (1 + 5 c^T S^-1 c): with w = adj(S) c and D = det(S),  n / |n| = -w / |w|  and  1 / |n| = (D / 5 + c . w) / |w|  —
+// exactly the (pa, pb, pc, pd) the reference forms from Eigen's column-pivoted QR solution (:783-791), from ~110 vector instructions
+// instead of ~300, and better conditioned in float: the QR works on coordinates of magnitude |c| (tens of metres) whose five rows differ
+// by decimetres (relative error ~ cond(A) eps ~ 1e-4 for a far patch), the scatter matrix on the differences alone.  Where the five points
+// are close to ONE LINE (second eigenvalue of S under 1e-2 of the first: adj(S) loses its digits, and the reference's answer is whatever
+// the pivoted QR makes of a rank-deficient system) the QR runs as before: `false` is returned.
+#ifndef LISREG_PLANE_CLOSED
+#define LISREG_PLANE_CLOSED 1
+#endif
+#ifndef LISREG_PLANE_LINE_RATIO
+#define LISREG_PLANE_LINE_RATIO 1e-2f
+#endif
+__device__ __forceinline__ bool plane5_closed(const float4 nb[5], float& pa, float& pb, float& pc, float& pd)
+{
+    const float cx = ((nb[0].x + nb[1].x) + (nb[2].x + nb[3].x) + nb[4].x) * 0.2f;
+    const float cy = ((nb[0].y + nb[1].y) + (nb[2].y + nb[3].y) + nb[4].y) * 0.2f;
+    const float cz = ((nb[0].z + nb[1].z) + (nb[2].z + nb[3].z) + nb[4].z) * 0.2f;
+    float sxx = 0.f, sxy = 0.f, sxz = 0.f, syy = 0.f, syz = 0.f, szz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float dx = nb[j].x - cx, dy = nb[j].y - cy, dz = nb[j].z - cz;
+        sxx += dx * dx; sxy += dx * dy; sxz += dx * dz; syy += dy * dy; syz += dy * dz; szz += dz * dz;
+    }
+    const float axx = syy * szz - syz * syz, axy = sxz * syz - sxy * szz, axz = sxy * syz - sxz * syy;
+    const float ayy = sxx * szz - sxz * sxz, ayz = sxy * sxz - sxx * syz, azz = sxx * syy - sxy * sxy;
+    const float tr = sxx + syy + szz, tra = axx + ayy + azz;               // l1 + l2 + l3,  l1 l2 + l1 l3 + l2 l3
+    const float wx = axx * cx + axy * cy + axz * cz, wy = axy * cx + ayy * cy + ayz * cz, wz = axz * cx + ayz * cy + azz * cz;
+    const float det = sxx * axx + sxy * axy + sxz * axz;
+    const float ww = wx * wx + wy * wy + wz * wz;
+    const float iw = __builtin_amdgcn_rsqf(ww);
+    pa = -wx * iw; pb = -wy * iw; pc = -wz * iw;
+    pd = (det * 0.2f + (cx * wx + cy * wy + cz * wz)) * iw;
+    return tra > LISREG_PLANE_LINE_RATIO * (tr * tr) && ww > 0.f && ww < 3.0e38f;
+}
+
 __device__ __forceinline__ float4 surf_model(const float4 nb[5], const DevParams& P)
 {
-    float X[3];
-    lstsq5x3(nb, X);
-    float pa = X[0], pb = X[1], pc = X[2], pd = 1.f;
-    const float ps = fsqrt(pa * pa + pb * pb + pc * pc);
-    if (kExactArith) { pa /= ps; pb /= ps; pc /= ps; pd /= ps; }          // :790-791
-    else { const float ips = __builtin_amdgcn_rcpf(ps); pa *= ips; pb *= ips; pc *= ips; pd = ips; }   // 1-ulp reciprocal (<= 2 ulp from the divisions)
+    float pa, pb, pc, pd;
+    bool closed = false;
+    if (!kExactArith && LISREG_PLANE_CLOSED) closed = plane5_closed(nb, pa, pb, pc, pd);
+#if LISREG_PLANE_CLOSED == 2        /* timing experiment: never the QR */
+    closed = true;
+#endif
+    if (!closed) {
+        float X[3];
+        lstsq5x3(nb, X);
+        pa = X[0]; pb = X[1]; pc = X[2]; pd = 1.f;
+        const float ps = fsqrt(pa * pa + pb * pb + pc * pc);
+        if (kExactArith) { pa /= ps; pb /= ps; pc /= ps; pd /= ps; }          // :790-791
+        else { const float ips = __builtin_amdgcn_rcpf(ps); pa *= ips; pb *= ips; pc *= ips; pd = ips; }   // 1-ulp reciprocal (<= 2 ulp from the divisions)
+    }
     bool valid = true;
 #pragma unroll
     for (int j = 0; j < 5; ++j)
