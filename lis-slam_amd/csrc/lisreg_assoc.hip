@@ -52,6 +52,9 @@ namespace {
 namespace LISREG_ASSOC_NS {
 
 constexpr bool kExactArith = LISREG_EXACT != 0;
+#ifndef LISREG_KEEP_SRC
+#define LISREG_KEEP_SRC 1        // one-lane-per-query kernels keep the source record in registers across the search (see k_assoc_walk)
+#endif
 // (Round 5 built three variants of this file that measured no gain and were taken out again — the 28 wave sums on the matrix pipe
 // (v_mfma_f32_16x16x4_f32: gfx950's f32 MFMA runs at the f32 vector rate), the heads of the cell rows staged in LDS, the plane fit's pivot
 // swaps as selects: profiles/r05_kernel_experiments.md sections 1, 3, 11; the code is profiles/r05_xp_mfma_stage_select.patch.)
@@ -1311,8 +1314,13 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     // addressed with the batch-wide position qflat, so that one register serves the source and the seed arrays.
     const float4* qsrc = sorted_all ? sorted_all : (const float4*)((uintptr_t)sg.src - (uintptr_t)sg.flat_base * sizeof(float4));
     float qx, qy, qz;
+#if LISREG_KEEP_SRC
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     {
+#if !LISREG_KEEP_SRC
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         if (valid) q0 = qsrc[qflat];
         qx = M[0] * q0.x + M[1] * q0.y + M[2] * q0.z + M[3];
         qy = M[4] * q0.x + M[5] * q0.y + M[6] * q0.z + M[7];
@@ -1495,11 +1503,17 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
                 atomicAdd(&counters[96 + it->iter], ((unsigned long long)__popcll(m) << 32) | (unsigned long long)(m == __ballot(true)));
         }
     }
-    // the source record is read again here rather than kept in four registers across the walk (8 waves per SIMD need <= 64)
+    // the source record: one lane per query keeps it in registers across the search (round 5: the closed-form plane fit freed the registers —
+    // 55-57 of 64 with it — and the second read, a dependent load at the end of a wavefront's chain, was 6 us of a 172 us launch);
+    // eight lanes per query read it again (the sharing variant is at its register limit)
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef LISREG_XP_NOSRC2         /* timing experiment (wrong results): no second read of the source record */
     q4 = make_float4(qx, qy, qz, 0.f);
 #else
+#if LISREG_KEEP_SRC
+    if (kQ == 1) q4 = q0;
+    else
+#endif
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
 #endif
     if (kQ == 1) {
