@@ -383,6 +383,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_FIRST_PASS_MM")) c->first_pass_r = 1e-3f * (float)atoi(m);
     if (const char* m = getenv("LISREG_WIDE_UNTIL")) c->wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_WIDE_UNTIL")) c->graph_wide_until = atoi(m);
+    if (const char* m = getenv("LISREG_CROW_WIDE_UNTIL")) c->crow_wide_until = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_HOPS")) c->graph_hops = atoi(m);
     if (const char* m = getenv("LISREG_CELL_ANCHOR_UNTIL")) c->cell_anchor_until = std::max(atoi(m), 0);
     if (const char* m = getenv("LISREG_XCD_ORDER")) c->xcd_order = atoi(m);
@@ -1058,7 +1059,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                      c->blocks.as<BlockDesc>() + b0, nb, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(),
                      c->items.as<ItemState>(), c->prm, c->sort_now ? c->sorted_all.as<float4>() : nullptr, c->partials.as<double>() + (size_t)b0 * kNumAcc,
                      c->mode_now, c->nn.as<int>(), c->n_elems, c->first_pass_r * c->first_pass_r,
-                     it >= (c->lanes_q == 8 ? c->wide_from_small : c->wide_from) && it <= (c->mode_now == 3 || c->mode_now == 5 ? c->graph_wide_until : c->wide_until), c->graph_hops,
+                     it >= (c->lanes_q == 8 ? c->wide_from_small : c->wide_from) && it <= (c->mode_now == 5 ? c->crow_wide_until : (c->mode_now == 3 ? c->graph_wide_until : c->wide_until)), c->graph_hops,
                      c->count_searches ? c->counters.as<unsigned long long>() : nullptr,
                      c->dump_neighbors ? c->dbg_nn.as<int>() : nullptr, c->lanes_q,
                      c->blocks_q.as<BlockDesc>(), (int)c->h_blocks_q.size(), c->coef.as<float4>(), c->coef_ok.as<int>(),

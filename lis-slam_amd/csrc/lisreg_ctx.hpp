@@ -191,6 +191,8 @@ struct lisreg_ctx {
     int       cell_anchor_until = 1;     // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
     int       graph_hops = 3;            // neighbour lists scanned per query (anchor, then nearest found, ...) before the walk takes over
     int       graph_wide_until = 1;      // search_mode 3: GN iterations 0..this run the centre-first variant of the fall-back walk
+    int       crow_wide_until = -1;      // search_mode 5: the same for the cell rows — never (1.4 % of the queries walk at iteration 0: the plain kernel's
+                                         // iteration 0 takes 317 us against 330 with the centre-first variant, iteration 1 201 against 205; same neighbours)
     bool      canonical_ties = false;    // "canonical_ties" (always on with exact_arithmetic)
     bool      exact = false;             // "exact_arithmetic": the correspondence launches and the pose cache run the reference's arithmetic (lisreg_assoc.hip)
     int       sort_sources = 2;          // 0: keep the caller order, 1: 2-D column sort, 2: auto (probe the order at prepare time)
