@@ -165,6 +165,71 @@ def test_surf_coeff_known_plane(oracle):
     assert L.orc_surf_coeff(fp(nb2), fp(q), 1.0, C.byref(p), fp(cf)) == 0
 
 
+def _plane_closed(nb, dtype):
+    """plane5_closed of lisreg_assoc.hip (the production build's plane fit), operation for operation, in `dtype`"""
+    nb = nb.astype(dtype)
+    c = ((nb[0] + nb[1]) + (nb[2] + nb[3]) + nb[4]) * dtype(0.2)
+    d = nb - c
+    sxx, sxy, sxz = (d[:, 0] * d[:, 0]).sum(dtype=dtype), (d[:, 0] * d[:, 1]).sum(dtype=dtype), (d[:, 0] * d[:, 2]).sum(dtype=dtype)
+    syy, syz, szz = (d[:, 1] * d[:, 1]).sum(dtype=dtype), (d[:, 1] * d[:, 2]).sum(dtype=dtype), (d[:, 2] * d[:, 2]).sum(dtype=dtype)
+    axx, axy, axz = syy * szz - syz * syz, sxz * syz - sxy * szz, sxy * syz - sxz * syy
+    ayy, ayz, azz = sxx * szz - sxz * sxz, sxy * sxz - sxx * syz, sxx * syy - sxy * sxy
+    tr, tra = sxx + syy + szz, axx + ayy + azz
+    w = np.array([axx * c[0] + axy * c[1] + axz * c[2], axy * c[0] + ayy * c[1] + ayz * c[2], axz * c[0] + ayz * c[1] + azz * c[2]], dtype)
+    det = sxx * axx + sxy * axy + sxz * axz
+    ww = (w * w).sum(dtype=dtype)
+    ok = bool(tra > dtype(1e-2) * (tr * tr) and ww > 0)
+    iw = dtype(1) / np.sqrt(ww) if ww > 0 else dtype(0)
+    return ok, np.append(-w * iw, (det * dtype(0.2) + (c * w).sum(dtype=dtype)) * iw)
+
+
+def test_closed_form_plane_is_the_least_squares_solution(oracle):
+    """Round 5: the production build forms (pa, pb, pc, pd) of surfOptimization (:783-791) in closed form — n = -5 S^-1 c / (1 + 5 c^T S^-1 c)
+    with c the centroid and S the scatter matrix of the five neighbours — instead of through Eigen's column-pivoted QR.  (1) In float64 the
+    formula IS the normalised least-squares solution of [p_j] n = -1 (numpy lstsq), for patches anywhere between the origin and 120 m;
+    (2) in float32, operation for operation as the kernel does it, the coefficients agree with the oracle's float QR to the QR's own
+    conditioning (a few 1e-4 for far patches) and are CLOSER to the float64 solution than the oracle's; (3) neighbourhoods close to one
+    line and coincident points are handed to the QR (ok = False)."""
+    L = oracle.lib()
+    p = oracle.default_params(1)
+    rng = np.random.default_rng(11)
+    worse = 0; n_cmp = 0
+    for trial in range(400):
+        centre = rng.normal(0, 1, 3); centre *= rng.uniform(1.0, 120.0) / np.linalg.norm(centre)
+        nrm = rng.normal(0, 1, 3); nrm /= np.linalg.norm(nrm)
+        if abs(nrm @ centre) < 0.5: continue                    # (a plane through the origin has no solution n . p = -1: not this test's business)
+        u = np.cross(nrm, [1.0, 0, 0]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+        spread = rng.uniform(0.05, 0.5)
+        nb64 = centre + np.outer(rng.uniform(-spread, spread, 5), u) + np.outer(rng.uniform(-spread, spread, 5), v) + np.outer(rng.normal(0, 0.01, 5), nrm)
+        nb = nb64.astype(f32)
+        ok64, ref = _plane_closed(nb.astype(np.float64), np.float64)
+        sol = np.linalg.lstsq(nb.astype(np.float64), -np.ones(5), rcond=None)[0]
+        want = np.append(sol, 1.0) / np.linalg.norm(sol)
+        assert np.abs(ref - want).max() <= 1e-7 * max(1.0, np.linalg.norm(centre))            # (1)
+        ok32, got = _plane_closed(nb, f32)
+        if not ok32: continue
+        # (2) the closed form in float: the normal to 2e-4, and the point-to-plane distance of a query ON the patch to 2e-5 m (pd alone is the
+        # plane's offset at the ORIGIN, tens of metres away: it moves with the normal's last digits, the distance near the patch does not)
+        q64 = nb64.mean(0) + 0.05 * nrm
+        assert np.abs(got[:3].astype(np.float64) - want[:3]).max() <= 2e-4, (trial, got, want)
+        assert abs((got[:3].astype(np.float64) @ q64 + float(got[3])) - (want[:3] @ q64 + want[3])) <= 2e-5, (trial, got, want)
+        # the oracle's float QR on the same neighbours: its coefficients for a query on the centroid's normal
+        q = q64.astype(f32)
+        cf = np.zeros(4, f32)
+        if L.orc_surf_coeff(fp(nb), fp(q), 1.0, C.byref(p), fp(cf)) != 1: continue
+        s_o = np.linalg.norm(cf[:3])
+        n_o = cf[:3].astype(np.float64) / s_o
+        n_cmp += 1
+        e_o = np.abs(n_o - want[:3]).max(); e_c = np.abs(got[:3].astype(np.float64) - want[:3]).max()
+        assert e_o <= 2e-3 and np.abs(n_o - got[:3]).max() <= 2e-3
+        worse += e_c > e_o + 1e-7
+    assert n_cmp >= 200 and worse <= n_cmp // 4, (worse, n_cmp)       # the closed form is (almost always) at least as close to the exact solution
+    # (3)
+    line = (np.array([20.0, 5.0, 1.0]) + np.outer(np.linspace(-0.4, 0.4, 5), [1.0, 0.2, 0.0]) + rng.normal(0, 1e-3, (5, 3))).astype(f32)
+    assert not _plane_closed(line, f32)[0]
+    assert not _plane_closed(np.tile(np.array([[3.0, 4.0, 5.0]], f32), (5, 1)), f32)[0]
+
+
 def test_jacobian_row_matches_finite_differences(oracle):
     """Row = d(coeff . (R(T) p + t))/dT in the order [roll, pitch, yaw, x, y, z] (LMOptimization :889-915)."""
     L = oracle.lib()
