@@ -800,32 +800,39 @@ __global__ __launch_bounds__(64 * LISREG_GRAPH_WPB) void k_graph_build_batched(c
 // k_crow_mark: one thread per target point ORs the octants it is near into the cells' masks (at most 2 x 2 x 2 octants: the margin is under
 // half an octant's edge) — a point-driven pass costs one or two atomics per point, where a cell-driven pass read every point of a 3 x 3 x 3
 // block per cell (7 ms of vector work per million cells).
+// The points arrive sorted by cell: neighbouring lanes mostly name the same cell with the same octants, and 3 000 wavefronts of device-scope
+// atomics in flight at once are what this launch waits for (a wavefront of the 10 k-point corner target lives 3.7 us, one of the 200 k-point
+// surf target 21 us).  A lane whose left neighbour (same 16-lane row) names the same cell with at least its bits leaves the atomic to it —
+// the left-most lane of such a run always sends, and its mask covers the run (each lane's mask is inside its sender's by induction).
 __global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin, int* __restrict__ omask)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= g.n) return;
-    const float4 p = g.pts[i];
-    if (!(p.x == p.x && p.y == p.y && p.z == p.z)) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < g.n) p = g.pts[i];
+    const bool valid = i < g.n && p.x == p.x && p.y == p.y && p.z == p.z;
     const float inv_h = 2.f * g.inv_cell;
     // octant coordinates (half cells) of p -/+ the margin, clamped to the grid
     const int ax0 = min(max((int)floorf((p.x - oct_margin - g.ox) * inv_h), 0), 2 * g.nx - 1), ax1 = min(max((int)floorf((p.x + oct_margin - g.ox) * inv_h), 0), 2 * g.nx - 1);
     const int ay0 = min(max((int)floorf((p.y - oct_margin - g.oy) * inv_h), 0), 2 * g.ny - 1), ay1 = min(max((int)floorf((p.y + oct_margin - g.oy) * inv_h), 0), 2 * g.ny - 1);
     const int az0 = min(max((int)floorf((p.z - oct_margin - g.oz) * inv_h), 0), 2 * g.nz - 1), az1 = min(max((int)floorf((p.z + oct_margin - g.oz) * inv_h), 0), 2 * g.nz - 1);
-#pragma unroll 1
-    for (int cx = ax0 >> 1; cx <= ax1 >> 1; ++cx) {
-        const int bx = (ax0 <= 2 * cx && 2 * cx <= ax1 ? 1 : 0) | (ax0 <= 2 * cx + 1 && 2 * cx + 1 <= ax1 ? 2 : 0);        // lower / upper half in range
-#pragma unroll 1
-        for (int cy = ay0 >> 1; cy <= ay1 >> 1; ++cy) {
-            const int by = (ay0 <= 2 * cy && 2 * cy <= ay1 ? 1 : 0) | (ay0 <= 2 * cy + 1 && 2 * cy + 1 <= ay1 ? 2 : 0);
-#pragma unroll 1
-            for (int cz = az0 >> 1; cz <= az1 >> 1; ++cz) {
-                const int bz = (az0 <= 2 * cz && 2 * cz <= az1 ? 1 : 0) | (az0 <= 2 * cz + 1 && 2 * cz + 1 <= az1 ? 2 : 0);
-                int m = 0;
+    // at most 2 x 2 x 2 cells (the margin is under half an octant's edge): slot s = the cell at offset (s & 1, s >> 1 & 1, s >> 2) from the first
 #pragma unroll
-                for (int o = 0; o < 8; ++o) if (((bx >> (o & 1)) & 1) && ((by >> ((o >> 1) & 1)) & 1) && ((bz >> ((o >> 2) & 1)) & 1)) m |= 1 << o;
-                atomicOr(&omask[(cx * g.ny + cy) * g.nz + cz], m);
-            }
-        }
+    for (int s = 0; s < 8; ++s) {
+        const int cx = (ax0 >> 1) + (s & 1), cy = (ay0 >> 1) + ((s >> 1) & 1), cz = (az0 >> 1) + (s >> 2);
+        const bool in = valid && cx <= (ax1 >> 1) && cy <= (ay1 >> 1) && cz <= (az1 >> 1);
+        const int bx = (ax0 <= 2 * cx && 2 * cx <= ax1 ? 1 : 0) | (ax0 <= 2 * cx + 1 && 2 * cx + 1 <= ax1 ? 2 : 0);        // lower / upper half in range
+        const int by = (ay0 <= 2 * cy && 2 * cy <= ay1 ? 1 : 0) | (ay0 <= 2 * cy + 1 && 2 * cy + 1 <= ay1 ? 2 : 0);
+        const int bz = (az0 <= 2 * cz && 2 * cz <= az1 ? 1 : 0) | (az0 <= 2 * cz + 1 && 2 * cz + 1 <= az1 ? 2 : 0);
+        // octant o = (x half) + 2 (y half) + 4 (z half): the mask is the outer product of the three two-bit ranges
+        const int mxy = ((by & 1) ? bx : 0) | ((by & 2) ? bx << 2 : 0);
+        int m = ((bz & 1) ? mxy : 0) | ((bz & 2) ? mxy << 4 : 0);
+        const int key = in ? (cx * g.ny + cy) * g.nz + cz : -1 - lane;          // (lanes without this slot: keys of their own)
+        if (!in) m = 0;
+        // left neighbour in the 16-lane row (row_shr:1; the row's first lane reads itself through bound_ctrl = 0 -> its own value: it never matches
+        // because its "neighbour mask" is then taken as 0)
+        const int pk = __builtin_amdgcn_update_dpp(-2 - lane, key, 0x111, 0xF, 0xF, false);
+        const int pm = __builtin_amdgcn_update_dpp(0, m, 0x111, 0xF, 0xF, false);
+        if (in && !(pk == key && (m & ~pm) == 0)) atomicOr(&omask[key], m);
     }
 }
 
