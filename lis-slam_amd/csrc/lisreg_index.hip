@@ -838,7 +838,13 @@ __global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin
 
 // k_crow_classify: one workgroup per tile of kCtX x kCtY columns over the whole z-range: the cell_start rows of the tile and its
 // two-column rim are staged in LDS once (two global reads per cell instead of fifty), every thread sums its cells' 5 x 5 columns from there.
-constexpr int kCtX = 8, kCtY = 8, kCtRim = 2;
+#ifndef LISREG_CT_X
+#define LISREG_CT_X 4            // tile of 4 x 8 columns (8 x 8 until round 5: 441 workgroups for a 200 k-point target left most of the chip idle; 17.8 -> 14.6-16.5 us)
+#endif
+#ifndef LISREG_CT_Y
+#define LISREG_CT_Y 8
+#endif
+constexpr int kCtX = LISREG_CT_X, kCtY = LISREG_CT_Y, kCtRim = 2;
 __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask)
 {
     extern __shared__ int s_cs[];                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows
