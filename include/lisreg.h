@@ -219,7 +219,8 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * such batch is probed again; the verdict decides speed only, the search is exact on any order),
  * "index_build" (how "rebuild_targets_each_run" rebuilds the target grids of a batch: 0 bucket sort with one global atomic per
  * point, 1 strip form — LDS histograms, one workgroup per strip of cells; an error if a grid does not fit its LDS tables —,
- * 2 [default] strip form whenever the grids fit; both produce the same index bit for bit), "index_strip_cells", "index_strip_cap",
+ * 2 [default] strip form whenever the grids fit; both produce the same index bit for bit), "index_strip_cells" (cells per strip aimed at; 0 [default]: 1024 for a batch of one or two
+ * targets, 2048 beyond — a shared submap is a handful of strips and wants them smaller), "index_strip_cap",
  * "xcd_order" (dispatch order of the correspondence workgroups of a graph-front-end batch: 0 block order, 1 by target sector so that
  * each of the 8 XCDs — each with its own L2 — works on one eighth of the target, 2 auto [default]: 1 for batches of >= 32 registrations;
  * results do not depend on it, bit for bit),

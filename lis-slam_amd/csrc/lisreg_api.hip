@@ -803,7 +803,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             ts.nx = t.g[k].nx; ts.ny = t.g[k].ny; ts.nz = t.g[k].nz;
             ts.grid_id = slot * 2 + k;
             ts.strip_base = tstrip;
-            ts.ystrip = std::max(1, std::min(ts.ny, (c->strip_cells + ts.nz / 2) / std::max(ts.nz, 1)));
+            // cells per strip: a batch of one or two targets (a shared submap: configs[1]) wants more, smaller strips than the 2048 cells that suit
+            // a batch of hundreds — its strip build is a handful of workgroups (k_strip_build<true> 22 -> 15.6 us with 1024; configs[3] loses
+            // 2.7 % with it): "index_strip_cells" = 0 (default) picks by the number of targets in the batch
+            const int strip_cells = c->strip_cells > 0 ? c->strip_cells : (c->batch_slots.size() <= 2 ? 1024 : 2048);
+            ts.ystrip = std::max(1, std::min(ts.ny, (strip_cells + ts.nz / 2) / std::max(ts.nz, 1)));
             // wide grids: fewer, longer strips so that nx * nstrips stays inside the partition histogram (kMaxStrips bins)
             if (ts.nx > 0 && ts.nx <= kMaxStrips) {
                 const int max_nstrips = std::max(1, kMaxStrips / ts.nx);
@@ -1182,7 +1186,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         c->index_build = value; c->prepared = false;
         return LISREG_OK;
     }
-    if (!strcmp(name, "index_strip_cells")) { c->strip_cells = std::max(value, 1); c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "index_strip_cells")) { c->strip_cells = std::max(value, 0); c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "index_strip_cap")) { c->strip_cap = std::min(std::max(value, 64), 16384); c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "count_searches")) {
         c->count_searches = value != 0;

@@ -222,7 +222,7 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
         ts.grid_id = k;
         // strip form of the build (the one a prepared batch's targets take, lisreg_batch_prepare): same layout rule
         ts.strip_base = tstrip;
-        ts.ystrip = std::max(1, std::min(ts.ny, (c->strip_cells + ts.nz / 2) / std::max(ts.nz, 1)));
+        ts.ystrip = std::max(1, std::min(ts.ny, ((c->strip_cells > 0 ? c->strip_cells : 2048) + ts.nz / 2) / std::max(ts.nz, 1)));      // (map batches: many maps, the big strips)
         if (ts.nx > 0 && ts.nx <= kMaxStrips) {
             const int max_nstrips = std::max(1, kMaxStrips / ts.nx);
             ts.ystrip = std::max(ts.ystrip, (ts.ny + max_nstrips - 1) / max_nstrips);

@@ -159,7 +159,7 @@ struct lisreg_ctx {
     std::vector<lisreg::BlockDesc> h_tchunks;          // the same targets in chunks of kPartChunkHost points (strip form of the build)
     int       t_strips = 0, t_max_units = 0, t_max_ucells = 0;
     int       index_build = 2;                          // 0 bucket sort, 1 strip form (error if a grid does not fit it), 2 strip form whenever it fits
-    int       strip_cells = 2048, strip_cap = 2048;     // cells per strip aimed at; points per strip of the small-workgroup variant
+    int       strip_cells = 0, strip_cap = 2048;        // cells per strip aimed at (0: 1024 for a batch of one or two targets, else 2048); points per strip of the small-workgroup variant
     bool      strip_now = false;
     hipStream_t side_stream = nullptr;                  // strip build: the big-strip kernel runs here, forked from / joined to `stream`
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
