@@ -460,6 +460,38 @@ def main():
                            note="two contexts on two HIP streams, each running the same device-resident batch step after step (index build inside every "
                                 "step); the streams' kernels share the chip, so per-kernel durations of this leg are not comparable with `roofline`")
 
+    # The same overlap inside ONE context and ONE batch: option "interleave" = 2 cuts a fixed-iteration run in two at a registration boundary
+    # and iterates the halves on two streams, each half's 6x6 solves and launch tails underneath the other half's correspondence launch
+    # (bit-identical results).  Off by default — a half-launch's duration is then no longer its own, and `roofline` is made of launch
+    # durations — and reported here, next to `value`, with the whole-step fraction it reaches.
+    interleave_leg = None
+    if rank == 0 and n_gpus == 1 and not own_targets and not os.environ.get("LISREG_BENCH_NO_OVERLAP"):
+        cx = lisreg.Context(dev_index)
+        sx = torch.cuda.Stream(device=dev)
+        cx.set_stream(sx.cuda_stream)
+        cx.set_option("rebuild_targets_each_run", 1)
+        cx.set_option("interleave", 2)
+        cx.set_target_device(tc_dev.data_ptr(), tc_dev.shape[0], ts_dev.data_ptr(), ts_dev.shape[0])
+        cx.batch_prepare_device(items, T_init, params)
+        for _ in range(3):
+            cx.batch_run()
+        torch.cuda.synchronize()
+        isteps = 2 * max(5, min(args.steps, 20))
+        ti0 = time.perf_counter()
+        for _ in range(isteps):
+            cx.batch_run()
+        torch.cuda.synchronize()
+        dti = time.perf_counter() - ti0
+        engaged = bool(cx.get_option("interleaved_now"))
+        Ti, _ = cx.batch_fetch()
+        cx.close()
+        iv = batch * isteps / dti
+        interleave_leg = dict(value=round(iv, 2), unit="registrations/s", ms_per_step=round(1e3 * dti / isteps, 3), steps=isteps, engaged=engaged,
+                              poses_equal_single_stream_run=bool(np.array_equal(np.asarray(Ti), T_gpu)),
+                              step_frac=round(float(roof["algorithmic_bytes_per_registration"]) * iv / (HBM_PEAK_GBS * 1e9), 5) if roof else None,
+                              note="option interleave = 2 (two halves of the batch on two streams, free-running); ONE context, the same batch and index "
+                                   "build per step as `value`; not the default because per-launch durations stop being a launch's own")
+
     # ---- PCIe-inclusive leg: pinned host clouds in the reference's 32-byte layout through lisreg_align_batch ------
     # At N > 1 EVERY rank runs it at the same time (between two barriers): the ranks' feeder threads and uploads then compete for the host's
     # cores, memory and PCIe root ports — the contention SURVEY.md section 8(e) names as the multi-GPU limit — and rank 0 reports the
@@ -507,7 +539,7 @@ def main():
                        "process_group": None if not use_dist else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                    "pose_gather": "lisreg_comm_init / lisreg_gather_results (the library's own RCCL all-gather)" if native_gather else "torch.distributed " + dist.get_backend(),
                                                                    "comm_nranks": comm_nranks, "ranks": rank_devices}},
-            "roofline": roof, "cpu_baseline": cpu, "pcl_reference": pcl_reference_note(), "pcie_inclusive": pcie, "two_batches_in_flight": overlap_leg, "exact_build": exact_leg,
+            "roofline": roof, "cpu_baseline": cpu, "pcl_reference": pcl_reference_note(), "pcie_inclusive": pcie, "two_batches_in_flight": overlap_leg, "interleaved_halves": interleave_leg, "exact_build": exact_leg,
             "accuracy": {"max_rot_err_vs_truth_rad": float(err_truth[:, :3].max()),
                          "max_trans_err_vs_truth_m": float(err_truth[:, 3:].max()),
                          "vs_cpu_oracle": parity,
