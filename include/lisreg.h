@@ -139,8 +139,7 @@ int  lisreg_default_params(int variant, lisreg_params* p);
  * option "rebuild_targets_each_run" every lisreg_batch_run re-reads them).  The index persists until the next call for
  * that slot, so a target shared by many registrations is built once.  Slot 0 is what lisreg_align uses.  A cloud with an
  * infinite coordinate, or with no finite point at all, is refused (LISREG_ERR_ARG); NaN points are simply never neighbours.
- * A cloud is limited to 2^28 - 1 points (the kernels address its 16-byte records by 32-bit byte offsets); with the cell rows
- * (search_mode 5 / auto) to 2^26 - 1. */
+ * A cloud is limited to 2^28 - 1 points (the kernels address its 16-byte records by 32-bit byte offsets). */
 int  lisreg_set_target(lisreg_ctx* ctx, const void* corner, int n_corner,
                        const void* surf, int n_surf, int stride_bytes, int fmt);
 int  lisreg_set_target_slot(lisreg_ctx* ctx, int slot, const void* corner, int n_corner,
@@ -271,6 +270,18 @@ int  lisreg_get_counters(lisreg_ctx* ctx, unsigned long long* out, int n);
  * (laserCloudOriFlag, :741 / :820).  out: host int[6][n_elems], n_elems = all source points of the batch in item order (corner
  * then surf of each item). */
 int  lisreg_get_neighbors(lisreg_ctx* ctx, int* out, int n_elems);
+
+/* Test hook: the DEVICE functions of the two residual models, one case per thread, on caller-given neighbourhoods — what the
+ * correspondence kernel computes for a query once its five neighbours are known.  kind 1 = surfOptimization's body
+ * (odomEstimationNode.cpp:776-821: plane through the five neighbours, |n.p + d| <= plane_tol test, point-to-plane residual, robust
+ * weight, accept test; in the production arithmetic the plane comes from the closed form `plane5_closed` with its hand-over to the
+ * column-pivoted QR), kind 0 = cornerOptimization's (:664-739).  neighbours: host float[n][5][3] (nearest first), queries: host
+ * float[n][3] (the TRANSFORMED query point), label weight 1.  exact != 0 runs the exact-arithmetic build of the same source.
+ * out: host float[n][10]: kind 1: pa, pb, pc, pd (NaN = plane rejected), 1 if the closed form produced it / 0 if the QR did,
+ * coeff x, y, z, intensity (:808-811), 1 if accepted (s > accept_s, :813); kind 0: centroid x, y, z and two components of the line
+ * direction (NaN = lambda-ratio test failed), coeff x, y, z, intensity (:729-732), accepted (:734). */
+int  lisreg_test_fit_models(lisreg_ctx* ctx, int kind, int n, const float* neighbours, const float* queries,
+                            const lisreg_params* params, int exact, float* out);
 
 /* Diagnostics (tests): the search index of target `slot`, kind 0 = corner / 1 = surf, as it stands in HBM after the work queued on
  * the context's stream: dims = {n, nx, ny, nz, n_cells}, geom = {ox, oy, oz, cell edge}, the cell-sorted records

@@ -618,7 +618,12 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->prm = make_dev_params(*params);
     c->prm.exact = c->exact ? 1 : 0;
     c->prm.ties = (c->canonical_ties || c->exact) ? 1 : 0;
-    c->prm.freeze_pose = getenv("LISREG_XP_FREEZE_POSE") ? 1 : 0;          // timing experiments only (tests/ab.sh): see DevParams
+#ifdef LISREG_XP_HOOKS      /* timing experiments that change results are compiled in only on request (csrc/Makefile: XP=1), never into the shipped library */
+    c->prm.freeze_pose = getenv("LISREG_XP_FREEZE_POSE") ? 1 : 0;          // tests/ab.sh: see DevParams
+    if (c->prm.freeze_pose) fprintf(stderr, "[lisreg] LISREG_XP_FREEZE_POSE is set: poses are NOT updated (timing experiment)\n");
+#else
+    c->prm.freeze_pose = 0;
+#endif
     c->n_items = n_items;
     c->h_blocks.clear(); c->h_segs.clear(); c->h_items.assign((size_t)n_items, ItemState());
     c->batch_slots.clear();
@@ -648,13 +653,6 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
             c->mode_now = (t_pts > 0 && qi >= (double)c->graph_min_ratio * t_pts) ? 3 : 1;
             if (t_pts > 0 && qi >= (double)c->cell_min_ratio * t_pts && t_pts * 5120.0 <= (double)c->cell_rows_max_mb * 1048576.0) c->mode_now = 5;
         }
-        // cell-row entries keep six bits next to the id (lisreg_internal.hpp, kCrowTagShift): targets of 2^26 points or more take the graph
-        if (c->mode_now == 5)
-            for (int sl : seen)
-                if (std::max(c->targets[(size_t)sl].n[0], c->targets[(size_t)sl].n[1]) > lisreg::kCrowIdMask) {
-                    if (c->search_mode == 5) return fail(c, LISREG_ERR_ARG, "batch_prepare: search_mode 5 (cell rows) takes targets of fewer than 2^26 points");
-                    c->mode_now = 3;
-                }
         // a batch this small cannot fill the chip with one lane per query: eight lanes share a query (k_assoc_walk<.., 8>)
         c->lanes_q = (c->mode_now == 1 && c->lanes_per_query_auto && total_src > 0 && total_src <= 131072) ? 8 : 1;
         // the cell rows re-make a target's grid with a margin the first time they are chosen for it: before anything below reads the geometry
@@ -679,6 +677,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
                     for (int k = 0; k < 2; ++k) {
                         Target& t = c->targets[(size_t)sl];
                         if (t.crow_valid[k]) { t.crow[k].release(); t.crow_meta[k].release(); t.crow_valid[k] = false; t.g[k].crow = nullptr; t.g[k].crow_meta = nullptr; t.g[k].crow_tab = nullptr; c->grids_dirty = true; }
+                        t.crow_chosen[k] = false;         // (the next set_target of this slot builds its grid without the rows' two-cell margin again)
                     }
             }
         }
@@ -1082,16 +1081,26 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         // alone, which is what the roofline figures of bench.py and the profiler tables are made of; 2: free-running (the launches of the
         // two streams share the chip whenever both are ready: same throughput, launch durations no longer comparable)
         const bool alternate = c->interleave == 1 && c->ev_ab && c->ev_ba;
-        for (int it = 0; it < c->prm.bound; ++it) {
-            if (alternate && it > 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ba, 0));            // B's launch of the iteration before is through
+        // a failing event call must not leave work of the second half un-joined on the side stream (the caller's next fetch on `st` would race
+        // with it): on any failure the side stream is drained by the HOST before the error is returned, and the run counts as not interleaved
+        hipError_t ie = hipSuccess;
+        for (int it = 0; it < c->prm.bound && ie == hipSuccess; ++it) {
+            if (alternate && it > 0) ie = hipStreamWaitEvent(st, c->ev_ba, 0);                   // B's launch of the iteration before is through
+            if (ie != hipSuccess) break;
             if (alternate) prof_mark(c, 0, 0);
             iteration(it, 0, split_item, 0, split_blk, st, 0, alternate ? c->ev_ab : nullptr);
-            if (alternate) HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_ab, 0));          // A's launch of this iteration is through
+            if (alternate) ie = hipStreamWaitEvent(c->side_stream, c->ev_ab, 0);                 // A's launch of this iteration is through
+            if (ie != hipSuccess) break;
             if (alternate) prof_mark(c, 0, 1);
             iteration(it, split_item, c->n_items - split_item, split_blk, c->n_blocks - split_blk, c->side_stream, 1, alternate ? c->ev_ba : nullptr);
         }
-        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        if (ie == hipSuccess) ie = hipEventRecord(c->ev_join, c->side_stream);
+        if (ie == hipSuccess) ie = hipStreamWaitEvent(st, c->ev_join, 0);
+        if (ie != hipSuccess) {
+            (void)hipStreamSynchronize(c->side_stream);
+            c->interleaved_now = false;
+            return lisreg::ctx_fail(c, LISREG_ERR_HIP, std::string("interleaved run: ") + hipGetErrorString(ie));
+        }
     } else
     for (int it = 0; it < c->prm.bound; ++it) {
         iteration(it, 0, c->n_items, 0, c->n_blocks, st, 0, nullptr);
@@ -1463,11 +1472,6 @@ int lisreg_get_target_cell_rows(lisreg_ctx* c, int slot, int kind, int* n_rows, 
     if ((rows_out || meta_out) && capacity_rows < rows) return fail(c, LISREG_ERR_ARG, "get_target_cell_rows: capacity_rows too small");
     if (rows_out && rows) {
         HIPCHK(c, hipMemcpy(rows_out, t.crow[kind].p, sizeof(float4) * kGraphK * (size_t)rows, hipMemcpyDeviceToHost));
-        // the device rows carry the entry's position next to the id (lisreg_internal.hpp, kCrowTagShift): the diagnostic view is the plain id
-        for (size_t e = 0; e < (size_t)rows * kGraphK; ++e) {
-            int w; memcpy(&w, rows_out + 4 * e + 3, 4);
-            w = lisreg::crow_id(w); memcpy(rows_out + 4 * e + 3, &w, 4);
-        }
     }
     if (meta_out && rows) HIPCHK(c, hipMemcpy(meta_out, t.crow_meta[kind].p, sizeof(float2) * (size_t)rows, hipMemcpyDeviceToHost));
     return LISREG_OK;
@@ -1480,6 +1484,31 @@ int lisreg_get_neighbors(lisreg_ctx* c, int* out, int n_elems)
         return fail(c, LISREG_ERR_ARG, "get_neighbors: set option dump_neighbors before preparing the batch (search modes 1, 3); n_elems must be the batch's source point count");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->dbg_nn.p, sizeof(int) * 6 * (size_t)n_elems, hipMemcpyDeviceToHost));
+    return LISREG_OK;
+}
+
+int lisreg_test_fit_models(lisreg_ctx* c, int kind, int n, const float* neighbours, const float* queries, const lisreg_params* params,
+                           int exact, float* out)
+{
+    if (!c) return LISREG_ERR_ARG;
+    if ((kind != 0 && kind != 1) || n < 0 || !params || (n > 0 && (!neighbours || !queries || !out)))
+        return fail(c, LISREG_ERR_ARG, "test_fit_models: bad arguments");
+    if (n == 0) return LISREG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf nb, q, o;
+    HIPCHK(c, nb.ensure(sizeof(float) * 15 * (size_t)n));
+    HIPCHK(c, q.ensure(sizeof(float) * 3 * (size_t)n));
+    HIPCHK(c, o.ensure(sizeof(float) * 10 * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(nb.p, neighbours, sizeof(float) * 15 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(q.p, queries, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    DevParams prm = make_dev_params(*params);
+    prm.exact = exact ? 1 : 0;
+    if (exact) launch_test_fit_exact(kind, n, nb.as<float>(), q.as<float>(), prm, o.as<float>(), c->stream);
+    else launch_test_fit(kind, n, nb.as<float>(), q.as<float>(), prm, o.as<float>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, o.p, sizeof(float) * 10 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    nb.release(); q.release(); o.release();
     return LISREG_OK;
 }
 

@@ -196,6 +196,7 @@ void feeder_destroy(lisreg_ctx* c)
     // order: the copy stream drains first (its copies read the pinned staging buffers and write the device buffers), then the threads
     // are joined (nothing packs into a buffer that is about to go), then events, pinned and device memory
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
     delete c->pack_pool; c->pack_pool = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (c->pack_copied[b]) (void)hipEventDestroy(c->pack_copied[b]);
@@ -209,6 +210,9 @@ void feeder_destroy(lisreg_ctx* c)
     c->pack_raw_done = nullptr; c->pack_pending = nullptr;
     if (c->up_host) (void)hipHostFree(c->up_host);
     c->up_host = nullptr; c->up_cap = 0;
+    if (c->pack_kernels_done) (void)hipEventDestroy(c->pack_kernels_done);
+    c->pack_kernels_done = nullptr;
+    if (c->pack_stream) { (void)hipStreamDestroy(c->pack_stream); c->pack_stream = nullptr; }
     if (c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
 }
 
@@ -237,10 +241,24 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
     HIPCHK(c, hipSetDevice(c->device));
     const int b = c->pack_flip;
     c->pack_flip ^= 1;
-    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // The copy stream carries asynchronous copies and ONE event record per call — never a device-side wait, never a kernel.  HIP maps a
+    // process's streams onto a handful of hardware queues (four by default), so with a few contexts alive the copy stream shares an AQL
+    // queue with some compute stream, possibly this context's own: a wait or kernel packet of the copy stream then queues up BEHIND the
+    // kernels of the batch that is running, the copies ordered after it start when that batch is through, and the upload of batch k + 1
+    // no longer hides underneath batch k (measured, round 6: 12.8 k reg/s against 23.7 k for the same loop with the streams on separate
+    // queues — profiles/r06_pcie_overlap.md).  The copy engines themselves do not go through that queue.
+    static const bool feed_legacy = getenv("LISREG_FEED_LEGACY") != nullptr;      // A/B only (tests/pcie_prio_ab.sh): rounds 3-5's device-side wait and
+                                                                                  // packing kernels on the copy stream; same results, no overlap when queues alias
+    if (!c->copy_stream) {
+        const char* e = getenv("LISREG_COPY_PRIO");              // experiments: -1 (high) / 1 (low) put the stream into another queue pool
+        if (e) HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, atoi(e)));
+        else HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    }
     if (!c->pack_copied[b]) HIPCHK(c, hipEventCreateWithFlags(&c->pack_copied[b], hipEventDisableTiming));
     if (!c->pack_free[b]) HIPCHK(c, hipEventCreateWithFlags(&c->pack_free[b], hipEventDisableTiming));
-    else HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->pack_free[b], 0));      // the batch that last read device buffer b has run
+    else if (!feed_legacy) HIPCHK(c, hipEventSynchronize(c->pack_free[b]));      // the batch that last read device buffer b has run (two batches
+                                                                                 // back in a pipelined loop: long done; a HOST wait, for the reason above)
+    else HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->pack_free[b], 0));
     // the staging buffer's previous contents have left it (its copies are two calls old)
     if (c->pack_cap[b]) HIPCHK(c, hipEventSynchronize(c->pack_copied[b]));
     const size_t bytes = sizeof(lisreg_dpoint) * std::max<size_t>(total, 1);
@@ -283,6 +301,7 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         d.fmt = LISREG_FMT_DEVICE; d.stride_bytes = (int)sizeof(lisreg_dpoint);
     }
     const int n_chunks = (int)chunks.size();
+    c->pack_stolen = 0;
     if (n_chunks > 0) {
         // (no job is alive here: the previous call left through its JobGuard, so the flag array may be replaced)
         if ((int)c->pack_done.size() < n_chunks) c->pack_done = std::vector<std::atomic<int>>((size_t)n_chunks);
@@ -314,7 +333,7 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
                     const bool forced = force_one;
                     force_one = false;
                     if (job && c->feeder_engine > 0 && chunks[(size_t)lowest_stolen - 1].pinned &&
-                        (forced || c->feeder_engine > 1 || hipStreamQuery(c->copy_stream) == hipSuccess)) {
+                        (forced || c->feeder_engine > 1 || (hipStreamQuery(c->copy_stream) == hipSuccess && (!c->pack_stream || hipStreamQuery(c->pack_stream) == hipSuccess)))) {
                         const int k = job->take_back();
                         if (k >= 0) {
                             const PackChunk& ck = chunks[(size_t)k];
@@ -325,12 +344,16 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
                                 HIPCHK(c, c->pack_raw[b].ensure(worst));
                                 raw_dev = static_cast<unsigned char*>(c->pack_raw[b].p);
                             }
-                            HIPCHK(c, hipMemcpyAsync(raw_dev + raw_off, ck.src, bytes_k, hipMemcpyHostToDevice, c->copy_stream));
+                            // on a stream of their own: the packing kernel is a packet of a hardware queue that may be busy with the running
+                            // batch, and the packed chunks' copies must not be ordered behind it
+                            if (!c->pack_stream && !feed_legacy) HIPCHK(c, hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking));
+                            hipStream_t ps = feed_legacy ? c->copy_stream : c->pack_stream;
+                            HIPCHK(c, hipMemcpyAsync(raw_dev + raw_off, ck.src, bytes_k, hipMemcpyHostToDevice, ps));
                             launch_pack_cloud(raw_dev + raw_off, (size_t)ck.n, ck.stride, ck.fmt == LISREG_FMT_XYZIL ? 1 : 0,
-                                              reinterpret_cast<float4*>(dev + (ck.dst - host)), c->copy_stream);
+                                              reinterpret_cast<float4*>(dev + (ck.dst - host)), ps);
                             raw_off += (bytes_k + 63) & ~(size_t)63;
                             if (!c->pack_raw_done) HIPCHK(c, hipEventCreateWithFlags(&c->pack_raw_done, hipEventDisableTiming));
-                            HIPCHK(c, hipEventRecord(c->pack_raw_done, c->copy_stream));      // the engine has read the caller's memory up to here
+                            HIPCHK(c, hipEventRecord(c->pack_raw_done, ps));      // the engine has read the caller's memory up to here
                             lowest_stolen = k;
                             stole = true;
                             if (k <= i) break;                     // this very chunk went to the engine
@@ -360,6 +383,11 @@ int lisreg_stage_host_items(lisreg_ctx* c, int n_items, const lisreg_item* items
         // "the caller's clouds are not referenced after the call returns": chunks the copy engine took are read from the caller's own
         // (pinned) memory by asynchronous copies — wait for the last of those; the packed chunks left the caller's memory on the host
         if (c->pack_stolen > 0 && c->pack_raw_done) HIPCHK(c, hipEventSynchronize(c->pack_raw_done));
+    }
+    if (c->pack_stolen > 0 && c->pack_stream) {   // the packing kernels' output belongs to the batch: the one wait the copy stream ever gets, at its very end
+        if (!c->pack_kernels_done) HIPCHK(c, hipEventCreateWithFlags(&c->pack_kernels_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->pack_kernels_done, c->pack_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->pack_kernels_done, 0));
     }
     HIPCHK(c, hipEventRecord(c->pack_copied[b], c->copy_stream));
     c->pack_pending = c->pack_copied[b];          // the next batch_prepare makes the context's stream wait for it

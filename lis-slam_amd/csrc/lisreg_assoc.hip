@@ -41,9 +41,11 @@
 #if LISREG_EXACT
 #define LISREG_ASSOC_NS exact_arith
 #define LISREG_LAUNCH_ASSOC launch_assoc_exact
+#define LISREG_LAUNCH_TEST_FIT launch_test_fit_exact
 #else
 #define LISREG_ASSOC_NS fast_arith
 #define LISREG_LAUNCH_ASSOC launch_assoc
+#define LISREG_LAUNCH_TEST_FIT launch_test_fit
 #endif
 
 namespace lisreg {
@@ -527,8 +529,6 @@ __device__ __forceinline__ void row_and_reduce(bool ok, const float cf[4], const
 
 // Residual model shared by the search front-ends that re-fit every iteration.
 // (i0..i4) index g.pts, ascending by distance; i4 < 0 means "fewer than five neighbours within sqrt(tau)".
-// kTagged: the ids come out of cell rows and carry the entry's position in its row in their upper bits (crow_tagged): stripped here.
-template <bool kTagged = false>
 __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int i2, int i3, int i4, const GridIndex& g,
                                                 const float4 q4, float qx, float qy, float qz, const DevParams& P, int kind,
                                                 float cf[4])
@@ -547,12 +547,7 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
         n4.x = qx + 0.01f * (float)(i4 & 7); n4.y = qy + 0.21f; n4.z = qz; n4.w = 0.f;
 #else
         v4f n0, n1, n2, n3, n4;
-        if (kTagged) {
-            n0 = LISREG_LD4(gp, i0 & kCrowIdMask); n1 = LISREG_LD4(gp, i1 & kCrowIdMask); n2 = LISREG_LD4(gp, i2 & kCrowIdMask);
-            n3 = LISREG_LD4(gp, i3 & kCrowIdMask); n4 = LISREG_LD4(gp, i4 & kCrowIdMask);
-        } else {
-            n0 = LISREG_LD4(gp, i0); n1 = LISREG_LD4(gp, i1); n2 = LISREG_LD4(gp, i2); n3 = LISREG_LD4(gp, i3); n4 = LISREG_LD4(gp, i4);
-        }
+        n0 = LISREG_LD4(gp, i0); n1 = LISREG_LD4(gp, i1); n2 = LISREG_LD4(gp, i2); n3 = LISREG_LD4(gp, i3); n4 = LISREG_LD4(gp, i4);
 #endif
         nb[0] = make_float4(n0.x, n0.y, n0.z, n0.w); nb[1] = make_float4(n1.x, n1.y, n1.z, n1.w);
         nb[2] = make_float4(n2.x, n2.y, n2.z, n2.w); nb[3] = make_float4(n3.x, n3.y, n3.z, n3.w);
@@ -569,14 +564,13 @@ __device__ __forceinline__ bool residual_coeffs(bool valid, int i0, int i1, int 
     return ok;
 }
 
-template <bool kTagged = false>
 __device__ __forceinline__ void residual_and_reduce(bool valid, int i0, int i1, int i2, int i3, int i4,
                                                     const GridIndex& g, const float4 q4, float qx, float qy, float qz,
                                                     const float* jk, const DevParams& P, int kind,
                                                     float* s_red, double* __restrict__ out, int* dbg_ok = nullptr)
 {
     float cf[4];
-    const bool ok = residual_coeffs<kTagged>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
+    const bool ok = residual_coeffs(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, P, kind, cf);
     if (dbg_ok && valid) *dbg_ok = ok ? 1 : 0;          // "dump_neighbors": row 5 = this point contributed a correspondence
     row_and_reduce(ok, cf, q4, jk, P, s_red, out);
 }
@@ -1406,7 +1400,6 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
             }
         }
         if (need_walk) {
-            if (kGraph == 2 && scanned) { i0 = crow_id(i0); i1 = crow_id(i1); i2 = crow_id(i2); i3 = crow_id(i3); i4 = crow_id(i4); }   // the walk compares plain ids
             int sx0_ = 1, sx1_ = 0, sy0_ = 1, sy1_ = 0;
             if (kWide) {
                 LISREG_WALK_LIST(3.0e38f, true, false);
@@ -1493,7 +1486,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
         bool same = true;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const int o = ids[k] >= 0 ? __float_as_int(pts[kGraph == 2 ? crow_id(ids[k]) : ids[k]].w) : -1;
+            const int o = ids[k] >= 0 ? __float_as_int(pts[ids[k]].w) : -1;
             same = same && dbg_nn[(size_t)k * n_elems + qflat] == o;
             dbg_nn[(size_t)k * n_elems + qflat] = o;
         }
@@ -1517,7 +1510,7 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
     if (valid) { const v4f t = __builtin_nontemporal_load((const v4f*)&qsrc[qflat]); q4 = make_float4(t.x, t.y, t.z, t.w); }
 #endif
     if (kQ == 1) {
-        residual_and_reduce<kGraph == 2>(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out,
+        residual_and_reduce(valid, i0, i1, i2, i3, i4, g, q4, qx, qy, qz, it->jk, P, sg.kind, s_red, out,
                                          dbg_nn ? dbg_nn + 5 * (size_t)n_elems + qflat : nullptr);
     } else {
         // kQ lanes per query: the coefficients go to memory and k_rows_reduce builds the partial rows with the SAME 256-query
@@ -1564,6 +1557,34 @@ __global__ __launch_bounds__(kBlockQ) void k_rows_reduce(const BlockDesc* __rest
     }
     const float cf[4] = { c4.x, c4.y, c4.z, c4.w };
     row_and_reduce(ok, cf, q4, it->jk, P, s_red, out);
+}
+
+__global__ __launch_bounds__(64) void k_test_fit_models(int kind, int n, const float* __restrict__ nb15, const float* __restrict__ q3,
+                                                        DevParams P, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    float4 nb[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nb[j] = make_float4(nb15[i * 15 + 3 * j], nb15[i * 15 + 3 * j + 1], nb15[i * 15 + 3 * j + 2], 0.f);
+    const float qx = q3[3 * i], qy = q3[3 * i + 1], qz = q3[3 * i + 2];
+    float cf[4] = { 0.f, 0.f, 0.f, 0.f };
+    float* o = out + (size_t)i * 10;
+    if (kind == 1) {
+        float pa, pb, pc, pd;
+        bool closed = false;
+        if (!kExactArith && LISREG_PLANE_CLOSED) closed = plane5_closed(nb, pa, pb, pc, pd);
+        const float4 m = surf_model(nb, P);
+        const bool ok = surf_eval(m, qx, qy, qz, 1.f, P, cf);
+        o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = m.w; o[4] = closed ? 1.f : 0.f;
+        o[5] = cf[0]; o[6] = cf[1]; o[7] = cf[2]; o[8] = cf[3]; o[9] = ok ? 1.f : 0.f;
+    } else {
+        float4 m0, m1;
+        corner_model(nb, P, m0, m1);
+        const bool ok = corner_eval(m0, m1, qx, qy, qz, 1.f, P, cf);
+        o[0] = m0.x; o[1] = m0.y; o[2] = m0.z; o[3] = m1.x; o[4] = m1.y;
+        o[5] = cf[0]; o[6] = cf[1]; o[7] = cf[2]; o[8] = cf[3]; o[9] = ok ? 1.f : 0.f;
+    }
 }
 
 }  // namespace LISREG_ASSOC_NS
@@ -1718,6 +1739,18 @@ static void launch_assoc_impl(const BlockDesc* blocks, int n_blocks, const Segme
             k_assoc_walk<false, 1, 1, kTies><<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items, prm, sorted_all, nn, n_elems,
                                                                            first_pass_r2, graph_hops, counters, dbg_nn, coef, coef_ok, partials, xcd_order);
     }
+}
+
+// Test hook (lisreg_test_fit_models): the DEVICE functions of the two residual models on caller-given neighbourhoods, one thread per
+// case — corner_model / corner_eval (kind 0: odomEstimationNode.cpp:664-739) or surf_model / surf_eval (kind 1: :776-821; in the
+// production arithmetic that is plane5_closed with its hand-over to the column-pivoted QR).  out[i] = 10 floats:
+//   kind 1: pa, pb, pc, pd (NaN: the plane failed the |n.p + d| <= plane_tol test), 1 = closed form used / 0 = QR, cf[0..3], accepted
+//   kind 0: the line model m0.xyz (centroid), m1.xyz (direction; m1.x NaN: lambda-ratio test failed) packed as 6 floats -> out[0..5] is
+//           not the reference's representation, so only cf[0..3] (out[5..8]) and `accepted` (out[9]) are compared; out[0..4] = m0.xyz, m1.x, m1.y
+void LISREG_LAUNCH_TEST_FIT(int kind, int n, const float* nb15, const float* q3, DevParams prm, float* out, hipStream_t st)
+{
+    using namespace LISREG_ASSOC_NS;
+    if (n > 0) k_test_fit_models<<<(n + 63) / 64, 64, 0, st>>>(kind, n, nb15, q3, prm, out);
 }
 
 void LISREG_LAUNCH_ASSOC(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,

@@ -138,6 +138,8 @@ struct lisreg_ctx {
     hipEvent_t   pack_raw_done = nullptr;                 // the copy engine's last read of the CALLER's pinned memory (chunks it took over)
     int          pack_flip = 0, pack_last = -1, pack_in_use = -1;
     hipStream_t  copy_stream = nullptr;
+    hipStream_t  pack_stream = nullptr;                   // chunks the copy engine takes as they are: raw copy + k_pack_cloud (never on copy_stream: see lisreg_stage_host_items)
+    hipEvent_t   pack_kernels_done = nullptr;             // recorded on pack_stream behind the last k_pack_cloud of a staging call
     std::vector<lisreg::PackChunk> pack_chunks;
     std::vector<std::atomic<int>> pack_done;
     std::map<int, lisreg::MapIndex> maps;             // by slot (sparse: the local maps keep theirs at 60000 + id)

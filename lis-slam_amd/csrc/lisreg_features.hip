@@ -532,7 +532,12 @@ void launch_extract_features(const float4* pts, const uint32_t* rings, int n, li
     k_feat_extract<<<(hw + 16 + 255) / 256, 256, 0, st>>>(pts, fb.owner, fb.pos, H, W, fb);
     k_feat_smooth<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.curv, fb.pos, hw_sweep, n_sweeps);
     k_feat_occlude<<<(hw + 255) / 256, 256, 0, st>>>(fb.counts, fb.range, fb.col, fb.picked, fb.pos, hw_sweep, n_sweeps);
+#ifdef LISREG_XP_HOOKS      /* timing experiment (wrong features), compiled in only on request (csrc/Makefile: XP=1) */
     static const int xp_stop = getenv("LISREG_XP_FEAT_STOP") ? atoi(getenv("LISREG_XP_FEAT_STOP")) : 0;
+    if (xp_stop) fprintf(stderr, "[lisreg] LISREG_XP_FEAT_STOP is set: feature selection stops early (timing experiment)\n");
+#else
+    const int xp_stop = 0;
+#endif
     k_feat_select<<<H, 256, 0, st>>>(fb.pos, H, W, P, fb, rows_per_sweep, xp_stop);   // grid = sweeps x rings
     k_feat_surface_flags<<<(hw + 16 + 255) / 256, 256, 0, st>>>(fb.pos, H, W, fb);
     // the second scan goes to the upper half of `pos`; the lower half (ring boundaries) stays valid

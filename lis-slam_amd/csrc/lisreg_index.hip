@@ -1031,7 +1031,6 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
 }
 
 // one row: the entries of the list inside rho (the block's inscribed radius, or the first point left out), padded with (q, -1)
-template <bool kTag = true>
 __device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float qy, float qz, float rc, unsigned topk, int topi,
                                            float4* __restrict__ row_out, float2* __restrict__ meta_out, bool& keep, float4& e,
                                            const float4 topc = make_float4(0.f, 0.f, 0.f, 0.f), bool have_c = false)
@@ -1046,7 +1045,7 @@ __device__ __forceinline__ float crow_emit(const GridIndex& g, float qx, float q
     if (keep) {
         float4 c = topc;
         if (!have_c) c = g.pts[topi];
-        e = make_float4(c.x, c.y, c.z, __int_as_float(kTag ? crow_tagged(topi, lane) : topi));      // (the k-NN graph's rows carry plain ids)
+        e = make_float4(c.x, c.y, c.z, __int_as_float(topi));
     }
     row_out[lane] = e;
     if (lane == 0) *meta_out = make_float2(rho2, __int_as_float(cnt));
@@ -1060,7 +1059,7 @@ __device__ __forceinline__ void graph_row_q32(const GridIndex& g, const float4 q
     unsigned topk; int topi; float4 topc; bool have_c;
     crow_list<2>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c, s);
     bool keep; float4 e;
-    (void)crow_emit<false>(g, q.x, q.y, q.z, crow_inscribed<2>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e, topc, have_c);
+    (void)crow_emit(g, q.x, q.y, q.z, crow_inscribed<2>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e, topc, have_c);
 }
 
 // The row at the cell's centre q and, behind it, one row per octant in `mask`.  An octant row is derived from the centre row where that
@@ -1104,7 +1103,7 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
                 const bool okeep = oi >= 0 && __uint_as_float(k & ~0x7Fu) <= rho_o2;
                 const int ocnt = __popcll(__ballot(okeep));
                 float4 oe = make_float4(mx, my, mz, __int_as_float(-1));
-                if (okeep) oe = make_float4(ox, oy, oz, __int_as_float(crow_tagged(oi, lane)));
+                if (okeep) oe = make_float4(ox, oy, oz, __int_as_float(oi));
                 orow[lane] = oe;
                 if (lane == 0) meta_out[slot] = make_float2(rho_o2, __int_as_float(ocnt));
             } else {

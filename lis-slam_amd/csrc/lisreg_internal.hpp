@@ -40,14 +40,8 @@ struct GridIndex {
     const int*    crow_tab;
 };
 
-// Cell-row entries carry their position in the row next to the point's sorted position: w = id | tag << kCrowTagShift, tag = min(j + 1, 31)
-// for entry j (padded entries stay -1).  The scan stages the head of every row a wavefront needs in LDS once (lisreg_assoc.hip); a kept
-// neighbour whose tag says "among the staged entries" is then read back from LDS instead of being gathered from the point array.  Ids of
-// cell-row targets are therefore limited to 2^26 points (a bigger target takes another front-end).
-constexpr int kCrowTagShift = 26;
-constexpr int kCrowIdMask   = (1 << kCrowTagShift) - 1;
-__host__ __device__ __forceinline__ int crow_tagged(int id, int j) { return id | ((j + 1 < 31 ? j + 1 : 31) << kCrowTagShift); }
-__host__ __device__ __forceinline__ int crow_id(int w) { return w < 0 ? w : (w & kCrowIdMask); }
+// Cell-row entries carry plain ids (the sorted position of the listed point, -1 in padded entries) — the position tags of round 5 went with the
+// LDS-staged scan that read them (profiles/r05_xp_mfma_stage_select.patch); cell-row targets are limited only by their 32-bit record offsets.
 
 // centre coordinate of cell h (off = 0.5f) or of one of its halves (0.25f / 0.75f) along one axis: the build and the scan must agree to
 // the bit (the scan re-derives the list distances of a row from this centre) although their translation units are compiled with different
@@ -217,6 +211,9 @@ void launch_assoc_exact(const BlockDesc* blocks, int n_blocks, const Segment* se
                         int mode, int* nn, int n_elems, float first_pass_r2, bool wide, int graph_hops,
                         unsigned long long* counters, int* dbg_nn, int lanes_q, const BlockDesc* blocks_q, int n_blocks_q,
                         float4* coef, int* coef_ok, const int* xcd_order, hipStream_t st);
+// test hook: the device functions of the residual models on caller-given neighbourhoods (lisreg_test_fit_models)
+void launch_test_fit(int kind, int n, const float* nb15, const float* q3, DevParams prm, float* out, hipStream_t st);
+void launch_test_fit_exact(int kind, int n, const float* nb15, const float* q3, DevParams prm, float* out, hipStream_t st);
 // XCD-aware dispatch order of a shared-target batch: blocks ranked by the azimuth of their middle query around the target centre
 // (by_target: a batch with more than one target — blocks ranked by target slot instead, so that every XCD works on whole targets)
 void launch_xcd_order(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items,

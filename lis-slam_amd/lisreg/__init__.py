@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lisreg_device_count", "lisreg_create", "lisreg_destroy", "lisreg_last_error", "lisreg_set_stream",
     "lisreg_get_stream", "lisreg_default_params", "lisreg_set_target", "lisreg_set_target_slot",
     "lisreg_target_from_classes", "lisreg_align", "lisreg_align_batch", "lisreg_batch_prepare", "lisreg_batch_run",
-    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_concat_device", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_get_target_cell_rows", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
+    "lisreg_batch_fetch", "lisreg_stage_host_items", "lisreg_upload_cloud", "lisreg_concat_device", "lisreg_batch_result_device", "lisreg_set_option", "lisreg_get_option", "lisreg_get_counters", "lisreg_get_neighbors", "lisreg_test_fit_models", "lisreg_get_target_index", "lisreg_get_target_graph", "lisreg_get_target_cell_rows", "lisreg_keyframes_reset", "lisreg_keyframes_push", "lisreg_keyframes_target", "lisreg_get_trace",
     "lisreg_set_profiling", "lisreg_get_timing", "lisreg_pose_to_matrix", "lisreg_transform_update",
     "lisreg_comm_unique_id", "lisreg_comm_init", "lisreg_gather_results", "lisreg_comm_destroy",
     "lisreg_voxel_downsample", "lisreg_voxel_downsample_multi", "lisreg_transform_cloud",
@@ -215,6 +215,7 @@ def lib():
         L.lisreg_concat_device.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), vp, C.POINTER(C.c_int)]
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+        L.lisreg_test_fit_models.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Params), C.c_int, C.POINTER(C.c_float)]
         L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lisreg_get_target_graph.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.lisreg_get_target_cell_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
@@ -411,6 +412,18 @@ class Context:
         (-1: none), row 5 = 1 where the point contributed a correspondence."""
         out = np.full((6, n_elems), -1, np.int32)
         self._chk(self._L.lisreg_get_neighbors(self._h, out.ctypes.data_as(C.POINTER(C.c_int)), n_elems))
+        return out
+
+    def test_fit_models(self, kind: int, neighbours: np.ndarray, queries: np.ndarray, params, exact: bool = False) -> np.ndarray:
+        """Test hook: the device functions of the residual models (kind 1 = surfOptimization's body, 0 = cornerOptimization's) on
+        neighbours[n, 5, 3] / queries[n, 3]; returns float32[n, 10] as include/lisreg.h describes."""
+        nb = np.ascontiguousarray(neighbours, np.float32).reshape(-1, 15)
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, 3)
+        assert nb.shape[0] == q.shape[0]
+        out = np.zeros((nb.shape[0], 10), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._chk(self._L.lisreg_test_fit_models(self._h, int(kind), nb.shape[0], nb.ctypes.data_as(fp), q.ctypes.data_as(fp), C.byref(params),
+                                                 1 if exact else 0, out.ctypes.data_as(fp)))
         return out
 
     def front_end(self) -> int:
