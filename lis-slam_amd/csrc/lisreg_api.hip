@@ -190,12 +190,30 @@ int ensure_graph(lisreg_ctx* c, Target& t, int k, bool launch)
 // search_mode 5: cell rows of target kind k (the index itself must already be enqueued on the stream).  The row count depends on the
 // data, so the first build of a target classifies its cells, reads the count back (one host round trip, at set / prepare time) and sizes the
 // buffers; rebuilds inside a run (rebuild_targets_each_run) reuse that capacity — a cell that does not fit gets no row and its queries walk.
-lisreg::CrowBuffers crow_buffers(Target& t, int k)
+lisreg::CrowBuffers crow_buffers(Target& t, int k, bool with_reach = false)
 {
     lisreg::CrowBuffers cb;
     cb.need = t.crow_need[k].as<int>(); cb.omask = t.crow_omask[k].as<int>(); cb.scan = t.crow_scan[k].as<int>(); cb.scan_tmp = t.crow_scan_tmp[k].as<int>();
     cb.cap_rows = t.crow_cap[k];
+    cb.reach = with_reach && t.g[k].qmark ? t.crow_reach[k].as<unsigned>() : nullptr;      // (never for the classification that SIZES the row buffers)
     return cb;
+}
+
+// option "row_reach": mark and reach words of target kind k (one bit per grid cell, lisreg_internal.hpp) — made when a batch that rebuilds its
+// targets takes the cell rows; the pointer travels in the GridIndex (the device table is refreshed when it changes)
+int ensure_reach(lisreg_ctx* c, Target& t, int k, bool on)
+{
+    unsigned* want = nullptr;
+    int w = 0;
+    if (on && t.n[k] > 0 && t.g[k].crow_tab) {
+        w = (t.g[k].nz + 31) / 32;
+        const size_t words = (size_t)t.g[k].nx * (size_t)t.g[k].ny * (size_t)w;
+        HIPCHK(c, t.crow_qmark[k].ensure(sizeof(unsigned) * (words + 8)));
+        HIPCHK(c, t.crow_reach[k].ensure(sizeof(unsigned) * (words + 8)));
+        want = t.crow_qmark[k].as<unsigned>();
+    }
+    if (t.g[k].qmark != want || t.g[k].qmark_w != w) { t.g[k].qmark = want; t.g[k].qmark_w = w; c->grids_dirty = true; }
+    return LISREG_OK;
 }
 
 // may_decline (front-end chosen by auto): a target whose rows would not fit "cell_rows_max_mb" is left without them (crow_too_big) and the
@@ -387,6 +405,7 @@ int lisreg_create(int device, lisreg_ctx** out)
     if (const char* m = getenv("LISREG_GRAPH_HOPS")) c->graph_hops = atoi(m);
     if (const char* m = getenv("LISREG_CELL_ANCHOR_UNTIL")) c->cell_anchor_until = std::max(atoi(m), 0);
     if (const char* m = getenv("LISREG_XCD_ORDER")) c->xcd_order = atoi(m);
+    if (const char* m = getenv("LISREG_ROW_REACH")) c->row_reach = atoi(m);
     if (const char* m = getenv("LISREG_GRAPH_MIN_RATIO")) c->graph_min_ratio = atoi(m);
     if (const char* m = getenv("LISREG_CELL_MIN_RATIO")) c->cell_min_ratio = atoi(m);
     if (const char* m = getenv("LISREG_WIDE_FROM")) c->wide_from = c->wide_from_small = atoi(m);
@@ -402,7 +421,7 @@ void lisreg_destroy(lisreg_ctx* c)
     lisreg_comm_destroy(c);
     feeder_destroy(c);
     for (auto& t : c->targets) for (int k = 0; k < 2; ++k) { t.raw[k].release(); t.sorted[k].release(); t.cell_start[k].release(); t.nbr[k].release(); t.nbr_meta[k].release();
-        t.crow[k].release(); t.crow_meta[k].release(); t.crow_tab[k].release(); t.crow_need[k].release(); t.crow_omask[k].release(); t.crow_scan[k].release(); t.crow_scan_tmp[k].release(); }
+        t.crow[k].release(); t.crow_meta[k].release(); t.crow_tab[k].release(); t.crow_need[k].release(); t.crow_omask[k].release(); t.crow_scan[k].release(); t.crow_scan_tmp[k].release(); t.crow_qmark[k].release(); t.crow_reach[k].release(); }
     DevBuf* bufs[] = { &c->grids_dev, &c->hist, &c->bucket_start, &c->scan_tmp, &c->elem_bucket, &c->elem_sub,
                        &c->tmp_bucket, &c->tmp_sub, &c->tmp_idx, &c->tmp_pts, &c->bbox_dev, &c->bbox_scratch, &c->blocks, &c->segs,
                        &c->items, &c->sorted_all, &c->order_all, &c->partials, &c->results, &c->trace, &c->src_upload, &c->raw_upload, &c->dbg_nn, &c->blocks_q, &c->coef, &c->coef_ok, &c->nn, &c->counters, &c->tseg_dev, &c->tblk_dev, &c->tchunk_dev, &c->strip_tab, &c->done_dev, &c->xcd_tab, &c->vox_in, &c->vox_lab, &c->vox_order, &c->vox_sidx,
@@ -607,6 +626,8 @@ int lisreg_target_from_classes(lisreg_ctx* c, int slot, const void* pole, int n_
 }
 
 // ---- batch --------------------------------------------------------------------------------------------------
+static bool xcd_order_wanted(const lisreg_ctx* c);
+
 int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, const lisreg_params* params,
                          const float* T_init)
 {
@@ -784,6 +805,15 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
                 Target& t = c->targets[(size_t)slot];
                 if (!t.crow_valid[k] || !t.g[k].crow_tab) { rc = ensure_crows(c, t, k); if (rc) return rc; c->grids_dirty = true; }
             }
+    for (int slot : c->batch_slots)            // query marks for the row build of every run (option "row_reach"): buffers + the pointer in the grid
+        for (int k = 0; k < 2; ++k) {
+            const unsigned* before = c->targets[(size_t)slot].g[k].qmark;
+            rc = ensure_reach(c, c->targets[(size_t)slot], k, c->mode_now == 5 && c->rebuild_targets_each_run && c->row_reach != 0);
+            if (rc) return rc;
+            Target& t = c->targets[(size_t)slot];
+            if (t.g[k].qmark && t.g[k].qmark != before)       // new words: zero once, every run hands them back clean
+                HIPCHK(c, hipMemsetAsync(t.g[k].qmark, 0, sizeof(unsigned) * (size_t)t.g[k].nx * (size_t)t.g[k].ny * (size_t)t.g[k].qmark_w, c->stream));
+        }
     if (c->grids_dirty) { rc = upload_grids(c); if (rc) return rc; }
     // table for rebuilding every target index of this batch in ONE launch sequence (rebuild_targets_each_run)
     c->h_tsegs.clear(); c->h_tblocks.clear(); c->h_tchunks.clear();
@@ -893,6 +923,43 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         rc = ensure_sort_scratch(c, se, sbk);
         if (rc) return rc;
     }
+    // Query marks for the row builds of this batch's runs (option "row_reach"; cell rows, targets rebuilt inside every run).  A scan sees a
+    // part of its map — the lidar's elevation span leaves the upper walls of the benchmark room unseen: a fifth of the cells that would
+    // get rows — so every run builds rows only for the cells a query comes within two cells of under its INITIAL pose: one pass over the
+    // batch's source points (k_query_marks: the cell each falls into), the 5 x 5 x 5 dilation of those marks (`reach`, read by the
+    // classification of every run), the mark words handed back clean.  They depend on the sources and the initial poses — what this call
+    // is given — not on the target's points, which a run may find changed.
+    c->reach_ready = false;
+    if (c->mode_now == 5 && c->rebuild_targets_each_run && c->row_reach != 0 && c->lanes_q == 1 && c->n_blocks > 0) {
+        bool any = false;
+        for (int slot : c->batch_slots) for (int k = 0; k < 2; ++k) any = any || (c->targets[(size_t)slot].g[k].qmark != nullptr && c->targets[(size_t)slot].n[k] > 0);
+        if (any) {
+            launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), c->stream);      // (the pose caches of the initial poses)
+            launch_query_marks(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(), c->stream);
+            for (int slot : c->batch_slots)
+                for (int k = 0; k < 2; ++k) {
+                    Target& t = c->targets[(size_t)slot];
+                    if (!t.g[k].qmark || t.n[k] <= 0) continue;
+                    launch_reach_dilate(t.g[k], t.crow_reach[k].as<unsigned>(), c->stream);
+                    HIPCHK(c, hipMemsetAsync(t.g[k].qmark, 0, sizeof(unsigned) * (size_t)t.g[k].nx * (size_t)t.g[k].ny * (size_t)t.g[k].qmark_w, c->stream));
+                }
+            HIPCHK(c, hipGetLastError());
+            c->reach_ready = true;
+        }
+    }
+    // The dispatch order of the runs' correspondence launches (blocks ranked by the sector their queries fall into, one eighth per XCD) is a
+    // function of the same inputs — block descriptors, sources, initial poses, grid geometry: made here once instead of by every run
+    // (k_xcd_keys + a single-workgroup counting sort: 70 us per run on the side stream, which the shorter row build of "row_reach" had turned
+    // into the tail of a run's index phase).  Runs that sort their sources or split the batch in halves keep making their own.
+    c->xcd_cached = false;
+    if (xcd_order_wanted(c) && !c->sort_now && !c->exact && c->n_blocks > 0) {
+        HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
+        if (!c->reach_ready) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), c->stream);
+        launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
+                         nullptr, c->batch_slots.size() >= 8 && c->xcd_order == 1, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, c->stream);
+        HIPCHK(c, hipGetLastError());
+        c->xcd_cached = true;
+    }
     c->prepared = true;
     return LISREG_OK;
 }
@@ -921,6 +988,15 @@ static int exact_pose_caches(lisreg_ctx* c)
     return LISREG_OK;
 }
 
+// XCD-aware dispatch order for the prepared batch? (see run_impl)
+static bool xcd_order_wanted(const lisreg_ctx* c)
+{
+    const bool many_targets = c->batch_slots.size() >= 8 && c->xcd_order == 1;
+    return c->lanes_q != 8 && c->mode_now != 0 &&
+           (((c->mode_now == 3 || c->mode_now == 5) && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32))) ||
+            (many_targets && c->xcd_order != 0 && c->n_blocks >= 2048));
+}
+
 // Enqueue one full pass.  early_stop (synchronous entry points only): after every few iterations the host reads a
 // 4-byte "registrations finished" counter and stops launching once every item has converged — the reference's
 // `break` at :617 — instead of launching no-op kernels up to max_iters.  Results are identical either way.
@@ -938,9 +1014,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
     // (measured on configs[3], 256 own-target registrations through the cell walk: 13 539 reg/s against 13 716 in plain order — no gain, the walk
     //  is not bound by L2 misses either; the order by target is taken only with xcd_order = 1, profiles/r05_kernel_experiments.md)
     const bool many_targets = c->batch_slots.size() >= 8 && c->xcd_order == 1;
-    c->xcd_now = c->lanes_q != 8 && c->mode_now != 0 &&
-                 (((c->mode_now == 3 || c->mode_now == 5) && (c->xcd_order == 1 || (c->xcd_order == 2 && c->n_blocks >= 2048 && c->n_items >= 32))) ||
-                  (many_targets && c->xcd_order != 0 && c->n_blocks >= 2048));
+    c->xcd_now = xcd_order_wanted(c);
     if (c->xcd_now) HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
     // per-run reset of the registrations and the dispatch order: both depend on the batch only (items, initial poses, grid geometry), not on
     // the rebuilt index — with the cell rows they ride on the side stream behind the corner target's rows, underneath the surf target's
@@ -969,9 +1043,10 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
             if (split_blk * 4 < c->n_blocks || (c->n_blocks - split_blk) * 4 < c->n_blocks) { split_item = 0; split_blk = 0; }     // (a lop-sided cut hides nothing)
         }
     }
-    bool reset_done = false;
+    bool reset_done = false, order_done = false;
     auto dispatch_order = [&](hipStream_t s_) {
-        if (c->xcd_now) {
+        order_done = true;
+        if (c->xcd_now && !(c->xcd_cached && split_blk == 0)) {
             // (an interleaved run dispatches its halves separately: one table per half, positions and ids relative to the half)
             const int nb0 = split_blk ? split_blk : c->n_blocks;
             launch_xcd_order(c->blocks.as<BlockDesc>(), nb0, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
@@ -987,6 +1062,10 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         dispatch_order(s_);
         reset_done = true;
     };
+    // Round 6, option "row_reach": the rows of this run are built only for the cells a query of the batch comes within two cells of under
+    // its initial pose (`reach` words made by lisreg_batch_prepare: they depend on the sources and the initial poses alone, not on the target's
+    // points).  A query that ends up in a cell without rows all the same takes the cell walk: results cannot depend on the marks.
+    c->reach_now = c->rebuild_targets_each_run && c->mode_now == 5 && c->reach_ready && !c->exact;
     if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
         prof_mark(c, 2);
         if (c->strip_now) {
@@ -1028,8 +1107,8 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                 for (int slot : c->batch_slots) {
                     Target& t = c->targets[(size_t)slot];
                     if (t.n[k] <= 0) continue;
-                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k), sk, &t.omask_zero[k]);
-                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k), sk, &t.omask_zero[k]);
+                    launch_crow_classify(t.g[k], t.n_cells[k], crow_buffers(t, k, c->reach_now), sk, &t.omask_zero[k]);
+                    launch_crow_build(t.g[k], t.n_cells[k], crow_buffers(t, k, c->reach_now), sk, &t.omask_zero[k]);
                 }
             }
             if (fork && !c->sort_now && !c->exact) reset_and_order(c->side_stream);
@@ -1037,14 +1116,13 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         }
         prof_mark(c, -1);
     }
-    const bool early = reset_done;
-    if (!early) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
+    if (!reset_done) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
     if (c->exact) { int rc = exact_pose_caches(c); if (rc) return rc; }
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
                         c->n_elems, c->sort_now ? c->n_buckets : 0, sort_buffers(c), c->sorted_all.as<float4>(), c->order_all.as<int>(), st);
     prof_mark(c, -1);
-    if (!early) dispatch_order(st);                        // (after the source sort: the keys read the sorted records)
+    if (!order_done) dispatch_order(st);                   // (after the source sort: the keys read the sorted records)
     // how often the host looks at the "registrations finished" counter: a skipped launch of a big batch still dispatches tens of
     // thousands of workgroups (check every 3 iterations), a skipped launch of a single frame costs ~2 us (check every 6: one
     // round trip for the typical 3-6 iteration registration)
@@ -1180,6 +1258,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cell_min_ratio")) { c->cell_min_ratio = value; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "row_reach")) { c->row_reach = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cell_rows_max_mb")) {
         c->cell_rows_max_mb = value; c->prepared = false;
         for (auto& t : c->targets) for (int k = 0; k < 2; ++k) {        // a new bound: what was too big may fit now, what fitted may have to be capped
@@ -1189,7 +1268,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
         return LISREG_OK;
     }
     if (!strcmp(name, "early_stop_chunk")) { c->early_stop_chunk = value; return LISREG_OK; }
-    if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; return LISREG_OK; }
+    if (!strcmp(name, "xcd_order")) { if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "xcd_order: 0 off, 1 on, 2 auto"); c->xcd_order = value; c->xcd_cached = false; return LISREG_OK; }
     if (!strcmp(name, "index_build")) {
         if (value < 0 || value > 2) return fail(c, LISREG_ERR_ARG, "index_build: 0 bucket sort, 1 strip form, 2 auto");
         c->index_build = value; c->prepared = false;
@@ -1238,6 +1317,8 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "rebuild_targets_each_run")) { *value = c->rebuild_targets_each_run ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "graph_min_ratio")) { *value = c->graph_min_ratio; return LISREG_OK; }
     if (!strcmp(name, "cell_min_ratio")) { *value = c->cell_min_ratio; return LISREG_OK; }
+    if (!strcmp(name, "row_reach")) { *value = c->row_reach; return LISREG_OK; }
+    if (!strcmp(name, "row_reach_now")) { *value = c->reach_now ? 1 : 0; return LISREG_OK; }
     if (!strcmp(name, "cell_rows_max_mb")) { *value = c->cell_rows_max_mb; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { *value = c->xcd_order; return LISREG_OK; }
     if (!strcmp(name, "xcd_order_now")) { *value = c->xcd_now ? 1 : 0; return LISREG_OK; }

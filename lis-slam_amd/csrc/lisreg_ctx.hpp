@@ -42,6 +42,7 @@ struct Target {
     lisreg::DevBuf    nbr[2], nbr_meta[2];                // k-NN graph of the sorted points (search_mode 3)
     bool      graph_valid[2] = { false, false };
     lisreg::DevBuf    crow[2], crow_meta[2], crow_tab[2], crow_need[2], crow_omask[2], crow_scan[2], crow_scan_tmp[2];   // cell rows (search_mode 5)
+    lisreg::DevBuf    crow_qmark[2], crow_reach[2];    // query marks of the running batch and their two-cell dilation (option "row_reach"; GridIndex::qmark)
     float     bbox[2][6] = { { 0 }, { 0 } };           // the cloud's bounding box (the grid is made from it, with or without a margin)
     int       grid_margin[2] = { 0, 0 };               // cells the grid reaches past the cloud on every side (the cell rows want two)
     int       omask_zero[2] = { 0, 0 };                // cells at the head of crow_omask known to be zero (launch_crow_classify / _build)
@@ -163,6 +164,10 @@ struct lisreg_ctx {
     int       index_build = 2;                          // 0 bucket sort, 1 strip form (error if a grid does not fit it), 2 strip form whenever it fits
     int       strip_cells = 0, strip_cap = 2048;        // cells per strip aimed at (0: 1024 for a batch of one or two targets, else 2048); points per strip of the small-workgroup variant
     bool      strip_now = false;
+    int         row_reach = 1;                          // option "row_reach": rows only for the cells the batch's queries come within two cells of (runs that rebuild their targets)
+    bool        reach_ready = false;                    // lisreg_batch_prepare made the reach words of this batch's targets
+    bool        xcd_cached = false;                     // lisreg_batch_prepare made the dispatch-order table of this batch (runs reuse it)
+    bool        reach_now = false;                      // the last run built its rows that way
     hipStream_t side_stream = nullptr;                  // strip build: the big-strip kernel runs here, forked from / joined to `stream`
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t  ev_ab = nullptr, ev_ba = nullptr;       // interleaved runs: "half A's / half B's correspondence launch is through"

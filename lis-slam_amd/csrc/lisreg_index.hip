@@ -845,7 +845,16 @@ __global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin
 #define LISREG_CT_Y 8
 #endif
 constexpr int kCtX = LISREG_CT_X, kCtY = LISREG_CT_Y, kCtRim = 2;
-__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask)
+// (both classification kernels) reach != null: a populated cell that no query of the batch comes within two cells of gets no rows this
+// run — need 0, and bit 30 of its mask tells the build to write -1 ("no row: walk") instead of -2 ("nothing within two cells") into its table entry
+constexpr int kCrowUnreached = 1 << 30;
+__device__ __forceinline__ bool crow_reached(const GridIndex& g, const unsigned* __restrict__ reach, int ix, int iy, int iz)
+{
+    return !reach || ((reach[(size_t)(ix * g.ny + iy) * g.qmark_w + (iz >> 5)] >> (iz & 31)) & 1u) != 0u;
+}
+
+__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask,
+                                                       const unsigned* __restrict__ reach)
 {
     extern __shared__ int s_cs[];                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows
     constexpr int WX = kCtX + 2 * kCtRim, WY = kCtY + 2 * kCtRim;
@@ -875,13 +884,15 @@ __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y,
             }
         const int cid = (ix * g.ny + iy) * g.nz + iz;
         const int m = omask[cid] & 255;
-        need[cid] = cnt5 ? 1 + __popc(m) : 0;
-        omask[cid] = cnt5 ? (m | (min(cnt5, 0xffff) << 8)) : 0;
+        const bool r = cnt5 != 0 && crow_reached(g, reach, ix, iy, iz);
+        need[cid] = r ? 1 + __popc(m) : 0;
+        omask[cid] = cnt5 ? (r ? (m | (min(cnt5, 0xffff) << 8)) : kCrowUnreached) : 0;
     }
 }
 
 // the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~120 cells)
-__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, int* __restrict__ need, int* __restrict__ omask)
+__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, int* __restrict__ need, int* __restrict__ omask,
+                                                             const unsigned* __restrict__ reach)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;
     if (cid >= n_cells) return;
@@ -901,8 +912,9 @@ __global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_
         }
     }
     const int m = omask[cid] & 255;
-    need[cid] = cnt5 ? 1 + __popc(m) : 0;
-    omask[cid] = cnt5 ? (m | (min(cnt5, 0xffff) << 8)) : 0;
+    const bool r = cnt5 != 0 && crow_reached(g, reach, ix, iy, iz);
+    need[cid] = r ? 1 + __popc(m) : 0;
+    omask[cid] = cnt5 ? (r ? (m | (min(cnt5, 0xffff) << 8)) : kCrowUnreached) : 0;
 }
 
 // The sorts of the cell-row build work on 32-bit keys: the squared distance's float bits with the low 7 bits replaced by a payload (the
@@ -1153,7 +1165,7 @@ void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, int* _
         omask[first + lane] = 0;                            // handed back clean: the next classification ORs into it without a memset
         if (n_l) b_l = scan[first + lane];
         const bool fits = n_l != 0 && !(b_l + n_l > cap || b_l >= (1 << 23));
-        tab[first + lane] = n_l == 0 ? -2 : (fits ? (b_l << 8) | (om_l & 255) : -1);
+        tab[first + lane] = n_l == 0 ? ((om_l & kCrowUnreached) ? -1 : -2) : (fits ? (b_l << 8) | (om_l & 255) : -1);
         if (!fits) n_l = 0;
     }
     unsigned long long live = __ballot(n_l != 0);
@@ -1555,6 +1567,73 @@ void launch_build_graph_one(GridIndex g, hipStream_t st)
     k_graph_build_one<<<(g.n + LISREG_GRAPH_WPB * kGraphPPW - 1) / (LISREG_GRAPH_WPB * kGraphPPW), 64 * LISREG_GRAPH_WPB, 0, st>>>(g);
 }
 
+// Query marks: one thread per source point of the batch.  Consecutive points of a sweep fall into the same cell a dozen at a time: a lane
+// whose left neighbour names the same bit leaves it to that lane, and a lane that finds its bit set already (a plain, possibly stale,
+// load: a stale miss only repeats an atomic) sends nothing — after the first few thousand wavefronts almost no atomic is sent.
+__global__ __launch_bounds__(kBlockQ) void k_query_marks(const BlockDesc* __restrict__ blocks, const Segment* __restrict__ segs,
+                                                         const GridIndex* __restrict__ grids, const ItemState* __restrict__ items)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const Segment sg = segs[bd.seg];
+    const GridIndex g = grids[sg.target];
+    if (!g.qmark || g.n <= 0) return;
+    const float* M = items[bd.item].M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool valid = tid < bd.count;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) q0 = sg.src[bd.start + tid];
+    const float qx = M[0] * q0.x + M[1] * q0.y + M[2] * q0.z + M[3];
+    const float qy = M[4] * q0.x + M[5] * q0.y + M[6] * q0.z + M[7];
+    const float qz = M[8] * q0.x + M[9] * q0.y + M[10] * q0.z + M[11];
+    // the cell the scan would take the row of: the query's own, clamped into the grid (fminf / fmaxf first: a NaN or huge coordinate must not
+    // reach the float -> int conversion)
+    const int hx = (int)fminf(fmaxf(floorf((qx - g.ox) * g.inv_cell), 0.f), (float)(g.nx - 1));
+    const int hy = (int)fminf(fmaxf(floorf((qy - g.oy) * g.inv_cell), 0.f), (float)(g.ny - 1));
+    const int hz = (int)fminf(fmaxf(floorf((qz - g.oz) * g.inv_cell), 0.f), (float)(g.nz - 1));
+    const int word = (hx * g.ny + hy) * g.qmark_w + (hz >> 5);
+    const unsigned bit = 1u << (hz & 31);
+    const int key = valid ? (word << 5) | (hz & 31) : -1 - lane;
+    const int pk = __builtin_amdgcn_update_dpp(-2 - lane, key, 0x111, 0xF, 0xF, false);       // left neighbour in the 16-lane row
+    if (valid && pk != key && (g.qmark[word] & bit) == 0u) atomicOr(&g.qmark[word], bit);
+}
+
+// reach = the marks of the 5 x 5 x 5 block around every cell: one thread per (column, word); z through shifts with the carries of the
+// column's neighbouring words, x / y through the 25 columns around.
+__global__ __launch_bounds__(256) void k_reach_dilate(GridIndex g, unsigned* __restrict__ reach)
+{
+    const int W = g.qmark_w;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.nx * g.ny * W) return;
+    const int col = i / W, w = i - col * W, ix = col / g.ny, iy = col - ix * g.ny;
+    unsigned out = 0u;
+#pragma unroll 1
+    for (int dx = -2; dx <= 2; ++dx) {
+        const int x = ix + dx;
+        if (x < 0 || x >= g.nx) continue;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int y = iy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const unsigned* c = g.qmark + (size_t)(x * g.ny + y) * W;
+            const unsigned m = c[w], lo = w > 0 ? c[w - 1] : 0u, hi = w + 1 < W ? c[w + 1] : 0u;
+            out |= m | (m << 1) | (m << 2) | (m >> 1) | (m >> 2) | (lo >> 31) | (lo >> 30) | (hi << 31) | (hi << 30);
+        }
+    }
+    reach[i] = out;
+}
+
+void launch_query_marks(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items, hipStream_t st)
+{
+    if (n_blocks > 0) k_query_marks<<<n_blocks, kBlockQ, 0, st>>>(blocks, segs, grids, items);
+}
+
+void launch_reach_dilate(GridIndex g, unsigned* reach, hipStream_t st)
+{
+    if (!g.qmark || !reach || g.n <= 0) return;
+    const int n = g.nx * g.ny * g.qmark_w;
+    k_reach_dilate<<<(n + 255) / 256, 256, 0, st>>>(g, reach);
+}
+
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells)
 {
     if (g.n <= 0 || n_cells <= 0) return;
@@ -1567,9 +1646,9 @@ void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t 
     const size_t lds = sizeof(int) * (size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g.nz + 1);
     if (lds <= 64 * 1024) {
         const int tiles_x = (g.nx + kCtX - 1) / kCtX, tiles_y = (g.ny + kCtY - 1) / kCtY;
-        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, tiles_y, cb.need, cb.omask);
+        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, tiles_y, cb.need, cb.omask, g.qmark ? cb.reach : nullptr);
     } else
-        k_crow_classify_plain<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, cb.need, cb.omask);
+        k_crow_classify_plain<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, cb.need, cb.omask, g.qmark ? cb.reach : nullptr);
     exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
 }
 

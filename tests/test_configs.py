@@ -100,6 +100,46 @@ def test_cfg1_batch_vs_oracle(oracle, gpu_ctx):
         gpu_ctx.set_option("canonical_ties", 0)
 
 
+def test_cfg1_all_64_scans_of_the_bench_vs_oracle(oracle, gpu_ctx):
+    """The batch `bench.py` times, all of it: 64 device-resident 64x1800 scans against the shared 200 k-point submap,
+    10 fixed iterations, index and cell rows rebuilt inside the run, every option at its default (front-end by auto = the cell rows,
+    rows filtered by the batch's query marks, equal distances NOT canonicalised) — every one of the 64 poses against the oracle's, and a
+    second run of the prepared batch against the first bit for bit."""
+    import lisreg
+    from lisreg import synth
+    tc, ts = synth.make_submap(200000, 42)
+    n = 64
+    scans = [synth.make_scan(64, 1800, 1000 + i) for i in range(n)]
+    T0 = np.array([synth.perturb_pose(s["T_true"], np.random.default_rng(1000 + i + 7919)) for i, s in enumerate(scans)], np.float32)
+    p_o = oracle.default_params(1); p_o.fixed_iters = 10
+    p = copy_params(p_o, lisreg.Params)
+    tcd, tsd = _dev(tc), _dev(ts)
+    recs = [(_dev(s["corner"]), _dev(s["surf"])) for s in scans]
+    gpu_ctx.set_target_device(tcd.ptr, len(tc), tsd.ptr, len(ts))
+    items = [dict(corner_ptr=a.ptr, n_corner=a.shape[0], surf_ptr=b.ptr, n_surf=b.shape[0]) for a, b in recs]
+    gpu_ctx.set_option("rebuild_targets_each_run", 1)
+    try:
+        gpu_ctx.batch_prepare_device(items, T0, p)
+        assert gpu_ctx.get_option("front_end") == 5
+        gpu_ctx.batch_run()
+        T, st = gpu_ctx.batch_fetch()
+        assert gpu_ctx.get_option("row_reach_now") == 1
+        gpu_ctx.batch_run()
+        T2, st2 = gpu_ctx.batch_fetch()
+    finally:
+        gpu_ctx.set_option("rebuild_targets_each_run", 0)
+    assert np.array_equal(T, T2) and st == st2
+    worst_r = worst_t = 0.0
+    for i, s in enumerate(scans):
+        To, so, _ = oracle.align(tc, ts, s["corner"], s["surf"], T0[i], p_o, n_threads=ORACLE_THREADS, max_trace=1)
+        assert st[i]["status"] == so["status"] == 0 and st[i]["iters"] == so["iters"] == 10
+        assert abs(st[i]["n_corr_last"] - so["n_corr_last"]) <= max(3, 0.001 * so["n_corr_last"])
+        r, t = pose_err(T[i], To)
+        worst_r, worst_t = max(worst_r, r), max(worst_t, t)
+    print(f"[cfg1, 64 of 64] worst pose difference vs the oracle: {worst_r:.2e} rad, {worst_t:.2e} m")
+    assert worst_r <= TOL and worst_t <= TOL
+
+
 def test_cfg3_own_targets_256(oracle, gpu_ctx):
     """configs[3] shape on one GPU: 256 loop-closure style registrations, each against its OWN 200 k-point target (distinct
     seeds, one slot per item, all 512 indexes rebuilt inside the run); 8 sampled items against the oracle, and duplicates of

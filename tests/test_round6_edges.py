@@ -97,3 +97,54 @@ def test_upload_hides_under_kernels_with_other_contexts_alive():
     for sh in pool: hip.hipStreamDestroy(sh)
     if not os.environ.get("LISREG_FEED_LEGACY"):
         assert best <= 1.25 * max(t_stage, t_run) + 1.0e-4, (best, t_stage, t_run)
+
+
+@pytest.mark.gpu
+def test_row_reach_builds_fewer_rows_and_changes_nothing(gpu_ctx):
+    """Option "row_reach" (round 6, default on): a run that rebuilds its targets builds cell rows only for the cells a query of the batch
+    comes within two cells of under its initial pose (query marks made at the start of the run).  A query that reaches a cell without rows
+    takes the cell walk, so poses and statistics are the bits of the unfiltered run; the table says -1 ("no row") for the cells left out,
+    never -2 ("nothing within two cells"), and the cells that keep their rows keep the same octant masks."""
+    import lisreg
+    from lisreg import synth
+    D = lisreg.DeviceArray
+    tc, ts = synth.make_submap(60000)
+    n = 8
+    scans = [synth.make_scan(32, 900, 2000 + i) for i in range(n)]
+    T0 = np.array([synth.perturb_pose(s["T_true"], np.random.default_rng(9000 + i)) for i, s in enumerate(scans)], np.float32)
+    p = lisreg.default_params(1); p.fixed_iters = 8
+    tcd, tsd = D(lisreg.pack_device_records(tc)), D(lisreg.pack_device_records(ts))
+    recs = [(D(lisreg.pack_device_records(s["corner"])), D(lisreg.pack_device_records(s["surf"]))) for s in scans]
+    items = [dict(corner_ptr=a.ptr, n_corner=a.shape[0], surf_ptr=b.ptr, n_surf=b.shape[0]) for a, b in recs]
+    out = {}
+    try:
+        gpu_ctx.set_option("search_mode", 5); gpu_ctx.set_option("rebuild_targets_each_run", 1); gpu_ctx.set_option("sort_sources", 0)
+        for reach in (0, 1, 0):
+            gpu_ctx.set_option("row_reach", reach)
+            gpu_ctx.set_target_device(tcd.ptr, len(tc), tsd.ptr, len(ts))
+            gpu_ctx.batch_prepare_device(items, T0, p)
+            assert gpu_ctx.get_option("front_end") == 5
+            gpu_ctx.batch_run()
+            T, st = gpu_ctx.batch_fetch()
+            gpu_ctx.batch_run()                                   # a second run re-makes the marks from clean words: the same again
+            T2, st2 = gpu_ctx.batch_fetch()
+            assert np.array_equal(T, T2) and st == st2
+            assert gpu_ctx.get_option("row_reach_now") == reach
+            tabs = [gpu_ctx.target_cell_rows(0, k) for k in (0, 1)]
+            if reach in out:
+                assert np.array_equal(out[reach][0], T) and out[reach][1] == st           # (switching back restores the full table)
+                assert all(np.array_equal(a["table"], b["table"]) for a, b in zip(out[reach][2], tabs))
+            out[reach] = (T, st, tabs)
+    finally:
+        gpu_ctx.set_option("search_mode", 4); gpu_ctx.set_option("rebuild_targets_each_run", 0); gpu_ctx.set_option("sort_sources", 2)
+        gpu_ctx.set_option("row_reach", 1)
+    (Ta, sa, ta), (Tb, sb, tb) = out[0], out[1]
+    assert np.array_equal(Ta, Tb) and sa == sb
+    for k in (0, 1):
+        full, part = ta[k]["table"], tb[k]["table"]
+        assert np.array_equal(full == -2, part == -2)                       # "nothing within two cells" is a fact about the target, not about the batch
+        kept = part >= 0
+        assert np.all(full[kept] >= 0) and np.array_equal(full[kept] & 255, part[kept] & 255)
+        dropped = (full >= 0) & (part == -1)
+        print(f"[row_reach] kind {k}: {ta[k]['n_rows']} rows -> {tb[k]['n_rows']}; cells with rows {int((full >= 0).sum())} -> {int(kept.sum())}")
+        assert tb[k]["n_rows"] < ta[k]["n_rows"] and dropped.any()
