@@ -343,6 +343,8 @@ def main():
                     avg_launch_ms=round(avg_ms, 4), launches=timing["assoc_launches"],
                     algorithmic_bytes_per_launch=alg_bytes, search_front_end=ctx.front_end(),
                     launches_per_iteration=round(timing["assoc_launches"] / (prof_steps_ * ITERS), 3), interleaved=bool(ctx.get_option("interleaved_now")),
+                    row_reach=dict(on=bool(ctx.get_option("row_reach_now")), query_iterations_in_cells_without_rows=ctx.get_option("row_reach_misses"),
+                                   note="cell rows built only for the cells the batch's queries come within a metre of under their initial poses (marks made by lisreg_batch_prepare); a query elsewhere takes the cell walk: same results"),
                     per_step_ms=dict(assoc=round(timing["assoc_ms"] / prof_steps, 4), solve=round(timing["solve_ms"] / prof_steps, 4),
                                      index=round(timing["index_ms"] / prof_steps, 4), wall=round(ms_per_step, 4)))
 

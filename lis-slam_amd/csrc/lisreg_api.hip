@@ -791,7 +791,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         HIPCHK(c, hipMemsetAsync(c->dbg_nn.p, 0xff, sizeof(int) * 6 * (size_t)std::max(flat, 1), c->stream));
     }
     HIPCHK(c, c->partials.ensure(sizeof(double) * kNumAcc * (size_t)std::max(c->n_blocks, 1)));
-    HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * (size_t)std::max(n_items, 1)));
+    HIPCHK(c, c->results.ensure(sizeof(float) * kResultSize * ((size_t)std::max(n_items, 1) + 1)));      // (+ one record: the run's "row_reach" miss count)
     if (c->trace_cap > 0) HIPCHK(c, c->trace.ensure(sizeof(float) * kTraceStride * (size_t)c->trace_cap * (size_t)std::max(n_items, 1)));
     if (c->mode_now == 3)                        // the mode may have been chosen after the targets were set
         for (int slot : c->batch_slots)
@@ -930,7 +930,8 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     // classification of every run), the mark words handed back clean.  They depend on the sources and the initial poses — what this call
     // is given — not on the target's points, which a run may find changed.
     c->reach_ready = false;
-    if (c->mode_now == 5 && c->rebuild_targets_each_run && c->row_reach != 0 && c->lanes_q == 1 && c->n_blocks > 0) {
+    if (c->reach_backoff > 0) --c->reach_backoff;
+    else if (c->mode_now == 5 && c->rebuild_targets_each_run && c->row_reach != 0 && c->lanes_q == 1 && c->n_blocks > 0) {
         bool any = false;
         for (int slot : c->batch_slots) for (int k = 0; k < 2; ++k) any = any || (c->targets[(size_t)slot].g[k].qmark != nullptr && c->targets[(size_t)slot].n[k] > 0);
         if (any) {
@@ -1043,6 +1044,12 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
             if (split_blk * 4 < c->n_blocks || (c->n_blocks - split_blk) * 4 < c->n_blocks) { split_item = 0; split_blk = 0; }     // (a lop-sided cut hides nothing)
         }
     }
+    // Round 6, option "row_reach": the rows of this run are built only for the cells a query of the batch comes within two cells of under
+    // its initial pose (`reach` words made by lisreg_batch_prepare: they depend on the sources and the initial poses alone, not on the target's
+    // points).  A query that ends up in a cell without rows all the same takes the cell walk: results cannot depend on the marks.
+    c->reach_now = c->rebuild_targets_each_run && c->mode_now == 5 && c->reach_ready && !c->exact;
+    int* const miss_dev = reinterpret_cast<int*>(c->results.as<float>() + (size_t)std::max(c->n_items, 1) * kResultSize);
+    c->prm.reach_miss = c->reach_now ? miss_dev : nullptr;
     bool reset_done = false, order_done = false;
     auto dispatch_order = [&](hipStream_t s_) {
         order_done = true;
@@ -1058,14 +1065,10 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         }
     };
     auto reset_and_order = [&](hipStream_t s_) {
-        launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), s_);
+        launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), s_, miss_dev);
         dispatch_order(s_);
         reset_done = true;
     };
-    // Round 6, option "row_reach": the rows of this run are built only for the cells a query of the batch comes within two cells of under
-    // its initial pose (`reach` words made by lisreg_batch_prepare: they depend on the sources and the initial poses alone, not on the target's
-    // points).  A query that ends up in a cell without rows all the same takes the cell walk: results cannot depend on the marks.
-    c->reach_now = c->rebuild_targets_each_run && c->mode_now == 5 && c->reach_ready && !c->exact;
     if (c->rebuild_targets_each_run) {                 // the reference rebuilds both kd-trees per registration (:602-603)
         prof_mark(c, 2);
         if (c->strip_now) {
@@ -1116,7 +1119,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         }
         prof_mark(c, -1);
     }
-    if (!reset_done) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
+    if (!reset_done) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st, miss_dev);
     if (c->exact) { int rc = exact_pose_caches(c); if (rc) return rc; }
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
@@ -1209,7 +1212,7 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
     if (!c->prepared) return fail(c, LISREG_ERR_ARG, "batch_fetch: no prepared batch");
     HIPCHK(c, hipSetDevice(c->device));
     // results (and, for lisreg_align, the trace) land in pinned memory: asynchronous copies, ONE synchronisation
-    const size_t res_floats = (size_t)std::max(c->n_items, 1) * kResultSize;
+    const size_t res_floats = ((size_t)std::max(c->n_items, 1) + 1) * kResultSize;
     const size_t trace_floats = c->fetch_trace_records > 0 ? (size_t)kTraceStride * (size_t)c->fetch_trace_records : 0;
     if ((res_floats + trace_floats) * sizeof(float) > c->fetch_cap) {
         if (c->fetch_host) (void)hipHostFree(c->fetch_host);
@@ -1218,10 +1221,20 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
         HIPCHK(c, hipHostMalloc((void**)&c->fetch_host, want, hipHostMallocDefault));
         c->fetch_cap = want;
     }
-    if (c->n_items) HIPCHK(c, hipMemcpyAsync(c->fetch_host, c->results.p, sizeof(float) * kResultSize * (size_t)c->n_items, hipMemcpyDeviceToHost, c->stream));
+    const bool with_miss = c->n_items > 0 && c->reach_now;
+    if (c->n_items) HIPCHK(c, hipMemcpyAsync(c->fetch_host, c->results.p, sizeof(float) * kResultSize * ((size_t)c->n_items + (with_miss ? 1 : 0)), hipMemcpyDeviceToHost, c->stream));
     if (trace_floats && c->trace.p) HIPCHK(c, hipMemcpyAsync(c->fetch_host + res_floats, c->trace.p, sizeof(float) * trace_floats, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_results.assign(c->fetch_host, c->fetch_host + res_floats);
+    if (with_miss) {
+        // "row_reach" watches itself: the marks are the queries' cells under their INITIAL poses grown by a metre; a batch whose first steps move
+        // its points farther than that sends queries into cells without rows, where they walk (exact, but slow: configs[4] with a 0.5 m
+        // dilation ran 30 % longer).  More than one query-iteration in a thousand there: the prepared batch's later runs, and the next 32
+        // batches prepared on this context, build all rows.
+        int miss; memcpy(&miss, c->fetch_host + (size_t)c->n_items * kResultSize, sizeof miss);
+        c->reach_miss_last = miss;
+        if ((long long)miss * 1000LL > (long long)c->n_elems * (long long)std::max(c->prm.bound, 1)) { c->reach_ready = false; c->reach_backoff = 32; }
+    }
     if (!c->ev.empty()) prof_collect(c);          // events of every profiled run since the last fetch (profiling may be off again by now)
     c->last_launches = 0;
     for (int i = 0; i < c->n_items; ++i) {
@@ -1258,7 +1271,7 @@ int lisreg_set_option(lisreg_ctx* c, const char* name, int value)
     }
     if (!strcmp(name, "graph_min_ratio")) { c->graph_min_ratio = value; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cell_min_ratio")) { c->cell_min_ratio = value; c->prepared = false; return LISREG_OK; }
-    if (!strcmp(name, "row_reach")) { c->row_reach = value; c->prepared = false; return LISREG_OK; }
+    if (!strcmp(name, "row_reach")) { c->row_reach = value; c->reach_backoff = 0; c->prepared = false; return LISREG_OK; }
     if (!strcmp(name, "cell_rows_max_mb")) {
         c->cell_rows_max_mb = value; c->prepared = false;
         for (auto& t : c->targets) for (int k = 0; k < 2; ++k) {        // a new bound: what was too big may fit now, what fitted may have to be capped
@@ -1319,6 +1332,7 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "cell_min_ratio")) { *value = c->cell_min_ratio; return LISREG_OK; }
     if (!strcmp(name, "row_reach")) { *value = c->row_reach; return LISREG_OK; }
     if (!strcmp(name, "row_reach_now")) { *value = c->reach_now ? 1 : 0; return LISREG_OK; }
+    if (!strcmp(name, "row_reach_misses")) { *value = c->reach_miss_last; return LISREG_OK; }
     if (!strcmp(name, "cell_rows_max_mb")) { *value = c->cell_rows_max_mb; return LISREG_OK; }
     if (!strcmp(name, "xcd_order")) { *value = c->xcd_order; return LISREG_OK; }
     if (!strcmp(name, "xcd_order_now")) { *value = c->xcd_now ? 1 : 0; return LISREG_OK; }
@@ -1454,7 +1468,7 @@ int lisreg_align(lisreg_ctx* c, const void* src_corner, int n_corner, const void
         if (st.status == LISREG_NOT_ENOUGH_FEATURES) c->last_trace_n = 0;
         c->last_trace.assign((size_t)kTraceStride * (size_t)std::max(c->last_trace_n, 1), 0.f);
         if (c->last_trace_n > 0 && c->fetch_host)
-            memcpy(c->last_trace.data(), c->fetch_host + (size_t)kResultSize, sizeof(float) * kTraceStride * (size_t)c->last_trace_n);
+            memcpy(c->last_trace.data(), c->fetch_host + 2 * (size_t)kResultSize, sizeof(float) * kTraceStride * (size_t)c->last_trace_n);      // (one item + the "row_reach" record in front: lisreg_batch_fetch)
         if (stats) *stats = st;
         rc = st.status;
     }

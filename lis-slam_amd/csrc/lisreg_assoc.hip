@@ -1343,6 +1343,10 @@ __global__ __launch_bounds__(kBlockQ) __attribute__((amdgpu_waves_per_eu(kShare 
                 const int gx = (int)floorf(tx), gy = (int)floorf(ty), gz = (int)floorf(tz);
                 const int hx = min(max(gx, 0), g.nx - 1), hy = min(max(gy, 0), g.ny - 1), hz = min(max(gz, 0), g.nz - 1);
                 const int v = ((gptr_i32)g.crow_tab)[(hx * g.ny + hy) * g.nz + hz];
+                if (P.reach_miss) {                        // rows filtered by the batch's query marks: how many queries find their cell without them
+                    const unsigned long long mm = __ballot(v == -1);
+                    if (mm != 0ull && (int)(__ffsll((long long)mm) - 1) == (tid & 63)) atomicAdd(P.reach_miss, __popcll(mm));
+                }
                 if (v >= 0) {
                     float fx = 0.5f, fy = 0.5f, fz = 0.5f;
                     row_ = v >> 8;

@@ -167,6 +167,8 @@ struct lisreg_ctx {
     int         row_reach = 1;                          // option "row_reach": rows only for the cells the batch's queries come within two cells of (runs that rebuild their targets)
     bool        reach_ready = false;                    // lisreg_batch_prepare made the reach words of this batch's targets
     bool        xcd_cached = false;                     // lisreg_batch_prepare made the dispatch-order table of this batch (runs reuse it)
+    int         reach_backoff = 0;                      // batches still to be prepared without the marks after a run that missed too often
+    int         reach_miss_last = 0;                    // query-iterations of the last fetched run that found their cell without rows
     bool        reach_now = false;                      // the last run built its rows that way
     hipStream_t side_stream = nullptr;                  // strip build: the big-strip kernel runs here, forked from / joined to `stream`
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
@@ -179,8 +181,9 @@ struct lisreg_ctx {
     int       mode_now = 1;              // front-end of the prepared batch
     int       lanes_q = 1;               // lanes per query of the prepared batch (8 for small walk-mode batches)
     bool      lanes_per_query_auto = true;
-    int       cell_min_ratio = 170;      // auto: query-iterations per target point from which the cell rows pay (they cost ~3x the graph to build and
-                                         // halve the first iterations of a batch; measured break-even ~170: 24 scans against 200 k points lose 4 %, 32 win 2 %)
+    int       cell_min_ratio = 110;      // auto: query-iterations per target point from which the cell rows pay (they cost more than the graph to build and
+                                         // halve the first iterations of a batch).  Round 6, rows filtered by the query marks: 16 scans against 200 k points
+                                         // (92) draw, 24 (138) win 1.5 %, 32 (184) win 7 % (170 in rounds 4-5: 24 scans lost 4 %, 32 won 2 %)
     int       cell_rows_max_mb = 16384;  // auto: cell rows only while the targets' rows are expected to fit this (about 5 KB per target point)
     int       graph_min_ratio = 60;      // auto: query-iterations per target point from which the graph build pays (measured break-even ~55)
     int       interleave = 0;            // "interleave": big batches that run a fixed number of iterations are cut in two halves iterating on two

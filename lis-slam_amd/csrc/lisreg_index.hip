@@ -1597,9 +1597,10 @@ __global__ __launch_bounds__(kBlockQ) void k_query_marks(const BlockDesc* __rest
     if (valid && pk != key && (g.qmark[word] & bit) == 0u) atomicOr(&g.qmark[word], bit);
 }
 
-// reach = the marks of the 5 x 5 x 5 block around every cell: one thread per (column, word); z through shifts with the carries of the
-// column's neighbouring words, x / y through the 25 columns around.
-__global__ __launch_bounds__(256) void k_reach_dilate(GridIndex g, unsigned* __restrict__ reach)
+// reach = the marks of the (2 D + 1)^3 block around every cell: one thread per (column, word); z through shifts with the carries of the
+// column's neighbouring words, x / y through the (2 D + 1)^2 columns around.  D cells = one metre (at least two cells): the distance the
+// first Gauss-Newton steps may move a query from where its initial pose put it without leaving the cells that have rows.
+__global__ __launch_bounds__(256) void k_reach_dilate(GridIndex g, unsigned* __restrict__ reach, int D)
 {
     const int W = g.qmark_w;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1607,16 +1608,18 @@ __global__ __launch_bounds__(256) void k_reach_dilate(GridIndex g, unsigned* __r
     const int col = i / W, w = i - col * W, ix = col / g.ny, iy = col - ix * g.ny;
     unsigned out = 0u;
 #pragma unroll 1
-    for (int dx = -2; dx <= 2; ++dx) {
+    for (int dx = -D; dx <= D; ++dx) {
         const int x = ix + dx;
         if (x < 0 || x >= g.nx) continue;
-#pragma unroll
-        for (int dy = -2; dy <= 2; ++dy) {
+#pragma unroll 1
+        for (int dy = -D; dy <= D; ++dy) {
             const int y = iy + dy;
             if (y < 0 || y >= g.ny) continue;
             const unsigned* c = g.qmark + (size_t)(x * g.ny + y) * W;
             const unsigned m = c[w], lo = w > 0 ? c[w - 1] : 0u, hi = w + 1 < W ? c[w + 1] : 0u;
-            out |= m | (m << 1) | (m << 2) | (m >> 1) | (m >> 2) | (lo >> 31) | (lo >> 30) | (hi << 31) | (hi << 30);
+            out |= m;
+#pragma unroll 1
+            for (int sft = 1; sft <= D; ++sft) out |= (m << sft) | (m >> sft) | (lo >> (32 - sft)) | (hi << (32 - sft));
         }
     }
     reach[i] = out;
@@ -1631,7 +1634,8 @@ void launch_reach_dilate(GridIndex g, unsigned* reach, hipStream_t st)
 {
     if (!g.qmark || !reach || g.n <= 0) return;
     const int n = g.nx * g.ny * g.qmark_w;
-    k_reach_dilate<<<(n + 255) / 256, 256, 0, st>>>(g, reach);
+    const int D = std::min(std::max((int)std::ceil(1.0f / g.cell - 1e-3f), 2), 16);
+    k_reach_dilate<<<(n + 255) / 256, 256, 0, st>>>(g, reach, D);
 }
 
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells)

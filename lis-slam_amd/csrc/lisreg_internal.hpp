@@ -100,6 +100,7 @@ struct DevParams {
     int   exact;               // "exact_arithmetic" (the launches pick launch_assoc_exact; the host supplies the pose caches' sin / cos)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
     int   cell_anchor_until;   // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
+    int*  reach_miss;          // cell rows built under "row_reach": queries that found their cell without rows (-1) are counted here (null: not counted)
     int   freeze_pose;         // timing experiments only (env LISREG_XP_FREEZE_POSE): the solve leaves T as it is, so that every launch of a run
                                // sees the same queries whatever a variant under test writes into the normal equations
 };
@@ -204,7 +205,7 @@ void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st,
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
                          hipStream_t st);
-void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st);
+void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st, int* zero_too = nullptr);
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 3 k-NN graph scan (walk without a certificate) */,

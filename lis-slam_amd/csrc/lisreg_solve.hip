@@ -213,9 +213,10 @@ __device__ void write_pose_cache(ItemState* it, const float* trig = nullptr)
 }
 
 __global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P,
-                                                    int* __restrict__ done_counter)
+                                                    int* __restrict__ done_counter, int* __restrict__ zero_too)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i == 0 && zero_too) *zero_too = 0;               // (the run's count of queries in cells left without rows: "row_reach")
     if (i >= n_items) return;
     ItemState* it = &items[i];
     for (int k = 0; k < 6; ++k) it->T[k] = it->T_init[k];
@@ -507,10 +508,10 @@ void launch_pose_cache_from_trig(ItemState* items, int n_items, const float* tri
     if (n_items > 0) k_pose_cache_from_trig<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, trig);
 }
 
-void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st)
+void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st, int* zero_too)
 {
     (void)hipMemsetAsync(done_counter, 0, sizeof(int), st);
-    if (n_items > 0) k_reset_items<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, done_counter);
+    if (n_items > 0) k_reset_items<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, done_counter, zero_too);
 }
 
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,

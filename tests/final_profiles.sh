@@ -2,6 +2,7 @@
 # regenerates the bench lines / kernel tables kept under profiles/ (on the GPU box): tests/final_profiles.sh <tag>
 TAG=${1:-r03}; R=$(pwd); O=$R/gpurun_out/final_$TAG; rm -rf $O; mkdir -p $O
 for w in cfg1 cfg3 odom cfg4 cfg5 cfg4_icp; do timeout 300 python bench.py --workload $w 2>/dev/null | tail -1 > $O/${TAG}_bench_$w.json; done
+timeout 300 python bench.py --workload cfg5 --batch 32 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg5_b32.json        # "B >= 8" — both ends reported
 timeout 300 python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json
 LISREG_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 2 --cpu-regs 0 --no-pcie 2>/dev/null | tail -1 > $O/${TAG}_bench_force_dist_1rank.json
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --output-format csv --kernel-trace --stats -d $O/icp_trace -o trace -- python $R/bench.py --workload cfg4_icp --steps 2 --warmup 1 --cpu-regs 0 > $O/icp_trace.log 2>&1 )
@@ -25,16 +26,30 @@ cp gpurun_out/prof_$TAG/traffic.json $O/traffic.json 2>/dev/null
 { echo "configs[1]:"; AB_ITERS=10 timeout 400 bash tests/ab.sh base 2>/dev/null | tail -2
   echo "configs[3] (cfg4):"; AB_ITERS=10 BENCH_ARGS="--workload cfg4" timeout 400 bash tests/ab.sh base 2>/dev/null | tail -2
   echo "configs[4] (cfg5):"; AB_ITERS=30 BENCH_ARGS="--workload cfg5" timeout 400 bash tests/ab.sh base 2>/dev/null | tail -2; } > $O/${TAG}_per_iteration.txt
-for w in cfg4 cfg5; do
-  ( cd /tmp; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1; rocprofv3 --output-format csv --kernel-trace --stats -d $O/tr_$w -o trace -- python $R/bench.py --workload $w --steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 > $O/tr_$w.log 2>&1 )
+# per-kernel tables of configs[3] / configs[4] restricted to the STEPS: everything after the batch was prepared (the last k_count_jumps — the
+# source-order probe of lisreg_batch_prepare; the 512 lisreg_set_target calls of configs[3] in front of it are set-up, outside the timed region:
+# round 5's table had their 514 x k_target_keys / k_bbox_* / k_scan_* launches next to the steps' kernels)
+for w in cfg4 cfg5 cfg5b32; do
+  a="--workload $w"; [ $w = cfg5b32 ] && a="--workload cfg5 --batch 32"
+  ( cd /tmp; export TMPDIR=/tmp LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1; rocprofv3 --output-format csv --kernel-trace -d $O/tr_$w -o trace -- python $R/bench.py $a --steps 3 --warmup 1 --cpu-regs 0 --no-profile --no-pcie --min-seconds 0 > $O/tr_$w.log 2>&1 )
   python - "$O" "$TAG" "$w" <<'PY'
-import csv, glob, sys
+import csv, glob, sys, re, collections
 O, TAG, W = sys.argv[1:4]
-f = glob.glob(f"{O}/tr_{W}/**/*kernel_stats.csv", recursive=True)
+f = glob.glob(f"{O}/tr_{W}/**/*kernel_trace.csv", recursive=True)
 if f:
-    rows = [r for r in csv.DictReader(open(f[0])) if "lisreg" in r["Name"]]
+    rows = sorted([r for r in csv.DictReader(open(f[0])) if "lisreg" in r["Kernel_Name"]], key=lambda r: int(r["Start_Timestamp"]))
+    last = max([i for i, r in enumerate(rows) if "k_count_jumps" in r["Kernel_Name"]] or [-1])
+    rows = rows[last + 1:]
+    agg = collections.OrderedDict()
+    for r in rows:
+        n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("lisreg::", "").replace("fast_arith::", "")).replace("void ", "")
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = agg.setdefault(n, [0, 0, 1 << 62, 0]); a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
     with open(f"{O}/{TAG}_{W}_kernel_stats.csv", "w") as o:
-        w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+        o.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,pct_of_step_kernel_time\n")
+        for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"\"{n}\",{a[0]},{a[1]},{a[1] / a[0]:.1f},{a[2]},{a[3]},{100.0 * a[1] / max(tot, 1):.2f}\n")
 PY
   rm -rf $O/tr_$w
 done
