@@ -116,6 +116,39 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int* __restrict__ out, 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
 }
 
+// Round 6: the second and third launch in one for up to 4 096 tiles (8 M entries): every workgroup sums the tile totals in front of it itself
+// (at most 16 loads per thread of an L2-resident table, one wave reduction, a four-entry LDS exchange) instead of waiting for a single-workgroup
+// launch to scan them — one dependent launch (~5 us of latency) less wherever a scan sits on a critical path: the row counts of the cell rows
+// in every configs[1] step, the voxel grids and cell tables of the frame loops.  block_sums keeps the raw totals.
+constexpr int kScanFusedMaxTiles = 4096;
+__global__ __launch_bounds__(kScanBlock) void k_scan_add_sum(int* __restrict__ out, const int* __restrict__ block_sums, int n, int nb)
+{
+    __shared__ int s_part[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (block 0 also owes the grand total: it sums every tile, the others the tiles in front of them)
+    const int upto = b == 0 ? nb : b;
+    int acc = 0;
+    for (int j = threadIdx.x; j < upto; j += kScanBlock) acc += block_sums[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) s_part[wave] = acc;
+    __syncthreads();
+    const int sum = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    const int off = b == 0 ? 0 : sum;
+    const int base = b * kScanTile + threadIdx.x * kScanItems;
+    if (off != 0) {
+        if ((base + kScanItems <= n) && (((uintptr_t)out & 15u) == 0)) {
+            int4 a = *reinterpret_cast<int4*>(out + base), c = *reinterpret_cast<int4*>(out + base + 4);
+            a.x += off; a.y += off; a.z += off; a.w += off; c.x += off; c.y += off; c.z += off; c.w += off;
+            *reinterpret_cast<int4*>(out + base) = a; *reinterpret_cast<int4*>(out + base + 4) = c;
+        } else {
+#pragma unroll
+            for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] += off;
+        }
+    }
+    if (b == 0 && threadIdx.x == 0) out[n] = sum;
+}
+
 // short arrays (the counts of a single frame: strips, voxels of a down-sampled cloud): ONE workgroup, one launch instead of three — in a
 // frame loop the three launches of a 5 k-entry scan are 13 us of a 1 ms frame, a dozen times per frame.  1024 threads x 8 items per
 // round, the carry in a register.  in == out is fine (a round reads its items before it writes them).
@@ -150,6 +183,7 @@ void exclusive_scan(const int* in, int* out /* [n+1] */, int* tmp, int n, hipStr
     if (n <= kScanSmallMax) { k_scan_small<<<1, 1024, 0, st>>>(in, out, n); return; }
     const int nb = (n + kScanTile - 1) / kScanTile;
     k_scan_local<<<nb, kScanBlock, 0, st>>>(in, out, tmp, n);
+    if (nb <= kScanFusedMaxTiles) { k_scan_add_sum<<<nb, kScanBlock, 0, st>>>(out, tmp, n, nb); return; }
     k_scan_tops<<<1, kScanBlock, 0, st>>>(tmp, nb);
     k_scan_add<<<nb, kScanBlock, 0, st>>>(out, tmp, n, nb);
 }
