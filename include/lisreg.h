@@ -249,13 +249,21 @@ void* lisreg_batch_result_device(const lisreg_ctx* ctx);
  * half's 6x6 solves run underneath the other half's correspondence launch — 1: the halves' launches alternate, 2: free-running; same
  * kernels on the same data in the same order per registration, results identical to the bit; measured +1.7 % (mode 2) on
  * BASELINE configs[1], +5.8 % on configs[4], at the price of per-kernel durations that are no longer a launch's own — off),
- * "graph_min_ratio", "cell_min_ratio", "cell_rows_max_mb", "first_pass_mm", "count_searches", "early_stop_chunk". */
+ * "row_reach" (1 [default]: a batch that takes the cell rows and rebuilds its targets inside every run ("rebuild_targets_each_run") builds
+ * rows only for the grid cells its queries come within a metre of under their INITIAL poses — lisreg_batch_prepare makes one pass over
+ * the batch's source points for that —; a query that reaches a cell without rows takes the cell walk, so results do not depend on it,
+ * bit for bit.  A run counts such queries; more than one query-iteration in a thousand and the prepared batch's later runs, and the next
+ * 32 batches prepared on the context, build all rows.  0: all rows always),
+ * "graph_min_ratio", "cell_min_ratio" (auto takes the cell rows from this many query-iterations per target point: 110), "cell_rows_max_mb",
+ * "first_pass_mm", "count_searches", "early_stop_chunk". */
 int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
 /* Read back an option, or "front_end" = the search front-end the prepared batch actually runs (auto resolved), or
  * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the
  * sector dispatch order, "interleaved_now" = 1 if it ran as two halves; size of the prepared batch's search index: "index_kib_grid"
  * (sorted records + cell tables of its targets), "index_kib_front_end" (k-NN graph rows or cell rows + their tables; 0 for the cell
- * walk), "index_target_points" (points in those targets) — bench.py's roofline.index_bytes_per_target_point. */
+ * walk), "index_target_points" (points in those targets) — bench.py's roofline.index_bytes_per_target_point; "row_reach_now" = 1 if the last
+ * run built its cell rows for the cells the query marks reach only, "row_reach_misses" = query-iterations of the last FETCHED run that
+ * found their cell without rows. */
 int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);
 
 /* Diagnostics of the motion certificate (enable with option "count_searches" = 1; accumulates until re-enabled):

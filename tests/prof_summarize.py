@@ -71,9 +71,10 @@ if n_f and n_w:
     tj = {"k_assoc_hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
           "source": f"profiles/{tag}_rocprofv3_summary.txt: FETCH_SIZE={fetch_kb:.4g} KB (x2 gfx950 correction), WRITE_SIZE={write_kb:.4g} KB, "
                     f"average over {n_f} dispatches of k_assoc_walk (all instantiations)",
-          "note": "compulsory streams per launch: 118 MB source read twice (the record is re-read after the search instead of being "
-                  "held in registers); the cell-row front-end carries nothing between iterations (the graph front-end adds 29 MB anchor "
-                  "read + 29 MB anchor write); the submap, its cell table and most of the row heads are served from L2 / Infinity Cache"}
+          "note": "compulsory stream per launch: 118 MB of source records, read once (since round 5 the record stays in registers across the "
+                  "search); the cell-row front-end carries nothing between iterations (the graph front-end adds 29 MB anchor read + 29 MB anchor "
+                  "write); the rest is row heads and neighbour records that miss the L2s: the submap, its cell table and most row heads are served "
+                  "from L2 / Infinity Cache"}
     json.dump(tj, open(os.path.join(root, "traffic.json"), "w"), indent=1)
     print("== traffic.json:", json.dumps(tj))
 
