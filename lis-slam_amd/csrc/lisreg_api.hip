@@ -739,6 +739,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         st.degenerate_in = in.degenerate_in;
         st.imu = in.imu;
         st.n_sc = in.n_corner; st.n_ss = in.n_surf;
+        if (!(st.n_sc > c->prm.edge_min && st.n_ss > c->prm.surf_min)) ++c->prm.n_guard_failed;      // (:598; the done counter's value after a reset)
         st.blk_begin = (int)c->h_blocks.size();
         for (int k = 0; k < 2; ++k) {
             Segment sg;
@@ -923,6 +924,11 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         rc = ensure_sort_scratch(c, se, sbk);
         if (rc) return rc;
     }
+    // The registrations start reset (pose caches of the initial poses, done counter = the guard failures): every run leaves them reset again
+    // for the next one (launch_finalize), so a run has no reset launch of its own.  The "row_reach" miss count is cumulative from here.
+    launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), c->stream,
+                       reinterpret_cast<int*>(c->results.as<float>() + (size_t)std::max(c->n_items, 1) * kResultSize));
+    c->items_reset = true; c->reach_miss_seen = 0; c->runs_since_fetch = 0;
     // Query marks for the row builds of this batch's runs (option "row_reach"; cell rows, targets rebuilt inside every run).  A scan sees a
     // part of its map — the lidar's elevation span leaves the upper walls of the benchmark room unseen: a fifth of the cells that would
     // get rows — so every run builds rows only for the cells a query comes within two cells of under its INITIAL pose: one pass over the
@@ -935,7 +941,6 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
         bool any = false;
         for (int slot : c->batch_slots) for (int k = 0; k < 2; ++k) any = any || (c->targets[(size_t)slot].g[k].qmark != nullptr && c->targets[(size_t)slot].n[k] > 0);
         if (any) {
-            launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), c->stream);      // (the pose caches of the initial poses)
             launch_query_marks(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(), c->stream);
             for (int slot : c->batch_slots)
                 for (int k = 0; k < 2; ++k) {
@@ -955,7 +960,6 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->xcd_cached = false;
     if (xcd_order_wanted(c) && !c->sort_now && !c->exact && c->n_blocks > 0) {
         HIPCHK(c, c->xcd_tab.ensure(sizeof(int) * 2 * (size_t)c->n_blocks));
-        if (!c->reach_ready) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), c->stream);
         launch_xcd_order(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->grids_dev.as<GridIndex>(), c->items.as<ItemState>(),
                          nullptr, c->batch_slots.size() >= 8 && c->xcd_order == 1, c->xcd_tab.as<int>(), c->xcd_tab.as<int>() + c->n_blocks, c->stream);
         HIPCHK(c, hipGetLastError());
@@ -1064,8 +1068,11 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
                                  c->xcd_tab.as<int>() + split_blk, c->xcd_tab.as<int>() + c->n_blocks + split_blk, s_);
         }
     };
+    // (the registrations are reset already — by lisreg_batch_prepare or by the run before, launch_finalize — unless a run ended in an error)
+    if (c->items_reset) reset_done = true;
+    c->items_reset = false;
     auto reset_and_order = [&](hipStream_t s_) {
-        launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), s_, miss_dev);
+        if (!reset_done) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), s_);
         dispatch_order(s_);
         reset_done = true;
     };
@@ -1093,8 +1100,20 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         if (c->mode_now == 3)
             launch_build_graph(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),
                                c->grids_dev.as<GridIndex>(), st);
+        static const bool crow_pair = !(getenv("LISREG_CROW_PAIR") && atoi(getenv("LISREG_CROW_PAIR")) == 0);      // A/B: 0 = rounds 4-5's side stream
+        if (c->mode_now == 5 && crow_pair) {
+            // corner and surf target of a slot in ONE launch sequence on this stream (launch_crow_rows_pair): no side stream, no event hops
+            for (int slot : c->batch_slots) {
+                Target& t = c->targets[(size_t)slot];
+                const GridIndex g2[2] = { t.g[0], t.g[1] };
+                const int nc2[2] = { t.n_cells[0], t.n_cells[1] };
+                const lisreg::CrowBuffers cb2[2] = { crow_buffers(t, 0, c->reach_now), crow_buffers(t, 1, c->reach_now) };
+                int* oz2[2] = { &t.omask_zero[0], &t.omask_zero[1] };
+                launch_crow_rows_pair(g2, nc2, cb2, st, oz2);
+            }
+        } else
         if (c->mode_now == 5) {
-            // the rows of the corner targets (a few ten thousand rows: launches that leave most of the chip idle) are built on the side stream,
+            // (LISREG_CROW_PAIR=0) the rows of the corner targets (a few ten thousand rows: launches that leave most of the chip idle) are built on the side stream,
             // underneath the surf targets' — separate buffers per target kind, joined before the first correspondence launch
             if (!c->side_stream) {
                 if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
@@ -1119,7 +1138,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
         }
         prof_mark(c, -1);
     }
-    if (!reset_done) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st, miss_dev);
+    if (!reset_done) launch_reset_items(c->items.as<ItemState>(), c->n_items, c->prm, c->done_dev.as<int>(), st);
     if (c->exact) { int rc = exact_pose_caches(c); if (rc) return rc; }
     prof_mark(c, 2);
     launch_sort_sources(c->blocks.as<BlockDesc>(), c->n_blocks, c->segs.as<Segment>(), c->n_segs, c->items.as<ItemState>(),
@@ -1193,7 +1212,8 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
             next_check += c->early_stop_chunk > 0 ? chunk : std::min(chunk, 3);
         }
     }
-    launch_finalize(c->items.as<ItemState>(), c->n_items, c->prm, c->results.as<float>(), st);
+    launch_finalize(c->items.as<ItemState>(), c->n_items, c->prm, c->results.as<float>(), st, c->done_dev.as<int>());      // (+ reset for the next run)
+    c->items_reset = true; ++c->runs_since_fetch;
     HIPCHK(c, hipGetLastError());
     if (c->pack_in_use >= 0 && c->pack_free[c->pack_in_use])      // the staged source buffer may be overwritten once this run is through
         HIPCHK(c, hipEventRecord(c->pack_free[c->pack_in_use], st));
@@ -1231,9 +1251,11 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
         // its points farther than that sends queries into cells without rows, where they walk (exact, but slow: configs[4] with a 0.5 m
         // dilation ran 30 % longer).  More than one query-iteration in a thousand there: the prepared batch's later runs, and the next 32
         // batches prepared on this context, build all rows.
-        int miss; memcpy(&miss, c->fetch_host + (size_t)c->n_items * kResultSize, sizeof miss);
+        int cum; memcpy(&cum, c->fetch_host + (size_t)c->n_items * kResultSize, sizeof cum);      // (cumulative since the batch was prepared)
+        const int miss = cum - c->reach_miss_seen;
+        c->reach_miss_seen = cum;
         c->reach_miss_last = miss;
-        if ((long long)miss * 1000LL > (long long)c->n_elems * (long long)std::max(c->prm.bound, 1)) { c->reach_ready = false; c->reach_backoff = 32; }
+        if ((long long)miss * 1000LL > (long long)c->n_elems * (long long)std::max(c->prm.bound, 1) * (long long)std::max(c->runs_since_fetch, 1)) { c->reach_ready = false; c->reach_backoff = 32; }
     }
     if (!c->ev.empty()) prof_collect(c);          // events of every profiled run since the last fetch (profiling may be off again by now)
     c->last_launches = 0;
@@ -1246,6 +1268,7 @@ int lisreg_batch_fetch(lisreg_ctx* c, float* T, lisreg_stats* stats)
             stats[i].degenerate = (int)r[9]; stats[i].n_corr_last = (int)r[10]; stats[i].status = (int)r[11];
         }
     }
+    c->runs_since_fetch = 0;
     return LISREG_OK;
 }
 

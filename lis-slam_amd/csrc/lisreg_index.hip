@@ -49,11 +49,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* s_wave /*
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_local(const int* __restrict__ in, int* __restrict__ out,
-                                                           int* __restrict__ block_sums, int n)
+__device__ __forceinline__ void scan_local_body(const int* __restrict__ in, int* __restrict__ out, int* __restrict__ block_sums, int n, int blk_, int* s_wave)
 {
-    __shared__ int s_wave[4];
-    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    const int base = blk_ * kScanTile + threadIdx.x * kScanItems;
     int v[kScanItems], sum = 0;
     // full tiles of 16-byte aligned arrays move as two int4 per thread (the cell tables of a batch of targets are tens of
     // millions of entries: this pass and k_scan_add are pure streaming)
@@ -78,7 +76,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_local(const int* __restrict
 #pragma unroll
         for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
     }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) block_sums[blk_] = total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const int* __restrict__ in, int* __restrict__ out,
+                                                           int* __restrict__ block_sums, int n)
+{
+    __shared__ int s_wave[4];
+    scan_local_body(in, out, block_sums, n, blockIdx.x, s_wave);
 }
 
 // single workgroup: exclusive scan of the per-tile sums in place, grand total appended at [nb]
@@ -121,10 +126,9 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int* __restrict__ out, 
 // launch to scan them — one dependent launch (~5 us of latency) less wherever a scan sits on a critical path: the row counts of the cell rows
 // in every configs[1] step, the voxel grids and cell tables of the frame loops.  block_sums keeps the raw totals.
 constexpr int kScanFusedMaxTiles = 4096;
-__global__ __launch_bounds__(kScanBlock) void k_scan_add_sum(int* __restrict__ out, const int* __restrict__ block_sums, int n, int nb)
+__device__ __forceinline__ void scan_add_sum_body(int* __restrict__ out, const int* __restrict__ block_sums, int n, int nb, int blk_, int* s_part)
 {
-    __shared__ int s_part[4];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blk_, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // (block 0 also owes the grand total: it sums every tile, the others the tiles in front of them)
     const int upto = b == 0 ? nb : b;
     int acc = 0;
@@ -147,6 +151,27 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add_sum(int* __restrict__ o
         }
     }
     if (b == 0 && threadIdx.x == 0) out[n] = sum;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_add_sum(int* __restrict__ out, const int* __restrict__ block_sums, int n, int nb)
+{
+    __shared__ int s_part[4];
+    scan_add_sum_body(out, block_sums, n, nb, blockIdx.x, s_part);
+}
+
+// two independent scans in one launch pair (the row counts of a slot's corner and surf target): workgroups [0, nb0) work on the first
+struct ScanPair { const int* in[2]; int* out[2]; int* tmp[2]; int n[2]; int nb[2]; };
+__global__ __launch_bounds__(kScanBlock) void k_scan_local_pair(ScanPair p)
+{
+    __shared__ int s_wave[4];
+    const int k = (int)blockIdx.x < p.nb[0] ? 0 : 1;
+    scan_local_body(p.in[k], p.out[k], p.tmp[k], p.n[k], (int)blockIdx.x - (k ? p.nb[0] : 0), s_wave);
+}
+__global__ __launch_bounds__(kScanBlock) void k_scan_add_sum_pair(ScanPair p)
+{
+    __shared__ int s_part[4];
+    const int k = (int)blockIdx.x < p.nb[0] ? 0 : 1;
+    scan_add_sum_body(p.out[k], p.tmp[k], p.n[k], p.nb[k], (int)blockIdx.x - (k ? p.nb[0] : 0), s_part);
 }
 
 // short arrays (the counts of a single frame: strips, voxels of a down-sampled cloud): ONE workgroup, one launch instead of three — in a
@@ -838,9 +863,9 @@ __global__ __launch_bounds__(64 * LISREG_GRAPH_WPB) void k_graph_build_batched(c
 // atomics in flight at once are what this launch waits for (a wavefront of the 10 k-point corner target lives 3.7 us, one of the 200 k-point
 // surf target 21 us).  A lane whose left neighbour (same 16-lane row) names the same cell with at least its bits leaves the atomic to it —
 // the left-most lane of such a run always sends, and its mask covers the run (each lane's mask is inside its sender's by induction).
-__global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin, int* __restrict__ omask)
+__device__ __forceinline__ void crow_mark_body(const GridIndex& g, float oct_margin, int* __restrict__ omask, int blk_)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int i = blk_ * 256 + threadIdx.x, lane = threadIdx.x & 63;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < g.n) p = g.pts[i];
     const bool valid = i < g.n && p.x == p.x && p.y == p.y && p.z == p.z;
@@ -870,6 +895,8 @@ __global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin
     }
 }
 
+__global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin, int* __restrict__ omask) { crow_mark_body(g, oct_margin, omask, blockIdx.x); }
+
 // k_crow_classify: one workgroup per tile of kCtX x kCtY columns over the whole z-range: the cell_start rows of the tile and its
 // two-column rim are staged in LDS once (two global reads per cell instead of fifty), every thread sums its cells' 5 x 5 columns from there.
 #ifndef LISREG_CT_X
@@ -887,13 +914,13 @@ __device__ __forceinline__ bool crow_reached(const GridIndex& g, const unsigned*
     return !reach || ((reach[(size_t)(ix * g.ny + iy) * g.qmark_w + (iz >> 5)] >> (iz & 31)) & 1u) != 0u;
 }
 
-__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask,
-                                                       const unsigned* __restrict__ reach)
+__device__ __forceinline__ void crow_classify_body(const GridIndex& g, int tiles_y, int* __restrict__ need, int* __restrict__ omask,
+                                                   const unsigned* __restrict__ reach, int blk_, int* s_cs)
 {
-    extern __shared__ int s_cs[];                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows
+    //                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows
     constexpr int WX = kCtX + 2 * kCtRim, WY = kCtY + 2 * kCtRim;
     const int nz1 = g.nz + 1;
-    const int tx0 = (int)(blockIdx.x / tiles_y) * kCtX, ty0 = (int)(blockIdx.x % tiles_y) * kCtY;
+    const int tx0 = (int)(blk_ / tiles_y) * kCtX, ty0 = (int)(blk_ % tiles_y) * kCtY;
     for (int i = threadIdx.x; i < WX * WY * nz1; i += 256) {
         const int c = i / nz1, z = i - c * nz1;
         const int x = tx0 - kCtRim + c / WY, y = ty0 - kCtRim + c % WY;
@@ -924,11 +951,18 @@ __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y,
     }
 }
 
-// the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~120 cells)
-__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, int* __restrict__ need, int* __restrict__ omask,
-                                                             const unsigned* __restrict__ reach)
+__global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask,
+                                                       const unsigned* __restrict__ reach)
 {
-    const int cid = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ int s_cs[];
+    crow_classify_body(g, tiles_y, need, omask, reach, blockIdx.x, s_cs);
+}
+
+// the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~120 cells)
+__device__ __forceinline__ void crow_classify_plain_body(const GridIndex& g, int n_cells, int* __restrict__ need, int* __restrict__ omask,
+                                                         const unsigned* __restrict__ reach, int blk_)
+{
+    const int cid = blk_ * 256 + threadIdx.x;
     if (cid >= n_cells) return;
     const int iz = cid % g.nz, t = cid / g.nz, iy = t % g.ny, ix = t / g.ny;
     const int z0 = max(iz - 2, 0), z1 = min(iz + 2, g.nz - 1);
@@ -949,6 +983,12 @@ __global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_
     const bool r = cnt5 != 0 && crow_reached(g, reach, ix, iy, iz);
     need[cid] = r ? 1 + __popc(m) : 0;
     omask[cid] = cnt5 ? (r ? (m | (min(cnt5, 0xffff) << 8)) : kCrowUnreached) : 0;
+}
+
+__global__ __launch_bounds__(256) void k_crow_classify_plain(GridIndex g, int n_cells, int* __restrict__ need, int* __restrict__ omask,
+                                                             const unsigned* __restrict__ reach)
+{
+    crow_classify_plain_body(g, n_cells, need, omask, reach, blockIdx.x);
 }
 
 // The sorts of the cell-row build work on 32-bit keys: the squared distance's float bits with the low 7 bits replaced by a payload (the
@@ -1180,17 +1220,12 @@ constexpr int kCrowCPW = LISREG_CROW_CPW;
                                      // chain of dependent loads per cell: measured (profiles/r05_kernel_experiments.md) 6 waves with 3 spilled registers beat 5
                                      // without by 2-3 % of a configs[1] step; 7 and 8 waves (10 / 18 spilled) lose it again
 #endif
-#if LISREG_CROW_WAVES
-__global__ __launch_bounds__(64 * LISREG_CROW_WPB) __attribute__((amdgpu_waves_per_eu(LISREG_CROW_WAVES, LISREG_CROW_WAVES)))
-#else
-__global__ __launch_bounds__(64 * LISREG_CROW_WPB)
-#endif
-void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, int* __restrict__ omask,
-                                                    const int* __restrict__ scan, int cap, int use_r3 /* 0: never the 7^3 block (experiments) */)
+__device__ __forceinline__ void crow_build_body(const GridIndex& g, int n_cells, const int* __restrict__ need, int* __restrict__ omask,
+                                                const int* __restrict__ scan, int cap, int use_r3 /* 0: never the 7^3 block (experiments) */,
+                                                int blk_, int (*s_off)[64], int (*s_js)[64])
 {
-    __shared__ int s_off[LISREG_CROW_WPB][64], s_js[LISREG_CROW_WPB][64];
     const int lane = threadIdx.x & 63;
-    const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * LISREG_CROW_WPB + (int)(threadIdx.x >> 6)) * kCrowCPW);
+    const int first = __builtin_amdgcn_readfirstlane((blk_ * LISREG_CROW_WPB + (int)(threadIdx.x >> 6)) * kCrowCPW);
     int* tab = const_cast<int*>(g.crow_tab);
     int n_l = 0, b_l = 0, om_l = 0;
     if (lane < kCrowCPW && first + lane < n_cells) {
@@ -1220,6 +1255,47 @@ void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, int* _
         if (mask != 0u || !use_r3 || (int)(om >> 8) >= kGraphK) crow_build_wave<2>(g, q, hx, hy, hz, mask, row, meta, s_off, s_js);
         else crow_build_wave<3>(g, q, hx, hy, hz, 0u, row, meta, s_off, s_js);
     }
+}
+
+#if LISREG_CROW_WAVES
+#define LISREG_CROW_BUILD_ATTR __global__ __launch_bounds__(64 * LISREG_CROW_WPB) __attribute__((amdgpu_waves_per_eu(LISREG_CROW_WAVES, LISREG_CROW_WAVES)))
+#else
+#define LISREG_CROW_BUILD_ATTR __global__ __launch_bounds__(64 * LISREG_CROW_WPB)
+#endif
+LISREG_CROW_BUILD_ATTR void k_crow_build(GridIndex g, int n_cells, const int* __restrict__ need, int* __restrict__ omask,
+                                         const int* __restrict__ scan, int cap, int use_r3)
+{
+    __shared__ int s_off[LISREG_CROW_WPB][64], s_js[LISREG_CROW_WPB][64];
+    crow_build_body(g, n_cells, need, omask, scan, cap, use_r3, blockIdx.x, s_off, s_js);
+}
+
+// Round 6: the corner and the surf target of a slot through the row build in ONE launch sequence (marks, classification, two scan launches,
+// rows): workgroups [0, nb of job 0) work on job 0, the rest on job 1.  Until round 6 the corner target's (small) launches ran on a side
+// stream underneath the surf target's — two event hops on the critical path of every step (a marker in front of the marks, a wait in front
+// of the first correspondence launch: 6 us each on an otherwise gap-free stream).
+struct CrowJob { GridIndex g; int n_cells; int* need; int* omask; int* scan; int cap; const unsigned* reach; int tiles_y; int plain; int nb; };
+struct CrowJobs { CrowJob j[2]; };
+__global__ __launch_bounds__(256) void k_crow_mark_pair(CrowJobs J, float margin_cells)
+{
+    const int k = (int)blockIdx.x < J.j[0].nb ? 0 : 1;
+    const CrowJob& j = J.j[k];
+    crow_mark_body(j.g, margin_cells * j.g.cell, j.omask, (int)blockIdx.x - (k ? J.j[0].nb : 0));
+}
+__global__ __launch_bounds__(256) void k_crow_classify_pair(CrowJobs J)
+{
+    extern __shared__ int s_cs[];
+    const int k = (int)blockIdx.x < J.j[0].nb ? 0 : 1;
+    const CrowJob& j = J.j[k];
+    const int blk = (int)blockIdx.x - (k ? J.j[0].nb : 0);
+    if (j.plain) crow_classify_plain_body(j.g, j.n_cells, j.need, j.omask, j.reach, blk);
+    else crow_classify_body(j.g, j.tiles_y, j.need, j.omask, j.reach, blk, s_cs);
+}
+LISREG_CROW_BUILD_ATTR void k_crow_build_pair(CrowJobs J, int use_r3)
+{
+    __shared__ int s_off[LISREG_CROW_WPB][64], s_js[LISREG_CROW_WPB][64];
+    const int k = (int)blockIdx.x < J.j[0].nb ? 0 : 1;
+    const CrowJob& j = J.j[k];
+    crow_build_body(j.g, j.n_cells, j.need, j.omask, j.scan, j.cap, use_r3, (int)blockIdx.x - (k ? J.j[0].nb : 0), s_off, s_js);
 }
 
 // Coherence probe for sort_sources = auto: how many consecutive source points are further apart than `thr`?
@@ -1696,6 +1772,60 @@ void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st,
     if (omask_zero_cells) *omask_zero_cells = n_cells;        // (k_crow_build zeroes the mask of every cell it is dealt, with or without rows)
     static const int use_r3 = getenv("LISREG_CROW_R3") ? atoi(getenv("LISREG_CROW_R3")) : 1;
     k_crow_build<<<(n_cells + LISREG_CROW_WPB * kCrowCPW - 1) / (LISREG_CROW_WPB * kCrowCPW), 64 * LISREG_CROW_WPB, 0, st>>>(g, n_cells, cb.need, cb.omask, cb.scan, cb.cap_rows, use_r3);
+}
+
+// classification + rows of the corner (job 0) and surf (job 1) target of one slot, five launches on ONE stream (see CrowJob)
+void launch_crow_rows_pair(const GridIndex g[2], const int n_cells[2], const CrowBuffers cb[2], hipStream_t st, int* omask_zero_cells[2])
+{
+    static const float margin = std::min(0.249f, std::max(0.f, getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.249f));
+    static const int use_r3 = getenv("LISREG_CROW_R3") ? atoi(getenv("LISREG_CROW_R3")) : 1;
+    CrowJobs J = {};
+    bool on[2];
+    for (int k = 0; k < 2; ++k) {
+        on[k] = g[k].n > 0 && n_cells[k] > 0 && cb[k].cap_rows > 0 && g[k].crow != nullptr;
+        CrowJob& j = J.j[k];
+        j.g = g[k]; j.n_cells = n_cells[k]; j.need = cb[k].need; j.omask = cb[k].omask; j.scan = cb[k].scan; j.cap = cb[k].cap_rows;
+        j.reach = g[k].qmark ? cb[k].reach : nullptr;
+        if (!on[k]) continue;
+        const bool zero_already = omask_zero_cells[k] && *omask_zero_cells[k] >= n_cells[k];
+        if (!zero_already) (void)hipMemsetAsync(cb[k].omask, 0, sizeof(int) * (size_t)n_cells[k], st);
+        if (omask_zero_cells[k]) *omask_zero_cells[k] = n_cells[k];      // (the marks go in and k_crow_build_pair takes them out again)
+    }
+    if (!on[0] && !on[1]) return;
+    auto grid = [&](int a, int b) { J.j[0].nb = on[0] ? a : 0; J.j[1].nb = on[1] ? b : 0; return (unsigned)(J.j[0].nb + J.j[1].nb); };
+    // marks
+    { const unsigned nb = grid((g[0].n + 255) / 256, (g[1].n + 255) / 256); k_crow_mark_pair<<<nb, 256, 0, st>>>(J, margin); }
+    // classification: LDS-tiled where the tile fits, per cell otherwise (decided per target)
+    {
+        size_t lds = 0; int nbk[2] = { 0, 0 };
+        for (int k = 0; k < 2; ++k) {
+            if (!on[k]) continue;
+            const size_t l = sizeof(int) * (size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g[k].nz + 1);
+            if (l <= 64 * 1024) { J.j[k].plain = 0; J.j[k].tiles_y = (g[k].ny + kCtY - 1) / kCtY; nbk[k] = ((g[k].nx + kCtX - 1) / kCtX) * J.j[k].tiles_y; lds = std::max(lds, l); }
+            else { J.j[k].plain = 1; nbk[k] = (n_cells[k] + 255) / 256; }
+        }
+        const unsigned nb = grid(nbk[0], nbk[1]);
+        k_crow_classify_pair<<<nb, 256, lds, st>>>(J);
+    }
+    // row counts -> first rows: both scans in two launches (tiled form whatever the size)
+    {
+        ScanPair sp = {};
+        for (int k = 0; k < 2; ++k) {
+            sp.in[k] = cb[k].need; sp.out[k] = cb[k].scan; sp.tmp[k] = cb[k].scan_tmp; sp.n[k] = on[k] ? n_cells[k] : 0;
+            sp.nb[k] = on[k] ? (n_cells[k] + kScanTile - 1) / kScanTile : 0;
+        }
+        if (sp.nb[0] <= kScanFusedMaxTiles && sp.nb[1] <= kScanFusedMaxTiles) {
+            k_scan_local_pair<<<sp.nb[0] + sp.nb[1], kScanBlock, 0, st>>>(sp);
+            k_scan_add_sum_pair<<<sp.nb[0] + sp.nb[1], kScanBlock, 0, st>>>(sp);
+        } else
+            for (int k = 0; k < 2; ++k) if (on[k]) exclusive_scan(cb[k].need, cb[k].scan, cb[k].scan_tmp, n_cells[k], st);
+    }
+    // rows
+    {
+        const int per = LISREG_CROW_WPB * kCrowCPW;
+        const unsigned nb = grid((n_cells[0] + per - 1) / per, (n_cells[1] + per - 1) / per);
+        k_crow_build_pair<<<nb, 64 * LISREG_CROW_WPB, 0, st>>>(J, use_r3);
+    }
 }
 
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,

@@ -100,6 +100,7 @@ struct DevParams {
     int   exact;               // "exact_arithmetic" (the launches pick launch_assoc_exact; the host supplies the pose caches' sin / cos)
     float wtab[32];            // w = (float)(2.0 - LabelSorce[label]) precomputed on the host
     int   cell_anchor_until;   // graph front-end: GN iterations 1 .. this also try an anchor out of the query's own grid column
+    int   n_guard_failed;      // registrations of the batch that fail the feature-count guard (known on the host): the done counter's value after a reset
     int*  reach_miss;          // cell rows built under "row_reach": queries that found their cell without rows (-1) are counted here (null: not counted)
     int   freeze_pose;         // timing experiments only (env LISREG_XP_FREEZE_POSE): the solve leaves T as it is, so that every launch of a run
                                // sees the same queries whatever a variant under test writes into the normal equations
@@ -201,11 +202,14 @@ void launch_reach_dilate(GridIndex g, unsigned* reach, hipStream_t st);
 // critical path of every step).  *omask_zero_cells = cells of the buffer's head known to be zero (0: unknown); both launchers keep it.
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells = nullptr);
 void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells = nullptr);
+// the same for the corner ([0]) and the surf ([1]) target of one slot in one launch sequence on one stream (round 6: no side stream, no event hops)
+void launch_crow_rows_pair(const GridIndex g[2], const int n_cells[2], const CrowBuffers cb[2], hipStream_t st, int* omask_zero_cells[2]);
 // sources of a whole batch: tile-sort every segment under its item's initial pose
 void launch_sort_sources(const BlockDesc* blocks, int n_blocks, const Segment* segs, int n_segs,
                          const ItemState* items, int n_elems, int n_buckets, SortBuffers sb, float4* sorted_all, int* order_all,
                          hipStream_t st);
 void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st, int* zero_too = nullptr);
+// (launch_finalize with done_counter != null also leaves every registration reset for the NEXT run of the prepared batch: see run_impl)
 void launch_assoc(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids,
                   const ItemState* items, DevParams prm, const float4* sorted_all, double* partials,
                   int mode /* 0 LDS-staged workgroup box, 1 per-lane grid walk, 3 k-NN graph scan (walk without a certificate) */,
@@ -236,7 +240,7 @@ void launch_pose_gather(const ItemState* items, int n_items, float* T_out, hipSt
 void launch_pose_cache_from_trig(ItemState* items, int n_items, const float* trig, hipStream_t st);
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
                   int trace_cap, int* done_counter, hipStream_t st);
-void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st);
+void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st, int* reset_done_counter = nullptr);
 
 // §8 f-1 (lisreg_index.hip)
 void launch_voxel_sort(const float4* pts, int n, VoxelDesc d, int n_buckets, SortBuffers sb, int* order, uint32_t* sidx,

@@ -212,26 +212,32 @@ __device__ void write_pose_cache(ItemState* it, const float* trig = nullptr)
     K[18] = crz * sry - cry * srx * srz;   K[19] = 0.f;                            K[20] = 0.f;
 }
 
-__global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P,
-                                                    int* __restrict__ done_counter, int* __restrict__ zero_too)
+// One registration back to the start of a run (member initialisers :70-71, guard :598, the pose cache of the initial pose).  The done
+// counter's start value is the number of registrations that fail the guard — a constant of the prepared batch the host knows
+// (DevParams::n_guard_failed) — written by ONE thread: no memset launch in front, no atomics here.
+__device__ __forceinline__ void reset_item(ItemState* it, const DevParams& P)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i == 0 && zero_too) *zero_too = 0;               // (the run's count of queries in cells left without rows: "row_reach")
-    if (i >= n_items) return;
-    ItemState* it = &items[i];
     for (int k = 0; k < 6; ++k) it->T[k] = it->T_init[k];
     for (int k = 0; k < 36; ++k) it->P[k] = 0.f;
     const bool guard_ok = (it->n_sc > P.edge_min) && (it->n_ss > P.surf_min);   // odomEstimationNode.cpp:598
     it->iter = 0;
     it->guard_failed = guard_ok ? 0 : 1;
     it->done = guard_ok ? 0 : 1;
-    if (!guard_ok) atomicAdd(done_counter, 1);
     it->iters_out = 0;
     it->deltaR = 100.f; it->deltaT = 100.f;                                      // member initialisers :70-71
     it->degenerate = it->degenerate_in;
     it->n_corr = 0;
     it->any_solved = 0;
     write_pose_cache(it);
+}
+
+__global__ __launch_bounds__(64) void k_reset_items(ItemState* __restrict__ items, int n_items, const DevParams P,
+                                                    int* __restrict__ done_counter, int* __restrict__ zero_too)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i == 0) { *done_counter = P.n_guard_failed; if (zero_too) *zero_too = 0; }      // (zero_too: the batch's count of queries in cells left without rows, "row_reach")
+    if (i >= n_items) return;
+    reset_item(&items[i], P);
 }
 
 constexpr int kSolveThreads = 512;
@@ -454,9 +460,10 @@ __device__ void q_get_rpy(Quat q, double& roll, double& pitch, double& yaw)
 __device__ float clampf(float v, float lim) { v = v < -lim ? -lim : v; return v > lim ? lim : v; }
 
 __global__ __launch_bounds__(64) void k_finalize(ItemState* __restrict__ items, int n_items, const DevParams P,
-                                                 float* __restrict__ results)
+                                                 float* __restrict__ results, int* __restrict__ reset_done_counter)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i == 0 && reset_done_counter) *reset_done_counter = P.n_guard_failed;      // (no solve is in flight any more: nobody else touches the counter)
     if (i >= n_items) return;
     ItemState* it = &items[i];
     float T[6];
@@ -481,6 +488,9 @@ __global__ __launch_bounds__(64) void k_finalize(ItemState* __restrict__ items, 
     for (int k = 0; k < 6; ++k) r[k] = T[k];
     r[6] = (float)it->iters_out; r[7] = it->deltaR; r[8] = it->deltaT;
     r[9] = (float)it->degenerate; r[10] = (float)it->n_corr; r[11] = (float)status;
+    // round 6: the run leaves its registrations reset for the next run of the prepared batch (what the head of every run used to do with a
+    // memset and a launch of its own on the critical path of the index phase — or behind an event hop on a side stream)
+    if (reset_done_counter) reset_item(it, P);
 }
 
 // exact build: the poses out, and the pose caches rebuilt from trig values the host computed (six per registration)
@@ -510,8 +520,7 @@ void launch_pose_cache_from_trig(ItemState* items, int n_items, const float* tri
 
 void launch_reset_items(ItemState* items, int n_items, DevParams prm, int* done_counter, hipStream_t st, int* zero_too)
 {
-    (void)hipMemsetAsync(done_counter, 0, sizeof(int), st);
-    if (n_items > 0) k_reset_items<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, done_counter, zero_too);
+    k_reset_items<<<(std::max(n_items, 1) + 63) / 64, 64, 0, st>>>(items, n_items, prm, done_counter, zero_too);
 }
 
 void launch_solve(ItemState* items, int n_items, DevParams prm, const double* partials, float* trace,
@@ -520,9 +529,9 @@ void launch_solve(ItemState* items, int n_items, DevParams prm, const double* pa
     if (n_items > 0) k_solve<<<n_items, kSolveThreads, 0, st>>>(items, prm, partials, trace, trace_cap, done_counter);
 }
 
-void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st)
+void launch_finalize(ItemState* items, int n_items, DevParams prm, float* results, hipStream_t st, int* reset_done_counter)
 {
-    if (n_items > 0) k_finalize<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, results);
+    if (n_items > 0) k_finalize<<<(n_items + 63) / 64, 64, 0, st>>>(items, n_items, prm, results, reset_done_counter);
 }
 
 }  // namespace lisreg
