@@ -863,7 +863,7 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     if (c->index_build == 1 && !c->strip_now)
         return fail(c, LISREG_ERR_ARG, "index_build 1: a target grid of this batch does not fit the strip form (strips per target or cells per strip)");
     HIPCHK(c, c->tchunk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tchunks.size(), 1)));
-    HIPCHK(c, c->strip_tab.ensure(sizeof(int) * (3 * ((size_t)tstrip + 4) + (size_t)tstrip / 2048 + 8)));
+    { const void* before = c->strip_tab.p; HIPCHK(c, c->strip_tab.ensure(sizeof(int) * (3 * ((size_t)tstrip + 4) + (size_t)tstrip / 2048 + 8))); if (c->strip_tab.p != before) c->strip_zero_ints = 0; }
     HIPCHK(c, c->tseg_dev.ensure(sizeof(TargetSeg) * std::max<size_t>(c->h_tsegs.size(), 1)));
     HIPCHK(c, c->tblk_dev.ensure(sizeof(BlockDesc) * std::max<size_t>(c->h_tblocks.size(), 1)));
     // every table crosses PCIe from ONE pinned staging buffer: five asynchronous copies, no host synchronisation
@@ -1092,7 +1092,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
             }
             sl.side = c->side_stream; sl.ev_fork = c->ev_fork; sl.ev_join = c->ev_join;
             if (launch_build_targets_strips(c->tchunk_dev.as<BlockDesc>(), (int)c->h_tchunks.size(), c->tseg_dev.as<TargetSeg>(),
-                                            (int)c->h_tsegs.size(), c->t_strips, c->t_max_units, c->t_max_ucells, c->strip_cap, sl, st))
+                                            (int)c->h_tsegs.size(), c->t_strips, c->t_max_units, c->t_max_ucells, c->strip_cap, sl, st, &c->strip_zero_ints))
                 return fail(c, LISREG_ERR_HIP, "strip index build: LDS configuration refused");
         } else
             launch_build_targets_batched(c->tblk_dev.as<BlockDesc>(), (int)c->h_tblocks.size(), c->tseg_dev.as<TargetSeg>(),

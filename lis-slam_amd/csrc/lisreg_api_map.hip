@@ -247,7 +247,7 @@ int lisreg_map_index_set_batch(lisreg_ctx* c, int n_maps, const int* slots, cons
     const std::vector<BlockDesc>& tb = strips ? tchunks : tblocks;
     HIPCHK(c, c->map_tsegs.ensure(sizeof(TargetSeg) * (size_t)n_maps));
     HIPCHK(c, c->map_tblocks.ensure(sizeof(BlockDesc) * std::max<size_t>(tb.size(), 1)));
-    if (strips) HIPCHK(c, c->strip_tab.ensure(sizeof(int) * (3 * ((size_t)tstrip + 4) + (size_t)tstrip / 2048 + 8)));
+    if (strips) { HIPCHK(c, c->strip_tab.ensure(sizeof(int) * (3 * ((size_t)tstrip + 4) + (size_t)tstrip / 2048 + 8))); c->strip_zero_ints = 0; }      // (this build leaves the counters as they are)
     HIPCHK(c, hipMemcpyAsync(c->map_tsegs.p, tsegs.data(), sizeof(TargetSeg) * (size_t)n_maps, hipMemcpyHostToDevice, st));
     if (!tb.empty()) HIPCHK(c, hipMemcpyAsync(c->map_tblocks.p, tb.data(), sizeof(BlockDesc) * tb.size(), hipMemcpyHostToDevice, st));
     for (int k = 0; k < n_maps; ++k)

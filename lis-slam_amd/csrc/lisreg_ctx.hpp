@@ -168,6 +168,7 @@ struct lisreg_ctx {
     bool        reach_ready = false;                    // lisreg_batch_prepare made the reach words of this batch's targets
     bool        xcd_cached = false;                     // lisreg_batch_prepare made the dispatch-order table of this batch (runs reuse it)
     int         reach_backoff = 0;                      // batches still to be prepared without the marks after a run that missed too often
+    int         strip_zero_ints = 0;                    // leading ints of strip_tab known to be zero (a strip build hands its counters back clean)
     bool        items_reset = false;                    // the device registrations are in their start-of-run state (prepare, or the run before: launch_finalize)
     int         reach_miss_seen = 0, runs_since_fetch = 0;
     int         reach_miss_last = 0;                    // query-iterations of the last fetched run that found their cell without rows

@@ -491,15 +491,34 @@ __device__ __forceinline__ int strip_of(const TargetSeg& t, float x, float y)
 }
 
 // kScatter = false: strip populations (cnt);  true: move the records (x, y, z, original index) to their strip's stretch of tmp_pts
-template <bool kScatter>
+template <int NT> __device__ __forceinline__ int block_excl_scan_nt(int v, int* s_wave);
+
+// kOwnScan (scatter pass, round 6; batches whose strips number at most kMaxStrips): every workgroup scans the strip populations itself —
+// `cnt` is complete at the kernel boundary, 8 K entries are eight per thread and one workgroup scan — and workgroup 0 writes `start_out` for
+// the strip builds: the single-workgroup scan launch between the two partition passes (5-7 us of a configs[1] step's serial head) is gone.
+template <bool kScatter, bool kOwnScan = false>
 __global__ __launch_bounds__(kPartThreads) void k_strip_partition(const BlockDesc* __restrict__ chunks, const TargetSeg* __restrict__ tsegs,
                                                                   int* __restrict__ cnt, const int* __restrict__ start,
-                                                                  int* __restrict__ fill, float4* __restrict__ tmp_pts)
+                                                                  int* __restrict__ fill, float4* __restrict__ tmp_pts,
+                                                                  int* __restrict__ start_out = nullptr, int n_strips_all = 0)
 {
     __shared__ int s_hist[kMaxStrips];
+    __shared__ int s_start[kOwnScan ? kMaxStrips + 1 : 1];
+    __shared__ int s_wv[kPartThreads / 64];
     const BlockDesc bd = chunks[blockIdx.x];
     const TargetSeg t = tsegs[bd.seg];
     const int tid = threadIdx.x, n_units = t.nx * t.nstrips;
+    if (kScatter && kOwnScan) {
+        constexpr int L = (kMaxStrips + kPartThreads - 1) / kPartThreads;
+        int v[L], sum = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i) { const int e = tid * L + i; v[i] = e < n_strips_all ? cnt[e] : 0; sum += v[i]; }
+        int run = block_excl_scan_nt<kPartThreads>(sum, s_wv);
+#pragma unroll
+        for (int i = 0; i < L; ++i) { const int e = tid * L + i; if (e <= n_strips_all) s_start[e] = run; run += v[i]; }
+        __syncthreads();
+        if (blockIdx.x == 0) for (int e = tid; e <= n_strips_all; e += kPartThreads) start_out[e] = s_start[e];
+    }
     for (int k = tid; k < n_units; k += kPartThreads) s_hist[k] = 0;
     __syncthreads();
     float4 p[kPartChunk / kPartThreads];
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(kPartThreads) void k_strip_partition(const BlockDes
     for (int k = tid; k < n_units; k += kPartThreads) {
         const int c = s_hist[k];
         if (c) {
-            if (kScatter) s_hist[k] = start[t.strip_base + k] + atomicAdd(&fill[t.strip_base + k], c);
+            if (kScatter) s_hist[k] = (kOwnScan ? s_start[t.strip_base + k] : start[t.strip_base + k]) + atomicAdd(&fill[t.strip_base + k], c);
             else atomicAdd(&cnt[t.strip_base + k], c);
         }
     }
@@ -613,11 +632,14 @@ __device__ __forceinline__ void strip_build_body(const TargetSeg& t, int y0, int
 template <bool kLarge>
 __global__ __launch_bounds__(kLarge ? 1024 : 256) void k_strip_build(const TargetSeg* __restrict__ tsegs, const int* __restrict__ start,
                                                                      const float4* __restrict__ tmp_pts, int cap_small, int cap_large,
-                                                                     uint32_t* __restrict__ g_slot_idx, uint32_t* __restrict__ g_slot_pos)
+                                                                     uint32_t* __restrict__ g_slot_idx, uint32_t* __restrict__ g_slot_pos,
+                                                                     int* __restrict__ zero_buf = nullptr, int zero_n = 0)
 {
     constexpr int NT = kLarge ? 1024 : 256;
     extern __shared__ int s_dyn[];
     __shared__ int s_wave[NT / 64];
+    // (round 6) the strip populations and scatter cursors go back clean for the next build of this batch: no memset launch in front of it
+    if (!kLarge && zero_buf && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < zero_n; i += NT) zero_buf[i] = 0;
     const TargetSeg t = tsegs[blockIdx.y];
     const int unit = blockIdx.x;
     if (t.n <= 0) { if (!kLarge && unit == 0 && threadIdx.x == 0) t.cell_start_out[0] = 0; return; }
@@ -1629,7 +1651,7 @@ void launch_build_targets_batched(const BlockDesc* blocks, int n_blocks, const T
 }
 
 int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const TargetSeg* tsegs, int n_tsegs, int n_strips, int max_units,
-                                int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st)
+                                int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st, int* zero_ints_known)
 {
     if (n_tsegs <= 0) return 0;
     const size_t hist_bytes = (size_t)(max_strip_cells + 1) * 4;
@@ -1647,10 +1669,18 @@ int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const Tar
         if (e1 != hipSuccess || e2 != hipSuccess) return 1;
         attr_set = true;
     }
-    (void)hipMemsetAsync(sb.cnt, 0, sizeof(int) * 2 * (size_t)(n_strips + 1), st);          // cnt and fill are one allocation
+    // cnt and fill are one allocation; a build hands them back clean (k_strip_build<false>) when they are small enough for one workgroup to wipe
+    const int need_zero = 2 * (n_strips + 1);
+    const bool hand_back = zero_ints_known && need_zero <= 65536;
+    if (!(zero_ints_known && *zero_ints_known >= need_zero)) (void)hipMemsetAsync(sb.cnt, 0, sizeof(int) * (size_t)need_zero, st);
+    if (zero_ints_known) *zero_ints_known = hand_back ? need_zero : 0;
     if (n_chunks > 0) k_strip_partition<false><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, sb.cnt, nullptr, nullptr, nullptr);
-    exclusive_scan(sb.cnt, sb.start, sb.scan_tmp, n_strips, st);
-    if (n_chunks > 0) k_strip_partition<true><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, nullptr, sb.start, sb.fill, sb.tmp_pts);
+    if (n_chunks > 0 && n_strips < kMaxStrips)
+        k_strip_partition<true, true><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, sb.cnt, nullptr, sb.fill, sb.tmp_pts, sb.start, n_strips);
+    else {
+        exclusive_scan(sb.cnt, sb.start, sb.scan_tmp, n_strips, st);
+        if (n_chunks > 0) k_strip_partition<true><<<n_chunks, kPartThreads, 0, st>>>(chunks, tsegs, nullptr, sb.start, sb.fill, sb.tmp_pts);
+    }
     const dim3 grid((unsigned)std::max(max_units, 1), (unsigned)n_tsegs);
     // the two variants work on disjoint strips: the few big strips (one workgroup per CU each) run on a side stream underneath
     // the many small ones instead of after them
@@ -1659,7 +1689,8 @@ int launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const Tar
                       hipStreamWaitEvent(sb.side, sb.ev_fork, 0) == hipSuccess;
     k_strip_build<true><<<grid, 1024, lds_large, fork ? sb.side : st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
     if (fork) (void)hipEventRecord(sb.ev_join, sb.side);
-    k_strip_build<false><<<grid, 256, lds_small, st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos);
+    k_strip_build<false><<<grid, 256, lds_small, st>>>(tsegs, sb.start, sb.tmp_pts, cap_small, cap_large, sb.slot_idx, sb.slot_pos,
+                                                      hand_back ? sb.cnt : nullptr, hand_back ? need_zero : 0);
     if (fork) (void)hipStreamWaitEvent(st, sb.ev_join, 0);
     return 0;
 }

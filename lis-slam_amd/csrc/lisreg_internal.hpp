@@ -184,7 +184,7 @@ struct StripBuffers {
     hipEvent_t  ev_fork, ev_join;
 };
 int  launch_build_targets_strips(const BlockDesc* chunks, int n_chunks, const TargetSeg* tsegs, int n_tsegs, int n_strips, int max_units,
-                                 int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st);
+                                 int max_strip_cells, int cap_small, StripBuffers sb, hipStream_t st, int* zero_ints_known = nullptr);
 // k-NN graph of every target in `tsegs` (grids[t.grid_id] must describe the finished index and carry nbr / nbr_meta)
 void launch_build_graph(const BlockDesc* blocks, int n_blocks, const TargetSeg* tsegs, const GridIndex* grids, hipStream_t st);
 void launch_build_graph_one(GridIndex g, hipStream_t st);
