@@ -53,5 +53,7 @@ if f:
 PY
   rm -rf $O/tr_$w
 done
+timeout 300 bash tests/timeline.sh > $O/${TAG}_step_timeline.txt 2>&1                  # the kernels of one configs[1] step in order
+timeout 600 python -m pytest tests/test_fit_device.py tests/test_round6_edges.py tests/test_configs.py -m gpu -q -s 2>&1 | grep -E "^\[|\|p\||unit normal|planes through|passed|failed" > $O/${TAG}_new_tests_output.txt
 LISREG_BENCH_OVERSUBSCRIBE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/${TAG}_bench_2ranks_one_gpu.json
 ls $O
