@@ -332,6 +332,7 @@ def main():
         a_reg = (ALG_BYTES_PER_POINT_ITER * ITERS * n_src + 40.0 * n_tgt_pts) / batch
         step_achieved = a_reg * (batch / (ms_per_step * 1e-3)) / 1e9
         fe_kib, grid_kib = ctx.get_option("index_kib_front_end"), ctx.get_option("index_kib_grid")
+        fe_built_kib = ctx.get_option("index_kib_front_end_built")          # cell rows the last run really built (row_reach): <= the allocation above
         roof = dict(bound="hbm", kernel="k_assoc_walk", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     step_frac=round(step_achieved / HBM_PEAK_GBS, 5), step_achieved=round(step_achieved, 2),
@@ -339,7 +340,8 @@ def main():
                     step_frac_note="A_reg x registrations/s per GPU / 8 TB/s (BASELINE.md section 3): the whole step incl. index build and solves",
                     index_bytes_per_target_point=round(1024.0 * (fe_kib + grid_kib) / max(n_tgt_pts, 1), 1),
                     index_bytes_per_target_point_parts=dict(grid=round(1024.0 * grid_kib / max(n_tgt_pts, 1), 1),
-                                                            front_end=round(1024.0 * fe_kib / max(n_tgt_pts, 1), 1)),
+                                                            front_end=round(1024.0 * fe_kib / max(n_tgt_pts, 1), 1),
+                                                            front_end_built_by_the_last_run=round(1024.0 * fe_built_kib / max(n_tgt_pts, 1), 1)),
                     avg_launch_ms=round(avg_ms, 4), launches=timing["assoc_launches"],
                     algorithmic_bytes_per_launch=alg_bytes, search_front_end=ctx.front_end(),
                     launches_per_iteration=round(timing["assoc_launches"] / (prof_steps_ * ITERS), 3), interleaved=bool(ctx.get_option("interleaved_now")),

@@ -261,7 +261,8 @@ int  lisreg_set_option(lisreg_ctx* ctx, const char* name, int value);
  * "index_build_now" = 1 if the prepared batch rebuilds its targets in strip form, "xcd_order_now" = 1 if the last run used the
  * sector dispatch order, "interleaved_now" = 1 if it ran as two halves; size of the prepared batch's search index: "index_kib_grid"
  * (sorted records + cell tables of its targets), "index_kib_front_end" (k-NN graph rows or cell rows + their tables; 0 for the cell
- * walk), "index_target_points" (points in those targets) — bench.py's roofline.index_bytes_per_target_point; "row_reach_now" = 1 if the last
+ * walk), "index_target_points" (points in those targets) — bench.py's roofline.index_bytes_per_target_point —, "index_kib_front_end_built" (the
+ * cell rows the last run really built, read back from the device: synchronous); "row_reach_now" = 1 if the last
  * run built its cell rows for the cells the query marks reach only, "row_reach_misses" = query-iterations of the last FETCHED run that
  * found their cell without rows. */
 int  lisreg_get_option(const lisreg_ctx* ctx, const char* name, int* value);

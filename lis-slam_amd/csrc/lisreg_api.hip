@@ -1363,6 +1363,26 @@ int lisreg_get_option(const lisreg_ctx* c, const char* name, int* value)
     if (!strcmp(name, "interleaved_now")) { *value = c->interleaved_now ? 1 : 0; return LISREG_OK; }
     // size of the search index of the prepared batch's targets, in KiB (what the front-end in use reads), and their points:
     //   index_kib_grid: sorted records + cell table; index_kib_front_end: k-NN graph rows (front-end 3) or cell rows + their table (front-end 5)
+    if (!strcmp(name, "index_kib_front_end_built")) {
+        // the cell rows the LAST run actually built (option "row_reach" leaves out the cells no query comes near): row counts read back from the
+        // device (a synchronous diagnostic); other front-ends: what "index_kib_front_end" says
+        if (c->mode_now != 5) return lisreg_get_option(c, "index_kib_front_end", value);
+        unsigned long long fe = 0;
+        for (int slot : c->batch_slots) {
+            if (slot < 0 || (size_t)slot >= c->targets.size()) continue;
+            const lisreg::Target& t = c->targets[(size_t)slot];
+            for (int k = 0; k < 2; ++k) {
+                if (t.n[k] <= 0 || !t.crow_scan[k].p) continue;
+                int rows = 0;
+                if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+                    hipMemcpy(&rows, t.crow_scan[k].as<int>() + t.n_cells[k], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LISREG_ERR_HIP;
+                rows = std::min(std::max(rows, 0), t.crow_cap[k]);
+                fe += (unsigned long long)rows * (sizeof(float4) * lisreg::kGraphK + sizeof(float2)) + (unsigned long long)t.n_cells[k] * sizeof(int);
+            }
+        }
+        *value = (int)std::min<unsigned long long>((fe + 1023) / 1024, 0x7fffffffULL);
+        return LISREG_OK;
+    }
     if (!strcmp(name, "index_kib_grid") || !strcmp(name, "index_kib_front_end") || !strcmp(name, "index_target_points")) {
         unsigned long long grid = 0, fe = 0, pts = 0;
         for (int slot : c->batch_slots) {
