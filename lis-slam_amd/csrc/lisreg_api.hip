@@ -931,8 +931,8 @@ int lisreg_batch_prepare(lisreg_ctx* c, int n_items, const lisreg_item* items, c
     c->items_reset = true; c->reach_miss_seen = 0; c->runs_since_fetch = 0;
     // Query marks for the row builds of this batch's runs (option "row_reach"; cell rows, targets rebuilt inside every run).  A scan sees a
     // part of its map — the lidar's elevation span leaves the upper walls of the benchmark room unseen: a fifth of the cells that would
-    // get rows — so every run builds rows only for the cells a query comes within two cells of under its INITIAL pose: one pass over the
-    // batch's source points (k_query_marks: the cell each falls into), the 5 x 5 x 5 dilation of those marks (`reach`, read by the
+    // get rows — so every run builds rows only for the cells a query comes within a metre of under its INITIAL pose: one pass over the
+    // batch's source points (k_query_marks: the cell each falls into), those marks grown by ceil(1 m / cell) cells (`reach`, read by the
     // classification of every run), the mark words handed back clean.  They depend on the sources and the initial poses — what this call
     // is given — not on the target's points, which a run may find changed.
     c->reach_ready = false;
@@ -1048,7 +1048,7 @@ static int run_impl(lisreg_ctx* c, bool early_stop)
             if (split_blk * 4 < c->n_blocks || (c->n_blocks - split_blk) * 4 < c->n_blocks) { split_item = 0; split_blk = 0; }     // (a lop-sided cut hides nothing)
         }
     }
-    // Round 6, option "row_reach": the rows of this run are built only for the cells a query of the batch comes within two cells of under
+    // Round 6, option "row_reach": the rows of this run are built only for the cells a query of the batch comes within a metre of under
     // its initial pose (`reach` words made by lisreg_batch_prepare: they depend on the sources and the initial poses alone, not on the target's
     // points).  A query that ends up in a cell without rows all the same takes the cell walk: results cannot depend on the marks.
     c->reach_now = c->rebuild_targets_each_run && c->mode_now == 5 && c->reach_ready && !c->exact;

@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin
 #define LISREG_CT_Y 8
 #endif
 constexpr int kCtX = LISREG_CT_X, kCtY = LISREG_CT_Y, kCtRim = 2;
-// (both classification kernels) reach != null: a populated cell that no query of the batch comes within two cells of gets no rows this
+// (both classification kernels) reach != null: a populated cell that no query of the batch comes within a metre of gets no rows this
 // run — need 0, and bit 30 of its mask tells the build to write -1 ("no row: walk") instead of -2 ("nothing within two cells") into its table entry
 constexpr int kCrowUnreached = 1 << 30;
 __device__ __forceinline__ bool crow_reached(const GridIndex& g, const unsigned* __restrict__ reach, int ix, int iy, int iz)

@@ -40,7 +40,7 @@ struct GridIndex {
     const int*    crow_tab;
     // query marks (round 6; null: every populated cell gets its rows): one bit per cell — column (ix * ny + iy) owns qmark_w consecutive
     // 32-bit words, bit iz & 31 of word iz >> 5 — set by k_query_marks for the cells the batch's queries fall into under their INITIAL
-    // poses.  The row build of a run leaves out the cells no query of the batch comes within two cells of (crow_tab -1: a query that gets
+    // poses.  The row build of a run leaves out the cells no query of the batch comes within a metre of (crow_tab -1: a query that gets
     // there all the same takes the cell walk — results never depend on the marks).
     unsigned*     qmark;
     int           qmark_w;
@@ -191,10 +191,10 @@ void launch_build_graph_one(GridIndex g, hipStream_t st);
 // cell rows of one target (search_mode 5).  classify: need[cell] = rows the cell wants (0 / 1 / 8), scan[cell] = first row, scan[n_cells] = rows
 // in all; build: crow_tab, then one wave per row (at most cap_rows of them: cells past the capacity get no row and their queries walk)
 struct CrowBuffers { int* need; int* omask; int* scan; int* scan_tmp; int cap_rows;
-                     const unsigned* reach = nullptr; };       // reach: the query marks dilated by two cells (same layout as GridIndex::qmark), or null
+                     const unsigned* reach = nullptr; };       // reach: the query marks grown by a metre (same layout as GridIndex::qmark), or null
 // Query marks (lisreg_index.hip): launch_query_marks sets, for every source point of the batch under its item's CURRENT pose cache (the
 // initial pose right after launch_reset_items), the bit of the grid cell it falls into (clamped into the grid: what the cell-row scan
-// does with a query outside); launch_reach_dilate ORs the marks of the 5 x 5 x 5 block around every cell into `reach`.
+// does with a query outside); launch_reach_dilate ORs the marks of the (2 D + 1)^3 block around every cell into `reach`, D = ceil(1 m / cell) >= 2.
 void launch_query_marks(const BlockDesc* blocks, int n_blocks, const Segment* segs, const GridIndex* grids, const ItemState* items, hipStream_t st);
 void launch_reach_dilate(GridIndex g, unsigned* reach, hipStream_t st);
 // The octant masks (cb.omask) are accumulated by atomic ORs and must start at zero: launch_crow_build hands every cell's mask back as zero
