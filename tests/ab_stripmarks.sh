@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the option it switches exists only with profiles/r06_xp_strip_marks.patch applied: the variant was slower and is not in the tree)
 # experiment helper (GPU box): octant marks inside the strip builds (default) against a marks launch of their own (LISREG_STRIP_MARKS=0)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; export LISREG_BENCH_NO_EXACT=1 LISREG_BENCH_NO_OVERLAP=1
 for rep in 1 2 3; do for r in 0 1; do
