@@ -919,6 +919,30 @@ __device__ __forceinline__ void crow_mark_body(const GridIndex& g, float oct_mar
 
 __global__ __launch_bounds__(256) void k_crow_mark(GridIndex g, float oct_margin, int* __restrict__ omask) { crow_mark_body(g, oct_margin, omask, blockIdx.x); }
 
+// The same marks into an LDS tile (round 6, the LDS-tiled classification): the octants point p is near, ORed into the masks of those of its
+// (at most 2 x 2 x 2) cells that lie inside the tile [tx0, tx0 + kCtX) x [ty0, ty0 + kCtY) x [0, nz) — LDS atomics, no dedupe needed.
+// Same arithmetic as crow_mark_point: the same bits in the same cells.
+__device__ __forceinline__ void crow_mark_point_tile(const GridIndex& g, const float4 p, float oct_margin, int tx0, int ty0, int ctx, int cty, int* s_mask)
+{
+    if (!(p.x == p.x && p.y == p.y && p.z == p.z)) return;
+    const float inv_h = 2.f * g.inv_cell;
+    const int ax0 = min(max((int)floorf((p.x - oct_margin - g.ox) * inv_h), 0), 2 * g.nx - 1), ax1 = min(max((int)floorf((p.x + oct_margin - g.ox) * inv_h), 0), 2 * g.nx - 1);
+    const int ay0 = min(max((int)floorf((p.y - oct_margin - g.oy) * inv_h), 0), 2 * g.ny - 1), ay1 = min(max((int)floorf((p.y + oct_margin - g.oy) * inv_h), 0), 2 * g.ny - 1);
+    const int az0 = min(max((int)floorf((p.z - oct_margin - g.oz) * inv_h), 0), 2 * g.nz - 1), az1 = min(max((int)floorf((p.z + oct_margin - g.oz) * inv_h), 0), 2 * g.nz - 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int cx = (ax0 >> 1) + (s & 1), cy = (ay0 >> 1) + ((s >> 1) & 1), cz = (az0 >> 1) + (s >> 2);
+        const bool in = cx <= (ax1 >> 1) && cy <= (ay1 >> 1) && cz <= (az1 >> 1);
+        const int bx = (ax0 <= 2 * cx && 2 * cx <= ax1 ? 1 : 0) | (ax0 <= 2 * cx + 1 && 2 * cx + 1 <= ax1 ? 2 : 0);
+        const int by = (ay0 <= 2 * cy && 2 * cy <= ay1 ? 1 : 0) | (ay0 <= 2 * cy + 1 && 2 * cy + 1 <= ay1 ? 2 : 0);
+        const int bz = (az0 <= 2 * cz && 2 * cz <= az1 ? 1 : 0) | (az0 <= 2 * cz + 1 && 2 * cz + 1 <= az1 ? 2 : 0);
+        const int mxy = ((by & 1) ? bx : 0) | ((by & 2) ? bx << 2 : 0);
+        const int m = ((bz & 1) ? mxy : 0) | ((bz & 2) ? mxy << 4 : 0);
+        const int lx = cx - tx0, ly = cy - ty0;
+        if (in && m != 0 && lx >= 0 && lx < ctx && ly >= 0 && ly < cty) atomicOr(&s_mask[(lx * cty + ly) * g.nz + cz], m);
+    }
+}
+
 // k_crow_classify: one workgroup per tile of kCtX x kCtY columns over the whole z-range: the cell_start rows of the tile and its
 // two-column rim are staged in LDS once (two global reads per cell instead of fifty), every thread sums its cells' 5 x 5 columns from there.
 #ifndef LISREG_CT_X
@@ -936,18 +960,35 @@ __device__ __forceinline__ bool crow_reached(const GridIndex& g, const unsigned*
     return !reach || ((reach[(size_t)(ix * g.ny + iy) * g.qmark_w + (iz >> 5)] >> (iz & 31)) & 1u) != 0u;
 }
 
+// Round 6: the octant masks of the tile's cells are made HERE, in LDS (s_mask, behind the staged cell_start rows): the points of the tile's
+// columns and of a one-column rim around it (a point marks cells at most one away; columns adjacent in y are adjacent in memory, so that is
+// one contiguous run of points per x) each OR their octants into the tile's masks with LDS atomics.  Until then the marks were a launch of
+// their own (k_crow_mark: one or two device-scope atomics per point into a global mask array, 26 us per configs[1] step on the stream's
+// serial head) whose result this kernel read back; a tile reads ~1.3 x its own points instead.  Same masks (crow_mark_point_tile).
 __device__ __forceinline__ void crow_classify_body(const GridIndex& g, int tiles_y, int* __restrict__ need, int* __restrict__ omask,
-                                                   const unsigned* __restrict__ reach, int blk_, int* s_cs)
+                                                   const unsigned* __restrict__ reach, int blk_, int* s_cs, float oct_margin)
 {
-    //                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows
+    //                            // [(kCtX + 2 rim) * (kCtY + 2 rim)][nz + 1] cell_start rows, then [kCtX * kCtY][nz] masks
     constexpr int WX = kCtX + 2 * kCtRim, WY = kCtY + 2 * kCtRim;
     const int nz1 = g.nz + 1;
     const int tx0 = (int)(blk_ / tiles_y) * kCtX, ty0 = (int)(blk_ % tiles_y) * kCtY;
+    int* s_mask = s_cs + WX * WY * nz1;
     for (int i = threadIdx.x; i < WX * WY * nz1; i += 256) {
         const int c = i / nz1, z = i - c * nz1;
         const int x = tx0 - kCtRim + c / WY, y = ty0 - kCtRim + c % WY;
         // a column outside the grid holds nothing: any constant row will do
         s_cs[i] = (x >= 0 && x < g.nx && y >= 0 && y < g.ny) ? g.cell_start[(x * g.ny + y) * g.nz + z] : 0;
+    }
+    for (int i = threadIdx.x; i < kCtX * kCtY * g.nz; i += 256) s_mask[i] = 0;
+    __syncthreads();
+    {
+        const int ylo = max(ty0 - 1, 0), yhi = min(ty0 + kCtY, g.ny - 1);
+        if (ylo <= yhi)
+            for (int x = max(tx0 - 1, 0); x <= min(tx0 + kCtX, g.nx - 1); ++x) {
+                const int c0 = (x - (tx0 - kCtRim)) * WY + (ylo - (ty0 - kCtRim)), c1 = (x - (tx0 - kCtRim)) * WY + (yhi - (ty0 - kCtRim));
+                const int p0 = s_cs[c0 * nz1], p1 = s_cs[c1 * nz1 + g.nz];
+                for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) crow_mark_point_tile(g, g.pts[p], oct_margin, tx0, ty0, kCtX, kCtY, s_mask);
+            }
     }
     __syncthreads();
     const int ncell = kCtX * kCtY * g.nz;
@@ -966,7 +1007,7 @@ __device__ __forceinline__ void crow_classify_body(const GridIndex& g, int tiles
                 cnt5 += row[z1 + 1] - row[z0];
             }
         const int cid = (ix * g.ny + iy) * g.nz + iz;
-        const int m = omask[cid] & 255;
+        const int m = s_mask[i] & 255;
         const bool r = cnt5 != 0 && crow_reached(g, reach, ix, iy, iz);
         need[cid] = r ? 1 + __popc(m) : 0;
         omask[cid] = cnt5 ? (r ? (m | (min(cnt5, 0xffff) << 8)) : kCrowUnreached) : 0;
@@ -974,10 +1015,10 @@ __device__ __forceinline__ void crow_classify_body(const GridIndex& g, int tiles
 }
 
 __global__ __launch_bounds__(256) void k_crow_classify(GridIndex g, int tiles_y, int* __restrict__ need, int* __restrict__ omask,
-                                                       const unsigned* __restrict__ reach)
+                                                       const unsigned* __restrict__ reach, float oct_margin)
 {
     extern __shared__ int s_cs[];
-    crow_classify_body(g, tiles_y, need, omask, reach, blockIdx.x, s_cs);
+    crow_classify_body(g, tiles_y, need, omask, reach, blockIdx.x, s_cs, oct_margin);
 }
 
 // the same per cell, straight from memory: grids whose tile does not fit the LDS (z-ranges beyond ~120 cells)
@@ -1303,14 +1344,14 @@ __global__ __launch_bounds__(256) void k_crow_mark_pair(CrowJobs J, float margin
     const CrowJob& j = J.j[k];
     crow_mark_body(j.g, margin_cells * j.g.cell, j.omask, (int)blockIdx.x - (k ? J.j[0].nb : 0));
 }
-__global__ __launch_bounds__(256) void k_crow_classify_pair(CrowJobs J)
+__global__ __launch_bounds__(256) void k_crow_classify_pair(CrowJobs J, float margin_cells)
 {
     extern __shared__ int s_cs[];
     const int k = (int)blockIdx.x < J.j[0].nb ? 0 : 1;
     const CrowJob& j = J.j[k];
     const int blk = (int)blockIdx.x - (k ? J.j[0].nb : 0);
     if (j.plain) crow_classify_plain_body(j.g, j.n_cells, j.need, j.omask, j.reach, blk);
-    else crow_classify_body(j.g, j.tiles_y, j.need, j.omask, j.reach, blk, s_cs);
+    else crow_classify_body(j.g, j.tiles_y, j.need, j.omask, j.reach, blk, s_cs, margin_cells * j.g.cell);
 }
 LISREG_CROW_BUILD_ATTR void k_crow_build_pair(CrowJobs J, int use_r3)
 {
@@ -1779,21 +1820,34 @@ void launch_reach_dilate(GridIndex g, unsigned* reach, hipStream_t st)
     k_reach_dilate<<<(n + 255) / 256, 256, 0, st>>>(g, reach, D);
 }
 
+// dynamic LDS of the tiled classification: the staged cell_start rows of the tile + its two-column rim, and the tile's octant masks
+static size_t crow_classify_lds(int nz)
+{
+    return sizeof(int) * ((size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(nz + 1) + (size_t)kCtX * kCtY * (size_t)nz);
+}
+
+float crow_oct_margin_cells()
+{
+    static const float margin = std::min(0.249f, std::max(0.f, getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.249f));
+    return margin;
+}
+
 void launch_crow_classify(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st, int* omask_zero_cells)
 {
     if (g.n <= 0 || n_cells <= 0) return;
     const bool zero_already = omask_zero_cells && *omask_zero_cells >= n_cells;
     if (omask_zero_cells) *omask_zero_cells = 0;              // the marks go in now; launch_crow_build takes them out again
     // octant margin in cells: under a quarter cell (half an octant's edge), so that a point is near at most two octants per axis
-    static const float margin = std::min(0.249f, std::max(0.f, getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.249f));
-    if (!zero_already) (void)hipMemsetAsync(cb.omask, 0, sizeof(int) * (size_t)n_cells, st);
-    k_crow_mark<<<(g.n + 255) / 256, 256, 0, st>>>(g, margin * g.cell, cb.omask);
-    const size_t lds = sizeof(int) * (size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g.nz + 1);
-    if (lds <= 64 * 1024) {
+    const float margin = crow_oct_margin_cells();
+    const size_t lds = crow_classify_lds(g.nz);
+    if (lds <= 64 * 1024) {                                   // the tiled classification makes the marks itself, in LDS
         const int tiles_x = (g.nx + kCtX - 1) / kCtX, tiles_y = (g.ny + kCtY - 1) / kCtY;
-        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, tiles_y, cb.need, cb.omask, g.qmark ? cb.reach : nullptr);
-    } else
+        k_crow_classify<<<tiles_x * tiles_y, 256, lds, st>>>(g, tiles_y, cb.need, cb.omask, g.qmark ? cb.reach : nullptr, margin * g.cell);
+    } else {
+        if (!zero_already) (void)hipMemsetAsync(cb.omask, 0, sizeof(int) * (size_t)n_cells, st);
+        k_crow_mark<<<(g.n + 255) / 256, 256, 0, st>>>(g, margin * g.cell, cb.omask);
         k_crow_classify_plain<<<(n_cells + 255) / 256, 256, 0, st>>>(g, n_cells, cb.need, cb.omask, g.qmark ? cb.reach : nullptr);
+    }
     exclusive_scan(cb.need, cb.scan, cb.scan_tmp, n_cells, st);
 }
 
@@ -1808,7 +1862,7 @@ void launch_crow_build(GridIndex g, int n_cells, CrowBuffers cb, hipStream_t st,
 // classification + rows of the corner (job 0) and surf (job 1) target of one slot, five launches on ONE stream (see CrowJob)
 void launch_crow_rows_pair(const GridIndex g[2], const int n_cells[2], const CrowBuffers cb[2], hipStream_t st, int* omask_zero_cells[2])
 {
-    static const float margin = std::min(0.249f, std::max(0.f, getenv("LISREG_CROW_MARGIN") ? (float)atof(getenv("LISREG_CROW_MARGIN")) : 0.249f));
+    const float margin = crow_oct_margin_cells();
     static const int use_r3 = getenv("LISREG_CROW_R3") ? atoi(getenv("LISREG_CROW_R3")) : 1;
     CrowJobs J = {};
     bool on[2];
@@ -1818,25 +1872,28 @@ void launch_crow_rows_pair(const GridIndex g[2], const int n_cells[2], const Cro
         j.g = g[k]; j.n_cells = n_cells[k]; j.need = cb[k].need; j.omask = cb[k].omask; j.scan = cb[k].scan; j.cap = cb[k].cap_rows;
         j.reach = g[k].qmark ? cb[k].reach : nullptr;
         if (!on[k]) continue;
+        j.plain = crow_classify_lds(g[k].nz) > 64 * 1024 ? 1 : 0;          // (the tiled classification makes its marks itself, in LDS)
         const bool zero_already = omask_zero_cells[k] && *omask_zero_cells[k] >= n_cells[k];
-        if (!zero_already) (void)hipMemsetAsync(cb[k].omask, 0, sizeof(int) * (size_t)n_cells[k], st);
-        if (omask_zero_cells[k]) *omask_zero_cells[k] = n_cells[k];      // (the marks go in and k_crow_build_pair takes them out again)
+        if (j.plain && !zero_already) (void)hipMemsetAsync(cb[k].omask, 0, sizeof(int) * (size_t)n_cells[k], st);
+        if (omask_zero_cells[k]) *omask_zero_cells[k] = n_cells[k];      // (k_crow_build_pair hands every mask back as zero)
     }
     if (!on[0] && !on[1]) return;
     auto grid = [&](int a, int b) { J.j[0].nb = on[0] ? a : 0; J.j[1].nb = on[1] ? b : 0; return (unsigned)(J.j[0].nb + J.j[1].nb); };
-    // marks
-    { const unsigned nb = grid((g[0].n + 255) / 256, (g[1].n + 255) / 256); k_crow_mark_pair<<<nb, 256, 0, st>>>(J, margin); }
+    // marks in a launch of their own only for targets whose tile does not fit the LDS (z-ranges beyond ~100 cells)
+    {
+        const unsigned nb = grid(J.j[0].plain ? (g[0].n + 255) / 256 : 0, J.j[1].plain ? (g[1].n + 255) / 256 : 0);
+        if (nb) k_crow_mark_pair<<<nb, 256, 0, st>>>(J, margin);
+    }
     // classification: LDS-tiled where the tile fits, per cell otherwise (decided per target)
     {
         size_t lds = 0; int nbk[2] = { 0, 0 };
         for (int k = 0; k < 2; ++k) {
             if (!on[k]) continue;
-            const size_t l = sizeof(int) * (size_t)(kCtX + 2 * kCtRim) * (kCtY + 2 * kCtRim) * (size_t)(g[k].nz + 1);
-            if (l <= 64 * 1024) { J.j[k].plain = 0; J.j[k].tiles_y = (g[k].ny + kCtY - 1) / kCtY; nbk[k] = ((g[k].nx + kCtX - 1) / kCtX) * J.j[k].tiles_y; lds = std::max(lds, l); }
-            else { J.j[k].plain = 1; nbk[k] = (n_cells[k] + 255) / 256; }
+            if (!J.j[k].plain) { J.j[k].tiles_y = (g[k].ny + kCtY - 1) / kCtY; nbk[k] = ((g[k].nx + kCtX - 1) / kCtX) * J.j[k].tiles_y; lds = std::max(lds, crow_classify_lds(g[k].nz)); }
+            else nbk[k] = (n_cells[k] + 255) / 256;
         }
         const unsigned nb = grid(nbk[0], nbk[1]);
-        k_crow_classify_pair<<<nb, 256, lds, st>>>(J);
+        k_crow_classify_pair<<<nb, 256, lds, st>>>(J, margin);
     }
     // row counts -> first rows: both scans in two launches (tiled form whatever the size)
     {
