@@ -1134,22 +1134,33 @@ constexpr unsigned kInfQ = 0x7f800000u;                     // +inf, payload bit
 // topc (x, y, z of the listed point, per lane) is filled where it costs no memory access: a block of at most 64 candidates is ONE chunk,
 // every candidate's record is in some lane's registers, and three lane permutes put it next to its key — the row is then written without
 // gathering the points a second time (have_c; a multi-chunk list leaves it to crow_emit's gather).
-template <int R>
+// Round 6 (kFilter; the k-NN graph's rows): a block of more than 64 candidates is FILTERED before it is sorted.  A row lists nothing beyond the block's inscribed radius rc
+// (crow_emit: rho^2 = min(rc^2, 64th distance), an entry is kept iff its key <= rho^2), and the sphere of that radius holds pi / 4 of a
+// surface's points inside the block's square: the ~75 candidates of a floor cell of BASELINE configs[1] become ~59 — ONE 64-key sort
+// instead of two sorts and a merge.  The survivors of every 64-candidate round are compacted (ballot + prefix count) into a 128-entry
+// queue in LDS; whenever it holds 64 they are sorted and merged as a chunk was before.  The predicate is crow_emit's own (the truncated
+// key against rc^2), so the rows are the same entry for entry.
+// Measured (profiles/r06_kernel_experiments.md): the graph build of configs[4] (1 M points, 0.25 m cells: 3-6 rounds per point) -2.6 % of a step;
+// the cell rows of configs[1] (two rounds per surface cell) LOSE 1.3 % of a step with it — the queue's LDS round trips and a sixth wavefront
+// per SIMD that no longer fits the registers cost more than the second sort they save — so the row build keeps the unfiltered loop.
+constexpr int kListQueueWaves = 4;                          // wavefronts per workgroup the queue is dimensioned for (both builds run 1)
+template <int R, bool kFilter = false>
 __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>& b, float qx, float qy, float qz,
                                           int (*s_off)[64], int (*s_js)[64], unsigned& topk, int& topi, float4& topc, bool& have_c,
-                                          int exclude = -1 /* a sorted position to leave out: the point itself, for the k-NN graph's rows */)
+                                          int exclude = -1 /* a sorted position to leave out: the point itself, for the k-NN graph's rows */,
+                                          float rc2 = 3.0e38f /* nothing farther than this (squared) can be listed: crow_emit's rc * rc */)
 {
     constexpr int W = 2 * R + 1, NR = W * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned s_qk[kListQueueWaves][128];
+    __shared__ int s_qj[kListQueueWaves][128];
     topk = kInfQ; topi = -1;                                // running kGraphK best, ascending: quantised key and id per lane
     topc = make_float4(0.f, 0.f, 0.f, 0.f);
     have_c = b.total <= 64;
-#pragma unroll 1
-    for (int c0 = 0; c0 < b.total; c0 += 64) {
-        const int t = c0 + lane;
-        unsigned k = kInfQ | (unsigned)lane;
-        int cj = -1;
-        float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // one 64-candidate round of the block: the lane's candidate (position j, record cc) and its truncated key, kInfQ if it has none
+    auto candidate = [&](int t, int& cj, float4& cc) -> unsigned {
+        unsigned ck = kInfQ;
+        cj = -1; cc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < b.total) {
             int lo = 0, hi = NR - 1;                        // last run whose offset is <= t
 #pragma unroll
@@ -1159,13 +1170,19 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
             cc = c;
             const float ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
             const float d2 = ex * ex + ey * ey + ez * ez;
-            if (j != exclude && d2 < 3.0e38f) { k = (__float_as_uint(d2) & ~0x7Fu) | (unsigned)lane; cj = j; }     // NaN / Inf points are never listed
+            if (j != exclude && d2 < 3.0e38f) { ck = __float_as_uint(d2) & ~0x7Fu; cj = j; }     // NaN / Inf points are never listed
         }
+        return ck;
+    };
+    // a sorted chunk (ck, cj per lane; kInfQ / -1 where empty) into the running best
+    bool first = true;
+    auto take = [&](unsigned ck_in, int cj, const float4 cc) {
+        unsigned k = ck_in | (unsigned)lane;
         k = sort64x32(k, lane);
         const int cs = __shfl(cj, (int)(k & 63u));
         const unsigned ck = k & ~0x7Fu;
         if (have_c) { const int sl = (int)(k & 63u); topc = make_float4(__shfl(cc.x, sl), __shfl(cc.y, sl), __shfl(cc.z, sl), 0.f); }
-        if (c0 == 0) { topk = ck; topi = cs; }
+        if (first) { topk = ck; topi = cs; first = false; }
         else {
             // the lane-wise minimum of the running list and the reversed chunk is the 64 smallest of both as one bitonic sequence
             const unsigned kt = topk | 64u | (unsigned)lane;
@@ -1176,6 +1193,45 @@ __device__ __forceinline__ void crow_list(const GridIndex& g, const CrowBlock<R>
             topi = (m & 64u) ? from_top : from_chunk;
             topk = m & ~0x7Fu;
         }
+    };
+    if (!kFilter || b.total <= 64) {                        // one chunk: nothing to save, and the records travel in registers (have_c); or no filter
+#pragma unroll 1
+        for (int c0 = 0; c0 < b.total; c0 += 64) {
+            int cj; float4 cc;
+            const unsigned ck = candidate(c0 + lane, cj, cc);
+            take(ck, cj, cc);
+        }
+        return;
+    }
+    int pend = 0;                                           // entries waiting in the queue (wave-uniform)
+#pragma unroll 1
+    for (int c0 = 0; c0 < b.total; c0 += 64) {
+        int cj; float4 cc;
+        const unsigned ck = candidate(c0 + lane, cj, cc);
+        const bool in = cj >= 0 && __uint_as_float(ck) <= rc2;
+        const unsigned long long m = __ballot(in);
+        if (in) {
+            const int slot = pend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            s_qk[wave][slot] = ck; s_qj[wave][slot] = cj;
+        }
+        pend += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (pend >= 64) {
+            const unsigned qk = s_qk[wave][lane]; const int qj = s_qj[wave][lane];
+            const int rest = pend - 64;
+            unsigned rk = 0u; int rj = 0;
+            if (lane < rest) { rk = s_qk[wave][64 + lane]; rj = s_qj[wave][64 + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) { s_qk[wave][lane] = rk; s_qj[wave][lane] = rj; }
+            pend = rest;
+            __builtin_amdgcn_wave_barrier();
+            take(qk, qj, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    if (pend > 0 || first) {
+        unsigned qk = kInfQ; int qj = -1;
+        if (lane < pend) { qk = s_qk[wave][lane]; qj = s_qj[wave][lane]; }
+        take(qk, qj, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
 
@@ -1206,9 +1262,10 @@ __device__ __forceinline__ void graph_row_q32(const GridIndex& g, const float4 q
 {
     const CrowBlock<2> b = crow_runs<2>(g, hx, hy, hz, s_off, s_js);
     unsigned topk; int topi; float4 topc; bool have_c;
-    crow_list<2>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c, s);
+    const float rc = crow_inscribed<2>(g, b, q.x, q.y, q.z);
+    crow_list<2, true>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c, s, rc * rc);
     bool keep; float4 e;
-    (void)crow_emit(g, q.x, q.y, q.z, crow_inscribed<2>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e, topc, have_c);
+    (void)crow_emit(g, q.x, q.y, q.z, rc, topk, topi, row_out, meta_out, keep, e, topc, have_c);
 }
 
 // The row at the cell's centre q and, behind it, one row per octant in `mask`.  An octant row is derived from the centre row where that
@@ -1224,9 +1281,10 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
     constexpr float kEps = 1e-3f;
     const CrowBlock<R> b = crow_runs<R>(g, hx, hy, hz, s_off, s_js);
     unsigned topk; int topi; float4 topc; bool have_c;
-    crow_list<R>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c);
+    const float rc = crow_inscribed<R>(g, b, q.x, q.y, q.z);
+    crow_list<R>(g, b, q.x, q.y, q.z, s_off, s_js, topk, topi, topc, have_c, -1, rc * rc);
     bool keep; float4 e;
-    const float rho2 = crow_emit(g, q.x, q.y, q.z, crow_inscribed<R>(g, b, q.x, q.y, q.z), topk, topi, row_out, meta_out, keep, e, topc, have_c);
+    const float rho2 = crow_emit(g, q.x, q.y, q.z, rc, topk, topi, row_out, meta_out, keep, e, topc, have_c);
     if (mask) {
         const float off = 0.25f * g.cell * 1.7320508f;                         // |octant centre - cell centre|
         const float rho_o = fmaxf(sqrtf(rho2) - off - 2.f * kEps, 0.f), rho_o2 = rho_o * rho_o;
@@ -1257,8 +1315,9 @@ __device__ __forceinline__ void crow_build_wave(const GridIndex& g, const float4
                 if (lane == 0) meta_out[slot] = make_float2(rho_o2, __int_as_float(ocnt));
             } else {
                 unsigned ok; int oi; bool okeep; float4 oe, oc; bool ohave;
-                crow_list<R>(g, b, mx, my, mz, s_off, s_js, ok, oi, oc, ohave);
-                (void)crow_emit(g, mx, my, mz, crow_inscribed<R>(g, b, mx, my, mz), ok, oi, orow, meta_out + slot, okeep, oe, oc, ohave);
+                const float orc = crow_inscribed<R>(g, b, mx, my, mz);
+                crow_list<R>(g, b, mx, my, mz, s_off, s_js, ok, oi, oc, ohave, -1, orc * orc);
+                (void)crow_emit(g, mx, my, mz, orc, ok, oi, orow, meta_out + slot, okeep, oe, oc, ohave);
             }
             ++slot;
         }
