@@ -215,7 +215,7 @@ def lib():
         L.lisreg_concat_device.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), vp, C.POINTER(C.c_int)]
         L.lisreg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
         L.lisreg_get_neighbors.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
-        L.lisreg_test_fit_models.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Params), C.c_int, C.POINTER(C.c_float)]
+        if hasattr(L, "lisreg_test_fit_models"): L.lisreg_test_fit_models.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Params), C.c_int, C.POINTER(C.c_float)]
         L.lisreg_get_target_index.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lisreg_get_target_graph.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.lisreg_get_target_cell_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
