@@ -854,13 +854,25 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
     torch.cuda.synchronize()
     ksteps = 3 * steps
     runs = []
-    for _ in range(3):                        # three back-to-back runs of the pipelined loop: the host side is the variable part
+    phase = dict(stage=0.0, fetch=0.0, prepare=0.0, run=0.0)      # host time of the calling thread per phase, last run of the three
+    for rep in range(3):                      # three back-to-back runs of the pipelined loop: the host side is the variable part
+        for k_ in phase: phase[k_] = 0.0
         t0 = time.perf_counter()
         a.stage(); a.launch()
         for _ in range(ksteps - 1):
+            ta = time.perf_counter()
             a.stage()                 # k + 1: host packing + H2D, underneath the kernels of k
+            tb = time.perf_counter()
             a.fetch()                 # k: D2H of poses and stats
-            a.launch()                # k + 1
+            tc = time.perf_counter()
+            L_ = a.ctx._L
+            rc_ = L_.lisreg_batch_prepare(a.ctx._h, n, a.staged, C.byref(params), a.Tin.ctypes.data_as(C.POINTER(C.c_float)))
+            td = time.perf_counter()
+            rc_ = rc_ or L_.lisreg_batch_run(a.ctx._h)       # k + 1
+            te = time.perf_counter()
+            if rc_:
+                raise RuntimeError(f"lisreg_batch_prepare / run failed: {rc_}")
+            phase["stage"] += tb - ta; phase["fetch"] += tc - tb; phase["prepare"] += td - tc; phase["run"] += te - td
         a.fetch()
         torch.cuda.synchronize()
         runs.append(time.perf_counter() - t0)
@@ -889,6 +901,8 @@ def pcie_inclusive_leg(lisreg, torch, np, dev_index, stream, scans, tc_dev, ts_d
                 chunks_taken_by_copy_engine=f"{by_engine} of {n_chunks} in the last pipelined step (structs that cross as they are — 32 B per point — and are "
                                             "packed on the device: the copy engine takes chunks from the far end of the batch whenever it is idle and the next packed chunk is not ready)",
                 stage_ms=round(1e3 * dtu, 3),
+                host_ms_per_step_by_phase={k_: round(1e3 * v_ / max(ksteps - 1, 1), 3) for k_, v_ in phase.items()},
+                host_ms_note="host time of the calling thread inside each call of the pipelined loop (last of the three runs): stage = feeder threads pack + copies are queued (blocks until the batch is packed), fetch = waits for the running batch, prepare = tables + marks, run = enqueue",
                 link_rate_GBps=round((n_bytes // 2) / dtu * 1e-9, 2),
                 link_rate_note="lisreg_stage_host_items alone, to completion: host packing of the structs (feeder threads) with the H2D copies of the 16-byte records following chunk by chunk; link bytes / that time — a lower bound of the achieved H2D rate",
                 in_series=dict(value=round(n * steps / dt, 2), ms_per_step=round(1e3 * dt / steps, 3), steps=steps,
